@@ -93,9 +93,14 @@ def rate_of_spread(loc_x, loc_y, new_x, new_y, w_0, delta, M_x, sigma, h, S_T, S
     out[ok] = R
     out = np.maximum(out, 0.0)                                        # :134
     if return_parts:
+        # R0: no-wind/no-slope rate; Rscale = R0 * (1 + phi_w + |phi_s|): the magnitude of the
+        # terms that are summed, i.e. the natural scale of the rounding error of R when
+        # 1 + phi_w + phi_s cancels (up-slope against the wind).
         R0 = np.zeros(n, dtype=np.float64)
         R0[ok] = (I_R * xi).astype(np.float64) / den.astype(np.float64)
-        return out, {"R0": R0}
+        Rs = np.zeros(n, dtype=np.float64)
+        Rs[ok] = R0[ok] * (1.0 + phi_w.astype(np.float64) + np.abs(phi_s))
+        return out, {"R0": R0, "Rscale": Rs}
     return out
 
 

@@ -335,7 +335,7 @@ def rothermel_vectors():
     R = compute_rate_of_spread(*g.values())
     _, parts = rothermel_np.rate_of_spread(*g.values(), return_parts=True)
     assert (rothermel_np.rate_of_spread(*g.values()) == R).all()
-    np.savez_compressed(os.path.join(HERE, "rothermel_grid.npz"), R=R, R0=parts["R0"],
+    np.savez_compressed(os.path.join(HERE, "rothermel_grid.npz"), R=R, R0=parts["R0"], Rscale=parts["Rscale"],
                         **{"in_" + k: v for k, v in g.items()})
     print(f"  rothermel_grid.npz: n={n}, R in [{R.min():.3g}, {R.max():.5g}]")
 

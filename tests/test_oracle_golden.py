@@ -1,0 +1,204 @@
+"""CPU tests: the oracles against the golden vectors generated from the real reference."""
+import numpy as np
+import pytest
+
+import _golden
+from oracle import fire_dense, fire_sprites, rothermel_np
+
+
+# ---------------------------------------------------------------- Rothermel chain
+def _inputs(d):
+    order = ["loc_x", "loc_y", "new_loc_x", "new_loc_y", "w_0", "delta", "M_x", "sigma", "h", "S_T",
+             "S_e", "p_p", "M_f", "U", "U_dir", "slope_mag", "slope_dir"]
+    return [d["in_" + k] for k in order]
+
+
+def test_rothermel_known_answer():
+    """simfire/world/_tests/test_rothermel.py:10-100 - published constants, 2 decimals."""
+    d = _golden.load("rothermel_known.npz")
+    for fn in (rothermel_np.rate_of_spread, fire_dense.compute_ros):
+        R = fn(*_inputs(d))
+        assert np.abs(R - d["R_published"]).max() < 5e-3
+        assert np.allclose(R, d["R"], rtol=1e-6, atol=0)
+
+
+def test_rothermel_directional_probe():
+    d = _golden.load("rothermel_known.npz")
+    a = _inputs(d)
+    a[0] = np.full(8, 1, np.float32)
+    a[1] = np.full(8, 1, np.float32)
+    for fn in (rothermel_np.rate_of_spread, fire_dense.compute_ros):
+        assert np.allclose(fn(*a), d["R_directional"], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("fn", [rothermel_np.rate_of_spread, fire_dense.compute_ros],
+                         ids=["numpy", "c_libm"])
+def test_rothermel_grid(fn):
+    """|R - R_ref| <= 1e-5 * Rscale, Rscale = R0 * (1 + phi_w + |phi_s|) >= R: relative 1e-5
+    w.r.t. the magnitude of the summed terms (identical to relative-to-R except where
+    1 + phi_w + phi_s cancels, i.e. fire pushed up-wind down a steep slope)."""
+    d = _golden.load("rothermel_grid.npz")
+    R = fn(*_inputs(d))
+    assert R.dtype == np.float64
+    err = np.abs(R - d["R"])
+    tol = 1e-5 * d["Rscale"]
+    assert (err <= tol).all(), float((err / np.maximum(tol, 1e-300)).max())
+    assert (R[d["in_w_0"] <= 0] == 0).all()
+    assert (R >= 0).all()
+
+
+def test_slopes_match_numpy_gradient():
+    rng = np.random.default_rng(3)
+    for shape in [(7, 9), (40, 48), (2, 2), (33, 5)]:
+        el = rng.normal(0, 50, size=shape)
+        m0, d0 = rothermel_np.slopes(el, 30.0)
+        m1, d1 = fire_dense.slopes(el, 30.0)
+        assert np.allclose(m0, m1, rtol=1e-14, atol=0)
+        assert np.allclose(d0, d1, rtol=1e-13, atol=1e-15)
+
+
+def test_rtable_c_vs_reference_table():
+    for name in ("g2_mixed_a1d1", "g4_lines_on_burning"):
+        d = _golden.load_traj(name)
+        o = fire_dense.DenseOracle(**_golden.engine_kwargs(d))
+        o.build_rtable(d["w_0"], d["delta"], d["M_x"], d["sigma"], d["elevation"], d["U"], d["U_dir"],
+                       float(d["M_f"]))
+        T = o.get_rtable()
+        ref = d["rtable"]
+        scale = np.maximum(ref.max(axis=0, keepdims=True), 1e-30)
+        assert (np.abs(T - ref) <= 1e-5 * scale).all()
+
+
+# ------------------------------------------------------------------- trajectories
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_dense_oracle_logic_parity(name):
+    """Reference-evaluated R table in, everything else recomputed: must be bit-exact."""
+    d = _golden.load_traj(name)
+    o = fire_dense.DenseOracle(**_golden.engine_kwargs(d))
+    o.set_rtable(d["rtable"])
+    o.reset([d["init_pos"]])
+    _golden.replay(o, d)
+    assert (o.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_dense_oracle_own_table(name):
+    """Own libm R table: fire_map still bit-identical because every fixture carries a tie
+    margin >= 1e-4 (far above the 1e-7-class differences between libm and NumPy SIMD)."""
+    d = _golden.load_traj(name)
+    assert float(d["tie_margin"]) >= 1e-4
+    o = fire_dense.DenseOracle(**_golden.engine_kwargs(d))
+    o.build_rtable(d["w_0"], d["delta"], d["M_x"], d["sigma"], d["elevation"], d["U"], d["U_dir"],
+                   float(d["M_f"]))
+    o.reset([d["init_pos"]])
+    _golden.replay(o, d)
+    # accumulated R*dt minus k*980: compare on the scale of the accumulated terms
+    assert (np.abs(o.burn(0) - d["burn"]) <= 1e-5 * (np.abs(d["burn"]) + 1e3)).all()
+
+
+class _SpriteEngine:
+    """Adapter: oracle/fire_sprites.SpriteFire behind the common engine interface."""
+
+    def __init__(self, d, rtable):
+        kw = _golden.engine_kwargs(d)
+        self.f = fire_sprites.SpriteFire(kw["shape"], d["init_pos"], kw["max_fire_duration"],
+                                         kw["pixel_scale"], kw["update_rate"], rtable=rtable,
+                                         max_time=kw["max_time"],
+                                         attenuate_line_ros=kw["attenuate_line_ros"],
+                                         diagonal_spread=kw["diagonal_spread"])
+        self.map = np.zeros(kw["shape"], dtype=np.int64)
+        self.map[d["init_pos"][1], d["init_pos"][0]] = 1
+        self.running = 1
+
+    def apply_mitigation(self, q):
+        fire_sprites.apply_mitigation(self.map, [(x, y, t) for (_, x, y, t) in q])
+
+    def step(self, n):
+        for _ in range(n):
+            if self.running:
+                self.map, st = self.f.update(self.map)
+                self.running = int(st == fire_sprites.RUNNING)
+
+    def fire_map(self, env=0):
+        return self.map.astype(np.uint8)
+
+    def status(self):
+        return np.array([[self.running, 0, 0, 0, 0, 0, 0, 0]]), np.array([self.f.elapsed_time])
+
+
+@pytest.mark.parametrize("name", ["g1_flat32", "g3_lines_a1", "g4_lines_on_burning", "g6_runtime",
+                                  "g7_early_return"])
+def test_sprite_oracle_golden(name):
+    d = _golden.load_traj(name)
+    eng = _SpriteEngine(d, d["rtable"])
+    _golden.replay(eng, d)
+    assert (eng.f.burn == d["burn"]).all()
+
+
+def test_sim_c1_128_final_state():
+    """BASELINE C1 (128^2, FireSimulation.run to QUIT): step count, mid-run maps, final hash."""
+    import hashlib
+    d = _golden.load("sim_c1_128.npz")
+    H = W = 128
+    w0, de, mx, sg = d["fuel"]
+    o = fire_dense.DenseOracle((H, W), max_fire_duration=4, pixel_scale=50.0, update_rate=1.0,
+                               max_time=1440, attenuate_line_ros=True, diagonal_spread=True)
+    o.build_rtable(np.full((H, W), w0), np.full((H, W), de), np.full((H, W), mx), np.full((H, W), sg),
+                   np.zeros((H, W)), np.full((H, W), 7 * 88.0), np.full((H, W), 90.0), 0.03)
+    o.reset([(16, 16)])
+    steps = 0
+    while o.status()[0][0, 0]:
+        o.step(1)
+        steps += 1
+        if f"map_{steps}" in d:
+            assert (o.fire_map(0) == d[f"map_{steps}"]).all(), steps
+    assert steps == int(d["steps"])
+    final = o.fire_map(0)
+    assert (final == d["final"]).all()
+    assert hashlib.sha256(final.astype(np.int8).tobytes()).hexdigest() == str(d["sha256"])
+    assert o.status()[1][0] == float(d["elapsed_time"])
+
+
+# ------------------------------------------- dense (order-free) vs literal sprite list
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_equals_sprite_list_random(seed):
+    """Randomised small worlds incl. lines drawn on burning cells, random R tables with exact
+    ties between directions: the order-free per-cell rule == the reference's list semantics."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(6, 20)), int(rng.integers(6, 20))
+    md = int(rng.integers(1, 6))
+    att, diag = bool(rng.integers(2)), bool(rng.integers(2))
+    ps = float(rng.choice([5.0, 20.0, 50.0]))
+    # coarse-valued table => many equal R's; zeros => non-burnable
+    R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.1] = 0.0
+    init = (int(rng.integers(W)), int(rng.integers(H)))
+    kw = dict(shape=(H, W), max_fire_duration=md, pixel_scale=ps, update_rate=float(rng.choice([1.0, 0.5, 1.5])),
+              max_time=(None if rng.random() < 0.6 else float(rng.integers(5, 30))),
+              attenuate_line_ros=att, diagonal_spread=diag)
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(R8)
+    o.reset([init])
+    s = fire_sprites.SpriteFire((H, W), init, md, ps, kw["update_rate"], rtable=R8, max_time=kw["max_time"],
+                                attenuate_line_ros=att, diagonal_spread=diag)
+    fm = np.zeros((H, W), dtype=np.int64)
+    fm[init[1], init[0]] = 1
+    running = True
+    for t in range(60):
+        if rng.random() < 0.4:
+            k = int(rng.integers(1, 6))
+            pts = [(int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(k)]
+            burning = np.argwhere(fm == 1)
+            if len(burning) and rng.random() < 0.7:
+                y, x = burning[rng.integers(len(burning))]
+                pts.append((int(x), int(y), int(rng.integers(3, 6))))
+            fire_sprites.apply_mitigation(fm, pts)
+            o.apply_mitigation([(0, x, y, ty) for (x, y, ty) in pts])
+        if running:
+            fm, st = s.update(fm)
+            running = st == fire_sprites.RUNNING
+        o.step(1)
+        assert (o.fire_map(0) == fm).all(), (seed, t)
+        assert (o.burn(0) == s.burn).all(), (seed, t)
+        stt, el = o.status()
+        assert bool(stt[0, 0]) == running and el[0] == s.elapsed_time
