@@ -1,0 +1,159 @@
+/*
+ * simfire_hip.h - C ABI of the MI355X (gfx950) Rothermel fire-spread stepper.
+ *
+ * This library is a drop-in for ONE path of mitrefireline/simfire (v2.0.1):
+ *
+ *   RothermelFireManager.__init__ / update      simfire/game/managers/fire.py:293-380, 616-719
+ *   compute_rate_of_spread                      simfire/world/rothermel.py:4-136
+ *   ControlLineManager.update (line scatter)    simfire/game/managers/mitigation.py:60-80
+ *   FireSimulation.update_mitigation            simfire/sim/simulation.py:449-478
+ *   FireSimulation.load_mitigation              simfire/sim/simulation.py:425-447
+ *
+ * batched over a leading environment axis (n_envs independent simulations that share the
+ * terrain / wind layers).  Plain C types only: host pointers in, host pointers out, an
+ * opaque handle in between.  Every function returns 0 (SF_OK) or a negative code;
+ * sf_last_error() gives the message for the calling thread.  No exception crosses the ABI.
+ *
+ * Ownership: the library owns all device memory.  Host arrays are caller-owned, read or
+ * written during the call only; nothing but the handle outlives a call.
+ * Threading: calls on one handle are not re-entrant; different handles may be driven from
+ * different threads.  One HIP stream per handle; every call returns after its work is done
+ * unless stated otherwise.
+ *
+ * Grid convention (same as the reference): arrays are [H][W] row-major, "x" is the column,
+ * "y" the row, positions are given as (x, y) like fire_initial_position
+ * (simulation.py:565-566) and mitigation points (column, row, type) (simulation.py:462).
+ */
+#ifndef SIMFIRE_HIP_H
+#define SIMFIRE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_EINVAL (-1)   /* bad argument value                         -> ValueError      */
+#define SF_ESHAPE (-2)   /* array shape mismatch (fire.py:406-428)     -> ValueError      */
+#define SF_EHIP (-3)     /* HIP runtime error                          -> RuntimeError    */
+#define SF_ENOTSUP (-4)  /* outside the supported envelope             -> NotImplementedError */
+#define SF_ESTATE (-5)   /* call sequence error (e.g. step before layers) -> RuntimeError */
+
+/* BurnStatus (simfire/enums.py:52-69) - the values stored in fire_map */
+#define SF_UNBURNED 0
+#define SF_BURNING 1
+#define SF_BURNED 2
+#define SF_FIRELINE 3
+#define SF_SCRATCHLINE 4
+#define SF_WETLINE 5
+
+/* Index k of the 8 travel directions of the R table: source cell = destination + SF_SRC_DX/DY[k].
+ * The order is the reference's tie-break priority (last sprite in list order wins the scatter at
+ * fire.py:705; the sprite list is sorted by ignition step, then y, then x, fire.py:566-579). */
+#define SF_NDIR 8
+static const int SF_SRC_DX[SF_NDIR] = {+1, 0, -1, +1, -1, +1, 0, -1};
+static const int SF_SRC_DY[SF_NDIR] = {+1, +1, +1, 0, 0, -1, -1, -1};
+
+/* Constructor arguments of RothermelFireManager (fire.py:293-307) + FuelParticle
+ * (world/parameters.py:7-27) + Environment.M_f (parameters.py:52-76) + batch size. */
+typedef struct sf_params {
+    int32_t n_envs;             /* independent simulations batched on this GPU (>= 1)          */
+    int32_t height, width;      /* terrain.screen_size = (H, W)                                */
+    int32_t max_fire_duration;  /* fire.py:60; supported: 1..5 (reference configs use 4 and 5) */
+    int32_t diagonal_spread;    /* fire.py:306   0 = 4-connected, 1 = 8-connected              */
+    int32_t attenuate_line_ros; /* fire.py:304                                                 */
+    int32_t has_max_time;       /* 0 <=> max_time is None (fire.py:303)                        */
+    int32_t device;             /* HIP device ordinal                                          */
+    double pixel_scale;         /* fire.py:298 (ft per pixel)                                  */
+    double update_rate;         /* fire.py:299 (minutes per step)                              */
+    double max_time;            /* fire.py:303 (minutes)                                       */
+    double h, S_T, S_e, p_p;    /* FuelParticle; rounded to float32 like fire.py:537,546        */
+    double M_f;                 /* Environment.M_f                                              */
+} sf_params;
+
+typedef struct sf_sim sf_sim; /* opaque */
+
+const char *sf_last_error(void);
+const char *sf_version(void);
+
+/* replaces RothermelFireManager.__init__ (fire.py:293-380) - allocation only */
+int sf_create(const sf_params *params, sf_sim **out);
+int sf_destroy(sf_sim *sim);
+
+/* Layers read once at construction (fire.py:354-380): fuel of every cell (terrain.fuels ->
+ * Fuel.w_0/delta/M_x/sigma, parameters.py:30-49), terrain.elevations, Environment.U / U_dir
+ * already broadcast to [H][W] (fire.py:382-434).  All arrays float64 [H*W]; the library rounds
+ * to float32 where the reference does.  Computes the slopes (fire.py:436-449, np.gradient) and
+ * the R table R8[k][y][x] on the device. */
+int sf_set_layers(sf_sim *sim, const double *w_0, const double *delta, const double *M_x,
+                  const double *sigma, const double *elevation, const double *U,
+                  const double *U_dir);
+
+/* Logic-parity mode: supply / read back the rate-of-spread table R8[SF_NDIR][H][W] (ft/min,
+ * not yet multiplied by update_rate). */
+int sf_set_rtable(sf_sim *sim, const double *R8);
+int sf_get_rtable(sf_sim *sim, double *R8_out);
+int sf_get_slopes(sf_sim *sim, double *slope_mag_out, double *slope_dir_out);
+
+/* FireSimulation.reset for every environment (simulation.py:202-214, 555-566): fire_map all
+ * UNBURNED except the ignition cell, burn_amounts 0, one sprite of duration 0, elapsed_time 0.
+ * init_xy = int32 [n_envs][2] = (x, y). */
+int sf_reset(sf_sim *sim, const int32_t *init_xy);
+int sf_reset_env(sf_sim *sim, int32_t env, int32_t x, int32_t y);
+
+/* FireSimulation.update_mitigation (simulation.py:449-478) for any number of environments:
+ * pts = int32 [n][4] rows (env, x, y, type); type in {3,4,5}, other types are skipped with the
+ * reference's semantics (simulation.py:469-473).  Within one call all FIRELINE writes land
+ * first, then SCRATCHLINE, then WETLINE (simulation.py:476-478); each write is unconditional
+ * (mitigation.py:75-78).  Out-of-range rows -> SF_EINVAL (the reference would raise IndexError). */
+int sf_apply_mitigation(sf_sim *sim, const int32_t *pts, int32_t n);
+
+/* FireSimulation.load_mitigation (simulation.py:425-447): fire_map of one environment is
+ * replaced wholesale (uint8 [H*W], values 0..5 else SF_EINVAL); burning sprites persist. */
+int sf_load_fire_map(sf_sim *sim, int32_t env, const uint8_t *fire_map);
+
+/* n_steps calls of RothermelFireManager.update (fire.py:616-719) on every environment that
+ * is still RUNNING - the loop of FireSimulation.run (simulation.py:533-544). */
+int sf_step(sf_sim *sim, int32_t n_steps);
+/* same; also reports the GPU time of the n_steps step kernels (HIP events on the handle's
+ * stream) so that callers can form bytes / launch-duration. */
+int sf_step_timed(sf_sim *sim, int32_t n_steps, float *ms_out);
+
+/* Outputs.  fire_map: uint8 [H*W] BurnStatus values; burn: RothermelFireManager.burn_amounts
+ * float64 [H*W]. */
+int sf_get_fire_map(sf_sim *sim, int32_t env, uint8_t *out);
+int sf_get_fire_maps(sf_sim *sim, uint8_t *out /* [n_envs][H*W] */);
+int sf_get_burn(sf_sim *sim, int32_t env, double *out);
+int sf_set_burn(sf_sim *sim, int32_t env, const double *burn);
+
+/* Per-environment result block, the quantities an RL harness turns into episode returns:
+ * status[e] = { running (1 = GameStatus.RUNNING), update() calls made (elapsed_steps),
+ *               count of cells in each BurnStatus 0..5 };   elapsed_time[e] minutes (may be NULL) */
+int sf_get_status(sf_sim *sim, int32_t *status /* [n_envs][8] */, double *elapsed_time);
+
+/* Device-side views for zero-copy consumers (RL observation tensors): pointer to the uint8
+ * status plane of environment 0, row pitch and environment stride in bytes.  Bit 7 of a byte
+ * is internal bookkeeping: mask with 0x07. */
+int sf_fire_map_device(sf_sim *sim, void **ptr, int64_t *row_pitch, int64_t *env_stride);
+/* Device buffer int32 [n_envs][8] filled by sf_update_status_device (same content as
+ * sf_get_status) - the block that is all-gathered over RCCL by the multi-GPU host code. */
+int sf_status_device(sf_sim *sim, void **ptr);
+int sf_update_status_device(sf_sim *sim);
+
+/* Drop-in for compute_rate_of_spread (rothermel.py:4-22): 17 float32 vectors of length n ->
+ * R float64[n] (ft/min). */
+int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const float *new_loc_x,
+                   const float *new_loc_y, const float *w_0, const float *delta, const float *M_x,
+                   const float *sigma, const float *h, const float *S_T, const float *S_e,
+                   const float *p_p, const float *M_f, const float *U, const float *U_dir,
+                   const float *slope_mag, const float *slope_dir, double *R_out, int32_t device);
+
+/* Introspection for benchmarks: bytes of device memory held, and the launch geometry. */
+int sf_memory_bytes(sf_sim *sim, int64_t *bytes);
+int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step kernel */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMFIRE_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI declared in ``include/simfire_hip.h``.
+
+The HIP library is built in-tree (``simfire_amd/csrc/libsimfire_hip.so``) by
+``__graft_entry__.build()`` / ``python -m simfire_amd.build``.  There is no CPU fallback:
+if the library is missing, importing the product path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsimfire_hip.so")
+
+SF_OK, SF_EINVAL, SF_ESHAPE, SF_EHIP, SF_ENOTSUP, SF_ESTATE = 0, -1, -2, -3, -4, -5
+
+
+class SimfireHipError(RuntimeError):
+    pass
+
+
+class SfParams(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("max_fire_duration", C.c_int32), ("diagonal_spread", C.c_int32),
+                ("attenuate_line_ros", C.c_int32), ("has_max_time", C.c_int32), ("device", C.c_int32),
+                ("pixel_scale", C.c_double), ("update_rate", C.c_double), ("max_time", C.c_double),
+                ("h", C.c_double), ("S_T", C.c_double), ("S_e", C.c_double), ("p_p", C.c_double),
+                ("M_f", C.c_double)]
+
+
+# name -> argtypes; every function returns int except the two string getters
+_VP, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
+SIGNATURES = {
+    "sf_create": [C.POINTER(SfParams), C.POINTER(_VP)],
+    "sf_destroy": [_VP],
+    "sf_set_layers": [_VP] + [_VP] * 7,
+    "sf_set_rtable": [_VP, _VP],
+    "sf_get_rtable": [_VP, _VP],
+    "sf_get_slopes": [_VP, _VP, _VP],
+    "sf_reset": [_VP, _VP],
+    "sf_reset_env": [_VP, _I32, _I32, _I32],
+    "sf_apply_mitigation": [_VP, _VP, _I32],
+    "sf_load_fire_map": [_VP, _I32, _VP],
+    "sf_step": [_VP, _I32],
+    "sf_step_timed": [_VP, _I32, C.POINTER(C.c_float)],
+    "sf_get_fire_map": [_VP, _I32, _VP],
+    "sf_get_fire_maps": [_VP, _VP],
+    "sf_get_burn": [_VP, _I32, _VP],
+    "sf_set_burn": [_VP, _I32, _VP],
+    "sf_get_status": [_VP, _VP, _VP],
+    "sf_fire_map_device": [_VP, C.POINTER(_VP), C.POINTER(_I64), C.POINTER(_I64)],
+    "sf_status_device": [_VP, C.POINTER(_VP)],
+    "sf_update_status_device": [_VP],
+    "sf_compute_ros": [_I64] + [_VP] * 18 + [_I32],
+    "sf_memory_bytes": [_VP, C.POINTER(_I64)],
+    "sf_set_rows_per_band": [_VP, _I32],
+}
+STRING_GETTERS = ("sf_last_error", "sf_version")
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises ``SimfireHipError`` if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SimfireHipError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python -m simfire_amd.build). "
+            "simfire_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name in STRING_GETTERS:
+        getattr(lib, name).restype = C.c_char_p
+        getattr(lib, name).argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a C return code onto the exception type the reference raises for that failure."""
+    if rc == SF_OK:
+        return
+    msg = load().sf_last_error().decode("utf-8", "replace")
+    if rc in (SF_EINVAL, SF_ESHAPE):
+        raise ValueError(msg)
+    if rc == SF_ENOTSUP:
+        raise NotImplementedError(msg)
+    raise SimfireHipError(msg)

@@ -1,0 +1,1144 @@
+// MI355X (gfx950 / CDNA4) Rothermel fire-spread stepper - kernels + C ABI (include/simfire_hip.h).
+//
+// What it replaces (reference mitrefireline/simfire v2.0.1):
+//   RothermelFireManager.update / _prune_sprites / _get_new_locs / _update_rate_of_spread /
+//   _update_with_new_locs          simfire/game/managers/fire.py:116-284, 550-589, 616-719
+//   RothermelFireManager._compute_slopes                         fire.py:436-449
+//   compute_rate_of_spread                                       simfire/world/rothermel.py:4-136
+//   ControlLineManager.update + FireSimulation.update_mitigation mitigation.py:60-80, simulation.py:449-478
+//
+// Design (see DESIGN.md for the derivation):
+//   * State per environment, structure-of-arrays in HBM, row pitch P = roundup(W, 16) bytes:
+//       status u8 [H][P]      BurnStatus in bits 0-2 (bit 7 = "line attenuation already settled")
+//       age    u8 [H+2][P]    bitmask of the live sprites of a cell, indexed by ABSOLUTE ignition
+//                             step modulo N = max_fire_duration + 3 (one zero guard row above/below)
+//       burn   f64 [H][P]     RothermelFireManager.burn_amounts
+//     shared by all environments: rt f64 [8][H][P], the rate-of-spread table (ft/min).
+//   * The reference's ordered sprite list is replaced by the order-free per-cell rule of
+//     SURVEY.md section 8a.  Ages are not shifted every step: a sprite ignited at step s owns
+//     bit (s mod N) until it is cleared at step s + max_fire_duration + 2, so the planes are
+//     only written where something happens, and a step can run IN PLACE: every concurrent
+//     writer of a step touches only the two slots (t and t - md - 2) that readers mask out.
+//   * One step = one launch.  Phase 1 (SWAR scan): every lane owns 16 cells of a row, slides a
+//     3-row register window down its band, and finds - 4 cells per VALU op - the cells that can
+//     matter: expiring sprites, cells next to a live sprite, control-line cells.  Horizontal
+//     neighbours come from the adjacent lanes by wavefront shuffles.  Those few cells are
+//     compacted into a per-wave LDS work list (ds_add_rtn allocation per lane).  Phase 2
+//     (frontier): the whole wave walks the compacted list, one cell per lane: winner source,
+//     R table lookup, float64 burn update, ignition.
+//   * The per-environment predicates of fire.py:637-652 (no sprite left -> QUIT, runtime
+//     exceeded -> QUIT, no candidate -> nothing happens) travel through a 3-deep ring of
+//     flag words: launch i reduces into ring[i % 3] with wave ballots + one atomicOr, launch
+//     i + 1 folds them into the environment state, so no extra launch sits between steps.
+//     The only consumer that needs a step's "any candidate" flag inside the same step - the
+//     attenuation of control-line cells that are not next to the fire (fire.py:271-278) - is
+//     deferred by one step (applied first thing when the cell is next touched).
+//
+// No MFMA: there is no dense contraction anywhere on this path; it is HBM-bound byte work.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: burn_amounts and the
+// ignition test burn > pixel_scale must round exactly like IEEE float64 on the CPU).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/simfire_hip.h"
+#include "rothermel_dev.h"
+
+// ------------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(SF_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+extern "C" const char *sf_last_error(void) { return g_err.c_str(); }
+extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------- device types
+namespace {
+
+constexpr int kWaves = 4;          // waves per workgroup (256 threads)
+constexpr int kListCap = 1024;     // cells one wave scans per row iteration = 64 lanes x 16
+constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
+constexpr uint32_t FLAG_CAND = 2u; // some sprite has a cell to spread into     (fire.py:651)
+
+struct EnvState {
+    int32_t running;    // GameStatus.RUNNING
+    int32_t steps;      // update() calls made so far; the next step has index t = steps + 1
+    int32_t prev_flag;  // the last executed step was a complete one (had a candidate)
+    int32_t time_quit;  // the next update() will hit the runtime check (fire.py:641-643)
+    double elapsed;     // RothermelFireManager.elapsed_time
+};
+
+struct Geo {
+    int E, H, W, P, PV;          // P: row pitch (bytes / elements), PV = P / 16
+    int LC, logLC, LR;           // lanes across a row chunk, bands per wave (LC * LR = 64)
+    int RB;                      // rows per band
+    int chunks_x, tiles_per_env; // workgroup tiles
+    int md, N;                   // max_fire_duration, slot count md + 3
+    int diag, att, has_max_time;
+    double pixel_scale, update_rate, max_time;
+    long long age_env, plane_env; // element strides between environments
+};
+
+struct StepArgs {
+    Geo g;
+    uint8_t *status;
+    uint8_t *age;        // points at row 0 of env 0 (guard row is at -P)
+    double *burn;
+    const double *rt;
+    EnvState *commit;    // [E]   state between API calls
+    EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
+    uint32_t *flags;     // [3][E] ring
+    int launch;          // index of this launch inside one sf_step call
+};
+
+struct Masks {
+    uint32_t b_new, b_exp, b_clr, m_live, m_prev;
+    int rot, N;
+};
+
+__host__ __device__ inline int slot_of(int s, int N)
+{
+    int r = s % N;
+    return r < 0 ? r + N : r;
+}
+
+// Bit layout of the age byte at step t (sprites are named by their ignition step s):
+//   live during step t (spread, fire.py:647):          s in [t - md, t - 1]
+//   live during step t - 1:                            s in [t - 1 - md, t - 2]
+//   pruned at step t (-> BURNED, fire.py:116-161):     s = t - md - 1
+//   bit cleared at step t (slot recycled for t + 1):   s = t - md - 2
+//   set at step t (new ignition, fire.py:571-587):     s = t
+__host__ __device__ inline Masks make_masks(int t, int md, int N)
+{
+    Masks m;
+    m.N = N;
+    m.b_new = 1u << slot_of(t, N);
+    m.b_exp = 1u << slot_of(t - md - 1, N);
+    m.b_clr = 1u << slot_of(t - md - 2, N);
+    m.m_live = 0;
+    m.m_prev = 0;
+    for (int s = t - md; s <= t - 1; ++s) m.m_live |= 1u << slot_of(s, N);
+    for (int s = t - 1 - md; s <= t - 2; ++s) m.m_prev |= 1u << slot_of(s, N);
+    m.rot = (N - 1) - slot_of(t - 1, N); // rotate left so that step t-1 lands on bit N-1
+    return m;
+}
+
+__device__ __forceinline__ uint32_t rep4(uint32_t b) { return b * 0x01010101u; }
+
+__device__ inline EnvState fold_state(EnvState s, uint32_t f, const Geo &g)
+{
+    if (!s.running) return s;                       // frozen: run() no longer calls update
+    s.steps += 1;
+    if (!(f & FLAG_LIVE)) { s.running = 0; s.prev_flag = 0; return s; }   // fire.py:637-638
+    if (s.time_quit) { s.running = 0; s.prev_flag = 0; return s; }        // fire.py:641-643
+    if (f & FLAG_CAND) { s.elapsed += g.update_rate; s.prev_flag = 1; }   // fire.py:717
+    else s.prev_flag = 0;                                                 // fire.py:651-652
+    s.time_quit = g.has_max_time && (g.update_rate > g.max_time || s.elapsed > g.max_time);
+    return s;
+}
+
+__device__ __forceinline__ double line_factor(uint32_t st)   // RoSAttenuation, enums.py:72-85
+{
+    return st == SF_FIRELINE ? 980.0 : (st == SF_SCRATCHLINE ? 490.0 : 245.0);
+}
+
+__device__ __forceinline__ uint32_t pick(const uint4 &v, int j)
+{
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ uint4 and4(uint4 a, uint32_t m) { return make_uint4(a.x & m, a.y & m, a.z & m, a.w & m); }
+__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+__device__ __forceinline__ uint32_t any4(uint4 a) { return a.x | a.y | a.z | a.w; }
+// 0/1 per byte: byte != 0
+__device__ __forceinline__ uint32_t nz01(uint32_t v)
+{
+    return ((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) >> 7) & 0x01010101u;
+}
+// 0/1 per byte for status bytes (0..7): status in {3,4,5,..}  (control line)
+__device__ __forceinline__ uint32_t ge3_01(uint32_t s7) { return ((s7 + 0x05050505u) >> 3) & 0x01010101u; }
+// 0/1 per byte: status == 0
+__device__ __forceinline__ uint32_t eq0_01(uint32_t s7) { return ~(s7 | (s7 >> 1) | (s7 >> 2)) & 0x01010101u; }
+// gather the 0/1 bytes of a dword into 4 bits
+__device__ __forceinline__ uint32_t pack4(uint32_t b01) { return (b01 * 0x01020408u) >> 24; }
+
+__constant__ int c_dx[8] = {+1, 0, -1, +1, -1, +1, 0, -1};
+__constant__ int c_dy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
+
+// One cell of the compacted frontier.  item = idx | status << 26 | settled << 29 | expired << 30
+__device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, const Masks &mk,
+                                             const EnvState &st, int e, bool spread, bool &cand_seen)
+{
+    const Geo &g = a.g;
+    const uint32_t idx = item & 0x03FFFFFFu;
+    const uint32_t s_pre = (item >> 26) & 7u;
+    const bool settled = (item >> 29) & 1u;
+    const bool expired = (item >> 30) & 1u;
+    const int y = idx / (uint32_t)g.P;
+    const int x = idx - y * g.P;
+    if (x >= g.W) return;                                           // pitch padding
+    uint8_t *ap = a.age + (long long)e * g.age_env + (long long)y * g.P + x;
+
+    // neighbour sprites (fire.py:163-234 seen from the destination cell)
+    int best = -1, bestk = 0;
+    bool prev_any = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = c_dx[k], dy = c_dy[k];
+        if (!g.diag && dx != 0 && dy != 0) continue;
+        const int xx = x + dx;
+        if (xx < 0 || xx >= g.W) continue;                          // rows are guarded by zero rows
+        const uint32_t v = ap[dy * g.P + dx];
+        prev_any |= (v & mk.m_prev) != 0;
+        const uint32_t l = v & mk.m_live;
+        if (l) {
+            // newest sprite of the neighbour: rotate so that ignition step t-1 is the top bit
+            const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
+            const int msb = 31 - __clz(r);
+            if (msb > best) { best = msb; bestk = k; }              // ties: earlier k wins
+        }
+    }
+    const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
+    const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
+    const bool is_cand = spread && eligible && best >= 0;
+    // attenuation of the previous step that was deferred (cell was a line, not a candidate)
+    const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && st.prev_flag && !prev_any;
+    if (!(is_cand || pending)) return;
+
+    const long long cell = (long long)e * g.plane_env + idx;
+    double bn = a.burn[cell];
+    if (pending) bn = bn - line_factor(s_pre);                      // fire.py:278 with ros = 0
+    if (is_cand) {
+        cand_seen = true;
+        double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+        if (s_post >= SF_FIRELINE)                                               // fire.py:271-282
+            ros = g.att ? ros - line_factor(s_post) : 0.0;
+        bn = bn + ros;                                                           // fire.py:710
+        if (bn > g.pixel_scale) {                                                // fire.py:568
+            a.status[cell] = (uint8_t)SF_BURNING;                                // fire.py:587
+            const uint32_t own = ap[0] & ~mk.b_clr;      // phase 1 may have cleared b_clr already
+            ap[0] = (uint8_t)(own | mk.b_new);                                   // fire.py:571-579
+        }
+    }
+    a.burn[cell] = bn;
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
+{
+    __shared__ uint32_t s_list[kWaves][kListCap];
+    __shared__ uint32_t s_cnt[kWaves];
+    const Geo &g = a.g;
+    const int e = blockIdx.x / g.tiles_per_env;
+    const int tile = blockIdx.x - e * g.tiles_per_env;
+
+    // environment state entering this step (folded from the previous launch's flags)
+    EnvState st;
+    if (a.launch == 0) st = a.commit[e];
+    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    if (tile == 0 && threadIdx.x == 0) {
+        a.tmp[(a.launch & 1) * g.E + e] = st;
+        a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
+    }
+    if (!st.running) return;
+
+    const int t = st.steps + 1;
+    const Masks mk = make_masks(t, g.md, g.N);
+    const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
+    const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
+    const int exp_sh = __ffs(mk.b_exp) - 1;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = tile % g.chunks_x, ty = tile / g.chunks_x;
+    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
+    const int cv = chunk * g.LC + c;
+    const bool col_ok = cv < g.PV;
+    const int y0 = ((ty * kWaves + wave) * g.LR + r) * g.RB;
+
+    uint8_t *age_e = a.age + (long long)e * g.age_env;
+    uint8_t *st_e = a.status + (long long)e * g.plane_env;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_age = [&](int y) -> uint4 {
+        // rows -1 and H are zero guard rows, so no bounds test on y for y in [-1, H]
+        if (col_ok && y <= g.H) return *reinterpret_cast<const uint4 *>(age_e + (long long)y * g.P + cv * 16);
+        return zero4;
+    };
+
+    if (lane == 0) s_cnt[wave] = 0;
+    uint4 up = load_age(y0 - 1), mid = load_age(y0), dn = load_age(y0 + 1);
+    uint32_t live_acc = 0;
+    bool cand_seen = false;
+
+    for (int i = 0; i < g.RB; ++i) {
+        const int y = y0 + i;
+        const bool row_ok = col_ok && y < g.H;
+        const uint4 nxt = (i + 1 < g.RB) ? load_age(y + 2) : zero4;   // prefetch next window row
+
+        // ---- phase 1: SWAR scan of 16 cells --------------------------------------------
+        const uint4 midL = and4(mid, L4);
+        const uint4 vsrc = and4(or4(up, dn), L4);
+        const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+        live_acc |= any4(midL);
+        // horizontal neighbours: byte from the lane to the left / right (same band)
+        uint32_t lin = __shfl_up(hsrc.w, 1, g.LC) >> 24;
+        uint32_t rin = __shfl_down(hsrc.x, 1, g.LC) & 0xFFu;
+        if (c == 0) {
+            lin = 0;
+            if (cv > 0 && row_ok) {        // chunk seam (W > 1024): fetch the column from memory
+                const uint8_t *q = age_e + (long long)y * g.P + cv * 16 - 1;
+                uint32_t v = q[0];
+                if (g.diag) v |= (uint32_t)q[-g.P] | (uint32_t)q[g.P];
+                lin = v & mk.m_live;
+            }
+        }
+        if (c == g.LC - 1) {
+            rin = 0;
+            if (cv + 1 < g.PV && row_ok) {
+                const uint8_t *q = age_e + (long long)y * g.P + cv * 16 + 16;
+                uint32_t v = q[0];
+                if (g.diag) v |= (uint32_t)q[-g.P] | (uint32_t)q[g.P];
+                rin = v & mk.m_live;
+            }
+        }
+        uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
+        nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
+        nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
+        nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
+        nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
+
+        const uint4 ex4 = and4(mid, EXP4);
+        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+        if (row_ok && (any_exp | any_clr | any_nb | (uint32_t)g.att)) {
+            const long long voff = (long long)y * g.P + cv * 16;
+            if (any_clr)   // recycle the slot of sprites that were pruned one step ago
+                *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
+            if (any_exp | any_nb | (uint32_t)g.att) {
+                const uint4 sraw = *reinterpret_cast<const uint4 *>(st_e + voff);
+                const uint4 s7 = and4(sraw, 0x07070707u);
+                // S1 prune: cells whose sprite reached max_fire_duration become BURNED
+                uint4 em;   // 0xFF per expiring byte
+                em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;
+                em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
+                em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
+                em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
+                uint4 snew;
+                snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
+                snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
+                snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
+                snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
+                if ((snew.x ^ sraw.x) | (snew.y ^ sraw.y) | (snew.z ^ sraw.z) | (snew.w ^ sraw.w))
+                    *reinterpret_cast<uint4 *>(st_e + voff) = snew;
+                // cells to hand to phase 2: eligible & next to a live sprite; every line cell
+                // when attenuation is on (their burn changes even away from the fire)
+                uint32_t m16 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t sj = pick(snew, j), pj = pick(s7, j);
+                    uint32_t push = (eq0_01(sj) | ge3_01(sj)) & nz01(pick(nb, j));
+                    if (g.att) push |= ge3_01(pj);
+                    m16 |= pack4(push) << (4 * j);
+                }
+                if (m16) {
+                    uint32_t pos = atomicAdd(&s_cnt[wave], (uint32_t)__popc(m16));
+                    while (m16) {
+                        const int b = __ffs(m16) - 1;
+                        m16 &= m16 - 1;
+                        const int j = b >> 2, sh = (b & 3) * 8;
+                        const uint32_t raw = (pick(sraw, j) >> sh) & 0xFFu;
+                        const uint32_t exd = (pick(em, j) >> sh) & 1u;
+                        s_list[wave][pos++] = (uint32_t)(voff + b) | ((raw & 7u) << 26) |
+                                              ((raw >> 7) << 29) | (exd << 30);
+                    }
+                }
+            }
+        }
+
+        // ---- phase 2: the wave walks its compacted frontier ----------------------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t n_items = s_cnt[wave];
+        if (n_items) {
+            // phase-1 stores of this wave must land before the byte stores below
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t j = lane; j < n_items; j += 64)
+                process_cell(s_list[wave][j], a, mk, st, e, spread, cand_seen);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) s_cnt[wave] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        up = mid; mid = dn; dn = nxt;
+    }
+
+    // per-environment predicates: wave ballot, then at most one atomic per wave
+    const bool w_live = __ballot(live_acc != 0) != 0ull;
+    const bool w_cand = __ballot(cand_seen) != 0ull;
+    if (lane == 0 && (w_live || w_cand)) {
+        uint32_t *f = a.flags + (a.launch % 3) * g.E + e;
+        const uint32_t want = (w_live ? FLAG_LIVE : 0u) | (w_cand ? FLAG_CAND : 0u);
+        const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((have & want) != want) atomicOr(f, want);
+    }
+}
+
+// Fold the flags of the last launch of a sf_step call into the committed state, zero the ring.
+__global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t *flags, int last_launch)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.E) return;
+    commit[e] = fold_state(tmp[(last_launch & 1) * g.E + e], flags[(last_launch % 3) * g.E + e], g);
+    flags[e] = 0; flags[g.E + e] = 0; flags[2 * g.E + e] = 0;
+}
+
+__global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commit, const int32_t *xy,
+                           int env0, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = env0 + i;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
+    age[(long long)e * g.age_env + (long long)y * g.P + x] = 1u;                // ignition step 0
+    EnvState s;
+    s.running = 1; s.steps = 0; s.prev_flag = 0; s.elapsed = 0.0;
+    s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
+    commit[e] = s;
+}
+
+// ------------------------------------------------------------------ layers -> R table
+// np.gradient(elevations, pixel_scale) (fire.py:446): centred 2nd-order differences inside,
+// one-sided 1st-order at the borders; slope_mag / slope_dir (fire.py:447-448) in float64.
+__global__ void k_slopes(int H, int W, const double *el, double ps, double *mag, double *dir)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const long long i = (long long)y * W + x;
+    double gy, gx;
+    if (H == 1) gy = 0.0;
+    else if (y == 0) gy = (el[i + W] - el[i]) / ps;
+    else if (y == H - 1) gy = (el[i] - el[i - W]) / ps;
+    else gy = (el[i + W] - el[i - W]) / (2.0 * ps);
+    if (W == 1) gx = 0.0;
+    else if (x == 0) gx = (el[i + 1] - el[i]) / ps;
+    else if (x == W - 1) gx = (el[i] - el[i - 1]) / ps;
+    else gx = (el[i + 1] - el[i - 1]) / (2.0 * ps);
+    mag[i] = sqrt(gx * gx + gy * gy);
+    dir[i] = atan2(gy, gx + 0.000001);
+}
+
+struct Thetas { float v[8]; };
+
+// One thread per cell: direction-independent terms once, then the 8 travel directions.
+__global__ void k_rtable(int H, int W, int P, const double *w0, const double *delta, const double *Mx,
+                         const double *sigma, const double *U, const double *Udir, const double *mag,
+                         const double *dir, float h, float S_T, float S_e, float p_p, float M_f,
+                         Thetas th, double *rt)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= P) return;
+    const long long o = (long long)y * P + x, plane = (long long)H * P;
+    if (x >= W) {
+        for (int k = 0; k < 8; ++k) rt[k * plane + o] = 0.0;
+        return;
+    }
+    const long long i = (long long)y * W + x;
+    // every input is rounded to float32 first (fire.py:537,546)
+    const sfdev::CellTerms t = sfdev::cell_terms((float)w0[i], (float)delta[i], (float)Mx[i], (float)sigma[i], h,
+                                                 S_T, S_e, p_p, M_f, (float)U[i], (float)Udir[i],
+                                                 (float)mag[i], (float)dir[i]);
+    for (int k = 0; k < 8; ++k) rt[k * plane + o] = sfdev::ros_dir(t, th.v[k]);
+}
+
+__global__ void k_compute_ros(long long n, const float *lx, const float *ly, const float *nx, const float *ny,
+                              const float *w0, const float *delta, const float *Mx, const float *sigma,
+                              const float *h, const float *S_T, const float *S_e, const float *p_p,
+                              const float *M_f, const float *U, const float *Udir, const float *mag,
+                              const float *dir, double *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float theta = (float)atan2((double)(ly[i] - ny[i]), (double)(nx[i] - lx[i]));   // rothermel.py:102
+    const sfdev::CellTerms t = sfdev::cell_terms(w0[i], delta[i], Mx[i], sigma[i], h[i], S_T[i], S_e[i], p_p[i],
+                                                 M_f[i], U[i], Udir[i], mag[i], dir[i]);
+    out[i] = sfdev::ros_dir(t, theta);
+}
+
+// pitched <-> dense plane copies
+__global__ void k_pack_rt(int H, int W, int P, const double *dense, double *pitched)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= P) return;
+    pitched[((long long)k * H + y) * P + x] = x < W ? dense[((long long)k * H + y) * W + x] : 0.0;
+}
+__global__ void k_unpack_f64(int H, int W, int P, const double *pitched, double *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= W) return;
+    dense[((long long)k * H + y) * W + x] = pitched[((long long)k * H + y) * P + x];
+}
+__global__ void k_unpack_status(Geo g, const uint8_t *status, int env0, uint8_t *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, i = blockIdx.z;
+    if (x >= g.W) return;
+    dense[((long long)i * g.H + y) * g.W + x] = status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x] & 7u;
+}
+
+// Is the attenuation of the last executed step still owed to this (line) cell?
+__device__ inline bool owes_attenuation(const Geo &g, const EnvState &s, const uint8_t *age_e, uint32_t sraw,
+                                        int x, int y)
+{
+    if (!g.att || !s.prev_flag || (sraw & 0x80u) || (sraw & 7u) < SF_FIRELINE) return false;
+    const Masks mk = make_masks(s.steps + 1, g.md, g.N);
+    const uint8_t *ap = age_e + (long long)y * g.P + x;
+    for (int k = 0; k < 8; ++k) {
+        const int dx = c_dx[k], dy = c_dy[k];
+        if (!g.diag && dx != 0 && dy != 0) continue;
+        const int xx = x + dx;
+        if (xx < 0 || xx >= g.W) continue;
+        if (ap[dy * g.P + dx] & mk.m_prev) return false;   // it was a candidate: already applied
+    }
+    return true;
+}
+
+// burn_amounts as the reference would hold them now (deferred attenuation resolved on the fly)
+__global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint8_t *age, const double *burn,
+                              const EnvState *commit, int e, double *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    double b = burn[o];
+    const uint32_t sraw = status[o];
+    if (owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y)) b = b - line_factor(sraw & 7u);
+    dense[(long long)y * g.W + x] = b;
+}
+
+// Make the deferred attenuation of one environment real and mark every line cell settled.
+// Used before fire_map / burn are overwritten wholesale (load_mitigation, set_burn).
+__global__ void k_settle_env(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+                             int e, int apply)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    const uint32_t sraw = status[o];
+    if ((sraw & 7u) < SF_FIRELINE) return;
+    if (apply && owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y))
+        burn[o] = burn[o] - line_factor(sraw & 7u);
+    status[o] = (uint8_t)(sraw | 0x80u);
+}
+
+__global__ void k_pack_status(Geo g, uint8_t *status, int e, const uint8_t *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const uint32_t v = dense[(long long)y * g.W + x];
+    // a freshly loaded line cell owes nothing for the step that ran before it existed
+    status[(long long)e * g.plane_env + (long long)y * g.P + x] = (uint8_t)((g.att && v >= SF_FIRELINE) ? (v | 0x80u) : v);
+}
+__global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    burn[(long long)e * g.plane_env + (long long)y * g.P + x] = dense[(long long)y * g.W + x];
+}
+
+// ------------------------------------------------------------------------- mitigation
+// One workgroup per environment that received points.  pts rows (env, x, y, type) are grouped
+// by environment on the host; seg[b] .. seg[b+1] is the row range of workgroup b.
+// Phase A (attenuation mode only): the first writer of a cell settles what the cell is still
+// owed for the last step under its OLD status.  Phases B1-B3: FIRELINE, SCRATCHLINE, WETLINE
+// writes in the reference's order (simulation.py:476-478), so for duplicates the later type wins.
+__global__ __launch_bounds__(256) void k_mitigate(Geo g, uint8_t *status, const uint8_t *age, double *burn,
+                                                  const EnvState *commit, const int32_t *pts, const int32_t *seg)
+{
+    const int b = blockIdx.x;
+    const int lo = seg[b], hi = seg[b + 1];
+    if (lo >= hi) return;
+    const int e = pts[4 * lo];
+    uint8_t *st_e = status + (long long)e * g.plane_env;
+    if (g.att) {
+        const EnvState s = commit[e];
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const int x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
+            if (ty < SF_FIRELINE || ty > SF_WETLINE) continue;
+            const long long o = (long long)y * g.P + x;
+            uint32_t *word = reinterpret_cast<uint32_t *>(st_e + (o & ~3ll));
+            const int sh = (int)(o & 3) * 8;
+            const uint32_t old = atomicOr(word, 0x80u << sh);
+            const uint32_t sraw = (old >> sh) & 0xFFu;
+            if (!(sraw & 0x80u) && owes_attenuation(g, s, age + (long long)e * g.age_env, sraw, x, y)) {
+                const long long c = (long long)e * g.plane_env + o;
+                burn[c] = burn[c] - line_factor(sraw & 7u);
+            }
+        }
+    }
+    const uint8_t mark = g.att ? 0x80u : 0u;
+    for (int kind = SF_FIRELINE; kind <= SF_WETLINE; ++kind) {
+        __syncthreads();
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x)
+            if (pts[4 * i + 3] == kind)
+                st_e[(long long)pts[4 * i + 2] * g.P + pts[4 * i + 1]] = (uint8_t)(kind | mark);   // mitigation.py:75-78
+    }
+}
+
+// ------------------------------------------------------------- per-environment results
+__global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, const EnvState *commit,
+                                                int32_t *out)
+{
+    __shared__ int32_t h[8];
+    const int e = blockIdx.y;
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    int32_t loc[6] = {0, 0, 0, 0, 0, 0};
+    const uint8_t *st_e = status + (long long)e * g.plane_env;
+    for (int y = blockIdx.x; y < g.H; y += gridDim.x)
+        for (int x = threadIdx.x; x < g.W; x += blockDim.x) {
+            const uint32_t v = st_e[(long long)y * g.P + x] & 7u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) loc[k] += (v == (uint32_t)k);
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int32_t v = loc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && h[threadIdx.x]) atomicAdd(&out[e * 8 + 2 + threadIdx.x], h[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[e * 8 + 0] = commit[e].running;
+        out[e * 8 + 1] = commit[e].steps;
+    }
+}
+
+__global__ void k_elapsed(int E, const EnvState *commit, double *out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) out[e] = commit[e].elapsed;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------- handle
+struct sf_sim {
+    sf_params p;
+    Geo g;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t *status = nullptr, *age_alloc = nullptr, *age = nullptr;
+    double *burn = nullptr, *rt = nullptr;
+    double *lay[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // w0 delta Mx sigma elev U Udir (dense)
+    double *smag = nullptr, *sdir = nullptr;
+    EnvState *commit = nullptr, *tmp = nullptr;
+    uint32_t *flags = nullptr;
+    int32_t *status_block = nullptr;   // [E][8]
+    double *elapsed_dev = nullptr;     // [E]
+    void *stage = nullptr;             // dense staging for host copies
+    size_t stage_bytes = 0;
+    int32_t *pts_dev = nullptr, *seg_dev = nullptr;
+    size_t pts_cap = 0, seg_cap = 0;
+    bool have_rt = false, was_reset = false;
+    int64_t bytes = 0;
+};
+
+static int ensure_stage(sf_sim *s, size_t bytes)
+{
+    if (bytes <= s->stage_bytes) return SF_OK;
+    if (s->stage) HIPCHK(hipFree(s->stage));
+    s->stage = nullptr; s->stage_bytes = 0;
+    HIPCHK(hipMalloc(&s->stage, bytes));
+    s->stage_bytes = bytes;
+    return SF_OK;
+}
+
+template <typename T>
+static int dev_alloc(sf_sim *s, T **p, size_t n)
+{
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+    s->bytes += (int64_t)(n * sizeof(T));
+    return SF_OK;
+}
+
+static void choose_rows_per_band(Geo &g, int rows)
+{
+    if (rows < 1) rows = 1;
+    g.RB = rows;
+    const int tile_h = kWaves * g.LR * g.RB;
+    g.tiles_per_env = g.chunks_x * ((g.H + tile_h - 1) / tile_h);
+}
+
+extern "C" int sf_create(const sf_params *p, sf_sim **out)
+{
+    if (!p || !out) return fail(SF_EINVAL, "sf_create: null argument");
+    if (p->n_envs < 1 || p->height < 1 || p->width < 1)
+        return fail(SF_EINVAL, "sf_create: n_envs, height and width must be >= 1 (got %d, %d, %d)", p->n_envs,
+                    p->height, p->width);
+    if (p->max_fire_duration < 1)
+        return fail(SF_EINVAL, "sf_create: max_fire_duration must be >= 1 (got %d)", p->max_fire_duration);
+    if (p->max_fire_duration > 5)
+        return fail(SF_ENOTSUP, "sf_create: max_fire_duration %d > 5 is not supported by the 8-bit age plane",
+                    p->max_fire_duration);
+    if (!(p->update_rate > 0.0)) return fail(SF_EINVAL, "sf_create: update_rate must be > 0");
+    const long long P = ((long long)p->width + 15) / 16 * 16;
+    if ((long long)p->height * P > (1ll << 26))
+        return fail(SF_ENOTSUP, "sf_create: grids above 2^26 cells per environment are not supported");
+    HIPCHK(hipSetDevice(p->device));
+    sf_sim *s = new sf_sim();
+    s->p = *p;
+    Geo &g = s->g;
+    g.E = p->n_envs; g.H = p->height; g.W = p->width; g.P = (int)P; g.PV = g.P / 16;
+    g.LC = 1; g.logLC = 0;
+    while (g.LC < g.PV && g.LC < 64) { g.LC <<= 1; g.logLC++; }
+    g.LR = 64 / g.LC;
+    g.chunks_x = (g.PV + g.LC - 1) / g.LC;
+    g.md = p->max_fire_duration; g.N = g.md + 3;
+    g.diag = p->diagonal_spread != 0; g.att = p->attenuate_line_ros != 0; g.has_max_time = p->has_max_time != 0;
+    g.pixel_scale = p->pixel_scale; g.update_rate = p->update_rate; g.max_time = p->max_time;
+    g.age_env = (long long)(g.H + 2) * g.P; g.plane_env = (long long)g.H * g.P;
+    // rows per band: enough workgroups to fill 256 CUs several times over when the batch is
+    // large, short bands when a single environment has to spread over the chip
+    long long rows_total = (long long)g.E * g.H;
+    int rb = rows_total >= 65536 ? 8 : (rows_total >= 16384 ? 4 : 2);
+    choose_rows_per_band(g, rb);
+
+    int rc;
+#define TRY(x) do { rc = (x); if (rc != SF_OK) { sf_destroy(s); return rc; } } while (0)
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(SF_EHIP, "hipStreamCreate failed"); }
+    hipEventCreate(&s->ev0); hipEventCreate(&s->ev1);
+    const size_t cells = (size_t)g.E * g.plane_env;
+    TRY(dev_alloc(s, &s->status, cells));
+    TRY(dev_alloc(s, &s->age_alloc, (size_t)g.E * g.age_env + 2 * (size_t)g.P));
+    s->age = s->age_alloc + g.P;   // row 0 of env 0; guard rows at -1 and H of every env
+    TRY(dev_alloc(s, &s->burn, cells));
+    TRY(dev_alloc(s, &s->rt, (size_t)8 * g.plane_env));
+    for (int i = 0; i < 7; ++i) TRY(dev_alloc(s, &s->lay[i], (size_t)g.H * g.W));
+    TRY(dev_alloc(s, &s->smag, (size_t)g.H * g.W));
+    TRY(dev_alloc(s, &s->sdir, (size_t)g.H * g.W));
+    TRY(dev_alloc(s, &s->commit, (size_t)g.E));
+    TRY(dev_alloc(s, &s->tmp, (size_t)2 * g.E));
+    TRY(dev_alloc(s, &s->flags, (size_t)3 * g.E));
+    TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
+    TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
+#undef TRY
+    HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
+    HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
+    HIPCHK(hipMemsetAsync(s->age_alloc, 0, (size_t)g.E * g.age_env + 2 * (size_t)g.P, s->stream));
+    HIPCHK(hipMemsetAsync(s->status, 0, cells, s->stream));
+    HIPCHK(hipMemsetAsync(s->burn, 0, cells * sizeof(double), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *out = s;
+    return SF_OK;
+}
+
+extern "C" int sf_destroy(sf_sim *s)
+{
+    if (!s) return SF_OK;
+    hipSetDevice(s->p.device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
+                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags,
+                    s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->seg_dev};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return SF_OK;
+}
+
+extern "C" int sf_memory_bytes(sf_sim *s, int64_t *bytes)
+{
+    if (!s || !bytes) return fail(SF_EINVAL, "sf_memory_bytes: null argument");
+    *bytes = s->bytes + (int64_t)s->stage_bytes;
+    return SF_OK;
+}
+
+extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
+{
+    if (!s || rows < 1 || rows > 4096) return fail(SF_EINVAL, "sf_set_rows_per_band: rows must be in [1, 4096]");
+    choose_rows_per_band(s->g, rows);
+    return SF_OK;
+}
+
+extern "C" int sf_set_layers(sf_sim *s, const double *w_0, const double *delta, const double *M_x,
+                             const double *sigma, const double *elevation, const double *U, const double *U_dir)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_layers: null handle");
+    const double *src[7] = {w_0, delta, M_x, sigma, elevation, U, U_dir};
+    for (int i = 0; i < 7; ++i) if (!src[i]) return fail(SF_EINVAL, "sf_set_layers: null layer pointer (#%d)", i);
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t n = (size_t)g.H * g.W;
+    for (int i = 0; i < 7; ++i) HIPCHK(hipMemcpyAsync(s->lay[i], src[i], n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    hipLaunchKernelGGL(k_slopes, grd, blk, 0, s->stream, g.H, g.W, s->lay[4], g.pixel_scale, s->smag, s->sdir);
+    Thetas th;
+    for (int k = 0; k < 8; ++k)   // theta = arctan2(src_y - dst_y, dst_x - src_x), float32 (rothermel.py:102)
+        th.v[k] = atan2f((float)SF_SRC_DY[k], (float)(-SF_SRC_DX[k]));
+    dim3 grd2((g.P + 255) / 256, g.H);
+    hipLaunchKernelGGL(k_rtable, grd2, blk, 0, s->stream, g.H, g.W, g.P, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
+                       s->lay[5], s->lay[6], s->smag, s->sdir, (float)s->p.h, (float)s->p.S_T, (float)s->p.S_e,
+                       (float)s->p.p_p, (float)s->p.M_f, th, s->rt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->have_rt = true;
+    return SF_OK;
+}
+
+extern "C" int sf_set_rtable(sf_sim *s, const double *R8)
+{
+    if (!s || !R8) return fail(SF_EINVAL, "sf_set_rtable: null argument");
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
+    int rc = ensure_stage(s, n);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->stage, R8, n, hipMemcpyHostToDevice, s->stream));
+    dim3 blk(256), grd((g.P + 255) / 256, g.H, 8);
+    hipLaunchKernelGGL(k_pack_rt, grd, blk, 0, s->stream, g.H, g.W, g.P, (const double *)s->stage, s->rt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->have_rt = true;
+    return SF_OK;
+}
+
+extern "C" int sf_get_rtable(sf_sim *s, double *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_rtable: null argument");
+    if (!s->have_rt) return fail(SF_ESTATE, "sf_get_rtable: no layers / table set");
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
+    int rc = ensure_stage(s, n);
+    if (rc) return rc;
+    dim3 blk(256), grd((g.W + 255) / 256, g.H, 8);
+    hipLaunchKernelGGL(k_unpack_f64, grd, blk, 0, s->stream, g.H, g.W, g.P, (const double *)s->rt, (double *)s->stage);
+    HIPCHK(hipMemcpyAsync(out, s->stage, n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_get_slopes(sf_sim *s, double *mag, double *dir)
+{
+    if (!s || !mag || !dir) return fail(SF_EINVAL, "sf_get_slopes: null argument");
+    HIPCHK(hipSetDevice(s->p.device));
+    const size_t n = (size_t)s->g.H * s->g.W * sizeof(double);
+    HIPCHK(hipMemcpyAsync(mag, s->smag, n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(dir, s->sdir, n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
+{
+    const Geo &g = s->g;
+    for (int i = 0; i < n; ++i)
+        if (xy[2 * i] < 0 || xy[2 * i] >= g.W || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= g.H)
+            return fail(SF_EINVAL, "reset: ignition (%d, %d) of environment %d is outside the %dx%d grid", xy[2 * i],
+                        xy[2 * i + 1], env0 + i, g.H, g.W);
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
+    HIPCHK(hipMemsetAsync(s->age + (long long)env0 * g.age_env - g.P, 0, (size_t)n * g.age_env, s->stream));
+    HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
+    int rc = ensure_stage(s, (size_t)n * 2 * sizeof(int32_t));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->stage, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
+                       (const int32_t *)s->stage, env0, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_reset(sf_sim *s, const int32_t *init_xy)
+{
+    if (!s || !init_xy) return fail(SF_EINVAL, "sf_reset: null argument");
+    int rc = reset_range(s, 0, s->g.E, init_xy);
+    if (rc == SF_OK) s->was_reset = true;
+    return rc;
+}
+
+extern "C" int sf_reset_env(sf_sim *s, int32_t env, int32_t x, int32_t y)
+{
+    if (!s) return fail(SF_EINVAL, "sf_reset_env: null handle");
+    if (env < 0 || env >= s->g.E) return fail(SF_EINVAL, "sf_reset_env: environment %d out of range", env);
+    if (!s->was_reset) return fail(SF_ESTATE, "sf_reset_env: call sf_reset once first");
+    const int32_t xy[2] = {x, y};
+    return reset_range(s, env, 1, xy);
+}
+
+extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
+{
+    if (!s) return fail(SF_EINVAL, "sf_apply_mitigation: null handle");
+    if (n < 0 || (n > 0 && !pts)) return fail(SF_EINVAL, "sf_apply_mitigation: bad point list");
+    if (n == 0) return SF_OK;
+    const Geo &g = s->g;
+    // validate, drop unknown types (simulation.py:469-473), group by environment (stable)
+    std::vector<int32_t> cnt(g.E + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        const int32_t *q = pts + 4 * i;
+        if (q[0] < 0 || q[0] >= g.E || q[1] < 0 || q[1] >= g.W || q[2] < 0 || q[2] >= g.H)
+            return fail(SF_EINVAL, "sf_apply_mitigation: point %d = (env %d, x %d, y %d) is out of range", i, q[0], q[1], q[2]);
+        if (q[3] >= SF_FIRELINE && q[3] <= SF_WETLINE) cnt[q[0] + 1]++;
+    }
+    std::vector<int32_t> start(g.E + 1, 0);
+    for (int e = 0; e < g.E; ++e) start[e + 1] = start[e] + cnt[e + 1];
+    const int m = start[g.E];
+    if (m == 0) return SF_OK;
+    std::vector<int32_t> sorted((size_t)4 * m), fill(start.begin(), start.end() - 1), seg;
+    for (int i = 0; i < n; ++i) {
+        const int32_t *q = pts + 4 * i;
+        if (q[3] < SF_FIRELINE || q[3] > SF_WETLINE) continue;
+        memcpy(&sorted[(size_t)4 * fill[q[0]]++], q, 4 * sizeof(int32_t));
+    }
+    for (int e = 0; e < g.E; ++e) if (start[e + 1] > start[e]) seg.push_back(start[e]);
+    const int nseg = (int)seg.size();
+    seg.push_back(m);
+    HIPCHK(hipSetDevice(s->p.device));
+    if ((size_t)4 * m > s->pts_cap) {
+        if (s->pts_dev) HIPCHK(hipFree(s->pts_dev));
+        s->pts_cap = (size_t)4 * m * 2;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->pts_dev), s->pts_cap * sizeof(int32_t)));
+    }
+    if ((size_t)nseg + 1 > s->seg_cap) {
+        if (s->seg_dev) HIPCHK(hipFree(s->seg_dev));
+        s->seg_cap = ((size_t)nseg + 1) * 2;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->seg_dev), s->seg_cap * sizeof(int32_t)));
+    }
+    HIPCHK(hipMemcpyAsync(s->pts_dev, sorted.data(), (size_t)4 * m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->seg_dev, seg.data(), ((size_t)nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_mitigate, dim3(nseg), dim3(256), 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+                       (const EnvState *)s->commit, (const int32_t *)s->pts_dev, (const int32_t *)s->seg_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));   // host vectors go out of scope
+    return SF_OK;
+}
+
+extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
+{
+    if (!s || !map) return fail(SF_EINVAL, "sf_load_fire_map: null argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_load_fire_map: environment %d out of range", env);
+    const size_t n = (size_t)g.H * g.W;
+    for (size_t i = 0; i < n; ++i)
+        if (map[i] > SF_WETLINE) return fail(SF_EINVAL, "sf_load_fire_map: value %d at cell %zu is not a BurnStatus", map[i], i);
+    HIPCHK(hipSetDevice(s->p.device));
+    int rc = ensure_stage(s, n);
+    if (rc) return rc;
+    dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    if (g.att)
+        hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+                           (const EnvState *)s->commit, env, 1);
+    HIPCHK(hipMemcpyAsync(s->stage, map, n, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_pack_status, grd, blk, 0, s->stream, g, s->status, env, (const uint8_t *)s->stage);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+static int step_impl(sf_sim *s, int n_steps, float *ms)
+{
+    if (!s) return fail(SF_EINVAL, "sf_step: null handle");
+    if (n_steps < 0) return fail(SF_EINVAL, "sf_step: n_steps must be >= 0");
+    if (!s->have_rt) return fail(SF_ESTATE, "sf_step: call sf_set_layers or sf_set_rtable first");
+    if (!s->was_reset) return fail(SF_ESTATE, "sf_step: call sf_reset first");
+    if (ms) *ms = 0.f;
+    if (n_steps == 0) return SF_OK;
+    HIPCHK(hipSetDevice(s->p.device));
+    StepArgs a;
+    a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
+    a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags;
+    const dim3 grid((unsigned)(s->g.tiles_per_env * s->g.E)), block(kWaves * 64);
+    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+    for (int i = 0; i < n_steps; ++i) {
+        a.launch = i;
+        hipLaunchKernelGGL(k_step, grid, block, 0, s->stream, a);
+    }
+    if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
+    hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
+                       (const EnvState *)s->tmp, s->flags, n_steps - 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (ms) HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return SF_OK;
+}
+
+extern "C" int sf_step(sf_sim *s, int32_t n_steps) { return step_impl(s, n_steps, nullptr); }
+extern "C" int sf_step_timed(sf_sim *s, int32_t n_steps, float *ms_out)
+{
+    if (!ms_out) return fail(SF_EINVAL, "sf_step_timed: null ms_out");
+    return step_impl(s, n_steps, ms_out);
+}
+
+static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
+{
+    const Geo &g = s->g;
+    HIPCHK(hipSetDevice(s->p.device));
+    const size_t bytes = (size_t)n * g.H * g.W;
+    int rc = ensure_stage(s, bytes);
+    if (rc) return rc;
+    dim3 blk(256), grd((g.W + 255) / 256, g.H, n);
+    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, env0, (uint8_t *)s->stage);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_get_fire_map(sf_sim *s, int32_t env, uint8_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_fire_map: null argument");
+    if (env < 0 || env >= s->g.E) return fail(SF_EINVAL, "sf_get_fire_map: environment %d out of range", env);
+    return get_maps(s, env, 1, out);
+}
+
+extern "C" int sf_get_fire_maps(sf_sim *s, uint8_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_fire_maps: null argument");
+    const int chunk = 64;   // bound the staging buffer
+    for (int e = 0; e < s->g.E; e += chunk) {
+        const int n = s->g.E - e < chunk ? s->g.E - e : chunk;
+        int rc = get_maps(s, e, n, out + (size_t)e * s->g.H * s->g.W);
+        if (rc) return rc;
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_burn: null argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_burn: environment %d out of range", env);
+    HIPCHK(hipSetDevice(s->p.device));
+    const size_t bytes = (size_t)g.H * g.W * sizeof(double);
+    int rc = ensure_stage(s, bytes);
+    if (rc) return rc;
+    dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    hipLaunchKernelGGL(k_unpack_burn, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)s->age,
+                       (const double *)s->burn, (const EnvState *)s->commit, env, (double *)s->stage);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
+{
+    if (!s || !burn) return fail(SF_EINVAL, "sf_set_burn: null argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_set_burn: environment %d out of range", env);
+    HIPCHK(hipSetDevice(s->p.device));
+    const size_t bytes = (size_t)g.H * g.W * sizeof(double);
+    int rc = ensure_stage(s, bytes);
+    if (rc) return rc;
+    dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    if (g.att)   // the caller's values are the truth now: nothing is owed any more
+        hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+                           (const EnvState *)s->commit, env, 0);
+    HIPCHK(hipMemcpyAsync(s->stage, burn, bytes, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_pack_burn, grd, blk, 0, s->stream, g, s->burn, env, (const double *)s->stage);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_update_status_device(sf_sim *s)
+{
+    if (!s) return fail(SF_EINVAL, "sf_update_status_device: null handle");
+    const Geo &g = s->g;
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
+    int bx = g.H < 64 ? g.H : 64;
+    hipLaunchKernelGGL(k_counts, dim3(bx, g.E), dim3(256), 0, s->stream, g, (const uint8_t *)s->status,
+                       (const EnvState *)s->commit, s->status_block);
+    hipLaunchKernelGGL(k_elapsed, dim3((g.E + 255) / 256), dim3(256), 0, s->stream, g.E, (const EnvState *)s->commit,
+                       s->elapsed_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_get_status(sf_sim *s, int32_t *status, double *elapsed)
+{
+    if (!s || !status) return fail(SF_EINVAL, "sf_get_status: null argument");
+    int rc = sf_update_status_device(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(status, s->status_block, sizeof(int32_t) * 8 * s->g.E, hipMemcpyDeviceToHost));
+    if (elapsed) HIPCHK(hipMemcpy(elapsed, s->elapsed_dev, sizeof(double) * s->g.E, hipMemcpyDeviceToHost));
+    return SF_OK;
+}
+
+extern "C" int sf_status_device(sf_sim *s, void **ptr)
+{
+    if (!s || !ptr) return fail(SF_EINVAL, "sf_status_device: null argument");
+    *ptr = s->status_block;
+    return SF_OK;
+}
+
+extern "C" int sf_fire_map_device(sf_sim *s, void **ptr, int64_t *row_pitch, int64_t *env_stride)
+{
+    if (!s || !ptr || !row_pitch || !env_stride) return fail(SF_EINVAL, "sf_fire_map_device: null argument");
+    *ptr = s->status; *row_pitch = s->g.P; *env_stride = s->g.plane_env;
+    return SF_OK;
+}
+
+extern "C" int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const float *new_loc_x,
+                              const float *new_loc_y, const float *w_0, const float *delta, const float *M_x,
+                              const float *sigma, const float *h, const float *S_T, const float *S_e,
+                              const float *p_p, const float *M_f, const float *U, const float *U_dir,
+                              const float *slope_mag, const float *slope_dir, double *R_out, int32_t device)
+{
+    const float *in[17] = {loc_x, loc_y, new_loc_x, new_loc_y, w_0, delta, M_x, sigma, h, S_T, S_e, p_p, M_f, U, U_dir,
+                           slope_mag, slope_dir};
+    if (n < 0) return fail(SF_EINVAL, "sf_compute_ros: n must be >= 0");
+    if (n == 0) return SF_OK;
+    for (int i = 0; i < 17; ++i) if (!in[i]) return fail(SF_EINVAL, "sf_compute_ros: null input #%d", i);
+    if (!R_out) return fail(SF_EINVAL, "sf_compute_ros: null output");
+    HIPCHK(hipSetDevice(device));
+    float *d_in = nullptr;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_in), (size_t)17 * n * sizeof(float)));
+    if (hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)n * sizeof(double)) != hipSuccess) {
+        hipFree(d_in);
+        return fail(SF_EHIP, "sf_compute_ros: out of device memory");
+    }
+    int rc = SF_OK;
+    for (int i = 0; i < 17 && rc == SF_OK; ++i)
+        if (hipMemcpy(d_in + (size_t)i * n, in[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(SF_EHIP, "sf_compute_ros: upload failed");
+    if (rc == SF_OK) {
+        const float *p = d_in;
+        hipLaunchKernelGGL(k_compute_ros, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (long long)n, p, p + n,
+                           p + 2 * n, p + 3 * n, p + 4 * n, p + 5 * n, p + 6 * n, p + 7 * n, p + 8 * n, p + 9 * n,
+                           p + 10 * n, p + 11 * n, p + 12 * n, p + 13 * n, p + 14 * n, p + 15 * n, p + 16 * n, d_out);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            rc = fail(SF_EHIP, "sf_compute_ros: kernel failed");
+        else if (hipMemcpy(R_out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(SF_EHIP, "sf_compute_ros: download failed");
+    }
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+}

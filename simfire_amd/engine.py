@@ -1,0 +1,179 @@
+"""``FireEngine``: object wrapper around one ``sf_sim`` handle of the C ABI.
+
+This is the only module that touches the HIP library; the reference-shaped classes in
+``fire.py`` / ``simulation.py`` are written on top of it.  Arrays cross the boundary as
+NumPy host arrays (copied during the call); nothing here depends on torch.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FireEngine:
+    """n_envs batched Rothermel fire simulations sharing one terrain on one GPU.
+
+    Mirrors the constructor arguments of the reference's ``RothermelFireManager``
+    (simfire/game/managers/fire.py:293-307)."""
+
+    def __init__(self, shape, n_envs=1, max_fire_duration=4, pixel_scale=50.0, update_rate=1.0,
+                 max_time=None, attenuate_line_ros=True, diagonal_spread=True, M_f=0.03,
+                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0):
+        self._L = _lib.load()
+        self.H, self.W = int(shape[0]), int(shape[1])
+        self.n_envs = int(n_envs)
+        h, S_T, S_e, p_p = particle
+        self.params = _lib.SfParams(
+            n_envs=self.n_envs, height=self.H, width=self.W, max_fire_duration=int(max_fire_duration),
+            diagonal_spread=int(bool(diagonal_spread)), attenuate_line_ros=int(bool(attenuate_line_ros)),
+            has_max_time=int(max_time is not None), device=int(device), pixel_scale=float(pixel_scale),
+            update_rate=float(update_rate), max_time=float(0.0 if max_time is None else max_time),
+            h=float(h), S_T=float(S_T), S_e=float(S_e), p_p=float(p_p), M_f=float(M_f))
+        self._h = C.c_void_p()
+        _lib.check(self._L.sf_create(C.byref(self.params), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.sf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ construction
+    def _plane(self, a, name):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 0:
+            a = np.full((self.H, self.W), float(a))
+        if a.shape != (self.H, self.W):
+            raise ValueError(f"The input parameter shape of {a.shape} should match the terrain "
+                             f"shape of {(self.H, self.W)} ({name})")
+        return np.ascontiguousarray(a)
+
+    def set_layers(self, w_0, delta, M_x, sigma, elevation, U, U_dir):
+        arrs = [self._plane(a, n) for a, n in zip(
+            (w_0, delta, M_x, sigma, elevation, U, U_dir),
+            ("w_0", "delta", "M_x", "sigma", "elevation", "U", "U_dir"))]
+        _lib.check(self._L.sf_set_layers(self._h, *[_ptr(a) for a in arrs]))
+
+    def set_rtable(self, R8):
+        R8 = np.ascontiguousarray(R8, dtype=np.float64)
+        if R8.shape != (8, self.H, self.W):
+            raise ValueError(f"R table shape {R8.shape} != {(8, self.H, self.W)}")
+        _lib.check(self._L.sf_set_rtable(self._h, _ptr(R8)))
+
+    def get_rtable(self):
+        out = np.empty((8, self.H, self.W), dtype=np.float64)
+        _lib.check(self._L.sf_get_rtable(self._h, _ptr(out)))
+        return out
+
+    def get_slopes(self):
+        mag = np.empty((self.H, self.W))
+        dr = np.empty((self.H, self.W))
+        _lib.check(self._L.sf_get_slopes(self._h, _ptr(mag), _ptr(dr)))
+        return mag, dr
+
+    # ------------------------------------------------------------------------ running
+    def reset(self, init_xy):
+        xy = np.ascontiguousarray(np.asarray(init_xy, dtype=np.int32).reshape(-1, 2))
+        if xy.shape[0] == 1 and self.n_envs > 1:
+            xy = np.ascontiguousarray(np.repeat(xy, self.n_envs, axis=0))
+        if xy.shape[0] != self.n_envs:
+            raise ValueError(f"need {self.n_envs} ignition points, got {xy.shape[0]}")
+        _lib.check(self._L.sf_reset(self._h, _ptr(xy)))
+
+    def reset_env(self, env, x, y):
+        _lib.check(self._L.sf_reset_env(self._h, int(env), int(x), int(y)))
+
+    def apply_mitigation(self, pts):
+        """pts: rows (env, x, y, type)."""
+        q = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 4))
+        if len(q):
+            _lib.check(self._L.sf_apply_mitigation(self._h, _ptr(q), len(q)))
+
+    def load_fire_map(self, env, fire_map):
+        m = np.asarray(fire_map)
+        if m.shape != (self.H, self.W):
+            raise ValueError(f"fire_map shape {m.shape} != {(self.H, self.W)}")
+        if m.min() < 0 or m.max() > 5:
+            raise ValueError("fire_map holds values outside BurnStatus")
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        _lib.check(self._L.sf_load_fire_map(self._h, int(env), _ptr(m)))
+
+    def step(self, n=1):
+        _lib.check(self._L.sf_step(self._h, int(n)))
+
+    def step_timed(self, n=1):
+        """Returns the GPU milliseconds spent in the n step kernels."""
+        ms = C.c_float(0.0)
+        _lib.check(self._L.sf_step_timed(self._h, int(n), C.byref(ms)))
+        return float(ms.value)
+
+    # ------------------------------------------------------------------------ outputs
+    def fire_map(self, env=0):
+        out = np.empty((self.H, self.W), dtype=np.uint8)
+        _lib.check(self._L.sf_get_fire_map(self._h, int(env), _ptr(out)))
+        return out
+
+    def fire_maps(self):
+        out = np.empty((self.n_envs, self.H, self.W), dtype=np.uint8)
+        _lib.check(self._L.sf_get_fire_maps(self._h, _ptr(out)))
+        return out
+
+    def burn(self, env=0):
+        out = np.empty((self.H, self.W), dtype=np.float64)
+        _lib.check(self._L.sf_get_burn(self._h, int(env), _ptr(out)))
+        return out
+
+    def set_burn(self, env, burn):
+        b = np.ascontiguousarray(burn, dtype=np.float64)
+        if b.shape != (self.H, self.W):
+            raise ValueError(f"burn shape {b.shape} != {(self.H, self.W)}")
+        _lib.check(self._L.sf_set_burn(self._h, int(env), _ptr(b)))
+
+    def status(self):
+        """(int32 [E, 8]: running, steps, counts of BurnStatus 0..5; float64 [E] elapsed_time)"""
+        st = np.zeros((self.n_envs, 8), dtype=np.int32)
+        el = np.zeros(self.n_envs, dtype=np.float64)
+        _lib.check(self._L.sf_get_status(self._h, _ptr(st), _ptr(el)))
+        return st, el
+
+    def memory_bytes(self):
+        v = C.c_int64(0)
+        _lib.check(self._L.sf_memory_bytes(self._h, C.byref(v)))
+        return int(v.value)
+
+    def set_rows_per_band(self, rows):
+        _lib.check(self._L.sf_set_rows_per_band(self._h, int(rows)))
+
+    def status_device_ptr(self):
+        """Device address of the int32 [E, 8] result block (after ``update_status_device``)."""
+        p = C.c_void_p()
+        _lib.check(self._L.sf_status_device(self._h, C.byref(p)))
+        return p.value
+
+    def update_status_device(self):
+        _lib.check(self._L.sf_update_status_device(self._h))
+
+
+def compute_ros(arrays, device=0):
+    """17 float32 vectors -> R float64 through ``sf_compute_ros``."""
+    L = _lib.load()
+    arrs = [np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1)) for a in arrays]
+    if len(arrs) != 17:
+        raise ValueError("compute_rate_of_spread takes 17 arrays")
+    n = arrs[0].shape[0]
+    for a in arrs:
+        if a.shape[0] != n:
+            raise ValueError("all inputs must have the same length")
+    out = np.zeros(n, dtype=np.float64)
+    _lib.check(L.sf_compute_ros(n, *[_ptr(a) for a in arrs], _ptr(out), int(device)))
+    return out

@@ -1,0 +1,291 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden
+vectors generated from the real reference.  Run with ``pytest -m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+
+import _golden
+from oracle import fire_dense, fire_sprites, rothermel_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(d, n_envs=1, **over):
+    from simfire_amd.engine import FireEngine
+    kw = _golden.engine_kwargs(d)
+    kw.update(over)
+    return FireEngine(n_envs=n_envs, M_f=float(d["M_f"]), **kw)
+
+
+def _set_layers(eng, d):
+    eng.set_layers(d["w_0"], d["delta"], d["M_x"], d["sigma"], d["elevation"], d["U"], d["U_dir"])
+
+
+def _inputs(d):
+    order = ["loc_x", "loc_y", "new_loc_x", "new_loc_y", "w_0", "delta", "M_x", "sigma", "h", "S_T",
+             "S_e", "p_p", "M_f", "U", "U_dir", "slope_mag", "slope_dir"]
+    return [d["in_" + k] for k in order]
+
+
+# ------------------------------------------------------------------ rate of spread
+def test_ros_known_answer():
+    """simfire/world/_tests/test_rothermel.py:10-100: published constants to 2 places."""
+    from simfire_amd.rothermel import compute_rate_of_spread
+    d = _golden.load("rothermel_known.npz")
+    R = compute_rate_of_spread(*_inputs(d))
+    assert R.dtype == np.float64 and R.shape == (8,)
+    for r, k in zip(R.tolist(), d["R_published"].tolist()):
+        assert round(abs(r - k), 2) == 0          # assertAlmostEqual(places=2)
+    assert np.allclose(R, d["R"], rtol=1e-6, atol=0)
+
+
+def test_ros_grid_vs_reference():
+    """rate-of-spread floats within 1e-5 relative of the reference (north_star tolerance);
+    relative to Rscale = R0 * (1 + phi_w + |phi_s|), see tests/test_oracle_golden.py."""
+    from simfire_amd.rothermel import compute_rate_of_spread
+    d = _golden.load("rothermel_grid.npz")
+    R = compute_rate_of_spread(*_inputs(d))
+    err = np.abs(R - d["R"])
+    assert (err <= 1e-5 * d["Rscale"]).all(), float((err / np.maximum(d["Rscale"], 1e-300)).max())
+    assert (R[d["in_w_0"] <= 0] == 0).all() and (R >= 0).all()
+    # and against the libm oracle: mostly the very same bits
+    Ro = fire_dense.compute_ros(*_inputs(d))
+    assert (np.abs(R - Ro) <= 1e-5 * d["Rscale"]).all()
+
+
+def test_ros_empty_and_ragged():
+    from simfire_amd.rothermel import compute_rate_of_spread
+    e = np.zeros(0, np.float32)
+    assert compute_rate_of_spread(*([e] * 17)).shape == (0,)
+    with pytest.raises(ValueError):
+        compute_rate_of_spread(*([np.zeros(3, np.float32)] * 16 + [np.zeros(2, np.float32)]))
+
+
+@pytest.mark.parametrize("name", ["g2_mixed_a1d1", "g4_lines_on_burning"])
+def test_rtable_and_slopes(name):
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    _set_layers(eng, d)
+    mag, dr = eng.get_slopes()
+    assert np.allclose(mag, d["slope_mag"], rtol=1e-13, atol=0)
+    assert np.allclose(dr, d["slope_dir"], rtol=1e-12, atol=1e-15)
+    T = eng.get_rtable()
+    ref = d["rtable"]
+    scale = np.maximum(ref.max(axis=0, keepdims=True), 1e-30)
+    assert (np.abs(T - ref) <= 1e-5 * scale).all()
+    # direction order / layout: same as the oracle's table, entry by entry
+    o = fire_dense.DenseOracle(**_golden.engine_kwargs(d))
+    o.build_rtable(d["w_0"], d["delta"], d["M_x"], d["sigma"], d["elevation"], d["U"], d["U_dir"], float(d["M_f"]))
+    To = o.get_rtable()
+    assert (np.abs(T - To) <= 1e-5 * scale).all()
+    assert (T == To).mean() > 0.5      # double-evaluated device chain ~ correctly rounded ~ glibc
+
+
+def test_rtable_roundtrip():
+    d = _golden.load_traj("g2_mixed_a1d1")
+    eng = _engine(d)
+    eng.set_rtable(d["rtable"])
+    assert (eng.get_rtable() == d["rtable"]).all()
+
+
+# ------------------------------------------------------------------- trajectories
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_traj_logic_parity(name):
+    """Reference R table in: fire_map, status, elapsed_time and burn_amounts bit-exact."""
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d)
+    assert (eng.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_traj_own_table(name):
+    """Device-built R table: fire_map bit-identical to the reference (tie margin >= 1e-4)."""
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    _set_layers(eng, d)
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d)
+    assert (np.abs(eng.burn(0) - d["burn"]) <= 1e-5 * (np.abs(d["burn"]) + 1e3)).all()
+
+
+@pytest.mark.parametrize("name", ["g3_lines_a1", "g4_lines_on_burning", "g7_early_return"])
+@pytest.mark.parametrize("rows", [1, 3, 16])
+def test_traj_band_geometry(name, rows):
+    """The result must not depend on the launch geometry (rows per band)."""
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    eng.set_rows_per_band(rows)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d, check_each_step=False)
+    assert (eng.burn(0) == d["burn"]).all()
+
+
+def test_traj_multi_step_launch():
+    """sf_step(n) == n x sf_step(1) (the flag ring / state fold across launches)."""
+    d = _golden.load_traj("g2_mixed_a1d1")
+    n = len(d["status"])
+    eng = _engine(d)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    eng.step(n + 7)                       # runs past QUIT: frozen afterwards
+    assert (eng.fire_map(0) == d["fire_maps"][-1]).all()
+    st, el = eng.status()
+    assert st[0, 0] == 0 and st[0, 1] == n and el[0] == d["elapsed"][-1]
+    assert (eng.burn(0) == d["burn"]).all()
+    counts = np.bincount(d["fire_maps"][-1].ravel(), minlength=6)
+    assert (st[0, 2:8] == counts).all()
+
+
+def test_batched_envs_independent():
+    """Different ignitions per environment; each must equal its own single-env oracle run."""
+    d = _golden.load_traj("g2_mixed_a1d1")
+    H, W = (int(v) for v in d["shape"])
+    rng = np.random.default_rng(7)
+    E = 5
+    xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
+    eng = _engine(d, n_envs=E)
+    eng.set_rtable(d["rtable"])
+    eng.reset(xy)
+    o = fire_dense.DenseOracle(n_envs=E, **_golden.engine_kwargs(d))
+    o.set_rtable(d["rtable"])
+    o.reset(xy)
+    for t in range(30):
+        pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+               for _ in range(4)]
+        eng.apply_mitigation(pts)
+        o.apply_mitigation(pts)
+        eng.step(1)
+        o.step(1)
+    maps = eng.fire_maps()
+    for e in range(E):
+        assert (maps[e] == o.fire_map(e)).all(), e
+        assert (eng.burn(e) == o.burn(e)).all(), e
+    st, el = eng.status()
+    so, eo = o.status()
+    assert (st == so).all() and (el == eo).all()
+    # per-env reset does not disturb the others
+    eng.reset_env(2, 3, 4)
+    o_map = o.fire_map(1)
+    assert (eng.fire_map(1) == o_map).all()
+    m2 = eng.fire_map(2)
+    assert m2[4, 3] == 1 and m2.sum() == 1
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_worlds_vs_oracles(seed):
+    """Randomised small worlds (coarse R tables with exact ties, lines on burning cells, runtime
+    cut-offs, 4/8 connectivity, odd sizes): HIP == dense C oracle == literal sprite list."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(5000 + seed)
+    H, W = int(rng.integers(5, 70)), int(rng.integers(5, 70))
+    md = int(rng.integers(1, 6))
+    att, diag = bool(rng.integers(2)), bool(rng.integers(2))
+    ps = float(rng.choice([5.0, 20.0, 50.0]))
+    R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.1] = 0.0
+    init = (int(rng.integers(W)), int(rng.integers(H)))
+    kw = dict(shape=(H, W), max_fire_duration=md, pixel_scale=ps, update_rate=float(rng.choice([1.0, 0.5, 1.5])),
+              max_time=(None if rng.random() < 0.6 else float(rng.integers(5, 30))),
+              attenuate_line_ros=att, diagonal_spread=diag)
+    eng = FireEngine(**kw)
+    eng.set_rows_per_band(int(rng.integers(1, 9)))
+    eng.set_rtable(R8)
+    eng.reset([init])
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(R8)
+    o.reset([init])
+    small = H * W <= 900
+    if small:
+        s = fire_sprites.SpriteFire((H, W), init, md, ps, kw["update_rate"], rtable=R8, max_time=kw["max_time"],
+                                    attenuate_line_ros=att, diagonal_spread=diag)
+        fm = np.zeros((H, W), dtype=np.int64)
+        fm[init[1], init[0]] = 1
+        running = True
+    for t in range(70):
+        if rng.random() < 0.4:
+            pts = [(int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(int(rng.integers(1, 8)))]
+            cur = o.fire_map(0)
+            burning = np.argwhere(cur == 1)
+            if len(burning) and rng.random() < 0.7:
+                y, x = burning[rng.integers(len(burning))]
+                pts.append((int(x), int(y), int(rng.integers(3, 6))))
+                pts.append((int(x), int(y), int(rng.integers(3, 6))))      # duplicate, maybe other type
+            q = [(0, x, y, ty) for (x, y, ty) in pts]
+            eng.apply_mitigation(q)
+            o.apply_mitigation(q)
+            if small:
+                fire_sprites.apply_mitigation(fm, pts)
+        if rng.random() < 0.05:
+            # load_mitigation (simulation.py:425-447): wholesale replacement, sprites persist
+            new = o.fire_map(0).copy()
+            new[rng.random((H, W)) < 0.05] = 0
+            eng.load_fire_map(0, new)
+            o.load_fire_map(0, new)
+            if small:
+                fm = new.astype(np.int64)
+        eng.step(1)
+        o.step(1)
+        assert (eng.fire_map(0) == o.fire_map(0)).all(), (seed, t)
+        assert (eng.burn(0) == o.burn(0)).all(), (seed, t)
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), (seed, t)
+        if small:
+            if running:
+                fm, stt = s.update(fm)
+                running = stt == fire_sprites.RUNNING
+            assert (o.fire_map(0) == fm).all() and (o.burn(0) == s.burn).all(), (seed, t)
+
+
+def test_reference_unit_scenarios():
+    """simfire/game/managers/_tests/test_fire.py:326-396: pixel_scale = 0 and burn = -1 on the
+    (transposed, sic) neighbour cells -> all 8 neighbours ignite in one update."""
+    d = _golden.load("fire_manager_tests.npz")
+    from simfire_amd.engine import FireEngine
+    from simfire_amd.parameters import Chaparral
+    H = W = 9
+    full = lambda v: np.full((H, W), v)
+    # the test builds the manager with pixel_scale 50 (slopes!) and only then sets it to 0
+    tab = FireEngine((H, W), max_fire_duration=4, pixel_scale=50.0, update_rate=1.0, max_time=1440)
+    tab.set_layers(full(Chaparral.w_0), full(Chaparral.delta), full(Chaparral.M_x), full(Chaparral.sigma),
+                   np.zeros((H, W)), full(7 * 88.0), full(90.0))
+    eng = FireEngine((H, W), max_fire_duration=4, pixel_scale=0.0, update_rate=1.0, max_time=1440)
+    eng.set_rtable(tab.get_rtable())
+    eng.reset([(4, 4)])
+    burn = np.zeros((H, W))
+    for (x, y) in [(5, 4), (5, 5), (4, 5), (3, 5), (3, 4), (3, 3), (4, 3), (5, 3)]:
+        burn[x, y] = -1
+    eng.set_burn(0, burn)
+    eng.load_fire_map(0, np.zeros((H, W), dtype=np.uint8))   # test passes an all-UNBURNED map
+    eng.step(1)
+    assert (eng.fire_map(0) == d["update_fire_map"]).all()
+    st, _ = eng.status()
+    assert st[0, 0] == int(d["update_running"])
+    assert np.allclose(eng.burn(0), d["update_burn"], rtol=1e-5)
+
+
+def test_errors():
+    from simfire_amd.engine import FireEngine
+    with pytest.raises(ValueError):
+        FireEngine((0, 5))
+    with pytest.raises(NotImplementedError):
+        FireEngine((8, 8), max_fire_duration=9)
+    eng = FireEngine((8, 8))
+    with pytest.raises(RuntimeError):
+        eng.step(1)                                   # no layers yet
+    with pytest.raises(ValueError):
+        eng.set_layers(*([np.zeros((9, 9))] * 7))     # fire.py:406-428 shape check
+    eng.set_rtable(np.zeros((8, 8, 8)))
+    with pytest.raises(ValueError):
+        eng.reset([(8, 0)])
+    eng.reset([(1, 1)])
+    with pytest.raises(ValueError):
+        eng.apply_mitigation([(0, 9, 0, 3)])
+    with pytest.raises(ValueError):
+        eng.load_fire_map(0, np.full((8, 8), 6))
+    eng.apply_mitigation([(0, 2, 2, 7)])              # unknown type: skipped (simulation.py:469-473)
+    assert eng.fire_map(0)[2, 2] == 0
