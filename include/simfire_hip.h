@@ -140,6 +140,9 @@ int sf_fire_map_device(sf_sim *sim, void **ptr, int64_t *row_pitch, int64_t *env
  * sf_get_status) - the block that is all-gathered over RCCL by the multi-GPU host code. */
 int sf_status_device(sf_sim *sim, void **ptr);
 int sf_update_status_device(sf_sim *sim);
+/* Refresh the result block and copy it (device to device) into caller-owned device memory,
+ * e.g. the torch tensor that is then all-gathered over RCCL. */
+int sf_copy_status_to(sf_sim *sim, void *device_dst /* int32 [n_envs][8] */);
 
 /* Drop-in for compute_rate_of_spread (rothermel.py:4-22): 17 float32 vectors of length n ->
  * R float64[n] (ft/min). */
@@ -149,7 +152,11 @@ int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const floa
                    const float *p_p, const float *M_f, const float *U, const float *U_dir,
                    const float *slope_mag, const float *slope_dir, double *R_out, int32_t device);
 
-/* Introspection for benchmarks: bytes of device memory held, and the launch geometry. */
+/* Introspection for benchmarks: out[0] = active cell-updates (cells whose burn_amounts were
+ * read+written: candidates and attenuated line cells), out[1] = ignitions, out[2] = cells handed
+ * to the frontier phase, out[3] = 0; summed over all steps since the last reset of the counters. */
+int sf_get_counters(sf_sim *sim, int64_t *out /* [4] */, int32_t reset);
+/* bytes of device memory held, and the launch geometry. */
 int sf_memory_bytes(sf_sim *sim, int64_t *bytes);
 int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step kernel */
 

@@ -109,6 +109,7 @@ struct StepArgs {
     EnvState *commit;    // [E]   state between API calls
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
     uint32_t *flags;     // [3][E] ring
+    unsigned long long *counters;   // [4] active cell-updates, ignitions, frontier items, spare
     int launch;          // index of this launch inside one sf_step call
 };
 
@@ -187,7 +188,8 @@ __constant__ int c_dy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
 
 // One cell of the compacted frontier.  item = idx | status << 26 | settled << 29 | expired << 30
 __device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, const Masks &mk,
-                                             const EnvState &st, int e, bool spread, bool &cand_seen)
+                                             const EnvState &st, int e, bool spread, bool &cand_seen,
+                                             uint32_t &n_active, uint32_t &n_ignite)
 {
     const Geo &g = a.g;
     const uint32_t idx = item & 0x03FFFFFFu;
@@ -226,6 +228,7 @@ __device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, c
     if (!(is_cand || pending)) return;
 
     const long long cell = (long long)e * g.plane_env + idx;
+    n_active++;
     double bn = a.burn[cell];
     if (pending) bn = bn - line_factor(s_pre);                      // fire.py:278 with ros = 0
     if (is_cand) {
@@ -235,6 +238,7 @@ __device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, c
             ros = g.att ? ros - line_factor(s_post) : 0.0;
         bn = bn + ros;                                                           // fire.py:710
         if (bn > g.pixel_scale) {                                                // fire.py:568
+            n_ignite++;
             a.status[cell] = (uint8_t)SF_BURNING;                                // fire.py:587
             const uint32_t own = ap[0] & ~mk.b_clr;      // phase 1 may have cleared b_clr already
             ap[0] = (uint8_t)(own | mk.b_new);                                   // fire.py:571-579
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
 
     if (lane == 0) s_cnt[wave] = 0;
     uint4 up = load_age(y0 - 1), mid = load_age(y0), dn = load_age(y0 + 1);
-    uint32_t live_acc = 0;
+    uint32_t live_acc = 0, n_active = 0, n_ignite = 0, n_items_acc = 0;
     bool cand_seen = false;
 
     for (int i = 0; i < g.RB; ++i) {
@@ -381,7 +385,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
             // phase-1 stores of this wave must land before the byte stores below
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (uint32_t j = lane; j < n_items; j += 64)
-                process_cell(s_list[wave][j], a, mk, st, e, spread, cand_seen);
+                process_cell(s_list[wave][j], a, mk, st, e, spread, cand_seen, n_active, n_ignite);
+            n_items_acc += (lane == 0) ? n_items : 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) s_cnt[wave] = 0;
@@ -399,6 +404,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
         const uint32_t want = (w_live ? FLAG_LIVE : 0u) | (w_cand ? FLAG_CAND : 0u);
         const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((have & want) != want) atomicOr(f, want);
+    }
+    // statistics for the roofline accounting (active cell-updates = phi * cells)
+    if (__ballot(n_active != 0) != 0ull) {
+        for (int off = 32; off > 0; off >>= 1) {
+            n_active += __shfl_down(n_active, off);
+            n_ignite += __shfl_down(n_ignite, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)n_active);
+            if (n_ignite) atomicAdd(&a.counters[1], (unsigned long long)n_ignite);
+            atomicAdd(&a.counters[2], (unsigned long long)n_items_acc);
+        }
     }
 }
 
@@ -653,6 +670,7 @@ struct sf_sim {
     double *smag = nullptr, *sdir = nullptr;
     EnvState *commit = nullptr, *tmp = nullptr;
     uint32_t *flags = nullptr;
+    unsigned long long *counters = nullptr;
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -739,10 +757,12 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->commit, (size_t)g.E));
     TRY(dev_alloc(s, &s->tmp, (size_t)2 * g.E));
     TRY(dev_alloc(s, &s->flags, (size_t)3 * g.E));
+    TRY(dev_alloc(s, &s->counters, (size_t)4));
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
 #undef TRY
     HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
+    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * 4, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->age_alloc, 0, (size_t)g.E * g.age_env + 2 * (size_t)g.P, s->stream));
     HIPCHK(hipMemsetAsync(s->status, 0, cells, s->stream));
@@ -758,7 +778,7 @@ extern "C" int sf_destroy(sf_sim *s)
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
-                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags,
+                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters,
                     s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->seg_dev};
     for (void *p : ptrs) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -969,7 +989,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     HIPCHK(hipSetDevice(s->p.device));
     StepArgs a;
     a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
-    a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags;
+    a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters;
     const dim3 grid((unsigned)(s->g.tiles_per_env * s->g.E)), block(kWaves * 64);
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int i = 0; i < n_steps; ++i) {
@@ -1087,6 +1107,26 @@ extern "C" int sf_get_status(sf_sim *s, int32_t *status, double *elapsed)
     if (rc) return rc;
     HIPCHK(hipMemcpy(status, s->status_block, sizeof(int32_t) * 8 * s->g.E, hipMemcpyDeviceToHost));
     if (elapsed) HIPCHK(hipMemcpy(elapsed, s->elapsed_dev, sizeof(double) * s->g.E, hipMemcpyDeviceToHost));
+    return SF_OK;
+}
+
+extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_counters: null argument");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(out, s->counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(s->counters, 0, sizeof(int64_t) * 4));
+    return SF_OK;
+}
+
+extern "C" int sf_copy_status_to(sf_sim *s, void *device_dst)
+{
+    if (!s || !device_dst) return fail(SF_EINVAL, "sf_copy_status_to: null argument");
+    int rc = sf_update_status_device(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(device_dst, s->status_block, sizeof(int32_t) * 8 * s->g.E, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
 

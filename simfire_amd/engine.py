@@ -160,6 +160,17 @@ class FireEngine:
         _lib.check(self._L.sf_status_device(self._h, C.byref(p)))
         return p.value
 
+    def copy_status_to(self, device_ptr):
+        """Refresh the result block and copy it into device memory at ``device_ptr``
+        (int32 [n_envs, 8]), e.g. ``tensor.data_ptr()`` of a torch tensor on the same GPU."""
+        _lib.check(self._L.sf_copy_status_to(self._h, C.c_void_p(int(device_ptr))))
+
+    def counters(self, reset=False):
+        """dict(active_cell_updates, ignitions, frontier_items) summed since the last reset."""
+        out = np.zeros(4, dtype=np.int64)
+        _lib.check(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
+        return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]))
+
     def update_status_device(self):
         _lib.check(self._L.sf_update_status_device(self._h))
 

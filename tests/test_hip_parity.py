@@ -289,3 +289,108 @@ def test_errors():
         eng.load_fire_map(0, np.full((8, 8), 6))
     eng.apply_mitigation([(0, 2, 2, 7)])              # unknown type: skipped (simulation.py:469-473)
     assert eng.fire_map(0)[2, 2] == 0
+
+
+# ------------------------------------------------------------- BASELINE-size cases
+def _workload_pair(w, steps, check_every, agent_pts=None, threads=8):
+    from simfire_amd.engine import FireEngine
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    T = eng.get_rtable()
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.set_rtable(T)                       # common table: step parity must then be bit-exact
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    done = 0
+    while done < steps:
+        k = min(check_every, steps - done)
+        if agent_pts is None:
+            eng.step(k)
+            o.step(k, threads)
+        else:
+            for s in range(k):
+                eng.apply_mitigation(agent_pts[done + s])
+                o.apply_mitigation(agent_pts[done + s])
+                eng.step(1)
+                o.step(1, threads)
+        done += k
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), done
+    maps = eng.fire_maps()
+    for e in range(w.n_envs):
+        assert (maps[e] == o.fire_map(e)).all(), e
+    for e in range(min(w.n_envs, 3)):
+        assert (eng.burn(e) == o.burn(e)).all(), e
+    return eng, o
+
+
+def test_c2_full_size_vs_oracle():
+    """BASELINE C2: 1024x1024, 1 env, 400 steps; counts checked every 50 steps, maps at the end."""
+    from simfire_amd import workloads
+    w = workloads.c2(1024, 1)
+    eng, o = _workload_pair(w, 400, 50)
+    st, _ = eng.status()
+    assert st[0, 4] > 10000            # the fire really spread
+
+
+def test_c2_table_vs_oracle_table():
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c2(1024, 1)
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    T = eng.get_rtable()
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.build_rtable(w.w_0, w.delta, w.M_x, w.sigma, w.elevation, w.U, w.U_dir, w.M_f)
+    To = o.get_rtable()
+    scale = np.maximum(To.max(axis=0, keepdims=True), 1e-30)
+    assert (np.abs(T - To) <= 1e-5 * scale).all()
+    assert (T[:, w.extra["codes"] == 98] == 0).all()         # water never receives fire
+    assert (T == To).mean() > 0.9
+
+
+def test_c3_batched_vs_oracle():
+    """C3 shape at reduced batch: 1024x1024 x 12 envs, random ignitions, 250 steps."""
+    from simfire_amd import workloads
+    w = workloads.c3(1024, 12)
+    _workload_pair(w, 250, 125)
+
+
+def test_c4_wide_grid_seam():
+    """2048-wide rows use two 1024-cell chunks per row: exercises the chunk seam path."""
+    from simfire_amd import workloads
+    w = workloads.c3(2048, 2)
+    w.init_xy[0] = (1023, 700)          # right at the seam
+    w.init_xy[1] = (1024, 1500)
+    _workload_pair(w, 150, 75)
+
+
+def test_c5_agents_vs_oracle():
+    """C5 shape at reduced batch: 512x512 x 6 envs, 64 agents per env writing one line cell per
+    step, attenuation on (lines land on burning cells too)."""
+    from simfire_amd import workloads
+    w = workloads.c5(512, 6, 64)
+    pts = workloads.agent_walk(6, 64, 512, 512, 160)
+    _workload_pair(w, 160, 40, agent_pts=pts)
+
+
+def test_idempotent_after_quit_and_checksum():
+    """Size-independent properties at C1 size: running past QUIT changes nothing; final map is
+    the reference's (sha256 of tests/golden/sim_c1_128.npz)."""
+    import hashlib
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    d = _golden.load("sim_c1_128.npz")
+    w = workloads.c1(128)
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    eng.reset(w.init_xy)
+    eng.step(int(d["steps"]))
+    st, el = eng.status()
+    assert st[0, 0] == 0 and st[0, 1] == int(d["steps"]) and el[0] == float(d["elapsed_time"])
+    m = eng.fire_map(0)
+    assert hashlib.sha256(m.astype(np.int8).tobytes()).hexdigest() == str(d["sha256"])
+    eng.step(10)
+    st2, el2 = eng.status()
+    assert (st2 == st).all() and el2[0] == el[0] and (eng.fire_map(0) == m).all()
