@@ -149,7 +149,6 @@ def main():
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else result
 
     timed_steps(eng, w, a.warmup, 0, agent_pts) if a.warmup else None
-    eng.counters(reset=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -170,7 +169,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # phi (fraction of cells whose burn_amounts were touched) from an untimed replay of the same
+    # deterministic rollout with the statistics atomics switched on
+    eng.reset(w.init_xy)
+    timed_steps(eng, w, a.warmup, 0, agent_pts) if a.warmup else None
+    eng.enable_counters(True)
+    eng.counters(reset=True)
+    timed_steps(eng, w, a.steps, a.warmup, agent_pts)
     cnt = eng.counters()
+    eng.enable_counters(False)
     cells_launch = H * W * w.n_envs
     phi = cnt["active_cell_updates"] / float(cells_launch * a.steps)
     alg_bytes = cells_launch * (4.0 + 24.0 * phi)
@@ -198,7 +205,10 @@ def main():
                        "agents_per_env": w.agents_per_env,
                        "envs_running_at_end": int(res[:, 0].sum()),
                        "burned_cells_total": int(res[:, 4].sum()),
-                       "active_fraction_phi": phi},
+                       "active_fraction_phi": phi,
+                       "active_waves_per_step": cnt["active_waves"] / a.steps,
+                       "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
+                       "frontier_items_per_step": cnt["frontier_items"] / a.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "launch_ms": launch_ms,

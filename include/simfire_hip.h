@@ -154,8 +154,12 @@ int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const floa
 
 /* Introspection for benchmarks: out[0] = active cell-updates (cells whose burn_amounts were
  * read+written: candidates and attenuated line cells), out[1] = ignitions, out[2] = cells handed
- * to the frontier phase, out[3] = 0; summed over all steps since the last reset of the counters. */
-int sf_get_counters(sf_sim *sim, int64_t *out /* [4] */, int32_t reset);
+ * to the frontier phase, out[3] = wavefronts that survived the quick reject, out[4] = frontier
+ * walks (row iterations with a non-empty work list), out[5..7] = 0; summed over all steps since the
+ * last reset of the counters. */
+int sf_get_counters(sf_sim *sim, int64_t *out /* [8] */, int32_t reset);
+/* The statistics cost a few atomics per active wavefront, so they are off by default. */
+int sf_enable_counters(sf_sim *sim, int32_t on);
 /* bytes of device memory held, and the launch geometry. */
 int sf_memory_bytes(sf_sim *sim, int64_t *bytes);
 int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step kernel */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "sf_update_status_device": [_VP],
     "sf_copy_status_to": [_VP, _VP],
     "sf_get_counters": [_VP, _VP, _I32],
+    "sf_enable_counters": [_VP, _I32],
     "sf_compute_ros": [_I64] + [_VP] * 18 + [_I32],
     "sf_memory_bytes": [_VP, C.POINTER(_I64)],
     "sf_set_rows_per_band": [_VP, _I32],

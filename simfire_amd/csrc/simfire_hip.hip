@@ -44,6 +44,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -77,7 +78,8 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 namespace {
 
 constexpr int kWaves = 4;          // waves per workgroup (256 threads)
-constexpr int kListCap = 1024;     // cells one wave scans per row iteration = 64 lanes x 16
+constexpr int kListCap = 2048;     // per-wave frontier list; one row iteration adds at most 64 x 16 cells
+constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
 constexpr uint32_t FLAG_CAND = 2u; // some sprite has a cell to spread into     (fire.py:651)
 
@@ -109,8 +111,9 @@ struct StepArgs {
     EnvState *commit;    // [E]   state between API calls
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
     uint32_t *flags;     // [3][E] ring
-    unsigned long long *counters;   // [4] active cell-updates, ignitions, frontier items, spare
+    unsigned long long *counters;   // [kCounterShards][8]: active cell-updates, ignitions, frontier items; null = off
     int launch;          // index of this launch inside one sf_step call
+    int debug;           // SF_DEBUG_CUT: bisect kernel cost (0 = normal)
 };
 
 struct Masks {
@@ -132,16 +135,20 @@ __host__ __device__ inline int slot_of(int s, int N)
 //   set at step t (new ignition, fire.py:571-587):     s = t
 __host__ __device__ inline Masks make_masks(int t, int md, int N)
 {
+    // N = md + 3, so relative to s0 = slot(t):  t-md-2 -> s0+1,  t-md-1 -> s0+2,  t-md -> s0+3
+    // (all mod N): one modulo, the rest are wrap-around adds and a rotate of a block of md ones.
     Masks m;
     m.N = N;
-    m.b_new = 1u << slot_of(t, N);
-    m.b_exp = 1u << slot_of(t - md - 1, N);
-    m.b_clr = 1u << slot_of(t - md - 2, N);
-    m.m_live = 0;
-    m.m_prev = 0;
-    for (int s = t - md; s <= t - 1; ++s) m.m_live |= 1u << slot_of(s, N);
-    for (int s = t - 1 - md; s <= t - 2; ++s) m.m_prev |= 1u << slot_of(s, N);
-    m.rot = (N - 1) - slot_of(t - 1, N); // rotate left so that step t-1 lands on bit N-1
+    const int s0 = slot_of(t, N);
+    auto wrap = [N](int v) { return v >= N ? v - N : v; };
+    auto rotl = [N](uint32_t v, int k) { return ((v << k) | (v >> (N - k))) & ((1u << N) - 1u); };
+    const uint32_t ones = (1u << md) - 1u;
+    m.b_new = 1u << s0;
+    m.b_clr = 1u << wrap(s0 + 1);
+    m.b_exp = 1u << wrap(s0 + 2);
+    m.m_live = rotl(ones, wrap(s0 + 3));
+    m.m_prev = rotl(ones, wrap(s0 + 2));
+    m.rot = (N - 1) - wrap(s0 + N - 1);   // rotate left so that step t-1 lands on bit N-1
     return m;
 }
 
@@ -201,6 +208,8 @@ __device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, c
     if (x >= g.W) return;                                           // pitch padding
     uint8_t *ap = a.age + (long long)e * g.age_env + (long long)y * g.P + x;
 
+    const long long cell = (long long)e * g.plane_env + idx;
+    double bn = a.burn[cell];     // requested up front: overlaps with the neighbour loads
     // neighbour sprites (fire.py:163-234 seen from the destination cell)
     int best = -1, bestk = 0;
     bool prev_any = false;
@@ -227,9 +236,7 @@ __device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, c
     const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && st.prev_flag && !prev_any;
     if (!(is_cand || pending)) return;
 
-    const long long cell = (long long)e * g.plane_env + idx;
     n_active++;
-    double bn = a.burn[cell];
     if (pending) bn = bn - line_factor(s_pre);                      // fire.py:278 with ros = 0
     if (is_cand) {
         cand_seen = true;
@@ -247,15 +254,74 @@ __device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, c
     a.burn[cell] = bn;
 }
 
+// Workgroup -> tile mapping.  The dispatcher places workgroup b on XCD b % 8 (observed, used for
+// speed only): renumber so that every XCD walks a contiguous range of tiles, i.e. whole
+// environments, and the halo rows shared by vertically adjacent tiles hit in that XCD's L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+{
+    const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
+    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// value of lane-1 / lane+1 inside groups of LC lanes; lanes at a group edge get 0
+template <bool FULL>
+__device__ __forceinline__ uint32_t from_left(uint32_t v, int c, int LC)
+{
+    if (FULL) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const uint32_t t = __shfl_up(v, 1, LC);
+    return c == 0 ? 0u : t;
+}
+template <bool FULL>
+__device__ __forceinline__ uint32_t from_right(uint32_t v, int c, int LC)
+{
+    if (FULL) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    const uint32_t t = __shfl_down(v, 1, LC);
+    return c == LC - 1 ? 0u : t;
+}
+
+// One step of every environment.  RB = rows per lane band (compile time: the RB + 2 window rows
+// live in registers and are all requested before anything is computed), FULL = a row chunk is
+// a whole wave (64 lanes x 16 cells; horizontal neighbours by DPP instead of ds_bpermute).
+template <int RB, bool FULL>
 __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
 {
     __shared__ uint32_t s_list[kWaves][kListCap];
     __shared__ uint32_t s_cnt[kWaves];
     const Geo &g = a.g;
-    const int e = blockIdx.x / g.tiles_per_env;
-    const int tile = blockIdx.x - e * g.tiles_per_env;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int e = bid / (uint32_t)g.tiles_per_env;
+    const int tile = bid - e * g.tiles_per_env;
 
-    // environment state entering this step (folded from the previous launch's flags)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = tile % g.chunks_x, ty = tile / g.chunks_x;
+    const int LC = FULL ? 64 : g.LC;
+    const int c = FULL ? lane : (lane & (g.LC - 1)), r = FULL ? 0 : (lane >> g.logLC);
+    const int cv = chunk * LC + c;
+    const bool col_ok = cv < g.PV;
+    const int y0 = ((ty * kWaves + wave) * (FULL ? 1 : g.LR) + r) * RB;
+
+    uint8_t *age_e = a.age + (long long)e * g.age_env;
+    uint8_t *st_e = a.status + (long long)e * g.plane_env;
+
+    // ---- request the whole register window: rows y0-1 .. y0+RB (zero guard rows at -1 and H)
+    uint4 rows[RB + 2];
+    const uint32_t voff0 = (uint32_t)((y0 - 1) * g.P + cv * 16);   // may wrap for y0 = 0: used as signed
+    const uint8_t *win = age_e + (int)voff0;
+#pragma unroll
+    for (int k = 0; k < RB + 2; ++k) {
+        rows[k] = make_uint4(0, 0, 0, 0);
+        if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
+    }
+    if (a.debug == 1) {
+        uint32_t h = 0;
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) h |= any4(rows[k]);
+        if (h == 0x12345u) a.flags[0] = h;
+        return;
+    }
+    // environment state entering this step (folded from the previous launch's flags); the
+    // scalar loads below overlap with the window loads already in flight
     EnvState st;
     if (a.launch == 0) st = a.commit[e];
     else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
@@ -264,6 +330,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
         a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
     }
     if (!st.running) return;
+    if (a.debug == 2) {
+        uint32_t h = 0;
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) h |= any4(rows[k]);
+        if (h == 0x12345u) a.flags[0] = h;
+        return;
+    }
 
     const int t = st.steps + 1;
     const Masks mk = make_masks(t, g.md, g.N);
@@ -271,31 +344,59 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
     const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
     const int exp_sh = __ffs(mk.b_exp) - 1;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = tile % g.chunks_x, ty = tile / g.chunks_x;
-    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
-    const int cv = chunk * g.LC + c;
-    const bool col_ok = cv < g.PV;
-    const int y0 = ((ty * kWaves + wave) * g.LR + r) * g.RB;
+    // chunk seams (rows wider than one wave, W > 1024): the column just outside the chunk
+    uint32_t seam[RB + 2];
+    const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
+    const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
+    if (g.chunks_x > 1) {
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            uint32_t v = 0;
+            if ((seam_l || seam_r) && y0 - 1 + k <= g.H) v = win[k * g.P + (seam_l ? -1 : 16)];
+            seam[k] = v & mk.m_live;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) seam[k] = 0;
+    }
 
-    uint8_t *age_e = a.age + (long long)e * g.age_env;
-    uint8_t *st_e = a.status + (long long)e * g.plane_env;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_age = [&](int y) -> uint4 {
-        // rows -1 and H are zero guard rows, so no bounds test on y for y in [-1, H]
-        if (col_ok && y <= g.H) return *reinterpret_cast<const uint4 *>(age_e + (long long)y * g.P + cv * 16);
-        return zero4;
-    };
+    // ---- quick reject: nothing alive, expiring or recyclable anywhere near this wave's band
+    uint32_t hot = 0;
+#pragma unroll
+    for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
+    hot &= (L4 | EXP4 | CLR4);
+    if (!g.att && __ballot(hot != 0) == 0ull) return;
+    if (a.debug == 3) return;
 
     if (lane == 0) s_cnt[wave] = 0;
-    uint4 up = load_age(y0 - 1), mid = load_age(y0), dn = load_age(y0 + 1);
-    uint32_t live_acc = 0, n_active = 0, n_ignite = 0, n_items_acc = 0;
+    uint32_t live_acc = 0, n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
+    uint32_t pend_bound = 0;   // wave-uniform upper bound of the list occupancy
     bool cand_seen = false;
 
-    for (int i = 0; i < g.RB; ++i) {
+    // phase 2: the whole wave walks its compacted frontier, one cell per lane
+    auto walk = [&]() {
+        n_phase2++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t n_items = s_cnt[wave];
+        // phase-1 stores of this wave must land before the byte stores below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t j = lane; j < n_items; j += 64)
+            process_cell(s_list[wave][j], a, mk, st, e, spread, cand_seen, n_active, n_ignite);
+        n_items_acc += (lane == 0) ? n_items : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_cnt[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
         const int y = y0 + i;
         const bool row_ok = col_ok && y < g.H;
-        const uint4 nxt = (i + 1 < g.RB) ? load_age(y + 2) : zero4;   // prefetch next window row
+        const uint4 up = rows[i], mid = rows[i + 1], dn = rows[i + 2];
 
         // ---- phase 1: SWAR scan of 16 cells --------------------------------------------
         const uint4 midL = and4(mid, L4);
@@ -303,26 +404,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
         const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
         live_acc |= any4(midL);
         // horizontal neighbours: byte from the lane to the left / right (same band)
-        uint32_t lin = __shfl_up(hsrc.w, 1, g.LC) >> 24;
-        uint32_t rin = __shfl_down(hsrc.x, 1, g.LC) & 0xFFu;
-        if (c == 0) {
-            lin = 0;
-            if (cv > 0 && row_ok) {        // chunk seam (W > 1024): fetch the column from memory
-                const uint8_t *q = age_e + (long long)y * g.P + cv * 16 - 1;
-                uint32_t v = q[0];
-                if (g.diag) v |= (uint32_t)q[-g.P] | (uint32_t)q[g.P];
-                lin = v & mk.m_live;
-            }
-        }
-        if (c == g.LC - 1) {
-            rin = 0;
-            if (cv + 1 < g.PV && row_ok) {
-                const uint8_t *q = age_e + (long long)y * g.P + cv * 16 + 16;
-                uint32_t v = q[0];
-                if (g.diag) v |= (uint32_t)q[-g.P] | (uint32_t)q[g.P];
-                rin = v & mk.m_live;
-            }
-        }
+        uint32_t lin = from_left<FULL>(hsrc.w, c, LC) >> 24;
+        uint32_t rin = from_right<FULL>(hsrc.x, c, LC) & 0xFFu;
+        const uint32_t sv = g.diag ? (seam[i] | seam[i + 1] | seam[i + 2]) : seam[i + 1];
+        if (seam_l) lin = sv;
+        if (seam_r) rin = sv;
         uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
         nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
         nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
@@ -331,16 +417,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
 
         const uint4 ex4 = and4(mid, EXP4);
         const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+        uint32_t m16 = 0;
+        uint4 sraw = make_uint4(0, 0, 0, 0), em = make_uint4(0, 0, 0, 0);
+        const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
         if (row_ok && (any_exp | any_clr | any_nb | (uint32_t)g.att)) {
-            const long long voff = (long long)y * g.P + cv * 16;
             if (any_clr)   // recycle the slot of sprites that were pruned one step ago
                 *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
             if (any_exp | any_nb | (uint32_t)g.att) {
-                const uint4 sraw = *reinterpret_cast<const uint4 *>(st_e + voff);
+                sraw = *reinterpret_cast<const uint4 *>(st_e + voff);
                 const uint4 s7 = and4(sraw, 0x07070707u);
                 // S1 prune: cells whose sprite reached max_fire_duration become BURNED
-                uint4 em;   // 0xFF per expiring byte
-                em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;
+                em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
                 em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
                 em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
                 em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
@@ -353,48 +440,39 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
                     *reinterpret_cast<uint4 *>(st_e + voff) = snew;
                 // cells to hand to phase 2: eligible & next to a live sprite; every line cell
                 // when attenuation is on (their burn changes even away from the fire)
-                uint32_t m16 = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t sj = pick(snew, j), pj = pick(s7, j);
-                    uint32_t push = (eq0_01(sj) | ge3_01(sj)) & nz01(pick(nb, j));
-                    if (g.att) push |= ge3_01(pj);
-                    m16 |= pack4(push) << (4 * j);
-                }
-                if (m16) {
-                    uint32_t pos = atomicAdd(&s_cnt[wave], (uint32_t)__popc(m16));
-                    while (m16) {
-                        const int b = __ffs(m16) - 1;
-                        m16 &= m16 - 1;
-                        const int j = b >> 2, sh = (b & 3) * 8;
-                        const uint32_t raw = (pick(sraw, j) >> sh) & 0xFFu;
-                        const uint32_t exd = (pick(em, j) >> sh) & 1u;
-                        s_list[wave][pos++] = (uint32_t)(voff + b) | ((raw & 7u) << 26) |
-                                              ((raw >> 7) << 29) | (exd << 30);
-                    }
-                }
+                const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+                const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+                const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+                const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+                m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+                if (g.att)
+                    m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
+                           (pack4(ge3_01(s7.w)) << 12);
             }
         }
 
-        // ---- phase 2: the wave walks its compacted frontier ----------------------------
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t n_items = s_cnt[wave];
-        if (n_items) {
-            // phase-1 stores of this wave must land before the byte stores below
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (uint32_t j = lane; j < n_items; j += 64)
-                process_cell(s_list[wave][j], a, mk, st, e, spread, cand_seen, n_active, n_ignite);
-            n_items_acc += (lane == 0) ? n_items : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) s_cnt[wave] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        // ---- compact the frontier cells of this row into the wave's LDS list; the list is
+        // walked once per band (or earlier if it could overflow): every walk costs two or
+        // three dependent memory round trips, so they are batched
+        const unsigned long long pushers = __ballot(m16 != 0);
+        if (pushers) {
+            const uint32_t bound = 16u * (uint32_t)__popcll(pushers);
+            if (pend_bound + bound > (uint32_t)kListCap) { walk(); pend_bound = 0; }
+            pend_bound += bound;
+            if (m16) {
+                uint32_t pos = atomicAdd(&s_cnt[wave], (uint32_t)__popc(m16));
+                while (m16) {
+                    const int b = __ffs(m16) - 1;
+                    m16 &= m16 - 1;
+                    const int j = b >> 2, sh = (b & 3) * 8;
+                    const uint32_t raw = (pick(sraw, j) >> sh) & 0xFFu;
+                    const uint32_t exd = (pick(em, j) >> sh) & 1u;
+                    s_list[wave][pos++] = (voff + b) | ((raw & 7u) << 26) | ((raw >> 7) << 29) | (exd << 30);
+                }
+            }
         }
-        up = mid; mid = dn; dn = nxt;
     }
+    if (pend_bound) walk();
 
     // per-environment predicates: wave ballot, then at most one atomic per wave
     const bool w_live = __ballot(live_acc != 0) != 0ull;
@@ -405,17 +483,35 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
         const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((have & want) != want) atomicOr(f, want);
     }
-    // statistics for the roofline accounting (active cell-updates = phi * cells)
-    if (__ballot(n_active != 0) != 0ull) {
+    // optional statistics for the roofline accounting (active cell-updates = phi * cells)
+    if (a.counters && lane == 0) {
+        unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+        atomicAdd(&cs[3], 1ull);                 // wavefronts that survived the quick reject
+        if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
+    }
+    if (a.counters && __ballot(n_active != 0) != 0ull) {
         for (int off = 32; off > 0; off >>= 1) {
             n_active += __shfl_down(n_active, off);
             n_ignite += __shfl_down(n_ignite, off);
         }
         if (lane == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)n_active);
-            if (n_ignite) atomicAdd(&a.counters[1], (unsigned long long)n_ignite);
-            atomicAdd(&a.counters[2], (unsigned long long)n_items_acc);
+            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+            atomicAdd(&cs[0], (unsigned long long)n_active);
+            if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+            atomicAdd(&cs[2], (unsigned long long)n_items_acc);
         }
+    }
+}
+
+typedef void (*StepKernel)(StepArgs);
+static StepKernel pick_step_kernel(int rb, bool full)
+{
+    switch (rb) {
+    case 1: return full ? k_step<1, true> : k_step<1, false>;
+    case 2: return full ? k_step<2, true> : k_step<2, false>;
+    case 4: return full ? k_step<4, true> : k_step<4, false>;
+    case 8: return full ? k_step<8, true> : k_step<8, false>;
+    default: return full ? k_step<16, true> : k_step<16, false>;
     }
 }
 
@@ -677,7 +773,7 @@ struct sf_sim {
     size_t stage_bytes = 0;
     int32_t *pts_dev = nullptr, *seg_dev = nullptr;
     size_t pts_cap = 0, seg_cap = 0;
-    bool have_rt = false, was_reset = false;
+    bool have_rt = false, was_reset = false, counters_on = false;
     int64_t bytes = 0;
 };
 
@@ -701,8 +797,9 @@ static int dev_alloc(sf_sim *s, T **p, size_t n)
 
 static void choose_rows_per_band(Geo &g, int rows)
 {
-    if (rows < 1) rows = 1;
-    g.RB = rows;
+    int rb = 1;
+    while (rb * 2 <= rows && rb < 16) rb *= 2;   // the kernel is instantiated for 1, 2, 4, 8, 16
+    g.RB = rb;
     const int tile_h = kWaves * g.LR * g.RB;
     g.tiles_per_env = g.chunks_x * ((g.H + tile_h - 1) / tile_h);
 }
@@ -757,12 +854,12 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->commit, (size_t)g.E));
     TRY(dev_alloc(s, &s->tmp, (size_t)2 * g.E));
     TRY(dev_alloc(s, &s->flags, (size_t)3 * g.E));
-    TRY(dev_alloc(s, &s->counters, (size_t)4));
+    TRY(dev_alloc(s, &s->counters, (size_t)kCounterShards * 8));
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
 #undef TRY
     HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
-    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * 4, s->stream));
+    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->age_alloc, 0, (size_t)g.E * g.age_env + 2 * (size_t)g.P, s->stream));
     HIPCHK(hipMemsetAsync(s->status, 0, cells, s->stream));
@@ -989,12 +1086,14 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     HIPCHK(hipSetDevice(s->p.device));
     StepArgs a;
     a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
-    a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters;
+    a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
+    { const char *dbg = getenv("SF_DEBUG_CUT"); a.debug = dbg ? atoi(dbg) : 0; }
     const dim3 grid((unsigned)(s->g.tiles_per_env * s->g.E)), block(kWaves * 64);
+    const StepKernel kern = pick_step_kernel(s->g.RB, s->g.LC == 64);
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int i = 0; i < n_steps; ++i) {
         a.launch = i;
-        hipLaunchKernelGGL(k_step, grid, block, 0, s->stream, a);
+        hipLaunchKernelGGL(kern, grid, block, 0, s->stream, a);
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
@@ -1110,13 +1209,24 @@ extern "C" int sf_get_status(sf_sim *s, int32_t *status, double *elapsed)
     return SF_OK;
 }
 
+extern "C" int sf_enable_counters(sf_sim *s, int32_t on)
+{
+    if (!s) return fail(SF_EINVAL, "sf_enable_counters: null handle");
+    s->counters_on = on != 0;
+    return SF_OK;
+}
+
 extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
 {
     if (!s || !out) return fail(SF_EINVAL, "sf_get_counters: null argument");
     HIPCHK(hipSetDevice(s->p.device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipMemcpy(out, s->counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(s->counters, 0, sizeof(int64_t) * 4));
+    std::vector<unsigned long long> h((size_t)kCounterShards * 8);
+    HIPCHK(hipMemcpy(h.data(), s->counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int i = 0; i < kCounterShards; ++i)
+        for (int k = 0; k < 5; ++k) out[k] += (int64_t)h[(size_t)i * 8 + k];
+    if (reset) HIPCHK(hipMemset(s->counters, 0, h.size() * sizeof(unsigned long long)));
     return SF_OK;
 }
 

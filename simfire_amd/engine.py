@@ -165,11 +165,16 @@ class FireEngine:
         (int32 [n_envs, 8]), e.g. ``tensor.data_ptr()`` of a torch tensor on the same GPU."""
         _lib.check(self._L.sf_copy_status_to(self._h, C.c_void_p(int(device_ptr))))
 
+    def enable_counters(self, on=True):
+        """Statistics for the roofline accounting; off by default (they cost atomics)."""
+        _lib.check(self._L.sf_enable_counters(self._h, int(bool(on))))
+
     def counters(self, reset=False):
         """dict(active_cell_updates, ignitions, frontier_items) summed since the last reset."""
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         _lib.check(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
-        return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]))
+        return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
+                    active_waves=int(out[3]), frontier_walks=int(out[4]))
 
     def update_status_device(self):
         _lib.check(self._L.sf_update_status_device(self._h))
