@@ -55,6 +55,7 @@ SIGNATURES = {
     "sf_compute_ros": [_I64] + [_VP] * 18 + [_I32],
     "sf_memory_bytes": [_VP, C.POINTER(_I64)],
     "sf_set_rows_per_band": [_VP, _I32],
+    "sf_set_dense": [_VP, _I32],
 }
 STRING_GETTERS = ("sf_last_error", "sf_version")
 

@@ -77,8 +77,11 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 // ------------------------------------------------------------------------- device types
 namespace {
 
+#ifndef SF_WAVES_PER_SIMD
+#define SF_WAVES_PER_SIMD 1
+#endif
 constexpr int kWaves = 4;          // waves per workgroup (256 threads)
-constexpr int kListCap = 2048;     // per-wave frontier list; one row iteration adds at most 64 x 16 cells
+constexpr int kListCap = 512;      // per-wave frontier list; half a wave adds at most 32 x 16 cells at a time
 constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
 constexpr uint32_t FLAG_CAND = 2u; // some sprite has a cell to spread into     (fire.py:651)
@@ -100,6 +103,9 @@ struct Geo {
     int diag, att, has_max_time;
     double pixel_scale, update_rate, max_time;
     long long age_env, plane_env; // element strides between environments
+    int lds_wave_bytes;           // dynamic LDS per wave: list + staged age tile
+    int TX, TY, TXp, TYp;         // wave tiles per environment (+ a zero guard ring in the flag maps)
+    int dense;                    // 1 = ignore the tile activity map (cross-check mode)
 };
 
 struct StepArgs {
@@ -112,6 +118,8 @@ struct StepArgs {
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
     uint32_t *flags;     // [3][E] ring
     unsigned long long *counters;   // [kCounterShards][8]: active cell-updates, ignitions, frontier items; null = off
+    uint8_t *tflags;     // [3][E][TYp][TXp] tile activity ring: bit0 = tile holds sprites, bit1 = tile holds control lines
+    int ring;            // ring slot read by this launch; (ring + 1) % 3 is written, (ring + 2) % 3 cleared
     int launch;          // index of this launch inside one sf_step call
     int debug;           // SF_DEBUG_CUT: bisect kernel cost (0 = normal)
 };
@@ -193,67 +201,6 @@ __device__ __forceinline__ uint32_t pack4(uint32_t b01) { return (b01 * 0x010204
 __constant__ int c_dx[8] = {+1, 0, -1, +1, -1, +1, 0, -1};
 __constant__ int c_dy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
 
-// One cell of the compacted frontier.  item = idx | status << 26 | settled << 29 | expired << 30
-__device__ __forceinline__ void process_cell(uint32_t item, const StepArgs &a, const Masks &mk,
-                                             const EnvState &st, int e, bool spread, bool &cand_seen,
-                                             uint32_t &n_active, uint32_t &n_ignite)
-{
-    const Geo &g = a.g;
-    const uint32_t idx = item & 0x03FFFFFFu;
-    const uint32_t s_pre = (item >> 26) & 7u;
-    const bool settled = (item >> 29) & 1u;
-    const bool expired = (item >> 30) & 1u;
-    const int y = idx / (uint32_t)g.P;
-    const int x = idx - y * g.P;
-    if (x >= g.W) return;                                           // pitch padding
-    uint8_t *ap = a.age + (long long)e * g.age_env + (long long)y * g.P + x;
-
-    const long long cell = (long long)e * g.plane_env + idx;
-    double bn = a.burn[cell];     // requested up front: overlaps with the neighbour loads
-    // neighbour sprites (fire.py:163-234 seen from the destination cell)
-    int best = -1, bestk = 0;
-    bool prev_any = false;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int dx = c_dx[k], dy = c_dy[k];
-        if (!g.diag && dx != 0 && dy != 0) continue;
-        const int xx = x + dx;
-        if (xx < 0 || xx >= g.W) continue;                          // rows are guarded by zero rows
-        const uint32_t v = ap[dy * g.P + dx];
-        prev_any |= (v & mk.m_prev) != 0;
-        const uint32_t l = v & mk.m_live;
-        if (l) {
-            // newest sprite of the neighbour: rotate so that ignition step t-1 is the top bit
-            const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
-            const int msb = 31 - __clz(r);
-            if (msb > best) { best = msb; bestk = k; }              // ties: earlier k wins
-        }
-    }
-    const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
-    const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
-    const bool is_cand = spread && eligible && best >= 0;
-    // attenuation of the previous step that was deferred (cell was a line, not a candidate)
-    const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && st.prev_flag && !prev_any;
-    if (!(is_cand || pending)) return;
-
-    n_active++;
-    if (pending) bn = bn - line_factor(s_pre);                      // fire.py:278 with ros = 0
-    if (is_cand) {
-        cand_seen = true;
-        double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
-        if (s_post >= SF_FIRELINE)                                               // fire.py:271-282
-            ros = g.att ? ros - line_factor(s_post) : 0.0;
-        bn = bn + ros;                                                           // fire.py:710
-        if (bn > g.pixel_scale) {                                                // fire.py:568
-            n_ignite++;
-            a.status[cell] = (uint8_t)SF_BURNING;                                // fire.py:587
-            const uint32_t own = ap[0] & ~mk.b_clr;      // phase 1 may have cleared b_clr already
-            ap[0] = (uint8_t)(own | mk.b_new);                                   // fire.py:571-579
-        }
-    }
-    a.burn[cell] = bn;
-}
-
 // Workgroup -> tile mapping.  The dispatcher places workgroup b on XCD b % 8 (observed, used for
 // speed only): renumber so that every XCD walks a contiguous range of tiles, i.e. whole
 // environments, and the halo rows shared by vertically adjacent tiles hit in that XCD's L2.
@@ -265,29 +212,57 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 }
 
 // value of lane-1 / lane+1 inside groups of LC lanes; lanes at a group edge get 0
-template <bool FULL>
 __device__ __forceinline__ uint32_t from_left(uint32_t v, int c, int LC)
 {
-    if (FULL) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
     const uint32_t t = __shfl_up(v, 1, LC);
     return c == 0 ? 0u : t;
 }
-template <bool FULL>
 __device__ __forceinline__ uint32_t from_right(uint32_t v, int c, int LC)
 {
-    if (FULL) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
     const uint32_t t = __shfl_down(v, 1, LC);
     return c == LC - 1 ? 0u : t;
 }
 
-// One step of every environment.  RB = rows per lane band (compile time: the RB + 2 window rows
-// live in registers and are all requested before anything is computed), FULL = a row chunk is
-// a whole wave (64 lanes x 16 cells; horizontal neighbours by DPP instead of ds_bpermute).
-template <int RB, bool FULL>
-__global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
+// Winner source of a destination cell from its 3x3 neighbourhood (bytes 0..2
+// of up3 / mid3 / dn3 = cells x-1, x, x+1 of the rows y-1, y, y+1): the newest live sprite
+// wins, ties are broken by the priority order k = 0..7.  Also reports whether any neighbour
+// was live during the previous step.
+__device__ __forceinline__ int pick_winner(uint32_t up3, uint32_t mid3, uint32_t dn3, const Masks &mk, bool diag,
+                                           bool &prev_any)
 {
-    __shared__ uint32_t s_list[kWaves][kListCap];
-    __shared__ uint32_t s_cnt[kWaves];
+    // k: 0 (+1,+1) 1 (0,+1) 2 (-1,+1) 3 (+1,0) 4 (-1,0) 5 (+1,-1) 6 (0,-1) 7 (-1,-1)
+    const uint32_t nbv[8] = {(dn3 >> 16) & 0xFFu, (dn3 >> 8) & 0xFFu, dn3 & 0xFFu, (mid3 >> 16) & 0xFFu,
+                             mid3 & 0xFFu, (up3 >> 16) & 0xFFu, (up3 >> 8) & 0xFFu, up3 & 0xFFu};
+    int best = -1, bestk = -1;
+    prev_any = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
+        uint32_t v = nbv[k];
+        if (diagonal_k && !diag) v = 0;
+        prev_any |= (v & mk.m_prev) != 0;
+        const uint32_t l = v & mk.m_live;
+        // newest sprite of the neighbour: rotate so that ignition step t-1 is the top bit
+        const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
+        const int msb = l ? 31 - __clz(r) : -1;
+        if (msb > best) { best = msb; bestk = k; }                  // ties: earlier k wins
+    }
+    return bestk;
+}
+
+// One step of every environment.
+//   RB   rows per lane band (compile time: the RB + 2 window rows live in registers and are all
+//        requested before any of them is used)
+// A wave owns a tile of LC x 16 cells by LR x RB rows (128 x 32 for large grids).  It first looks
+// at the activity flags of its 3 x 3 tile neighbourhood: if no tile there holds a sprite (and
+// its own tile holds no control line while attenuation is on) nothing in the tile can change in
+// this step and the wave retires without touching the cell planes.
+// Dynamic LDS, per wave: frontier list [kListCap] u32, then the staged age tile
+// [LR][RB + 2][LC * 16 + 32] bytes (16 pad bytes either side of a row hold the seam columns).
+template <int RB>
+__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int e = bid / (uint32_t)g.tiles_per_env;
@@ -295,33 +270,25 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunk = tile % g.chunks_x, ty = tile / g.chunks_x;
-    const int LC = FULL ? 64 : g.LC;
-    const int c = FULL ? lane : (lane & (g.LC - 1)), r = FULL ? 0 : (lane >> g.logLC);
+    const int LC = g.LC, LR = g.LR;
+    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
     const int cv = chunk * LC + c;
     const bool col_ok = cv < g.PV;
-    const int y0 = ((ty * kWaves + wave) * (FULL ? 1 : g.LR) + r) * RB;
+    const int tyw = ty * kWaves + wave;                // wave tile row
+    const int yw = tyw * LR * RB;                      // first row of this wave's tile
+    const int y0 = yw + r * RB;                        // first row of this lane's band
 
-    uint8_t *age_e = a.age + (long long)e * g.age_env;
-    uint8_t *st_e = a.status + (long long)e * g.plane_env;
+    // ---- tile activity: lanes 0..8 fetch the flags of the 3 x 3 tile neighbourhood
+    const long long fplane = (long long)g.TYp * g.TXp;
+    uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+    uint8_t *f_wr = a.tflags + ((long long)((a.ring + 1) % 3) * g.E + e) * fplane;
+    uint8_t *f_cl = a.tflags + ((long long)((a.ring + 2) % 3) * g.E + e) * fplane;
+    const long long f_own = (long long)(tyw + 1) * g.TXp + (chunk + 1);
+    const bool tile_ok = tyw < g.TY;
+    uint32_t fl = 0;
+    if (lane < 9 && tile_ok) fl = f_rd[f_own + (lane / 3 - 1) * g.TXp + (lane % 3 - 1)];
 
-    // ---- request the whole register window: rows y0-1 .. y0+RB (zero guard rows at -1 and H)
-    uint4 rows[RB + 2];
-    const uint32_t voff0 = (uint32_t)((y0 - 1) * g.P + cv * 16);   // may wrap for y0 = 0: used as signed
-    const uint8_t *win = age_e + (int)voff0;
-#pragma unroll
-    for (int k = 0; k < RB + 2; ++k) {
-        rows[k] = make_uint4(0, 0, 0, 0);
-        if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
-    }
-    if (a.debug == 1) {
-        uint32_t h = 0;
-#pragma unroll
-        for (int k = 0; k < RB + 2; ++k) h |= any4(rows[k]);
-        if (h == 0x12345u) a.flags[0] = h;
-        return;
-    }
-    // environment state entering this step (folded from the previous launch's flags); the
-    // scalar loads below overlap with the window loads already in flight
+    // environment state entering this step (folded from the previous launch's flags)
     EnvState st;
     if (a.launch == 0) st = a.commit[e];
     else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
@@ -329,13 +296,27 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
         a.tmp[(a.launch & 1) * g.E + e] = st;
         a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
     }
-    if (!st.running) return;
-    if (a.debug == 2) {
-        uint32_t h = 0;
-#pragma unroll
-        for (int k = 0; k < RB + 2; ++k) h |= any4(rows[k]);
-        if (h == 0x12345u) a.flags[0] = h;
+    if (!tile_ok) return;
+    const uint32_t own_fl = __shfl(fl, 4);
+    if (lane == 0) f_cl[f_own] = 0;                    // recycle the ring slot after the next one
+    if (!st.running) {                                 // frozen: carry the flags forward unchanged
+        if (lane == 0 && own_fl) f_wr[f_own] = (uint8_t)own_fl;
         return;
+    }
+    const bool tile_active = g.dense || __ballot(fl & 1u) != 0ull || (g.att && (own_fl & 2u));
+    if (!tile_active) return;                          // own flags are 0: nothing to carry forward
+    if (a.debug == 1) return;
+
+    uint8_t *age_e = a.age + (long long)e * g.age_env;
+    uint8_t *st_e = a.status + (long long)e * g.plane_env;
+
+    // ---- request the whole register window: rows y0-1 .. y0+RB (zero guard rows at -1 and H)
+    uint4 rows[RB + 2];
+    const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
+#pragma unroll
+    for (int k = 0; k < RB + 2; ++k) {
+        rows[k] = make_uint4(0, 0, 0, 0);
+        if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
     }
 
     const int t = st.steps + 1;
@@ -353,7 +334,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
         for (int k = 0; k < RB + 2; ++k) {
             uint32_t v = 0;
             if ((seam_l || seam_r) && y0 - 1 + k <= g.H) v = win[k * g.P + (seam_l ? -1 : 16)];
-            seam[k] = v & mk.m_live;
+            seam[k] = v;
         }
     } else {
 #pragma unroll
@@ -365,115 +346,221 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
 #pragma unroll
     for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
     hot &= (L4 | EXP4 | CLR4);
-    if (!g.att && __ballot(hot != 0) == 0ull) return;
+    // does the tile itself hold any sprite bit that survives this step's slot recycling?
+    uint32_t keep = 0;
+#pragma unroll
+    for (int k = 1; k <= RB; ++k) keep |= any4(rows[k]);
+    keep &= ~CLR4;
+    const bool tile_has_sprites = __ballot(keep != 0) != 0ull;
+    if (!g.att && __ballot(hot != 0) == 0ull) {
+        if (lane == 0 && tile_has_sprites) f_wr[f_own] = 1;   // unreachable in practice (hot covers keep)
+        return;
+    }
     if (a.debug == 3) return;
 
-    if (lane == 0) s_cnt[wave] = 0;
-    uint32_t live_acc = 0, n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
-    uint32_t pend_bound = 0;   // wave-uniform upper bound of the list occupancy
+    // ---- this wave is near the fire ---------------------------------------------------
+    const int row_pitch = LC * 16 + 32;
+    uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
+    uint32_t *s_list = reinterpret_cast<uint32_t *>(lds_wave);
+    uint8_t *tile_lds = lds_wave + kListCap * 4;
+    bool staged = false;
+
+    uint32_t live_acc = 0, n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, line_acc = 0;
+    uint32_t pend = 0;         // wave-uniform occupancy of the list (exact)
     bool cand_seen = false;
 
-    // phase 2: the whole wave walks its compacted frontier, one cell per lane
+    // phase 2: the whole wave walks its compacted frontier, one cell per lane.
+    // item = row in band (5) | owner lane (6) << 5 | cell in vector (4) << 11 | status before the
+    //        prune (3) << 15 | settled << 18 | expired << 19
     auto walk = [&]() {
         n_phase2++;
+        if (!staged) {   // stage the wave's age tile in LDS: the 3x3 neighbourhoods are read from it
+            staged = true;
+            uint8_t *band_lds = tile_lds + r * (RB + 2) * row_pitch;
+#pragma unroll
+            for (int k = 0; k < RB + 2; ++k) {
+                uint8_t *rp = band_lds + k * row_pitch;
+                *reinterpret_cast<uint4 *>(rp + 16 + c * 16) = rows[k];
+                if (c == 0) rp[15] = (uint8_t)(seam_l ? seam[k] : 0u);
+                if (c == LC - 1) rp[16 + LC * 16] = (uint8_t)(seam_r ? seam[k] : 0u);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t n_items = s_cnt[wave];
         // phase-1 stores of this wave must land before the byte stores below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t j = lane; j < n_items; j += 64)
-            process_cell(s_list[wave][j], a, mk, st, e, spread, cand_seen, n_active, n_ignite);
-        n_items_acc += (lane == 0) ? n_items : 0u;
+        if (a.debug != 5)
+        for (uint32_t j = lane; j < pend; j += 64) {
+            const uint32_t it = s_list[j];
+            const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
+            const uint32_t s_pre = (it >> 15) & 7u;
+            const bool settled = (it >> 18) & 1u, expired = (it >> 19) & 1u;
+            const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
+            const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
+            const uint32_t idx = (uint32_t)(y * g.P + x);
+            const long long cell = (long long)e * g.plane_env + idx;
+            double bn = a.burn[cell];     // requested first: the LDS work below hides part of it
+            // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
+            const uint8_t *q = tile_lds + (orr * (RB + 2) + i) * row_pitch + 16 + oc * 16 + b - 1;
+            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
+            const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
+            const uint32_t *qb = reinterpret_cast<const uint32_t *>(q - sh + row_pitch);
+            const uint32_t *qc = reinterpret_cast<const uint32_t *>(q - sh + 2 * row_pitch);
+            const uint32_t up3 = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh);
+            const uint32_t mid3 = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh);
+            const uint32_t dn3 = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh);
+            bool prev_any;
+            const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag, prev_any);
+            const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
+            const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
+            const bool is_cand = spread && eligible && bestk >= 0;
+            // attenuation of the previous step that was deferred (a line cell, not a candidate then)
+            const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && st.prev_flag && !prev_any;
+            if (!(is_cand || pending)) continue;
+            n_active++;
+            if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
+            if (is_cand) {
+                cand_seen = true;
+                double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+                if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
+                    ros = g.att ? ros - line_factor(s_post) : 0.0;
+                bn = bn + ros;                                                   // fire.py:710
+                if (bn > g.pixel_scale) {                                        // fire.py:568
+                    n_ignite++;
+                    a.status[cell] = (uint8_t)SF_BURNING;                        // fire.py:587
+                    const uint32_t own = (mid3 >> 8) & 0xFFu;
+                    age_e[idx] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);        // fire.py:571-579
+                }
+            }
+            a.burn[cell] = bn;
+        }
+        n_items_acc += (lane == 0) ? pend : 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) s_cnt[wave] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        pend = 0;
     };
 
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int y = y0 + i;
-        const bool row_ok = col_ok && y < g.H;
+    // per row: OR of the live masks of the (4 or 8) neighbours of each of the lane's 16 cells
+    auto neighbours = [&](int i) -> uint4 {
         const uint4 up = rows[i], mid = rows[i + 1], dn = rows[i + 2];
-
-        // ---- phase 1: SWAR scan of 16 cells --------------------------------------------
         const uint4 midL = and4(mid, L4);
         const uint4 vsrc = and4(or4(up, dn), L4);
         const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
-        live_acc |= any4(midL);
         // horizontal neighbours: byte from the lane to the left / right (same band)
-        uint32_t lin = from_left<FULL>(hsrc.w, c, LC) >> 24;
-        uint32_t rin = from_right<FULL>(hsrc.x, c, LC) & 0xFFu;
-        const uint32_t sv = g.diag ? (seam[i] | seam[i + 1] | seam[i + 2]) : seam[i + 1];
+        uint32_t lin = from_left(hsrc.w, c, LC) >> 24;
+        uint32_t rin = from_right(hsrc.x, c, LC) & 0xFFu;
+        const uint32_t sv = (g.diag ? (seam[i] | seam[i + 1] | seam[i + 2]) : seam[i + 1]) & mk.m_live;
         if (seam_l) lin = sv;
         if (seam_r) rin = sv;
-        uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
+        uint4 nb;
         nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
         nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
         nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
         nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
+        return nb;
+    };
 
-        const uint4 ex4 = and4(mid, EXP4);
-        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
-        uint32_t m16 = 0;
-        uint4 sraw = make_uint4(0, 0, 0, 0), em = make_uint4(0, 0, 0, 0);
+    // ---- phase 1a: which status vectors are needed?  Request them all before using any.
+    uint4 sraw[RB];
+    uint32_t need = 0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int y = y0 + i;
+        const uint4 mid = rows[i + 1];
+        const uint4 nb = neighbours(i);
+        live_acc |= any4(and4(mid, L4));
+        const uint32_t any_exp = any4(and4(mid, EXP4)), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
         const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
-        if (row_ok && (any_exp | any_clr | any_nb | (uint32_t)g.att)) {
+        sraw[i] = make_uint4(0, 0, 0, 0);
+        if (col_ok && y < g.H) {
             if (any_clr)   // recycle the slot of sprites that were pruned one step ago
                 *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
             if (any_exp | any_nb | (uint32_t)g.att) {
-                sraw = *reinterpret_cast<const uint4 *>(st_e + voff);
-                const uint4 s7 = and4(sraw, 0x07070707u);
-                // S1 prune: cells whose sprite reached max_fire_duration become BURNED
-                em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
-                em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
-                em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
-                em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
-                uint4 snew;
-                snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
-                snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
-                snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
-                snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
-                if ((snew.x ^ sraw.x) | (snew.y ^ sraw.y) | (snew.z ^ sraw.z) | (snew.w ^ sraw.w))
-                    *reinterpret_cast<uint4 *>(st_e + voff) = snew;
-                // cells to hand to phase 2: eligible & next to a live sprite; every line cell
-                // when attenuation is on (their burn changes even away from the fire)
-                const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
-                const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
-                const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
-                const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
-                m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
-                if (g.att)
-                    m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
-                           (pack4(ge3_01(s7.w)) << 12);
-            }
-        }
-
-        // ---- compact the frontier cells of this row into the wave's LDS list; the list is
-        // walked once per band (or earlier if it could overflow): every walk costs two or
-        // three dependent memory round trips, so they are batched
-        const unsigned long long pushers = __ballot(m16 != 0);
-        if (pushers) {
-            const uint32_t bound = 16u * (uint32_t)__popcll(pushers);
-            if (pend_bound + bound > (uint32_t)kListCap) { walk(); pend_bound = 0; }
-            pend_bound += bound;
-            if (m16) {
-                uint32_t pos = atomicAdd(&s_cnt[wave], (uint32_t)__popc(m16));
-                while (m16) {
-                    const int b = __ffs(m16) - 1;
-                    m16 &= m16 - 1;
-                    const int j = b >> 2, sh = (b & 3) * 8;
-                    const uint32_t raw = (pick(sraw, j) >> sh) & 0xFFu;
-                    const uint32_t exd = (pick(em, j) >> sh) & 1u;
-                    s_list[wave][pos++] = (voff + b) | ((raw & 7u) << 26) | ((raw >> 7) << 29) | (exd << 30);
-                }
+                need |= 1u << i;
+                sraw[i] = *reinterpret_cast<const uint4 *>(st_e + voff);
             }
         }
     }
-    if (pend_bound) walk();
 
+    // ---- phase 1b: prune, find the frontier cells, compact them into the wave's LDS list
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int y = y0 + i;
+        const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
+        uint32_t m16 = 0;
+        uint4 em = make_uint4(0, 0, 0, 0);
+        if (need & (1u << i)) {
+            const uint4 mid = rows[i + 1];
+            const uint4 nb = neighbours(i);
+            const uint4 ex4 = and4(mid, EXP4);
+            const uint4 s7 = and4(sraw[i], 0x07070707u);
+            // S1 prune: cells whose sprite reached max_fire_duration become BURNED
+            em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
+            em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
+            uint4 snew;
+            snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
+            snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
+            snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
+            snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
+            if ((snew.x ^ sraw[i].x) | (snew.y ^ sraw[i].y) | (snew.z ^ sraw[i].z) | (snew.w ^ sraw[i].w))
+                *reinterpret_cast<uint4 *>(st_e + voff) = snew;
+            // cells to hand to phase 2: eligible & next to a live sprite; every line cell
+            // when attenuation is on (their burn changes even away from the fire)
+            const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+            const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+            const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+            const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            if (g.att) {
+                m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
+                       (pack4(ge3_01(s7.w)) << 12);
+                line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
+            }
+            // pitch padding (x >= W) never takes part
+            const int xs = cv * 16;
+            if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
+        }
+        if (a.debug == 6) m16 = 0;
+        if (__ballot(m16 != 0) == 0ull) continue;
+        // Wave-level compaction without LDS atomics: for every cell position b one ballot gives
+        // both the slot of each lane's item (mbcnt = popcount of the lower lanes) and the running
+        // total; two passes of 8 positions so that one pass adds at most 64 x 8 = kListCap items.
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int b = pass * 8; b < pass * 8 + 8; ++b) tot += (uint32_t)__popcll(__ballot((m16 >> b) & 1u));
+            if (tot == 0) continue;
+            if (pend + tot > (uint32_t)kListCap) walk();
+#pragma unroll
+            for (int b = pass * 8; b < pass * 8 + 8; ++b) {
+                const bool has = (m16 >> b) & 1u;
+                const unsigned long long bal = __ballot(has);
+                if (has) {
+                    const uint32_t pos = pend + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    const uint32_t raw = (pick(sraw[i], b >> 2) >> ((b & 3) * 8)) & 0xFFu;
+                    const uint32_t exd = (pick(em, b >> 2) >> ((b & 3) * 8)) & 1u;
+                    s_list[pos] = (uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11) | ((raw & 7u) << 15) |
+                                  ((raw >> 7) << 18) | (exd << 19);
+                }
+                pend += (uint32_t)__popcll(bal);
+            }
+        }
+    }
+    if (pend) walk();
+
+    // tile activity for the next step: sprites left in the tile or ignited in it; control lines
+    // (a line cell that ignited this step is seen one step late - harmless, it is re-evaluated)
+    {
+        const bool ign = __ballot(n_ignite != 0) != 0ull;
+        const bool lines = g.att && __ballot(line_acc != 0) != 0ull;
+        const uint32_t nf = ((tile_has_sprites || ign) ? 1u : 0u) | (lines ? 2u : 0u);
+        if (lane == 0 && nf) f_wr[f_own] = (uint8_t)nf;
+    }
     // per-environment predicates: wave ballot, then at most one atomic per wave
     const bool w_live = __ballot(live_acc != 0) != 0ull;
     const bool w_cand = __ballot(cand_seen) != 0ull;
@@ -504,14 +591,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_step(StepArgs a)
 }
 
 typedef void (*StepKernel)(StepArgs);
-static StepKernel pick_step_kernel(int rb, bool full)
+static StepKernel pick_step_kernel(int rb)
 {
     switch (rb) {
-    case 1: return full ? k_step<1, true> : k_step<1, false>;
-    case 2: return full ? k_step<2, true> : k_step<2, false>;
-    case 4: return full ? k_step<4, true> : k_step<4, false>;
-    case 8: return full ? k_step<8, true> : k_step<8, false>;
-    default: return full ? k_step<16, true> : k_step<16, false>;
+    case 1: return k_step<1>;
+    case 2: return k_step<2>;
+    case 4: return k_step<4>;
+    default: return k_step<8>;
     }
 }
 
@@ -524,8 +610,8 @@ __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t 
     flags[e] = 0; flags[g.E + e] = 0; flags[2 * g.E + e] = 0;
 }
 
-__global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commit, const int32_t *xy,
-                           int env0, int n)
+__global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commit, uint8_t *tflags, int ring,
+                           const int32_t *xy, int env0, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -533,10 +619,34 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     const int x = xy[2 * i], y = xy[2 * i + 1];
     status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
     age[(long long)e * g.age_env + (long long)y * g.P + x] = 1u;                // ignition step 0
+    const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
+    tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1;
     EnvState s;
     s.running = 1; s.steps = 0; s.prev_flag = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
     commit[e] = s;
+}
+
+// Recompute the tile activity map of environments [env0, env0 + n) from the cell planes (after a
+// geometry change or a wholesale fire_map replacement).  One 64-lane workgroup per tile.
+__global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *status, const uint8_t *age,
+                                                       uint8_t *tflags, int ring, int env0)
+{
+    const int tx = blockIdx.x, tyw = blockIdx.y, e = env0 + blockIdx.z;
+    const int th = g.LR * g.RB, tw = g.LC * 16;
+    uint32_t has_age = 0, has_line = 0;
+    for (int i = threadIdx.x; i < th * tw; i += 64) {
+        const int y = tyw * th + i / tw, x = tx * tw + i % tw;
+        if (y >= g.H || x >= g.W) continue;
+        has_age |= age[(long long)e * g.age_env + (long long)y * g.P + x];
+        has_line |= (status[(long long)e * g.plane_env + (long long)y * g.P + x] & 7u) >= SF_FIRELINE;
+    }
+    const bool a_any = __ballot(has_age != 0) != 0ull, l_any = __ballot(has_line != 0) != 0ull;
+    if (threadIdx.x == 0) {
+        const long long o = (long long)(tyw + 1) * g.TXp + tx + 1, plane = (long long)g.TYp * g.TXp;
+        for (int k = 0; k < 3; ++k)
+            tflags[((long long)k * g.E + e) * plane + o] = (k == ring) ? (uint8_t)((a_any ? 1 : 0) | ((g.att && l_any) ? 2 : 0)) : 0;
+    }
 }
 
 // ------------------------------------------------------------------ layers -> R table
@@ -684,7 +794,8 @@ __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 // owed for the last step under its OLD status.  Phases B1-B3: FIRELINE, SCRATCHLINE, WETLINE
 // writes in the reference's order (simulation.py:476-478), so for duplicates the later type wins.
 __global__ __launch_bounds__(256) void k_mitigate(Geo g, uint8_t *status, const uint8_t *age, double *burn,
-                                                  const EnvState *commit, const int32_t *pts, const int32_t *seg)
+                                                  const EnvState *commit, const int32_t *pts, const int32_t *seg,
+                                                  uint8_t *tflags, int ring)
 {
     const int b = blockIdx.x;
     const int lo = seg[b], hi = seg[b + 1];
@@ -705,6 +816,9 @@ __global__ __launch_bounds__(256) void k_mitigate(Geo g, uint8_t *status, const 
                 const long long c = (long long)e * g.plane_env + o;
                 burn[c] = burn[c] - line_factor(sraw & 7u);
             }
+            // the tile now holds a control line: it has to be visited every step from now on
+            uint8_t *tf = tflags + (((long long)ring * g.E + e) * g.TYp + y / (g.LR * g.RB) + 1) * g.TXp + (x / 16) / g.LC + 1;
+            if (!(*tf & 2u)) *tf = (uint8_t)(*tf | 2u);   // idempotent: every racer writes the same bit
         }
     }
     const uint8_t mark = g.att ? 0x80u : 0u;
@@ -767,6 +881,9 @@ struct sf_sim {
     EnvState *commit = nullptr, *tmp = nullptr;
     uint32_t *flags = nullptr;
     unsigned long long *counters = nullptr;
+    uint8_t *tflags = nullptr;
+    size_t tflags_bytes = 0;
+    int ring = 0;                      // tile-flag ring slot the next step launch reads
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -798,10 +915,18 @@ static int dev_alloc(sf_sim *s, T **p, size_t n)
 static void choose_rows_per_band(Geo &g, int rows)
 {
     int rb = 1;
-    while (rb * 2 <= rows && rb < 16) rb *= 2;   // the kernel is instantiated for 1, 2, 4, 8, 16
+    while (rb * 2 <= rows && rb < 8) rb *= 2;    // the kernel is instantiated for 1, 2, 4, 8
+    // staged tile per wave = LR x (RB + 2) x (LC * 16 + 32) bytes; keep a workgroup below ~60 KB
+    auto wave_bytes = [&](int r) { return kListCap * 4 + g.LR * (r + 2) * (g.LC * 16 + 32); };
+    while (rb > 1 && kWaves * wave_bytes(rb) > 60 * 1024) rb /= 2;
     g.RB = rb;
+    g.lds_wave_bytes = (wave_bytes(rb) + 15) / 16 * 16;
     const int tile_h = kWaves * g.LR * g.RB;
     g.tiles_per_env = g.chunks_x * ((g.H + tile_h - 1) / tile_h);
+    g.TX = g.chunks_x;
+    g.TY = (g.H + g.LR * g.RB - 1) / (g.LR * g.RB);
+    g.TXp = g.TX + 2;
+    g.TYp = g.TY + 2;
 }
 
 extern "C" int sf_create(const sf_params *p, sf_sim **out)
@@ -824,10 +949,16 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     s->p = *p;
     Geo &g = s->g;
     g.E = p->n_envs; g.H = p->height; g.W = p->width; g.P = (int)P; g.PV = g.P / 16;
+    // lanes across a wave tile: 8 x 16 = 128 cells wide for large grids, so that a wave tile is
+    // 128 x (8 * RB) cells - squarish tiles cut the number of tiles a fire front crosses
     g.LC = 1; g.logLC = 0;
-    while (g.LC < g.PV && g.LC < 64) { g.LC <<= 1; g.logLC++; }
+    int lc_max = 8;
+    if (const char *v = getenv("SF_LC")) lc_max = atoi(v);   // developer knob
+    while (g.LC < g.PV && g.LC < lc_max) { g.LC <<= 1; g.logLC++; }
     g.LR = 64 / g.LC;
     g.chunks_x = (g.PV + g.LC - 1) / g.LC;
+    g.dense = 0;
+    if (const char *v = getenv("SF_DENSE")) g.dense = atoi(v) != 0;
     g.md = p->max_fire_duration; g.N = g.md + 3;
     g.diag = p->diagonal_spread != 0; g.att = p->attenuate_line_ros != 0; g.has_max_time = p->has_max_time != 0;
     g.pixel_scale = p->pixel_scale; g.update_rate = p->update_rate; g.max_time = p->max_time;
@@ -835,7 +966,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     // rows per band: enough workgroups to fill 256 CUs several times over when the batch is
     // large, short bands when a single environment has to spread over the chip
     long long rows_total = (long long)g.E * g.H;
-    int rb = rows_total >= 65536 ? 8 : (rows_total >= 16384 ? 4 : 2);
+    int rb = rows_total >= 4096 ? 4 : 2;
     choose_rows_per_band(g, rb);
 
     int rc;
@@ -855,10 +986,13 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->tmp, (size_t)2 * g.E));
     TRY(dev_alloc(s, &s->flags, (size_t)3 * g.E));
     TRY(dev_alloc(s, &s->counters, (size_t)kCounterShards * 8));
+    s->tflags_bytes = (size_t)3 * g.E * ((size_t)(g.H + g.LR - 1) / g.LR + 2) * (g.chunks_x + 2) + 64;
+    TRY(dev_alloc(s, &s->tflags, s->tflags_bytes));
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
 #undef TRY
     HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
+    HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->age_alloc, 0, (size_t)g.E * g.age_env + 2 * (size_t)g.P, s->stream));
@@ -875,7 +1009,7 @@ extern "C" int sf_destroy(sf_sim *s)
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
-                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters,
+                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags,
                     s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->seg_dev};
     for (void *p : ptrs) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -892,10 +1026,35 @@ extern "C" int sf_memory_bytes(sf_sim *s, int64_t *bytes)
     return SF_OK;
 }
 
+static int rebuild_tflags(sf_sim *s, int env0, int n)
+{
+    const Geo &g = s->g;
+    hipLaunchKernelGGL(k_rebuild_tflags, dim3(g.TX, g.TY, n), dim3(64), 0, s->stream, g, (const uint8_t *)s->status,
+                       (const uint8_t *)s->age, s->tflags, s->ring, env0);
+    HIPCHK(hipGetLastError());
+    return SF_OK;
+}
+
 extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
 {
     if (!s || rows < 1 || rows > 4096) return fail(SF_EINVAL, "sf_set_rows_per_band: rows must be in [1, 4096]");
+    HIPCHK(hipSetDevice(s->p.device));
     choose_rows_per_band(s->g, rows);
+    // the tile activity map is laid out per wave tile: rebuild it for the new geometry
+    HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
+    if (s->was_reset) {
+        int rc = rebuild_tflags(s, 0, s->g.E);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+/* 1 = visit every tile every step (cross-check of the tile activity map), 0 = default */
+extern "C" int sf_set_dense(sf_sim *s, int32_t dense)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_dense: null handle");
+    s->g.dense = dense != 0;
     return SF_OK;
 }
 
@@ -982,8 +1141,11 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     int rc = ensure_stage(s, (size_t)n * 2 * sizeof(int32_t));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->stage, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    const size_t fplane = (size_t)g.TYp * g.TXp;
+    for (int k = 0; k < 3; ++k)
+        HIPCHK(hipMemsetAsync(s->tflags + ((size_t)k * g.E + env0) * fplane, 0, (size_t)n * fplane, s->stream));
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
-                       (const int32_t *)s->stage, env0, n);
+                       s->tflags, s->ring, (const int32_t *)s->stage, env0, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
@@ -1047,7 +1209,8 @@ extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
     HIPCHK(hipMemcpyAsync(s->pts_dev, sorted.data(), (size_t)4 * m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->seg_dev, seg.data(), ((size_t)nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_mitigate, dim3(nseg), dim3(256), 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
-                       (const EnvState *)s->commit, (const int32_t *)s->pts_dev, (const int32_t *)s->seg_dev);
+                       (const EnvState *)s->commit, (const int32_t *)s->pts_dev, (const int32_t *)s->seg_dev, s->tflags,
+                       s->ring);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));   // host vectors go out of scope
     return SF_OK;
@@ -1071,6 +1234,8 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     HIPCHK(hipMemcpyAsync(s->stage, map, n, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_pack_status, grd, blk, 0, s->stream, g, s->status, env, (const uint8_t *)s->stage);
     HIPCHK(hipGetLastError());
+    rc = rebuild_tflags(s, env, 1);   // control lines may now sit in any tile
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
@@ -1089,11 +1254,14 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     { const char *dbg = getenv("SF_DEBUG_CUT"); a.debug = dbg ? atoi(dbg) : 0; }
     const dim3 grid((unsigned)(s->g.tiles_per_env * s->g.E)), block(kWaves * 64);
-    const StepKernel kern = pick_step_kernel(s->g.RB, s->g.LC == 64);
+    const StepKernel kern = pick_step_kernel(s->g.RB);
+    a.tflags = s->tflags;
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int i = 0; i < n_steps; ++i) {
         a.launch = i;
-        hipLaunchKernelGGL(kern, grid, block, 0, s->stream, a);
+        a.ring = s->ring;
+        hipLaunchKernelGGL(kern, grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
+        s->ring = (s->ring + 1) % 3;
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,

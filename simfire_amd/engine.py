@@ -154,6 +154,10 @@ class FireEngine:
     def set_rows_per_band(self, rows):
         _lib.check(self._L.sf_set_rows_per_band(self._h, int(rows)))
 
+    def set_dense(self, dense=True):
+        """Visit every tile every step (cross-check of the tile activity map)."""
+        _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))
+
     def status_device_ptr(self):
         """Device address of the int32 [E, 8] result block (after ``update_status_device``)."""
         p = C.c_void_p()

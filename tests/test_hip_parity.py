@@ -394,3 +394,16 @@ def test_idempotent_after_quit_and_checksum():
     eng.step(10)
     st2, el2 = eng.status()
     assert (st2 == st).all() and el2[0] == el[0] and (eng.fire_map(0) == m).all()
+
+
+@pytest.mark.parametrize("name", ["g3_lines_a1", "g4_lines_on_burning", "g2_mixed_a0d0"])
+def test_dense_mode_equals_tile_skipping(name):
+    """The tile activity map is an optimisation only: visiting every tile gives the same bits."""
+    d = _golden.load_traj(name)
+    for dense in (True, False):
+        eng = _engine(d)
+        eng.set_dense(dense)
+        eng.set_rtable(d["rtable"])
+        eng.reset([d["init_pos"]])
+        _golden.replay(eng, d, check_each_step=False)
+        assert (eng.burn(0) == d["burn"]).all()
