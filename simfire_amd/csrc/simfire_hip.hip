@@ -118,8 +118,10 @@ struct StepArgs {
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
     uint32_t *flags;     // [3][E] ring
     unsigned long long *counters;   // [kCounterShards][8]: active cell-updates, ignitions, frontier items; null = off
-    uint8_t *tflags;     // [3][E][TYp][TXp] tile activity ring: bit0 = tile holds sprites, bit1 = tile holds control lines
-    int ring;            // ring slot read by this launch; (ring + 1) % 3 is written, (ring + 2) % 3 cleared
+    uint8_t *tflags;     // [2][E][TYp][TXp] tile activity maps: bit0 = tile holds sprites, bit1 = tile holds control lines
+    int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
+    uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
+    uint32_t *n_active;  // its length
     int launch;          // index of this launch inside one sf_step call
     int debug;           // SF_DEBUG_CUT: bisect kernel cost (0 = normal)
 };
@@ -250,73 +252,114 @@ __device__ __forceinline__ int pick_winner(uint32_t up3, uint32_t mid3, uint32_t
     return bestk;
 }
 
-// One step of every environment.
-//   RB   rows per lane band (compile time: the RB + 2 window rows live in registers and are all
-//        requested before any of them is used)
-// A wave owns a tile of LC x 16 cells by LR x RB rows (128 x 32 for large grids).  It first looks
-// at the activity flags of its 3 x 3 tile neighbourhood: if no tile there holds a sprite (and
-// its own tile holds no control line while attenuation is on) nothing in the tile can change in
-// this step and the wave retires without touching the cell planes.
-// Dynamic LDS, per wave: frontier list [kListCap] u32, then the staged age tile
+// ------------------------------------------------------------------------------------------
+// One step = two launches.
+//
+// k_select  (one thread per wave tile): folds the per-environment predicates of the previous
+//   step into the environment state, looks at the activity flags of the tile's 3 x 3 tile
+//   neighbourhood and appends the tile to the active list if anything in it can change in this
+//   step: some tile of the neighbourhood holds a sprite, or (attenuation on) the tile itself
+//   holds a control line.  A wave ballot + one atomic per workgroup allocate the list slots.
+//   It also zeroes the "next" flag map, which k_step then fills for the tiles it visits.
+// k_step    (persistent waves, grid-stride over the active list): the actual update of a tile.
+//   RB = rows per lane band (compile time: the RB + 2 age rows and RB status rows of a lane live
+//   in registers and are all requested before any of them is used).  A wave tile is LC x 16
+//   cells by LR x RB rows (128 x 32 for large grids).
+// Dynamic LDS of k_step, per wave: frontier list [kListCap] u32, then the staged age tile
 // [LR][RB + 2][LC * 16 + 32] bytes (16 pad bytes either side of a row hold the seam columns).
-template <int RB>
-__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArgs a)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select(StepArgs a)
 {
-    extern __shared__ uint4 s_dyn[];
+    __shared__ uint32_t s_base, s_wsum[4];
     const Geo &g = a.g;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int e = bid / (uint32_t)g.tiles_per_env;
-    const int tile = bid - e * g.tiles_per_env;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = tile % g.chunks_x, ty = tile / g.chunks_x;
-    const int LC = g.LC, LR = g.LR;
-    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
-    const int cv = chunk * LC + c;
-    const bool col_ok = cv < g.PV;
-    const int tyw = ty * kWaves + wave;                // wave tile row
-    const int yw = tyw * LR * RB;                      // first row of this wave's tile
-    const int y0 = yw + r * RB;                        // first row of this lane's band
-
-    // ---- tile activity: lanes 0..8 fetch the flags of the 3 x 3 tile neighbourhood
-    const long long fplane = (long long)g.TYp * g.TXp;
-    uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
-    uint8_t *f_wr = a.tflags + ((long long)((a.ring + 1) % 3) * g.E + e) * fplane;
-    uint8_t *f_cl = a.tflags + ((long long)((a.ring + 2) % 3) * g.E + e) * fplane;
-    const long long f_own = (long long)(tyw + 1) * g.TXp + (chunk + 1);
-    const bool tile_ok = tyw < g.TY;
-    uint32_t fl = 0;
-    if (lane < 9 && tile_ok) fl = f_rd[f_own + (lane / 3 - 1) * g.TXp + (lane % 3 - 1)];
+    const int per_env = g.TY * g.TX;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = gid < (long long)g.E * per_env;
+    const int e = valid ? (int)(gid / per_env) : 0;
+    const int tile = valid ? (int)(gid - (long long)e * per_env) : 0;
+    const int tyw = tile / g.TX, tx = tile - tyw * g.TX;
 
     // environment state entering this step (folded from the previous launch's flags)
     EnvState st;
     if (a.launch == 0) st = a.commit[e];
     else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
-    if (tile == 0 && threadIdx.x == 0) {
+    if (valid && tile == 0) {
         a.tmp[(a.launch & 1) * g.E + e] = st;
         a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
     }
-    if (!tile_ok) return;
-    const uint32_t own_fl = __shfl(fl, 4);
-    if (lane == 0) f_cl[f_own] = 0;                    // recycle the ring slot after the next one
-    if (!st.running) {                                 // frozen: carry the flags forward unchanged
-        if (lane == 0 && own_fl) f_wr[f_own] = (uint8_t)own_fl;
-        return;
+
+    bool active = false;
+    if (valid) {
+        const long long fplane = (long long)g.TYp * g.TXp;
+        const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+        uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
+        const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
+        uint32_t any0 = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) any0 |= f_rd[o + dy * g.TXp + dx];
+        const uint32_t own = f_rd[o];
+        // frozen environments keep their flags (nothing reads them until the next reset)
+        f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
+        active = st.running && (g.dense || (any0 & 1u) || (g.att && (own & 2u)));
     }
-    const bool tile_active = g.dense || __ballot(fl & 1u) != 0ull || (g.att && (own_fl & 2u));
-    if (!tile_active) return;                          // own flags are 0: nothing to carry forward
-    if (a.debug == 1) return;
+    // compact: ballot -> rank inside the wave, one atomic per workgroup
+    const unsigned long long bal = __ballot(active);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        s_base = tot ? atomicAdd(a.n_active, tot) : 0u;
+    }
+    __syncthreads();
+    if (active) {
+        uint32_t off = s_base + rank;
+        for (int w = 0; w < wave; ++w) off += s_wsum[w];
+        a.tile_list[off] = (uint32_t)gid;
+    }
+}
+
+template <int RB>
+__device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
+                                          uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
+                                          uint32_t &n_items_acc, uint32_t &n_phase2)
+{
+    const Geo &g = a.g;
+    const int LC = g.LC, LR = g.LR;
+    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
+    const int cv = chunk * LC + c;
+    const bool col_ok = cv < g.PV;
+    const int yw = tyw * LR * RB;                      // first row of this wave's tile
+    const int y0 = yw + r * RB;                        // first row of this lane's band
 
     uint8_t *age_e = a.age + (long long)e * g.age_env;
     uint8_t *st_e = a.status + (long long)e * g.plane_env;
 
-    // ---- request the whole register window: rows y0-1 .. y0+RB (zero guard rows at -1 and H)
-    uint4 rows[RB + 2];
+    // ---- request everything the tile needs in one go: RB + 2 age rows (zero guard rows at -1
+    // and H), the seam columns, RB status rows
+    uint4 rows[RB + 2], sraw[RB];
     const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
 #pragma unroll
     for (int k = 0; k < RB + 2; ++k) {
         rows[k] = make_uint4(0, 0, 0, 0);
         if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
+    }
+    // seams (rows wider than the wave tile): the column just outside the tile
+    uint32_t seam[RB + 2];
+    const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
+    const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
+#pragma unroll
+    for (int k = 0; k < RB + 2; ++k) {
+        seam[k] = 0;
+        if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        sraw[i] = make_uint4(0, 0, 0, 0);
+        if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
     }
 
     const int t = st.steps + 1;
@@ -325,49 +368,21 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
     const int exp_sh = __ffs(mk.b_exp) - 1;
 
-    // chunk seams (rows wider than one wave, W > 1024): the column just outside the chunk
-    uint32_t seam[RB + 2];
-    const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
-    const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
-    if (g.chunks_x > 1) {
-#pragma unroll
-        for (int k = 0; k < RB + 2; ++k) {
-            uint32_t v = 0;
-            if ((seam_l || seam_r) && y0 - 1 + k <= g.H) v = win[k * g.P + (seam_l ? -1 : 16)];
-            seam[k] = v;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < RB + 2; ++k) seam[k] = 0;
-    }
-
-    // ---- quick reject: nothing alive, expiring or recyclable anywhere near this wave's band
-    uint32_t hot = 0;
-#pragma unroll
-    for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
-    hot &= (L4 | EXP4 | CLR4);
-    // does the tile itself hold any sprite bit that survives this step's slot recycling?
+    // tile activity for the next step, part 1: sprite bits that survive this step's recycling
     uint32_t keep = 0;
 #pragma unroll
     for (int k = 1; k <= RB; ++k) keep |= any4(rows[k]);
     keep &= ~CLR4;
     const bool tile_has_sprites = __ballot(keep != 0) != 0ull;
-    if (!g.att && __ballot(hot != 0) == 0ull) {
-        if (lane == 0 && tile_has_sprites) f_wr[f_own] = 1;   // unreachable in practice (hot covers keep)
-        return;
-    }
-    if (a.debug == 3) return;
+    const long long fplane = (long long)g.TYp * g.TXp;
+    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
 
-    // ---- this wave is near the fire ---------------------------------------------------
     const int row_pitch = LC * 16 + 32;
-    uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
     uint32_t *s_list = reinterpret_cast<uint32_t *>(lds_wave);
     uint8_t *tile_lds = lds_wave + kListCap * 4;
-    bool staged = false;
-
-    uint32_t live_acc = 0, n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, line_acc = 0;
+    bool staged = false, cand_seen = false, ignited = false;
+    uint32_t live_acc = 0, line_acc = 0;
     uint32_t pend = 0;         // wave-uniform occupancy of the list (exact)
-    bool cand_seen = false;
 
     // phase 2: the whole wave walks its compacted frontier, one cell per lane.
     // item = row in band (5) | owner lane (6) << 5 | cell in vector (4) << 11 | status before the
@@ -390,7 +405,6 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // phase-1 stores of this wave must land before the byte stores below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (a.debug != 5)
         for (uint32_t j = lane; j < pend; j += 64) {
             const uint32_t it = s_list[j];
             const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
@@ -428,6 +442,7 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
                 bn = bn + ros;                                                   // fire.py:710
                 if (bn > g.pixel_scale) {                                        // fire.py:568
                     n_ignite++;
+                    ignited = true;
                     a.status[cell] = (uint8_t)SF_BURNING;                        // fire.py:587
                     const uint32_t own = (mid3 >> 8) & 0xFFu;
                     age_e[idx] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);        // fire.py:571-579
@@ -441,59 +456,40 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
         pend = 0;
     };
 
-    // per row: OR of the live masks of the (4 or 8) neighbours of each of the lane's 16 cells
-    auto neighbours = [&](int i) -> uint4 {
+    // ---- phase 1: per row, SWAR over the lane's 16 cells: prune, find the frontier cells,
+    // compact them into the wave's LDS list
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int y = y0 + i;
         const uint4 up = rows[i], mid = rows[i + 1], dn = rows[i + 2];
         const uint4 midL = and4(mid, L4);
         const uint4 vsrc = and4(or4(up, dn), L4);
         const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+        live_acc |= any4(midL);
         // horizontal neighbours: byte from the lane to the left / right (same band)
         uint32_t lin = from_left(hsrc.w, c, LC) >> 24;
         uint32_t rin = from_right(hsrc.x, c, LC) & 0xFFu;
         const uint32_t sv = (g.diag ? (seam[i] | seam[i + 1] | seam[i + 2]) : seam[i + 1]) & mk.m_live;
         if (seam_l) lin = sv;
         if (seam_r) rin = sv;
-        uint4 nb;
+        uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
         nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
         nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
         nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
         nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
-        return nb;
-    };
 
-    // ---- phase 1a: which status vectors are needed?  Request them all before using any.
-    uint4 sraw[RB];
-    uint32_t need = 0;
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int y = y0 + i;
-        const uint4 mid = rows[i + 1];
-        const uint4 nb = neighbours(i);
-        live_acc |= any4(and4(mid, L4));
-        const uint32_t any_exp = any4(and4(mid, EXP4)), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+        const uint4 ex4 = and4(mid, EXP4);
+        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
         const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
-        sraw[i] = make_uint4(0, 0, 0, 0);
-        if (col_ok && y < g.H) {
-            if (any_clr)   // recycle the slot of sprites that were pruned one step ago
-                *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
-            if (any_exp | any_nb | (uint32_t)g.att) {
-                need |= 1u << i;
-                sraw[i] = *reinterpret_cast<const uint4 *>(st_e + voff);
-            }
-        }
-    }
+        const bool row_ok = col_ok && y < g.H;
+        if (row_ok && any_clr)   // recycle the slot of sprites that were pruned one step ago
+            *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
+        const bool lane_need = row_ok && (any_exp | any_nb | (uint32_t)g.att);
+        if (__ballot(lane_need) == 0ull) continue;
 
-    // ---- phase 1b: prune, find the frontier cells, compact them into the wave's LDS list
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int y = y0 + i;
-        const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
         uint32_t m16 = 0;
         uint4 em = make_uint4(0, 0, 0, 0);
-        if (need & (1u << i)) {
-            const uint4 mid = rows[i + 1];
-            const uint4 nb = neighbours(i);
-            const uint4 ex4 = and4(mid, EXP4);
+        if (lane_need) {
             const uint4 s7 = and4(sraw[i], 0x07070707u);
             // S1 prune: cells whose sprite reached max_fire_duration become BURNED
             em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
@@ -523,7 +519,6 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
             const int xs = cv * 16;
             if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
         }
-        if (a.debug == 6) m16 = 0;
         if (__ballot(m16 != 0) == 0ull) continue;
         // Wave-level compaction without LDS atomics: for every cell position b one ballot gives
         // both the slot of each lane's item (mbcnt = popcount of the lower lanes) and the running
@@ -556,10 +551,10 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     // tile activity for the next step: sprites left in the tile or ignited in it; control lines
     // (a line cell that ignited this step is seen one step late - harmless, it is re-evaluated)
     {
-        const bool ign = __ballot(n_ignite != 0) != 0ull;
+        const bool ign = __ballot(ignited) != 0ull;
         const bool lines = g.att && __ballot(line_acc != 0) != 0ull;
         const uint32_t nf = ((tile_has_sprites || ign) ? 1u : 0u) | (lines ? 2u : 0u);
-        if (lane == 0 && nf) f_wr[f_own] = (uint8_t)nf;
+        if (lane == 0 && nf) *f_own = (uint8_t)nf;
     }
     // per-environment predicates: wave ballot, then at most one atomic per wave
     const bool w_live = __ballot(live_acc != 0) != 0ull;
@@ -570,22 +565,40 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
         const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((have & want) != want) atomicOr(f, want);
     }
-    // optional statistics for the roofline accounting (active cell-updates = phi * cells)
-    if (a.counters && lane == 0) {
-        unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
-        atomicAdd(&cs[3], 1ull);                 // wavefronts that survived the quick reject
-        if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
+}
+
+template <int RB>
+__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
+    const uint32_t n_tiles = *a.n_active;
+    const int per_env = g.TY * g.TX;
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_tiles_done = 0;
+    for (uint32_t j = blockIdx.x * kWaves + wave; j < n_tiles; j += gridDim.x * kWaves) {
+        const uint32_t gid = a.tile_list[j];
+        const int e = gid / (uint32_t)per_env;
+        const int tile = gid - e * per_env;
+        const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
+        const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // already folded by k_select
+        step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2);
+        n_tiles_done++;
     }
-    if (a.counters && __ballot(n_active != 0) != 0ull) {
+    // optional statistics for the roofline accounting (active cell-updates = phi * cells)
+    if (a.counters && n_tiles_done) {
         for (int off = 32; off > 0; off >>= 1) {
             n_active += __shfl_down(n_active, off);
             n_ignite += __shfl_down(n_ignite, off);
         }
         if (lane == 0) {
             unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
-            atomicAdd(&cs[0], (unsigned long long)n_active);
+            if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
             if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
-            atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+            if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+            atomicAdd(&cs[3], (unsigned long long)n_tiles_done);   // wave tiles visited
+            if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
         }
     }
 }
@@ -644,7 +657,7 @@ __global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *sta
     const bool a_any = __ballot(has_age != 0) != 0ull, l_any = __ballot(has_line != 0) != 0ull;
     if (threadIdx.x == 0) {
         const long long o = (long long)(tyw + 1) * g.TXp + tx + 1, plane = (long long)g.TYp * g.TXp;
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 2; ++k)
             tflags[((long long)k * g.E + e) * plane + o] = (k == ring) ? (uint8_t)((a_any ? 1 : 0) | ((g.att && l_any) ? 2 : 0)) : 0;
     }
 }
@@ -883,7 +896,9 @@ struct sf_sim {
     unsigned long long *counters = nullptr;
     uint8_t *tflags = nullptr;
     size_t tflags_bytes = 0;
-    int ring = 0;                      // tile-flag ring slot the next step launch reads
+    int ring = 0;                      // tile activity map the next step reads (0/1)
+    uint32_t *tile_list = nullptr, *n_active = nullptr;
+    int n_cu = 256;
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -986,8 +1001,11 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->tmp, (size_t)2 * g.E));
     TRY(dev_alloc(s, &s->flags, (size_t)3 * g.E));
     TRY(dev_alloc(s, &s->counters, (size_t)kCounterShards * 8));
-    s->tflags_bytes = (size_t)3 * g.E * ((size_t)(g.H + g.LR - 1) / g.LR + 2) * (g.chunks_x + 2) + 64;
+    s->tflags_bytes = (size_t)2 * g.E * ((size_t)(g.H + g.LR - 1) / g.LR + 2) * (g.chunks_x + 2) + 64;
     TRY(dev_alloc(s, &s->tflags, s->tflags_bytes));
+    TRY(dev_alloc(s, &s->tile_list, (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x));
+    TRY(dev_alloc(s, &s->n_active, (size_t)16));
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) s->n_cu = prop.multiProcessorCount; }
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
 #undef TRY
@@ -1009,7 +1027,7 @@ extern "C" int sf_destroy(sf_sim *s)
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
-                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags,
+                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
                     s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->seg_dev};
     for (void *p : ptrs) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -1142,7 +1160,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->stage, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
     const size_t fplane = (size_t)g.TYp * g.TXp;
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 2; ++k)
         HIPCHK(hipMemsetAsync(s->tflags + ((size_t)k * g.E + env0) * fplane, 0, (size_t)n * fplane, s->stream));
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
                        s->tflags, s->ring, (const int32_t *)s->stage, env0, n);
@@ -1253,15 +1271,23 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     { const char *dbg = getenv("SF_DEBUG_CUT"); a.debug = dbg ? atoi(dbg) : 0; }
-    const dim3 grid((unsigned)(s->g.tiles_per_env * s->g.E)), block(kWaves * 64);
+    const dim3 block(kWaves * 64);
     const StepKernel kern = pick_step_kernel(s->g.RB);
-    a.tflags = s->tflags;
+    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active;
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+    const long long n_wave_tiles = (long long)s->g.E * s->g.TY * s->g.TX;
+    const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
+    // persistent step waves: enough workgroups to fill the chip, never more than there are tiles
+    long long want = (long long)s->n_cu * 4;
+    if (want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
+    const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
     for (int i = 0; i < n_steps; ++i) {
         a.launch = i;
         a.ring = s->ring;
-        hipLaunchKernelGGL(kern, grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
-        s->ring = (s->ring + 1) % 3;
+        HIPCHK(hipMemsetAsync(s->n_active, 0, sizeof(uint32_t), s->stream));
+        hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
+        hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
+        s->ring ^= 1;
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
