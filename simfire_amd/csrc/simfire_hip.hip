@@ -80,8 +80,11 @@ namespace {
 #ifndef SF_WAVES_PER_SIMD
 #define SF_WAVES_PER_SIMD 1
 #endif
-constexpr int kWaves = 4;          // waves per workgroup (256 threads)
-constexpr int kListCap = 512;      // per-wave frontier list; half a wave adds at most 32 x 16 cells at a time
+#ifndef SF_WAVES_PER_GROUP
+#define SF_WAVES_PER_GROUP 1
+#endif
+constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each wave works on its own tiles)
+constexpr int kListCap = 1024;     // per-wave frontier list: one row of a wave (64 lanes x 16 cells) always fits
 constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
 constexpr uint32_t FLAG_CAND = 2u; // some sprite has a cell to spread into     (fire.py:651)
@@ -294,15 +297,16 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
         const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
         uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
         const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
-        uint32_t any0 = 0;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) any0 |= f_rd[o + dy * g.TXp + dx];
+        // flag bits: 0 sprites anywhere, 1 control lines, 2 / 3 sprites in the top / bottom row,
+        // 4 / 5 sprites in the left / right column of the tile
         const uint32_t own = f_rd[o];
+        const uint32_t up = f_rd[o - g.TXp], dn = f_rd[o + g.TXp], lf = f_rd[o - 1], rt = f_rd[o + 1];
+        const uint32_t ul = f_rd[o - g.TXp - 1], ur = f_rd[o - g.TXp + 1], dl = f_rd[o + g.TXp - 1], dr = f_rd[o + g.TXp + 1];
+        const bool near = (own & 1u) || (up & 8u) || (dn & 4u) || (lf & 32u) || (rt & 16u) ||
+                          ((ul & 40u) == 40u) || ((ur & 24u) == 24u) || ((dl & 36u) == 36u) || ((dr & 20u) == 20u);
         // frozen environments keep their flags (nothing reads them until the next reset)
         f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
-        active = st.running && (g.dense || (any0 & 1u) || (g.att && (own & 2u)));
+        active = st.running && (g.dense || near || (g.att && (own & 2u)));
     }
     // compact: ballot -> rank inside the wave, one atomic per workgroup
     const unsigned long long bal = __ballot(active);
@@ -312,7 +316,8 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-        s_base = tot ? atomicAdd(a.n_active, tot) : 0u;
+        s_base = tot ? atomicAdd(&a.n_active[a.launch & 1], tot) : 0u;
+        if (blockIdx.x == 0) a.n_active[(a.launch + 1) & 1] = 0;   // counter of the next step
     }
     __syncthreads();
     if (active) {
@@ -322,6 +327,81 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     }
 }
 
+struct WalkAcc {
+    uint32_t n_active, n_ignite, cand, edges;   // edges: tile flag bits 0, 2..5 set by ignitions
+};
+__device__ __forceinline__ void acc_merge(WalkAcc &t, const WalkAcc &w)
+{
+    t.n_active += w.n_active; t.n_ignite += w.n_ignite; t.cand |= w.cand; t.edges |= w.edges;
+}
+
+// Phase 2: the whole wave walks the compacted frontier of its tile, one cell per lane.
+// item = row in band (5) | owner lane (6) << 5 | cell in vector (4) << 11 | status before the
+//        prune (3) << 15 | settled << 18 | expired << 19
+template <int RB>
+__device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, bool spread,
+                                             int prev_flag, const uint8_t *tile_lds, const uint32_t *s_list,
+                                             uint32_t pend, int lane)
+{
+    const Geo &g = a.g;
+    const int LC = g.LC, row_pitch = LC * 16 + 32;
+    uint8_t *age_e = a.age + (long long)e * g.age_env;
+    WalkAcc acc = {0u, 0u, 0u, 0u};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // phase-1 stores of this wave must land before the byte stores below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t j = lane; j < pend; j += 64) {
+        const uint32_t it = s_list[j];
+        const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
+        const uint32_t s_pre = (it >> 15) & 7u;
+        const bool settled = (it >> 18) & 1u, expired = (it >> 19) & 1u;
+        const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
+        const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
+        const uint32_t idx = (uint32_t)(y * g.P + x);
+        const long long cell = (long long)e * g.plane_env + idx;
+        double bn = a.burn[cell];     // requested first: the LDS work below hides part of it
+        // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
+        const uint8_t *q = tile_lds + (orr * (RB + 2) + i) * row_pitch + 16 + oc * 16 + b - 1;
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
+        const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
+        const uint32_t *qb = reinterpret_cast<const uint32_t *>(q - sh + row_pitch);
+        const uint32_t *qc = reinterpret_cast<const uint32_t *>(q - sh + 2 * row_pitch);
+        const uint32_t up3 = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh);
+        const uint32_t mid3 = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh);
+        const uint32_t dn3 = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh);
+        bool prev_any;
+        const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag, prev_any);
+        const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
+        const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
+        const bool is_cand = spread && eligible && bestk >= 0;
+        // attenuation of the previous step that was deferred (a line cell, not a candidate then)
+        const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && prev_flag && !prev_any;
+        if (!(is_cand || pending)) continue;
+        acc.n_active++;
+        if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
+        if (is_cand) {
+            acc.cand = 1;
+            double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+            if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
+                ros = g.att ? ros - line_factor(s_post) : 0.0;
+            bn = bn + ros;                                                   // fire.py:710
+            if (bn > g.pixel_scale) {                                        // fire.py:568
+                acc.n_ignite++;
+                acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
+                             ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
+                a.status[cell] = (uint8_t)SF_BURNING;                        // fire.py:587
+                const uint32_t own = (mid3 >> 8) & 0xFFu;
+                age_e[idx] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);        // fire.py:571-579
+            }
+        }
+        a.burn[cell] = bn;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return acc;
+}
 template <int RB>
 __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
                                           uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
@@ -338,206 +418,187 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     uint8_t *age_e = a.age + (long long)e * g.age_env;
     uint8_t *st_e = a.status + (long long)e * g.plane_env;
 
-    // ---- request everything the tile needs in one go: RB + 2 age rows (zero guard rows at -1
-    // and H), the seam columns, RB status rows
-    uint4 rows[RB + 2], sraw[RB];
-    const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
-#pragma unroll
-    for (int k = 0; k < RB + 2; ++k) {
-        rows[k] = make_uint4(0, 0, 0, 0);
-        if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
-    }
-    // seams (rows wider than the wave tile): the column just outside the tile
-    uint32_t seam[RB + 2];
-    const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
-    const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
-#pragma unroll
-    for (int k = 0; k < RB + 2; ++k) {
-        seam[k] = 0;
-        if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        sraw[i] = make_uint4(0, 0, 0, 0);
-        if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
-    }
-
     const int t = st.steps + 1;
     const Masks mk = make_masks(t, g.md, g.N);
     const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
     const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
     const int exp_sh = __ffs(mk.b_exp) - 1;
 
-    // tile activity for the next step, part 1: sprite bits that survive this step's recycling
-    uint32_t keep = 0;
-#pragma unroll
-    for (int k = 1; k <= RB; ++k) keep |= any4(rows[k]);
-    keep &= ~CLR4;
-    const bool tile_has_sprites = __ballot(keep != 0) != 0ull;
-    const long long fplane = (long long)g.TYp * g.TXp;
-    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
-
+    // LDS of this wave: frontier list | age tile [LR][RB + 2][LC * 16 + 32] | status tile [LR][RB][LC * 16]
     const int row_pitch = LC * 16 + 32;
     uint32_t *s_list = reinterpret_cast<uint32_t *>(lds_wave);
     uint8_t *tile_lds = lds_wave + kListCap * 4;
-    bool staged = false, cand_seen = false, ignited = false;
+    uint8_t *stat_lds = tile_lds + LR * (RB + 2) * row_pitch;
+    uint8_t *band_lds = tile_lds + r * (RB + 2) * row_pitch;
+    uint8_t *band_st = stat_lds + (r * RB) * (LC * 16);
+    uint32_t tile_flags;
+    {
+        // ---- request everything the tile needs in one go: RB + 2 age rows (zero guard rows at
+        // -1 and H), the seam columns, RB status rows; then park it all in LDS
+        uint4 rows[RB + 2], sraw[RB];
+        const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            rows[k] = make_uint4(0, 0, 0, 0);
+            if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
+        }
+        // seams (rows wider than the wave tile): the column just outside the tile
+        uint32_t seam[RB + 2];
+        const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
+        const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            seam[k] = 0;
+            if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            sraw[i] = make_uint4(0, 0, 0, 0);
+            if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
+        }
+
+        // ---- quick reject: nothing alive, expiring or recyclable in or next to this tile
+        uint32_t hot = 0;
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
+        if (!g.att && __ballot(hot != 0) == 0ull) return;
+
+        // tile activity for the next step, part 1: sprite bits that survive this step's recycling,
+        // overall and along the four tile edges (a neighbour tile only has to look if they are set)
+        uint32_t keep = 0, e_lft = 0, e_rgt = 0;
+#pragma unroll
+        for (int k = 1; k <= RB; ++k) {
+            keep |= any4(rows[k]);
+            e_lft |= rows[k].x & 0xFFu;
+            e_rgt |= rows[k].w >> 24;
+        }
+        keep &= ~CLR4;
+        const uint32_t e_top = (r == 0) ? (any4(rows[1]) & ~CLR4) : 0u;
+        const uint32_t e_bot = (r == LR - 1) ? (any4(rows[RB]) & ~CLR4) : 0u;
+        e_lft = (c == 0) ? (e_lft & ~mk.b_clr) : 0u;
+        e_rgt = (c == LC - 1) ? (e_rgt & ~mk.b_clr) : 0u;
+        tile_flags = (__ballot(keep != 0) ? 1u : 0u) | (__ballot(e_top != 0) ? 4u : 0u) |
+                     (__ballot(e_bot != 0) ? 8u : 0u) | (__ballot(e_lft != 0) ? 16u : 0u) |
+                     (__ballot(e_rgt != 0) ? 32u : 0u);
+
+        // ---- stage: everything below works out of LDS, so the registers above die here
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            uint8_t *rp = band_lds + k * row_pitch;
+            *reinterpret_cast<uint4 *>(rp + 16 + c * 16) = rows[k];
+            if (c == 0) rp[15] = (uint8_t)(seam_l ? seam[k] : 0u);
+            if (c == LC - 1) rp[16 + LC * 16] = (uint8_t)(seam_r ? seam[k] : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = sraw[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const long long fplane = (long long)g.TYp * g.TXp;
+    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
+    WalkAcc tot_acc = {0u, 0u, 0u, 0u};
     uint32_t live_acc = 0, line_acc = 0;
     uint32_t pend = 0;         // wave-uniform occupancy of the list (exact)
 
-    // phase 2: the whole wave walks its compacted frontier, one cell per lane.
-    // item = row in band (5) | owner lane (6) << 5 | cell in vector (4) << 11 | status before the
-    //        prune (3) << 15 | settled << 18 | expired << 19
-    auto walk = [&]() {
-        n_phase2++;
-        if (!staged) {   // stage the wave's age tile in LDS: the 3x3 neighbourhoods are read from it
-            staged = true;
-            uint8_t *band_lds = tile_lds + r * (RB + 2) * row_pitch;
-#pragma unroll
-            for (int k = 0; k < RB + 2; ++k) {
-                uint8_t *rp = band_lds + k * row_pitch;
-                *reinterpret_cast<uint4 *>(rp + 16 + c * 16) = rows[k];
-                if (c == 0) rp[15] = (uint8_t)(seam_l ? seam[k] : 0u);
-                if (c == LC - 1) rp[16 + LC * 16] = (uint8_t)(seam_r ? seam[k] : 0u);
+    // ---- phase 1: per row, SWAR over the lane's 16 cells: prune, find the frontier cells and
+    // compact them into the wave's list; the list is walked (phase 2) after the last row, or
+    // earlier if it cannot take the next row.  A real loop: one copy of the row code and of the
+    // walk, few live registers, everything read from LDS.
+#pragma unroll 1
+    for (int i = 0; i <= RB; ++i) {
+        uint32_t m16 = 0, row_tot = 0;
+        uint4 sr = make_uint4(0, 0, 0, 0), em = make_uint4(0, 0, 0, 0);
+        if (i < RB) {
+            const int y = y0 + i;
+            const uint8_t *rp = band_lds + i * row_pitch + 16 + c * 16;
+            const uint4 up = *reinterpret_cast<const uint4 *>(rp);
+            const uint4 mid = *reinterpret_cast<const uint4 *>(rp + row_pitch);
+            const uint4 dn = *reinterpret_cast<const uint4 *>(rp + 2 * row_pitch);
+            const uint4 midL = and4(mid, L4);
+            const uint4 vsrc = and4(or4(up, dn), L4);
+            const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+            live_acc |= any4(midL);
+            // horizontal neighbours: the bytes just left / right of the lane's 16 cells (the
+            // neighbour lane's data, or the seam column parked in the row padding)
+            uint32_t lin = rp[row_pitch - 1], rin = rp[row_pitch + 16];
+            if (g.diag) {
+                lin |= (uint32_t)rp[-1] | (uint32_t)rp[2 * row_pitch - 1];
+                rin |= (uint32_t)rp[16] | (uint32_t)rp[2 * row_pitch + 16];
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // phase-1 stores of this wave must land before the byte stores below
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t j = lane; j < pend; j += 64) {
-            const uint32_t it = s_list[j];
-            const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
-            const uint32_t s_pre = (it >> 15) & 7u;
-            const bool settled = (it >> 18) & 1u, expired = (it >> 19) & 1u;
-            const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
-            const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
-            const uint32_t idx = (uint32_t)(y * g.P + x);
-            const long long cell = (long long)e * g.plane_env + idx;
-            double bn = a.burn[cell];     // requested first: the LDS work below hides part of it
-            // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
-            const uint8_t *q = tile_lds + (orr * (RB + 2) + i) * row_pitch + 16 + oc * 16 + b - 1;
-            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
-            const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
-            const uint32_t *qb = reinterpret_cast<const uint32_t *>(q - sh + row_pitch);
-            const uint32_t *qc = reinterpret_cast<const uint32_t *>(q - sh + 2 * row_pitch);
-            const uint32_t up3 = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh);
-            const uint32_t mid3 = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh);
-            const uint32_t dn3 = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh);
-            bool prev_any;
-            const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag, prev_any);
-            const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
-            const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
-            const bool is_cand = spread && eligible && bestk >= 0;
-            // attenuation of the previous step that was deferred (a line cell, not a candidate then)
-            const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && st.prev_flag && !prev_any;
-            if (!(is_cand || pending)) continue;
-            n_active++;
-            if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
-            if (is_cand) {
-                cand_seen = true;
-                double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
-                if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
-                    ros = g.att ? ros - line_factor(s_post) : 0.0;
-                bn = bn + ros;                                                   // fire.py:710
-                if (bn > g.pixel_scale) {                                        // fire.py:568
-                    n_ignite++;
-                    ignited = true;
-                    a.status[cell] = (uint8_t)SF_BURNING;                        // fire.py:587
-                    const uint32_t own = (mid3 >> 8) & 0xFFu;
-                    age_e[idx] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);        // fire.py:571-579
+            lin &= mk.m_live;
+            rin &= mk.m_live;
+            uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
+            nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
+            nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
+            nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
+            nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
+
+            const uint4 ex4 = and4(mid, EXP4);
+            const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+            const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
+            const bool row_ok = col_ok && y < g.H;
+            if (row_ok && any_clr)   // recycle the slot of sprites that were pruned one step ago
+                *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
+            if (row_ok && (any_exp | any_nb | (uint32_t)g.att)) {
+                sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
+                const uint4 s7 = and4(sr, 0x07070707u);
+                // S1 prune: cells whose sprite reached max_fire_duration become BURNED
+                em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
+                em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
+                em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
+                em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
+                uint4 snew;
+                snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
+                snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
+                snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
+                snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
+                if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w))
+                    *reinterpret_cast<uint4 *>(st_e + voff) = snew;
+                // cells to hand to phase 2: eligible & next to a live sprite; every line cell
+                // when attenuation is on (their burn changes even away from the fire)
+                const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+                const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+                const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+                const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+                m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+                if (g.att) {
+                    m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
+                           (pack4(ge3_01(s7.w)) << 12);
+                    line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
                 }
+                // pitch padding (x >= W) never takes part
+                const int xs = cv * 16;
+                if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
             }
-            a.burn[cell] = bn;
-        }
-        n_items_acc += (lane == 0) ? pend : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        pend = 0;
-    };
-
-    // ---- phase 1: per row, SWAR over the lane's 16 cells: prune, find the frontier cells,
-    // compact them into the wave's LDS list
+            if (__ballot(m16 != 0) != 0ull) {
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int y = y0 + i;
-        const uint4 up = rows[i], mid = rows[i + 1], dn = rows[i + 2];
-        const uint4 midL = and4(mid, L4);
-        const uint4 vsrc = and4(or4(up, dn), L4);
-        const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
-        live_acc |= any4(midL);
-        // horizontal neighbours: byte from the lane to the left / right (same band)
-        uint32_t lin = from_left(hsrc.w, c, LC) >> 24;
-        uint32_t rin = from_right(hsrc.x, c, LC) & 0xFFu;
-        const uint32_t sv = (g.diag ? (seam[i] | seam[i + 1] | seam[i + 2]) : seam[i + 1]) & mk.m_live;
-        if (seam_l) lin = sv;
-        if (seam_r) rin = sv;
-        uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
-        nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
-        nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
-        nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
-        nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
-
-        const uint4 ex4 = and4(mid, EXP4);
-        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
-        const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
-        const bool row_ok = col_ok && y < g.H;
-        if (row_ok && any_clr)   // recycle the slot of sprites that were pruned one step ago
-            *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
-        const bool lane_need = row_ok && (any_exp | any_nb | (uint32_t)g.att);
-        if (__ballot(lane_need) == 0ull) continue;
-
-        uint32_t m16 = 0;
-        uint4 em = make_uint4(0, 0, 0, 0);
-        if (lane_need) {
-            const uint4 s7 = and4(sraw[i], 0x07070707u);
-            // S1 prune: cells whose sprite reached max_fire_duration become BURNED
-            em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
-            em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
-            em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
-            em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
-            uint4 snew;
-            snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
-            snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
-            snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
-            snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
-            if ((snew.x ^ sraw[i].x) | (snew.y ^ sraw[i].y) | (snew.z ^ sraw[i].z) | (snew.w ^ sraw[i].w))
-                *reinterpret_cast<uint4 *>(st_e + voff) = snew;
-            // cells to hand to phase 2: eligible & next to a live sprite; every line cell
-            // when attenuation is on (their burn changes even away from the fire)
-            const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
-            const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
-            const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
-            const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
-            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
-            if (g.att) {
-                m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
-                       (pack4(ge3_01(s7.w)) << 12);
-                line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
+                for (int b = 0; b < 16; ++b) row_tot += (uint32_t)__popcll(__ballot((m16 >> b) & 1u));
             }
-            // pitch padding (x >= W) never takes part
-            const int xs = cv * 16;
-            if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
         }
-        if (__ballot(m16 != 0) == 0ull) continue;
-        // Wave-level compaction without LDS atomics: for every cell position b one ballot gives
-        // both the slot of each lane's item (mbcnt = popcount of the lower lanes) and the running
-        // total; two passes of 8 positions so that one pass adds at most 64 x 8 = kListCap items.
+        if (i == RB || pend + row_tot > (uint32_t)kListCap) {
+            if (pend) {
+                const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.prev_flag, tile_lds, s_list, pend, lane);
+                acc_merge(tot_acc, w);
+                n_items_acc += (lane == 0) ? pend : 0u;
+                n_phase2++;
+                pend = 0;
+            }
+            if (i == RB) break;
+        }
+        if (row_tot) {
+            // Wave-level compaction without LDS atomics: for every cell position b one ballot
+            // gives the slot of each lane's item (mbcnt = popcount of the lower lanes) and the
+            // running total.
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            uint32_t tot = 0;
-#pragma unroll
-            for (int b = pass * 8; b < pass * 8 + 8; ++b) tot += (uint32_t)__popcll(__ballot((m16 >> b) & 1u));
-            if (tot == 0) continue;
-            if (pend + tot > (uint32_t)kListCap) walk();
-#pragma unroll
-            for (int b = pass * 8; b < pass * 8 + 8; ++b) {
+            for (int b = 0; b < 16; ++b) {
                 const bool has = (m16 >> b) & 1u;
                 const unsigned long long bal = __ballot(has);
                 if (has) {
                     const uint32_t pos = pend + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    const uint32_t raw = (pick(sraw[i], b >> 2) >> ((b & 3) * 8)) & 0xFFu;
+                    const uint32_t raw = (pick(sr, b >> 2) >> ((b & 3) * 8)) & 0xFFu;
                     const uint32_t exd = (pick(em, b >> 2) >> ((b & 3) * 8)) & 1u;
                     s_list[pos] = (uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11) | ((raw & 7u) << 15) |
                                   ((raw >> 7) << 18) | (exd << 19);
@@ -546,19 +607,22 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             }
         }
     }
-    if (pend) walk();
+    n_active += tot_acc.n_active;
+    n_ignite += tot_acc.n_ignite;
 
-    // tile activity for the next step: sprites left in the tile or ignited in it; control lines
-    // (a line cell that ignited this step is seen one step late - harmless, it is re-evaluated)
+    // tile activity for the next step: sprites left in the tile or ignited in it (with their
+    // edge bits); control lines (a line cell that ignited this step is seen one step late -
+    // harmless, it is re-evaluated)
     {
-        const bool ign = __ballot(ignited) != 0ull;
+        uint32_t ed = tot_acc.edges;
+        for (int off = 32; off > 0; off >>= 1) ed |= __shfl_xor(ed, off);
         const bool lines = g.att && __ballot(line_acc != 0) != 0ull;
-        const uint32_t nf = ((tile_has_sprites || ign) ? 1u : 0u) | (lines ? 2u : 0u);
+        const uint32_t nf = tile_flags | ed | (lines ? 2u : 0u);
         if (lane == 0 && nf) *f_own = (uint8_t)nf;
     }
     // per-environment predicates: wave ballot, then at most one atomic per wave
     const bool w_live = __ballot(live_acc != 0) != 0ull;
-    const bool w_cand = __ballot(cand_seen) != 0ull;
+    const bool w_cand = __ballot(tot_acc.cand != 0) != 0ull;
     if (lane == 0 && (w_live || w_cand)) {
         uint32_t *f = a.flags + (a.launch % 3) * g.E + e;
         const uint32_t want = (w_live ? FLAG_LIVE : 0u) | (w_cand ? FLAG_CAND : 0u);
@@ -574,7 +638,7 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     const Geo &g = a.g;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
-    const uint32_t n_tiles = *a.n_active;
+    const uint32_t n_tiles = a.n_active[a.launch & 1];
     const int per_env = g.TY * g.TX;
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_tiles_done = 0;
     for (uint32_t j = blockIdx.x * kWaves + wave; j < n_tiles; j += gridDim.x * kWaves) {
@@ -615,9 +679,10 @@ static StepKernel pick_step_kernel(int rb)
 }
 
 // Fold the flags of the last launch of a sf_step call into the committed state, zero the ring.
-__global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t *flags, int last_launch)
+__global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t *flags, int last_launch, uint32_t *n_active)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) { n_active[0] = 0; n_active[1] = 0; }
     if (e >= g.E) return;
     commit[e] = fold_state(tmp[(last_launch & 1) * g.E + e], flags[(last_launch % 3) * g.E + e], g);
     flags[e] = 0; flags[g.E + e] = 0; flags[2 * g.E + e] = 0;
@@ -633,7 +698,7 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
     age[(long long)e * g.age_env + (long long)y * g.P + x] = 1u;                // ignition step 0
     const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
-    tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1;
+    tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
     EnvState s;
     s.running = 1; s.steps = 0; s.prev_flag = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
@@ -658,7 +723,7 @@ __global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *sta
     if (threadIdx.x == 0) {
         const long long o = (long long)(tyw + 1) * g.TXp + tx + 1, plane = (long long)g.TYp * g.TXp;
         for (int k = 0; k < 2; ++k)
-            tflags[((long long)k * g.E + e) * plane + o] = (k == ring) ? (uint8_t)((a_any ? 1 : 0) | ((g.att && l_any) ? 2 : 0)) : 0;
+            tflags[((long long)k * g.E + e) * plane + o] = (k == ring) ? (uint8_t)((a_any ? (1 | 4 | 8 | 16 | 32) : 0) | ((g.att && l_any) ? 2 : 0)) : 0;
     }
 }
 
@@ -932,8 +997,8 @@ static void choose_rows_per_band(Geo &g, int rows)
     int rb = 1;
     while (rb * 2 <= rows && rb < 8) rb *= 2;    // the kernel is instantiated for 1, 2, 4, 8
     // staged tile per wave = LR x (RB + 2) x (LC * 16 + 32) bytes; keep a workgroup below ~60 KB
-    auto wave_bytes = [&](int r) { return kListCap * 4 + g.LR * (r + 2) * (g.LC * 16 + 32); };
-    while (rb > 1 && kWaves * wave_bytes(rb) > 60 * 1024) rb /= 2;
+    auto wave_bytes = [&](int r) { return kListCap * 4 + g.LR * (r + 2) * (g.LC * 16 + 32) + g.LR * r * g.LC * 16; };
+    while (rb > 1 && wave_bytes(rb) > 40 * 1024) rb /= 2;
     g.RB = rb;
     g.lds_wave_bytes = (wave_bytes(rb) + 15) / 16 * 16;
     const int tile_h = kWaves * g.LR * g.RB;
@@ -1011,6 +1076,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
 #undef TRY
     HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->age_alloc, 0, (size_t)g.E * g.age_env + 2 * (size_t)g.P, s->stream));
@@ -1278,20 +1344,19 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     const long long n_wave_tiles = (long long)s->g.E * s->g.TY * s->g.TX;
     const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
     // persistent step waves: enough workgroups to fill the chip, never more than there are tiles
-    long long want = (long long)s->n_cu * 4;
+    long long want = (long long)s->n_cu * 16 / kWaves;
     if (want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
     const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
     for (int i = 0; i < n_steps; ++i) {
         a.launch = i;
         a.ring = s->ring;
-        HIPCHK(hipMemsetAsync(s->n_active, 0, sizeof(uint32_t), s->stream));
         hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
         hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
         s->ring ^= 1;
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
-                       (const EnvState *)s->tmp, s->flags, n_steps - 1);
+                       (const EnvState *)s->tmp, s->flags, n_steps - 1, s->n_active);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     if (ms) HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
