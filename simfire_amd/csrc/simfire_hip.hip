@@ -335,35 +335,40 @@ __device__ __forceinline__ void acc_merge(WalkAcc &t, const WalkAcc &w)
     t.n_active += w.n_active; t.n_ignite += w.n_ignite; t.cand |= w.cand; t.edges |= w.edges;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
 // Phase 2: the whole wave walks the compacted frontier of its tile, one cell per lane.
-// item = row in band (5) | owner lane (6) << 5 | cell in vector (4) << 11 | status before the
-//        prune (3) << 15 | settled << 18 | expired << 19
+// item = row in band | owner lane << 5 | cell in vector << 11.  Everything about the cell is read
+// from the LDS copies of the tile (3 x 3 neighbourhood of sprite masks, status byte); an ignition
+// is written back into those copies - the cell planes in HBM are updated once, from LDS, at the end.
 template <int RB>
 __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, bool spread,
-                                             int prev_flag, const uint8_t *tile_lds, const uint32_t *s_list,
+                                             int prev_flag, uint8_t *tile_lds, uint8_t *stat_lds, const uint16_t *s_list,
                                              uint32_t pend, int lane)
 {
     const Geo &g = a.g;
     const int LC = g.LC, row_pitch = LC * 16 + 32;
-    uint8_t *age_e = a.age + (long long)e * g.age_env;
     WalkAcc acc = {0u, 0u, 0u, 0u};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // phase-1 stores of this wave must land before the byte stores below
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t j = lane; j < pend; j += 64) {
         const uint32_t it = s_list[j];
         const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
-        const uint32_t s_pre = (it >> 15) & 7u;
-        const bool settled = (it >> 18) & 1u, expired = (it >> 19) & 1u;
         const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
         const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
         const uint32_t idx = (uint32_t)(y * g.P + x);
         const long long cell = (long long)e * g.plane_env + idx;
         double bn = a.burn[cell];     // requested first: the LDS work below hides part of it
         // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
-        const uint8_t *q = tile_lds + (orr * (RB + 2) + i) * row_pitch + 16 + oc * 16 + b - 1;
+        uint8_t *own_age = tile_lds + (orr * (RB + 2) + i + 1) * row_pitch + 16 + oc * 16 + b;
+        const uint8_t *q = own_age - row_pitch - 1;
         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
         const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
         const uint32_t *qb = reinterpret_cast<const uint32_t *>(q - sh + row_pitch);
@@ -371,6 +376,11 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         const uint32_t up3 = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh);
         const uint32_t mid3 = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh);
         const uint32_t dn3 = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh);
+        uint8_t *own_st = stat_lds + ((orr * RB + i) * LC + oc) * 16 + b;
+        const uint32_t own = (mid3 >> 8) & 0xFFu;
+        // the status tile still holds the value from before this step's prune
+        const uint32_t raw = *own_st, s_pre = raw & 7u;
+        const bool settled = raw & 0x80u, expired = (own & mk.b_exp) != 0;
         bool prev_any;
         const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag, prev_any);
         const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
@@ -378,30 +388,34 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         const bool is_cand = spread && eligible && bestk >= 0;
         // attenuation of the previous step that was deferred (a line cell, not a candidate then)
         const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && prev_flag && !prev_any;
-        if (!(is_cand || pending)) continue;
-        acc.n_active++;
-        if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
-        if (is_cand) {
-            acc.cand = 1;
-            double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
-            if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
-                ros = g.att ? ros - line_factor(s_post) : 0.0;
-            bn = bn + ros;                                                   // fire.py:710
-            if (bn > g.pixel_scale) {                                        // fire.py:568
-                acc.n_ignite++;
-                acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
-                             ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
-                a.status[cell] = (uint8_t)SF_BURNING;                        // fire.py:587
-                const uint32_t own = (mid3 >> 8) & 0xFFu;
-                age_e[idx] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);        // fire.py:571-579
+        uint32_t st_new = s_post;                        // S1 prune + settled bit cleared
+        if (is_cand || pending) {
+            acc.n_active++;
+            if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
+            if (is_cand) {
+                acc.cand = 1;
+                double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+                if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
+                    ros = g.att ? ros - line_factor(s_post) : 0.0;
+                bn = bn + ros;                                                   // fire.py:710
+                if (bn > g.pixel_scale) {                                        // fire.py:568
+                    acc.n_ignite++;
+                    acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
+                                 ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
+                    st_new = SF_BURNING;                                         // fire.py:587
+                    *own_age = (uint8_t)((own & ~mk.b_clr) | mk.b_new);          // fire.py:571-579
+                }
             }
+            a.burn[cell] = bn;
         }
-        a.burn[cell] = bn;
+        *own_st = (uint8_t)st_new;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return acc;
 }
+
 template <int RB>
 __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
                                           uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
@@ -424,10 +438,10 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
     const int exp_sh = __ffs(mk.b_exp) - 1;
 
-    // LDS of this wave: frontier list | age tile [LR][RB + 2][LC * 16 + 32] | status tile [LR][RB][LC * 16]
+    // LDS of this wave: frontier list (u16) | age tile [LR][RB + 2][LC * 16 + 32] | status tile [LR][RB][LC * 16]
     const int row_pitch = LC * 16 + 32;
-    uint32_t *s_list = reinterpret_cast<uint32_t *>(lds_wave);
-    uint8_t *tile_lds = lds_wave + kListCap * 4;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(lds_wave);
+    uint8_t *tile_lds = lds_wave + kListCap * 2;
     uint8_t *stat_lds = tile_lds + LR * (RB + 2) * row_pitch;
     uint8_t *band_lds = tile_lds + r * (RB + 2) * row_pitch;
     uint8_t *band_st = stat_lds + (r * RB) * (LC * 16);
@@ -496,123 +510,169 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const long long fplane = (long long)g.TYp * g.TXp;
-    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
-    WalkAcc tot_acc = {0u, 0u, 0u, 0u};
-    uint32_t live_acc = 0, line_acc = 0;
-    uint32_t pend = 0;         // wave-uniform occupancy of the list (exact)
-
-    // ---- phase 1: per row, SWAR over the lane's 16 cells: prune, find the frontier cells and
-    // compact them into the wave's list; the list is walked (phase 2) after the last row, or
-    // earlier if it cannot take the next row.  A real loop: one copy of the row code and of the
-    // walk, few live registers, everything read from LDS.
+    // ---- phase 1: per row, SWAR over the lane's 16 cells: which cells are frontier cells
+    // (eligible and next to a live sprite; all control-line cells when attenuation is on), which
+    // sprites expire / which slots are recycled.  A real loop: one copy of the row code, few
+    // live registers, operands from LDS.  fm[i / 2] collects the 16-bit cell masks of the rows.
+    uint32_t fm[(RB + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < (RB + 1) / 2; ++k) fm[k] = 0;
+    uint32_t live_acc = 0, line_acc = 0, dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
 #pragma unroll 1
-    for (int i = 0; i <= RB; ++i) {
-        uint32_t m16 = 0, row_tot = 0;
-        uint4 sr = make_uint4(0, 0, 0, 0), em = make_uint4(0, 0, 0, 0);
-        if (i < RB) {
-            const int y = y0 + i;
-            const uint8_t *rp = band_lds + i * row_pitch + 16 + c * 16;
-            const uint4 up = *reinterpret_cast<const uint4 *>(rp);
-            const uint4 mid = *reinterpret_cast<const uint4 *>(rp + row_pitch);
-            const uint4 dn = *reinterpret_cast<const uint4 *>(rp + 2 * row_pitch);
-            const uint4 midL = and4(mid, L4);
-            const uint4 vsrc = and4(or4(up, dn), L4);
-            const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
-            live_acc |= any4(midL);
-            // horizontal neighbours: the bytes just left / right of the lane's 16 cells (the
-            // neighbour lane's data, or the seam column parked in the row padding)
-            uint32_t lin = rp[row_pitch - 1], rin = rp[row_pitch + 16];
-            if (g.diag) {
-                lin |= (uint32_t)rp[-1] | (uint32_t)rp[2 * row_pitch - 1];
-                rin |= (uint32_t)rp[16] | (uint32_t)rp[2 * row_pitch + 16];
-            }
-            lin &= mk.m_live;
-            rin &= mk.m_live;
-            uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
-            nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
-            nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
-            nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
-            nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
+    for (int i = 0; i < RB; ++i) {
+        const int y = y0 + i;
+        uint8_t *rp = band_lds + i * row_pitch + 16 + c * 16;
+        const uint4 up = *reinterpret_cast<const uint4 *>(rp);
+        const uint4 mid = *reinterpret_cast<const uint4 *>(rp + row_pitch);
+        const uint4 dn = *reinterpret_cast<const uint4 *>(rp + 2 * row_pitch);
+        const uint4 midL = and4(mid, L4);
+        const uint4 vsrc = and4(or4(up, dn), L4);
+        const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+        live_acc |= any4(midL);
+        // horizontal neighbours: the bytes just left / right of the lane's 16 cells (the
+        // neighbour lane's data, or the seam column parked in the row padding)
+        uint32_t lin = rp[row_pitch - 1], rin = rp[row_pitch + 16];
+        if (g.diag) {
+            lin |= (uint32_t)rp[-1] | (uint32_t)rp[2 * row_pitch - 1];
+            rin |= (uint32_t)rp[16] | (uint32_t)rp[2 * row_pitch + 16];
+        }
+        lin &= mk.m_live;
+        rin &= mk.m_live;
+        uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
+        nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
+        nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
+        nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
+        nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
 
-            const uint4 ex4 = and4(mid, EXP4);
-            const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
-            const uint32_t voff = (uint32_t)(y * g.P + cv * 16);
-            const bool row_ok = col_ok && y < g.H;
-            if (row_ok && any_clr)   // recycle the slot of sprites that were pruned one step ago
-                *reinterpret_cast<uint4 *>(age_e + voff) = and4(mid, ~CLR4);
-            if (row_ok && (any_exp | any_nb | (uint32_t)g.att)) {
-                sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
-                const uint4 s7 = and4(sr, 0x07070707u);
-                // S1 prune: cells whose sprite reached max_fire_duration become BURNED
-                em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;   // 0xFF per expiring byte
-                em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
-                em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
-                em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
-                uint4 snew;
-                snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
-                snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
-                snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
-                snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
-                if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w))
-                    *reinterpret_cast<uint4 *>(st_e + voff) = snew;
-                // cells to hand to phase 2: eligible & next to a live sprite; every line cell
-                // when attenuation is on (their burn changes even away from the fire)
-                const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
-                const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
-                const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
-                const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
-                m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
-                if (g.att) {
-                    m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
-                           (pack4(ge3_01(s7.w)) << 12);
-                    line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
-                }
-                // pitch padding (x >= W) never takes part
-                const int xs = cv * 16;
-                if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
-            }
-            if (__ballot(m16 != 0) != 0ull) {
-#pragma unroll
-                for (int b = 0; b < 16; ++b) row_tot += (uint32_t)__popcll(__ballot((m16 >> b) & 1u));
-            }
+        const uint4 ex4 = and4(mid, EXP4);
+        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+        const bool row_ok = col_ok && y < g.H;
+        if (row_ok && any_clr) {   // recycle the slot of sprites that were pruned one step ago
+            *reinterpret_cast<uint4 *>(rp + row_pitch) = and4(mid, ~CLR4);
+            dirty |= 0x10000u << i;
         }
-        if (i == RB || pend + row_tot > (uint32_t)kListCap) {
-            if (pend) {
-                const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.prev_flag, tile_lds, s_list, pend, lane);
-                acc_merge(tot_acc, w);
-                n_items_acc += (lane == 0) ? pend : 0u;
-                n_phase2++;
-                pend = 0;
+        uint32_t m16 = 0;
+        if (row_ok && (any_exp | any_nb | (uint32_t)g.att)) {
+            const uint4 sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
+            const uint4 s7 = and4(sr, 0x07070707u);
+            // S1 prune: cells whose sprite reached max_fire_duration become BURNED
+            uint4 em;   // 0xFF per expiring byte
+            em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
+            uint4 snew;
+            snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
+            snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
+            snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
+            snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
+            if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) dirty |= 1u << i;
+            // frontier cells: eligible & next to a live sprite; every line cell when attenuation
+            // is on (their burn changes even away from the fire)
+            const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+            const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+            const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+            const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            if (g.att) {
+                m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
+                       (pack4(ge3_01(s7.w)) << 12);
+                line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
             }
-            if (i == RB) break;
+            // pitch padding (x >= W) never takes part
+            const int xs = cv * 16;
+            if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
+            // the frontier cells get their new status from the walk; the others here: the walk
+            // reads the OLD status from LDS, so only non-frontier bytes may be replaced now
+            uint4 keepm;   // 0xFF where the cell is a frontier cell
+            keepm.x = ((m16 & 1u) * 0xFFu) | (((m16 >> 1) & 1u) * 0xFF00u) | (((m16 >> 2) & 1u) * 0xFF0000u) | (((m16 >> 3) & 1u) * 0xFF000000u);
+            keepm.y = (((m16 >> 4) & 1u) * 0xFFu) | (((m16 >> 5) & 1u) * 0xFF00u) | (((m16 >> 6) & 1u) * 0xFF0000u) | (((m16 >> 7) & 1u) * 0xFF000000u);
+            keepm.z = (((m16 >> 8) & 1u) * 0xFFu) | (((m16 >> 9) & 1u) * 0xFF00u) | (((m16 >> 10) & 1u) * 0xFF0000u) | (((m16 >> 11) & 1u) * 0xFF000000u);
+            keepm.w = (((m16 >> 12) & 1u) * 0xFFu) | (((m16 >> 13) & 1u) * 0xFF00u) | (((m16 >> 14) & 1u) * 0xFF0000u) | (((m16 >> 15) & 1u) * 0xFF000000u);
+            uint4 mix;
+            mix.x = (sr.x & keepm.x) | (snew.x & ~keepm.x);
+            mix.y = (sr.y & keepm.y) | (snew.y & ~keepm.y);
+            mix.z = (sr.z & keepm.z) | (snew.z & ~keepm.z);
+            mix.w = (sr.w & keepm.w) | (snew.w & ~keepm.w);
+            *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = mix;
+            if (m16) dirty |= (1u << i);       // the walk rewrites those bytes (settled bit, ignition)
         }
-        if (row_tot) {
-            // Wave-level compaction without LDS atomics: for every cell position b one ballot
-            // gives the slot of each lane's item (mbcnt = popcount of the lower lanes) and the
-            // running total.
+        if (i & 1) fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16 << 16; else fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16;
+    }
+
+    // ---- compact the frontier cells into the wave's list and walk it.  One prefix sum over the
+    // lanes gives every lane its slots.  If a tile has more frontier cells than the list holds
+    // (only with dense control lines) it is processed row by row.
+    uint32_t mine = 0;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const bool has = (m16 >> b) & 1u;
-                const unsigned long long bal = __ballot(has);
-                if (has) {
-                    const uint32_t pos = pend + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    const uint32_t raw = (pick(sr, b >> 2) >> ((b & 3) * 8)) & 0xFFu;
-                    const uint32_t exd = (pick(em, b >> 2) >> ((b & 3) * 8)) & 1u;
-                    s_list[pos] = (uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11) | ((raw & 7u) << 15) |
-                                  ((raw >> 7) << 18) | (exd << 19);
-                }
-                pend += (uint32_t)__popcll(bal);
+    for (int k = 0; k < (RB + 1) / 2; ++k) mine += (uint32_t)__popc(fm[k]);
+    WalkAcc tot_acc = {0u, 0u, 0u, 0u};
+    if (__ballot(mine != 0) != 0ull) {
+        const uint32_t incl_all = wave_scan_incl(mine, lane);
+        const uint32_t total = __shfl(incl_all, 63);
+        const int n_chunks = total <= (uint32_t)kListCap ? 1 : RB;
+#pragma unroll 1
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            // rows of this chunk: all of them, or just row ch
+            uint32_t cnt = 0, excl, tot;
+            if (n_chunks == 1) { cnt = mine; excl = incl_all - mine; tot = total; }
+            else {
+                const uint32_t w = fm[(ch >> 1) < (RB + 1) / 2 ? (ch >> 1) : 0];
+                cnt = (uint32_t)__popc((ch & 1) ? (w >> 16) : (w & 0xFFFFu));
+                const uint32_t inc = wave_scan_incl(cnt, lane);
+                excl = inc - cnt; tot = __shfl(inc, 63);
             }
+            if (tot == 0) continue;
+            uint32_t pos = excl;
+#pragma unroll
+            for (int k = 0; k < (RB + 1) / 2; ++k) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * k + h;
+                    if (i >= RB || (n_chunks != 1 && i != ch)) continue;
+                    uint32_t m = h ? (fm[k] >> 16) : (fm[k] & 0xFFFFu);
+                    while (m) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        s_list[pos++] = (uint16_t)((uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.prev_flag, tile_lds, stat_lds, s_list, tot, lane);
+            acc_merge(tot_acc, w);
+            n_items_acc += (lane == 0) ? tot : 0u;
+            n_phase2++;
         }
     }
     n_active += tot_acc.n_active;
     n_ignite += tot_acc.n_ignite;
 
+    // ---- write the changed vectors of the tile back from LDS to the cell planes
+    if (dirty) {
+#pragma unroll 1
+        for (int i = 0; i < RB; ++i) {
+            const uint32_t voff = (uint32_t)((y0 + i) * g.P + cv * 16);
+            if (dirty & (1u << i)) {
+                uint4 v = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
+                v = and4(v, 0x07070707u);    // the settled marks end with this step
+                *reinterpret_cast<uint4 *>(st_e + voff) = v;
+            }
+            if (dirty & ((0x10000u | 1u) << i)) {
+                // bit i alone: an ignition may have set a sprite bit in this row
+                *reinterpret_cast<uint4 *>(age_e + voff) =
+                    *reinterpret_cast<const uint4 *>(band_lds + (i + 1) * row_pitch + 16 + c * 16);
+            }
+        }
+    }
+
     // tile activity for the next step: sprites left in the tile or ignited in it (with their
     // edge bits); control lines (a line cell that ignited this step is seen one step late -
     // harmless, it is re-evaluated)
+    const long long fplane = (long long)g.TYp * g.TXp;
+    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
     {
         uint32_t ed = tot_acc.edges;
         for (int off = 32; off > 0; off >>= 1) ed |= __shfl_xor(ed, off);
@@ -997,7 +1057,7 @@ static void choose_rows_per_band(Geo &g, int rows)
     int rb = 1;
     while (rb * 2 <= rows && rb < 8) rb *= 2;    // the kernel is instantiated for 1, 2, 4, 8
     // staged tile per wave = LR x (RB + 2) x (LC * 16 + 32) bytes; keep a workgroup below ~60 KB
-    auto wave_bytes = [&](int r) { return kListCap * 4 + g.LR * (r + 2) * (g.LC * 16 + 32) + g.LR * r * g.LC * 16; };
+    auto wave_bytes = [&](int r) { return kListCap * 2 + g.LR * (r + 2) * (g.LC * 16 + 32) + g.LR * r * g.LC * 16; };
     while (rb > 1 && wave_bytes(rb) > 40 * 1024) rb /= 2;
     g.RB = rb;
     g.lds_wave_bytes = (wave_bytes(rb) + 15) / 16 * 16;
