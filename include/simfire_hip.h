@@ -163,6 +163,9 @@ int sf_enable_counters(sf_sim *sim, int32_t on);
 /* bytes of device memory held, and the launch geometry. */
 int sf_memory_bytes(sf_sim *sim, int64_t *bytes);
 int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step kernel */
+/* Overwrite the ignition threshold only (the reference's tests assign manager.pixel_scale after
+ * construction, test_fire.py:334; slopes keep the constructor value, fire.py:377). */
+int sf_set_threshold(sf_sim *sim, double pixel_scale);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);
 

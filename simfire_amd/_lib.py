@@ -56,6 +56,7 @@ SIGNATURES = {
     "sf_memory_bytes": [_VP, C.POINTER(_I64)],
     "sf_set_rows_per_band": [_VP, _I32],
     "sf_set_dense": [_VP, _I32],
+    "sf_set_threshold": [_VP, C.c_double],
 }
 STRING_GETTERS = ("sf_last_error", "sf_version")
 

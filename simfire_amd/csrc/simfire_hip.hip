@@ -584,11 +584,12 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
             // the frontier cells get their new status from the walk; the others here: the walk
             // reads the OLD status from LDS, so only non-frontier bytes may be replaced now
-            uint4 keepm;   // 0xFF where the cell is a frontier cell
-            keepm.x = ((m16 & 1u) * 0xFFu) | (((m16 >> 1) & 1u) * 0xFF00u) | (((m16 >> 2) & 1u) * 0xFF0000u) | (((m16 >> 3) & 1u) * 0xFF000000u);
-            keepm.y = (((m16 >> 4) & 1u) * 0xFFu) | (((m16 >> 5) & 1u) * 0xFF00u) | (((m16 >> 6) & 1u) * 0xFF0000u) | (((m16 >> 7) & 1u) * 0xFF000000u);
-            keepm.z = (((m16 >> 8) & 1u) * 0xFFu) | (((m16 >> 9) & 1u) * 0xFF00u) | (((m16 >> 10) & 1u) * 0xFF0000u) | (((m16 >> 11) & 1u) * 0xFF000000u);
-            keepm.w = (((m16 >> 12) & 1u) * 0xFFu) | (((m16 >> 13) & 1u) * 0xFF00u) | (((m16 >> 14) & 1u) * 0xFF0000u) | (((m16 >> 15) & 1u) * 0xFF000000u);
+            // 0xFF where the cell is a frontier cell: 4 mask bits -> 4 byte LSBs -> full bytes
+            uint4 keepm;
+            keepm.x = (((m16 & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.y = ((((m16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.z = ((((m16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.w = ((((m16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
             uint4 mix;
             mix.x = (sr.x & keepm.x) | (snew.x & ~keepm.x);
             mix.y = (sr.y & keepm.y) | (snew.y & ~keepm.y);
@@ -1191,6 +1192,16 @@ extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+/* RothermelFireManager.pixel_scale is a plain attribute that the reference's own test overwrites
+ * after construction (test_fire.py:334): only the ignition threshold changes, the slopes keep the
+ * value used at construction (fire.py:377, 568). */
+extern "C" int sf_set_threshold(sf_sim *s, double pixel_scale)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_threshold: null handle");
+    s->g.pixel_scale = pixel_scale;
     return SF_OK;
 }
 

@@ -154,6 +154,11 @@ class FireEngine:
     def set_rows_per_band(self, rows):
         _lib.check(self._L.sf_set_rows_per_band(self._h, int(rows)))
 
+    def set_threshold(self, pixel_scale):
+        """Ignition threshold only (``manager.pixel_scale = v`` in the reference)."""
+        _lib.check(self._L.sf_set_threshold(self._h, float(pixel_scale)))
+        self.params.pixel_scale = float(pixel_scale)
+
     def set_dense(self, dense=True):
         """Visit every tile every step (cross-check of the tile activity map)."""
         _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))

@@ -1,0 +1,298 @@
+"""``FireSimulation`` / ``BatchedFireSimulation`` - the surface an RL harness talks to.
+
+``FireSimulation`` keeps the method names, arguments and return values of the reference class
+(simfire/sim/simulation.py:184-829) for everything that touches the fire-spread path; display,
+GIF, spread-graph and data-saving methods raise ``NotImplementedError`` (out of scope, SURVEY.md
+section 2).  The state lives on the GPU: ``run`` launches the step kernels, ``update_mitigation``
+is a device scatter, ``fire_map`` is copied out when ``run`` returns.
+``BatchedFireSimulation`` adds a leading environment axis (many independent simulations that
+share terrain and wind) - the form the hardware wants.
+"""
+import warnings
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .config import Config
+from .engine import FireEngine
+from .enums import BurnStatus, ElevationConstants, FuelConstants, GameStatus, WindConstants
+from .parameters import Environment, FuelParticle, fuel_planes
+from .units import str_to_minutes
+
+
+def _total_updates(time: Union[str, int], update_rate: float) -> int:
+    if isinstance(time, str):
+        return round(str_to_minutes(time) / update_rate)          # simulation.py:522-526
+    if isinstance(time, (int, np.integer)):
+        return int(time)
+    raise TypeError("time must be a string such as '1h 30m' or an int number of updates")
+
+
+class _TerrainView:
+    """What ``FireSimulation.terrain`` exposes to callers: ``fuels`` and ``elevations``."""
+
+    def __init__(self, fuels, elevations, screen_size):
+        self.fuels, self.elevations, self.screen_size = fuels, elevations, screen_size
+
+
+def _engine_from_config(config: Config, n_envs: int, device: int) -> Tuple[FireEngine, _TerrainView]:
+    fp = FuelParticle()
+    fuels = config.terrain.fuel_layer.data.squeeze()
+    elev = np.asarray(config.terrain.topography_layer.data.squeeze(), dtype=np.float64)
+    H, W = config.area.screen_size
+    eng = FireEngine((H, W), n_envs=n_envs, max_fire_duration=config.fire.max_fire_duration,
+                     pixel_scale=config.area.pixel_scale, update_rate=config.simulation.update_rate,
+                     max_time=config.simulation.runtime, attenuate_line_ros=config.mitigation.ros_attenuation,
+                     diagonal_spread=config.fire.diagonal_spread, M_f=config.environment.moisture,
+                     particle=(fp.h, fp.S_T, fp.S_e, fp.p_p), device=device)
+    eng.set_layers(*fuel_planes(fuels), elev, config.wind.speed, config.wind.direction)
+    return eng, _TerrainView(fuels, elev, (H, W))
+
+
+class FireSimulation:
+    def __init__(self, config: Config, device: int = 0) -> None:
+        self.config = config
+        self._device = device
+        self._rendering = False
+        self.agents: Dict[int, Tuple[int, int]] = {}
+        self.reset()
+
+    # ------------------------------------------------------------------------- life cycle
+    def reset(self) -> None:
+        """simulation.py:202-214: fire_map, agents, terrain, fire manager state, mitigations."""
+        cfg = self.config
+        self._engine, self.terrain = _engine_from_config(cfg, 1, self._device)
+        self.fuel_particle = FuelParticle()
+        self.environment = Environment(cfg.environment.moisture, cfg.wind.speed, cfg.wind.direction)
+        x, y = cfg.fire.fire_initial_position
+        self._engine.reset([(x, y)])
+        self.fire_map = np.full(cfg.area.screen_size, int(BurnStatus.UNBURNED))      # int64, simulation.py:561-566
+        self.fire_map[y, x] = int(BurnStatus.BURNING)
+        self._device_map = self.fire_map.copy()
+        self.agent_positions = np.zeros_like(self.fire_map)
+        self.agents.clear()
+        self.elapsed_steps = 0
+        self.elapsed_time = 0.0
+        self.fire_status = GameStatus.RUNNING
+        self.active = True
+
+    @property
+    def fire_manager(self):
+        """Read-only view with the attributes callers read off the reference's manager."""
+        sim = self
+
+        class _View:
+            elapsed_time = property(lambda s: float(sim._engine.status()[1][0]))
+            burn_amounts = property(lambda s: sim._engine.burn(0))
+            pixel_scale = sim.config.area.pixel_scale
+            update_rate = sim.config.simulation.update_rate
+            max_time = sim.config.simulation.runtime
+            slope_mag = property(lambda s: sim._engine.get_slopes()[0])
+            slope_dir = property(lambda s: sim._engine.get_slopes()[1])
+        return _View()
+
+    # ------------------------------------------------------------------------------- run
+    def _sync_to_device(self) -> None:
+        """``fire_map`` is a public attribute that callers may edit or replace; take that over."""
+        if self.fire_map.shape != self._device_map.shape or not np.array_equal(self.fire_map, self._device_map):
+            self._engine.load_fire_map(0, self.fire_map)
+            self._device_map = np.array(self.fire_map, dtype=np.int64)
+
+    def run(self, time: Union[str, int]) -> Tuple[np.ndarray, bool]:
+        """simulation.py:501-553: up to ``time`` updates while the fire is RUNNING."""
+        total = _total_updates(time, self.config.simulation.update_rate)
+        self._sync_to_device()
+        if self.fire_status == GameStatus.RUNNING and total > 0:
+            before = int(self._engine.status()[0][0, 1])
+            self._engine.step(total)
+            st, el = self._engine.status()
+            self.elapsed_steps += int(st[0, 1]) - before
+            self.elapsed_time = float(el[0])
+            self.fire_status = GameStatus.RUNNING if st[0, 0] else GameStatus.QUIT
+            self.fire_map = self._engine.fire_map(0).astype(np.int64)
+            self._device_map = self.fire_map.copy()
+        self.active = self.fire_status == GameStatus.RUNNING
+        return self.fire_map, self.active
+
+    # ------------------------------------------------------------------------ mitigation
+    def update_mitigation(self, points: Iterable[Tuple[int, int, int]]) -> None:
+        """simulation.py:449-478: (column, row, type) triples; FIRELINE writes land first, then
+        SCRATCHLINE, then WETLINE; unknown types are skipped with a warning."""
+        self._sync_to_device()
+        pts = []
+        for i, (column, row, mitigation) in enumerate(points):
+            if mitigation in (BurnStatus.FIRELINE, BurnStatus.SCRATCHLINE, BurnStatus.WETLINE):
+                pts.append((0, int(column), int(row), int(mitigation)))
+            else:
+                warnings.warn(f"The mitigation,{mitigation}, provided at location[{i}] is not an available "
+                              "mitigation strategy... Skipping")
+        if pts:
+            H, W = self.config.area.screen_size
+            for (_, x, y, _) in pts:
+                if not (0 <= x < W and 0 <= y < H):
+                    raise IndexError(f"mitigation point ({x}, {y}) is out of bounds for a {H}x{W} fire_map")
+            self._engine.apply_mitigation(pts)
+            for kind in (BurnStatus.FIRELINE, BurnStatus.SCRATCHLINE, BurnStatus.WETLINE):
+                for (_, x, y, t) in pts:
+                    if t == kind:
+                        self.fire_map[y, x] = int(kind)
+            self._device_map = self.fire_map.copy()
+
+    def load_mitigation(self, mitigation_map: np.ndarray) -> None:
+        """simulation.py:425-447: the map replaces ``fire_map`` if all values are BurnStatus values."""
+        category_values = [status.value for status in BurnStatus]
+        if np.isin(mitigation_map, category_values).all():
+            message = ("You are overwriting the current fire map with the given mitigation map - the current "
+                       "fire map data will be erased.")
+            self.fire_map = mitigation_map
+        else:
+            message = (f"Invalid values in {mitigation_map} - values need to be within {category_values}... Skipping")
+        warnings.warn(message)
+
+    def update_agent_positions(self, points: Iterable[Tuple[int, int, int]]) -> None:
+        """simulation.py:480-499"""
+        for column, row, agent_id in points:
+            self.agent_positions[self.agent_positions == agent_id] = 0
+            self.agent_positions[row][column] = agent_id
+            self.agents[agent_id] = (column, row)
+
+    # ----------------------------------------------------------------------- observation
+    def get_actions(self) -> Dict[str, int]:
+        return {"fireline": BurnStatus.FIRELINE, "scratchline": BurnStatus.SCRATCHLINE, "wetline": BurnStatus.WETLINE}
+
+    @property
+    def disaster_categories(self):
+        return BurnStatus
+
+    def get_disaster_categories(self) -> Dict[str, int]:
+        return {i.name: i.value for i in self.disaster_categories}
+
+    @staticmethod
+    def supported_attributes() -> List[str]:
+        return ["w_0", "sigma", "delta", "M_x", "elevation", "wind_speed", "wind_direction"]
+
+    def get_attribute_bounds(self) -> Dict[str, object]:
+        """simulation.py:334-374"""
+        return {
+            "w_0": {"min": FuelConstants.W_0_MIN, "max": FuelConstants.W_0_MAX},
+            "sigma": {"min": FuelConstants.SIGMA_MIN, "max": FuelConstants.SIGMA_MAX},
+            "delta": {"min": FuelConstants.DELTA_MIN, "max": FuelConstants.DELTA_MAX},
+            "M_x": {"min": FuelConstants.M_X_MIN, "max": FuelConstants.M_X_MAX},
+            "elevation": {"min": ElevationConstants.MIN_ELEVATION, "max": ElevationConstants.MAX_ELEVATION},
+            "wind_speed": {"min": WindConstants.MIN_SPEED, "max": WindConstants.MAX_SPEED},
+            "wind_direction": {"min": 0.0, "max": 360.0},
+        }
+
+    def get_attribute_data(self) -> Dict[str, np.ndarray]:
+        """simulation.py:376-403 (same dtypes; built without the per-pixel Python loop)."""
+        w_0, delta, M_x, sigma = fuel_planes(self.terrain.fuels)
+        return {"w_0": w_0.astype(np.float32), "sigma": sigma.astype(np.uint32), "delta": delta.astype(np.float32),
+                "M_x": M_x.astype(np.float32), "elevation": self.terrain.elevations,
+                "wind_speed": self.config.wind.speed, "wind_direction": self.config.wind.direction}
+
+    # -------------------------------------------------------------------- seeds / layers
+    def get_seeds(self) -> Dict[str, Optional[int]]:
+        """simulation.py:574-597: only the seeds that exist for the configured generators."""
+        seeds: Dict[str, Optional[int]] = {}
+        t = self.config.terrain
+        if t.topography_function is not None and "seed" in t.topography_function.kwargs:
+            seeds["elevation"] = t.topography_function.kwargs["seed"]
+        if t.fuel_function is not None and "seed" in t.fuel_function.kwargs:
+            seeds["fuel"] = t.fuel_function.kwargs["seed"]
+        if self.config.fire.seed is not None:
+            seeds["fire_initial_position"] = self.config.fire.seed
+        return seeds
+
+    def set_seeds(self, seeds: Dict[str, int]) -> bool:
+        """simulation.py:713-759; takes effect at the next ``reset()``."""
+        success = False
+        if "elevation" in seeds:
+            self.config.reset_terrain(topography_seed=seeds["elevation"])
+            success = True
+        if "fuel" in seeds:
+            self.config.reset_terrain(fuel_seed=seeds["fuel"])
+            success = True
+        if "fire_initial_position" in seeds:
+            self.config.reset_fire(seeds["fire_initial_position"])
+        valid = list(self.get_seeds().keys())
+        for key in seeds:
+            if key not in valid:
+                warnings.warn("No valid keys in the seeds dictionary were given to the set_seeds method. No seeds "
+                              f"will be changed. Valid keys are: {valid}")
+                success = False
+        return success
+
+    def set_fire_initial_position(self, pos: Tuple[int, int]) -> None:
+        self.config.reset_fire(pos=pos)
+
+    def get_layer_types(self) -> Dict[str, str]:
+        return {"elevation": self.config.terrain.topography_type, "fuel": self.config.terrain.fuel_type}
+
+    def set_layer_types(self, types: Dict[str, str]) -> bool:
+        raise NotImplementedError("switching to operational layers needs LANDFIRE downloads; build the Config with "
+                                  "Config.from_arrays instead")
+
+    # ---------------------------------------------------------------- display (out of scope)
+    @property
+    def rendering(self) -> bool:
+        return self._rendering
+
+    @rendering.setter
+    def rendering(self, value: bool) -> None:
+        if value:
+            raise NotImplementedError("PyGame rendering is outside simfire_amd's scope (SURVEY.md section 2)")
+        self._rendering = False
+
+    def save_gif(self, path=None):
+        raise NotImplementedError("display / GIF export is outside simfire_amd's scope")
+
+    def save_spread_graph(self, path=None):
+        raise NotImplementedError("the fire-spread graph is outside simfire_amd's scope")
+
+
+class BatchedFireSimulation:
+    """``n_envs`` independent fire simulations on one GPU that share the config's terrain and wind.
+
+    ``ignitions``: int [n_envs, 2] (x, y), or None to draw them like the reference's ``random``
+    fire position (``rng = default_rng(seed); x = rng.integers(W); y = rng.integers(H)``,
+    simfire/utils/config.py:810-813) from ``seeds`` (default ``1234 + env``)."""
+
+    def __init__(self, config: Config, n_envs: int, ignitions=None, seeds: Optional[Sequence[int]] = None,
+                 device: int = 0) -> None:
+        self.config = config
+        self.n_envs = int(n_envs)
+        H, W = config.area.screen_size
+        if ignitions is None:
+            seeds = list(seeds) if seeds is not None else [1234 + e for e in range(self.n_envs)]
+            ignitions = np.empty((self.n_envs, 2), dtype=np.int32)
+            for e, sd in enumerate(seeds):
+                rng = np.random.default_rng(sd)
+                ignitions[e] = (rng.integers(W, dtype=int), rng.integers(H, dtype=int))
+        self.ignitions = np.asarray(ignitions, dtype=np.int32).reshape(self.n_envs, 2)
+        self._engine, self.terrain = _engine_from_config(config, self.n_envs, device)
+        self.reset()
+
+    def reset(self, envs: Optional[Sequence[int]] = None) -> None:
+        if envs is None:
+            self._engine.reset(self.ignitions)
+        else:
+            for e in envs:
+                self._engine.reset_env(int(e), int(self.ignitions[e, 0]), int(self.ignitions[e, 1]))
+
+    def run(self, time: Union[str, int], return_maps: bool = True):
+        """Steps every environment that is still RUNNING; returns (fire_maps uint8 [E, H, W] or None,
+        active bool [E])."""
+        self._engine.step(_total_updates(time, self.config.simulation.update_rate))
+        st, _ = self._engine.status()
+        return (self._engine.fire_maps() if return_maps else None), st[:, 0].astype(bool)
+
+    def update_mitigation(self, points) -> None:
+        """rows (env, column, row, type)"""
+        self._engine.apply_mitigation(points)
+
+    def results(self):
+        """int32 [E, 8]: running, elapsed_steps, cell counts per BurnStatus; float64 [E] elapsed_time."""
+        return self._engine.status()
+
+    def fire_map(self, env: int) -> np.ndarray:
+        return self._engine.fire_map(env)

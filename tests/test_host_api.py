@@ -1,0 +1,209 @@
+"""GPU tests of the reference-shaped Python surface (FireSimulation / RothermelFireManager /
+compute_rate_of_spread), modelled on the reference's own unit tests."""
+import os
+
+import numpy as np
+import pytest
+
+import _golden
+from oracle import fire_dense
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "tests", "golden", "configs")
+
+
+def _sim(name="test_config_flat_simple.yml"):
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    return FireSimulation(Config(os.path.join(CFG, name)))
+
+
+def test_run_time_string_burns_everything():
+    """simfire/sim/_tests/test_simulation.py:84-104: run("1h") on the 9x9 flat config."""
+    from simfire_amd.enums import BurnStatus
+    sim = _sim()
+    fire_map, active = sim.run("1h")
+    assert fire_map.shape == (9, 9) and fire_map.dtype == np.int64
+    assert fire_map.max() == BurnStatus.BURNED
+    assert isinstance(active, bool)
+
+
+def test_run_one_update_elapsed_time():
+    """test_simulation.py:106-121: run(1) advances elapsed_time by update_rate."""
+    sim = _sim()
+    sim.run(1)
+    assert sim.elapsed_time == sim.config.simulation.update_rate
+    assert sim.elapsed_steps == 1 and sim.active
+
+
+def test_simulation_matches_reference_c1():
+    """FireSimulation on BASELINE C1 (128^2): same step count, final map and mid-run maps as the
+    reference run recorded in tests/golden/sim_c1_128.npz."""
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    d = _golden.load("sim_c1_128.npz")
+    y = yaml.safe_load(open(os.path.join(CFG, "functional_config.yml")))
+    y["area"]["screen_size"] = [128, 128]
+    y["terrain"]["topography"]["functional"]["function"] = "flat"
+    y["simulation"]["headless"] = True
+    sim = FireSimulation(Config(config_dict=y))
+    steps = 0
+    while sim.active:
+        sim.run(1)
+        steps += 1
+        if f"map_{steps}" in d:
+            assert (sim.fire_map == d[f"map_{steps}"]).all(), steps
+    assert steps == int(d["steps"]) and sim.elapsed_steps == steps
+    assert (sim.fire_map == d["final"]).all()
+    assert sim.elapsed_time == float(d["elapsed_time"])
+    # a further run() is a no-op, like the reference's loop guard (simulation.py:533)
+    m, active = sim.run(5)
+    assert not active and sim.elapsed_steps == steps
+
+
+def test_update_mitigation_and_precedence():
+    """simfire/game/managers/_tests/test_mitigation.py:65-99 + the type precedence of
+    simulation.py:476-478; unknown types are skipped with a warning."""
+    from simfire_amd.enums import BurnStatus
+    sim = _sim()
+    pts = [(1, 1, BurnStatus.FIRELINE), (2, 1, BurnStatus.SCRATCHLINE), (3, 1, BurnStatus.WETLINE),
+           (4, 4, BurnStatus.WETLINE), (4, 4, BurnStatus.FIRELINE), (7, 7, BurnStatus.SCRATCHLINE),
+           (7, 7, BurnStatus.FIRELINE)]
+    with pytest.warns(UserWarning):
+        sim.update_mitigation(pts + [(0, 0, 1)])
+    assert sim.fire_map[1, 1] == 3 and sim.fire_map[1, 2] == 4 and sim.fire_map[1, 3] == 5
+    assert sim.fire_map[4, 4] == 5 and sim.fire_map[7, 7] == 4 and sim.fire_map[0, 0] == 0
+    sim.run(1)
+    assert sim.fire_map[1, 1] == 3          # 980 ft/min attenuation holds the fire line for now
+
+
+def test_load_mitigation_validity():
+    """test_simulation.py:323-338"""
+    sim = _sim()
+    good = np.zeros((9, 9), dtype=np.int64)
+    good[0, :] = 3
+    with pytest.warns(UserWarning):
+        sim.load_mitigation(good)
+    assert (sim.fire_map == good).all()
+    bad = np.full((9, 9), 9)
+    with pytest.warns(UserWarning):
+        sim.load_mitigation(bad)
+    assert (sim.fire_map == good).all()
+    sim.run(2)                               # the replaced map is what the fire now sees
+    assert (sim.fire_map[0, :] >= 1).all()
+
+
+def test_attribute_data_and_actions():
+    sim = _sim()
+    a = sim.get_attribute_data()
+    assert set(a) == set(sim.supported_attributes())
+    assert a["w_0"].dtype == np.float32 and a["sigma"].dtype == np.uint32 and a["w_0"].shape == (9, 9)
+    assert sim.get_actions() == {"fireline": 3, "scratchline": 4, "wetline": 5}
+    assert sim.get_disaster_categories()["BURNED"] == 2
+    assert sim.get_seeds() == {"fuel": 1113}
+    with pytest.raises(NotImplementedError):
+        sim.rendering = True
+
+
+def _manager(**over):
+    from simfire_amd.config import Config
+    from simfire_amd.fire import RothermelFireManager
+    from simfire_amd.parameters import Chaparral, Environment, FuelParticle
+    import yaml
+    y = yaml.safe_load(open(os.path.join(CFG, "test_config_rothermel_manager.yml")))
+    y["terrain"]["topography"]["functional"]["function"] = "flat"    # the test builds Dummy layers anyway
+    y["wind"]["function"] = "simple"
+    y["area"]["screen_size"] = [45, 45]
+    cfg = Config(config_dict=y)
+    H, W = cfg.area.screen_size
+    terrain = {"fuels": np.full((H, W), Chaparral, dtype=object), "elevations": np.zeros((H, W))}   # Dummy layers
+    env = over.pop("environment", Environment(cfg.environment.moisture, cfg.wind.speed, cfg.wind.direction))
+    mgr = RothermelFireManager((W // 2, H // 2), cfg.display.fire_size, cfg.fire.max_fire_duration,
+                               cfg.area.pixel_scale, cfg.simulation.update_rate, FuelParticle(), terrain, env,
+                               max_time=cfg.simulation.runtime, headless=True)
+    return cfg, mgr
+
+
+def test_manager_wind_conversion():
+    """simfire/game/managers/_tests/test_fire.py:205-324: float / ndarray / nested-sequence wind,
+    ValueError on wrong shapes or flat sequences."""
+    from simfire_amd.parameters import Environment
+    cfg, mgr = _manager()
+    H, W = cfg.area.screen_size
+    for u, d in [(7.0, 90.0), (np.full((H, W), 7.0), np.full((H, W), 90.0)),
+                 ([[7.0] * W for _ in range(H)], [[90.0] * W for _ in range(H)])]:
+        _, m = _manager(environment=Environment(0.03, u, d))
+        assert isinstance(m.U, np.ndarray) and m.U.shape == (H, W) and m.U_dir.shape == (H, W)
+    with pytest.raises(ValueError):
+        _manager(environment=Environment(0.03, np.full((H + 1, W + 1), 7.0), np.full((H + 1, W + 1), 90.0)))
+    with pytest.raises(ValueError):
+        _manager(environment=Environment(0.03, [[7.0] * (W + 1) for _ in range(H + 1)],
+                                         [[90.0] * (W + 1) for _ in range(H + 1)]))
+    with pytest.raises(ValueError):
+        _manager(environment=Environment(0.03, [7.0] * W, [90.0] * W))
+
+
+def test_manager_update_scenario():
+    """test_fire.py:326-396: pixel_scale = 0 after construction, burn = -1 on the 8 neighbours,
+    all-UNBURNED fire_map in -> all 8 neighbours BURNING, status RUNNING, map updated in place."""
+    from simfire_amd.enums import BurnStatus, GameStatus
+    cfg, mgr = _manager()
+    H, W = cfg.area.screen_size
+    x, y = W // 2, H // 2
+    fire_map = np.full((H, W), int(BurnStatus.UNBURNED))
+    mgr.pixel_scale = 0
+    new_locs = [(x + 1, y), (x + 1, y + 1), (x, y + 1), (x - 1, y + 1), (x - 1, y), (x - 1, y - 1), (x, y - 1),
+                (x + 1, y - 1)]
+    burn = mgr.burn_amounts
+    for (a, b) in new_locs:
+        burn[a, b] = -1                      # sic: the reference test indexes [x, y]
+    mgr.burn_amounts = burn
+    out, status = mgr.update(fire_map)
+    assert out is fire_map and status == GameStatus.RUNNING
+    burning = {(int(xx), int(yy)) for yy, xx in np.argwhere(fire_map == BurnStatus.BURNING)}
+    assert burning == set(new_locs)
+    assert {(s.rect.x, s.rect.y) for s in mgr.sprites} == set(new_locs)
+    assert mgr.elapsed_time == cfg.simulation.update_rate
+
+
+def test_manager_takes_over_caller_edits():
+    """Lines written into the caller's fire_map between updates (ControlLineManager.update,
+    mitigation.py:75-78) are picked up by the next update."""
+    cfg, mgr = _manager()
+    H, W = cfg.area.screen_size
+    fire_map = np.zeros((H, W), dtype=np.int64)
+    fire_map[H // 2, W // 2] = 1
+    kw = dict(shape=(H, W), max_fire_duration=cfg.fire.max_fire_duration, pixel_scale=cfg.area.pixel_scale,
+              update_rate=cfg.simulation.update_rate, max_time=cfg.simulation.runtime, attenuate_line_ros=True,
+              diagonal_spread=True)
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(mgr._engine.get_rtable())
+    o.reset([(W // 2, H // 2)])
+    for t in range(12):
+        if t == 3:
+            fire_map[H // 2 - 3:H // 2 + 4, W // 2 + 3] = 3
+            o.apply_mitigation([(0, W // 2 + 3, yy, 3) for yy in range(H // 2 - 3, H // 2 + 4)])
+        fire_map, _ = mgr.update(fire_map)
+        o.step(1)
+        assert (fire_map == o.fire_map(0)).all(), t
+    assert (mgr.burn_amounts == o.burn(0)).all()
+
+
+def test_batched_simulation():
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import BatchedFireSimulation
+    y = yaml.safe_load(open(os.path.join(CFG, "test_config_flat_simple.yml")))
+    y["area"]["screen_size"] = [40, 40]
+    sim = BatchedFireSimulation(Config(config_dict=y), 6)
+    maps, active = sim.run(5)
+    assert maps.shape == (6, 40, 40) and maps.dtype == np.uint8 and active.all()
+    for e in range(6):
+        x, yy = sim.ignitions[e]
+        assert maps[e, yy, x] in (1, 2)
+    st, el = sim.results()
+    assert (st[:, 1] == 5).all() and (el == 5.0).all()
+    sim.reset([2])
+    assert sim.fire_map(2).sum() == 1
