@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-env measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--debug-cut", type=int, default=0, help="developer: SF_DEBUG_CUT during the timed steps")
+    ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-sweep roofline measurement")
     return ap.parse_args()
 
 
@@ -121,6 +123,43 @@ def cpu_baseline(w, steps, warmup, threads, agent_pts=None):
                       f"{k} timed steps after {warmup} warm-up steps, {dt:.1f} s"}
 
 
+def measure(eng, w, a, agent_pts, dense):
+    """Warm up, time K steps (kernel time via HIP events on the library's stream), then replay the
+    same deterministic rollout with the statistics atomics on to get the work actually performed."""
+    eng.set_dense(dense)
+    eng.reset(w.init_xy)
+    if a.warmup:
+        timed_steps(eng, w, a.warmup, 0, agent_pts)
+    st0, _ = eng.status()
+    kernel_ms = timed_steps(eng, w, a.steps, a.warmup, agent_pts)
+    st1, _ = eng.status()
+    env_steps = int((st1[:, 1] - st0[:, 1]).sum())
+    eng.reset(w.init_xy)
+    if a.warmup:
+        timed_steps(eng, w, a.warmup, 0, agent_pts)
+    eng.enable_counters(True)
+    eng.counters(reset=True)
+    timed_steps(eng, w, a.steps, a.warmup, agent_pts)
+    cnt = eng.counters()
+    eng.enable_counters(False)
+    return kernel_ms, env_steps, cnt
+
+
+def roofline_block(w, a, kernel_ms, cnt, tile_cells, traffic):
+    """bytes = cell_updates_performed x 4 + active_cell_updates x 24, per launch."""
+    performed = cnt["active_waves"] * tile_cells / a.steps            # cells scanned per step
+    active = cnt["active_cell_updates"] / a.steps
+    alg_bytes = performed * 4.0 + active * 24.0
+    launch_ms = kernel_ms / a.steps
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_select + k_step",
+            "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "cells_scanned_per_launch": performed, "active_cell_updates_per_launch": active,
+            "tiles_visited_per_launch": cnt["active_waves"] / a.steps,
+            "frontier_walks_per_launch": cnt["frontier_walks"] / a.steps}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -146,10 +185,14 @@ def main():
         agent_pts = workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup,
                                          env_offset=rank * envs_local)
     eng = run_gpu(w, a.steps, a.warmup, local_rank, a.rows_per_band)
+    eng.set_dense(a.dense)
     result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{local_rank}")
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else result
 
-    timed_steps(eng, w, a.warmup, 0, agent_pts) if a.warmup else None
+    if a.warmup:
+        timed_steps(eng, w, a.warmup, 0, agent_pts)
+    eng.copy_status_to(result.data_ptr())
+    steps_before = result[:, 1].sum().item()
 
     def fence():
         torch.cuda.synchronize()
@@ -157,6 +200,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ------------------------------------------------------------------ timed region
     fence()
     if a.debug_cut:
         os.environ["SF_DEBUG_CUT"] = str(a.debug_cut)
@@ -168,58 +212,56 @@ def main():
         dist.all_gather_into_tensor(gathered, result)  # RCCL over xGMI, once per rollout
     fence()
     dt = time.perf_counter() - t0
+    # ---------------------------------------------------------------------------------
+    env_steps = result[:, 1].sum().item() - steps_before      # update() calls really made
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        red = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = red[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # phi (fraction of cells whose burn_amounts were touched) from an untimed replay of the same
-    # deterministic rollout with the statistics atomics switched on
-    eng.reset(w.init_xy)
-    timed_steps(eng, w, a.warmup, 0, agent_pts) if a.warmup else None
-    eng.enable_counters(True)
-    eng.counters(reset=True)
-    timed_steps(eng, w, a.steps, a.warmup, agent_pts)
-    cnt = eng.counters()
-    eng.enable_counters(False)
-    cells_launch = H * W * w.n_envs
-    phi = cnt["active_cell_updates"] / float(cells_launch * a.steps)
-    alg_bytes = cells_launch * (4.0 + 24.0 * phi)
-    launch_ms = kernel_ms / a.steps
-    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        tot = red[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, env_steps = float(tmax.item()), float(tot.item())
     res = gathered.cpu().numpy()
 
     if rank == 0:
-        traffic = None
+        geo_tile_cells = 128 * 8 * (a.rows_per_band or 4) if W >= 128 else None
+        kms, env_steps_local, cnt = measure(eng, w, a, agent_pts, a.dense)
+        tile_cells = geo_tile_cells or (H * W)
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")
+        traffic = traffic_dense = None
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                j = json.load(f)
+                traffic = j.get("hbm_bytes_per_launch_dense" if a.dense else "hbm_bytes_per_launch")
+                traffic_dense = j.get("hbm_bytes_per_launch_dense")
         out = {
             "metric": "cell-updates/sec (grid x envs x steps)",
-            "value": H * W * w.n_envs * world * a.steps / dt,
+            # every update() call really made (environments that reached QUIT stop counting,
+            # like the loop guard of FireSimulation.run, simulation.py:533)
+            "value": H * W * env_steps / dt,
             "unit": "cell-updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 state + f64 burn_amounts", "data": "synthetic",
+            "dtype": "u8 status + u8 sprite masks + f64 burn_amounts", "data": "synthetic",
             "config": {"workload": w.name, "grid": [H, W], "envs_per_gpu": w.n_envs,
                        "envs_total": w.n_envs * world, "max_fire_duration": w.max_fire_duration,
                        "pixel_scale": w.pixel_scale, "ros_attenuation": w.attenuate_line_ros,
-                       "agents_per_env": w.agents_per_env,
+                       "agents_per_env": w.agents_per_env, "tile_skipping": not a.dense,
+                       "env_steps_executed": env_steps, "env_steps_requested": w.n_envs * world * a.steps,
                        "envs_running_at_end": int(res[:, 0].sum()),
-                       "burned_cells_total": int(res[:, 4].sum()),
-                       "active_fraction_phi": phi,
-                       "active_waves_per_step": cnt["active_waves"] / a.steps,
-                       "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
-                       "frontier_items_per_step": cnt["frontier_items"] / a.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step", "launch_ms": launch_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "frac_of_measured_traffic": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                         if traffic else None},
+                       "burned_cells_total": int(res[:, 4].sum())},
+            "roofline": roofline_block(w, a, kms, cnt, tile_cells, traffic),
         }
+        out["roofline"]["note"] = ("algorithmic bytes of the cell-updates actually performed (tiles visited x tile "
+                                   "cells x 4 B + active cells x 24 B); quiescent tiles are skipped via the tile "
+                                   "activity map" if not a.dense else "dense sweep: every tile visited every step")
+        if world == 1 and not a.dense and not a.no_dense_leg:
+            kd, _, cd = measure(eng, w, a, agent_pts, True)
+            out["roofline_dense"] = roofline_block(w, a, kd, cd, tile_cells, traffic_dense)
+            out["roofline_dense"]["note"] = "same workload with tile skipping off: every cell scanned every step"
+            out["roofline_dense"]["value_cell_updates_per_s"] = H * W * env_steps_local / (kd * 1e-3)
+            eng.set_dense(False)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, a.steps, a.warmup, a.cpu_threads, agent_pts)
         if world == 1 and not a.no_extra and a.workload == "c3":
@@ -228,14 +270,16 @@ def main():
             w2 = make_workload("c2", a.size, 1, 0)
             e2 = run_gpu(w2, a.steps, a.warmup, local_rank)
             e2.step(a.warmup)
+            s0, _ = e2.status()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            kms = e2.step_timed(a.steps)
+            kms2 = e2.step_timed(a.steps)
             dt2 = time.perf_counter() - t0
             st2, _ = e2.status()
+            done = int(st2[0, 1] - s0[0, 1])
             out["also"] = {"c2_operational_1env": {
-                "value": H * W * a.steps / dt2, "unit": "cell-updates/s", "ms_per_step": dt2 * 1e3 / a.steps,
-                "kernel_ms_per_step": kms / a.steps, "running_at_end": int(st2[0, 0]),
+                "value": H * W * done / dt2, "unit": "cell-updates/s", "ms_per_step": dt2 * 1e3 / a.steps,
+                "kernel_ms_per_step": kms2 / a.steps, "steps_executed": done, "running_at_end": int(st2[0, 0]),
                 "burned_cells": int(st2[0, 4])}}
         print(json.dumps(out))
     if dist is not None:

@@ -447,8 +447,8 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     uint8_t *band_st = stat_lds + (r * RB) * (LC * 16);
     uint32_t tile_flags;
     {
-        // ---- request everything the tile needs in one go: RB + 2 age rows (zero guard rows at
-        // -1 and H), the seam columns, RB status rows; then park it all in LDS
+        // ---- request the RB + 2 age rows (zero guard rows at -1 and H) and the seam columns in
+        // one go; after the quick reject the RB status rows; then park it all in LDS
         uint4 rows[RB + 2], sraw[RB];
         const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
 #pragma unroll
@@ -465,17 +465,18 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             seam[k] = 0;
             if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
         }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            sraw[i] = make_uint4(0, 0, 0, 0);
-            if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
-        }
 
         // ---- quick reject: nothing alive, expiring or recyclable in or next to this tile
         uint32_t hot = 0;
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
         if (!g.att && __ballot(hot != 0) == 0ull) return;
+        // only now the status rows (a quiescent tile costs its sprite rows only)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            sraw[i] = make_uint4(0, 0, 0, 0);
+            if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
+        }
 
         // tile activity for the next step, part 1: sprite bits that survive this step's recycling,
         // overall and along the four tile edges (a neighbour tile only has to look if they are set)
