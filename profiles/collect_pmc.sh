@@ -1,4 +1,5 @@
 #!/bin/bash
+# builds nothing; run from the repo root on the GPU box: bash profiles/collect_pmc.sh
 # rocprofv3 passes for profiles/ (run on the GPU box from the repo root)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r01
