@@ -407,3 +407,46 @@ def test_dense_mode_equals_tile_skipping(name):
         eng.reset([d["init_pos"]])
         _golden.replay(eng, d, check_each_step=False)
         assert (eng.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (2, 2), (3, 17), (17, 33), (16, 16), (33, 129)])
+def test_tiny_and_ragged_grids(shape):
+    """Degenerate shapes: single cell / single row / single column / widths that are not a
+    multiple of the 16-cell vector or of the 128-cell tile; ignition in a corner."""
+    from simfire_amd.engine import FireEngine
+    H, W = shape
+    rng = np.random.default_rng(H * 131 + W)
+    R8 = rng.choice([0.0, 9.0, 26.0, 60.0], size=(8, H, W))
+    for md, diag, init in [(1, True, (0, 0)), (5, False, (W - 1, H - 1)), (3, True, (W // 2, H // 2))]:
+        kw = dict(shape=(H, W), max_fire_duration=md, pixel_scale=25.0, update_rate=1.0, max_time=None,
+                  attenuate_line_ros=True, diagonal_spread=diag)
+        eng = FireEngine(**kw)
+        eng.set_rtable(R8)
+        eng.reset([init])
+        o = fire_dense.DenseOracle(**kw)
+        o.set_rtable(R8)
+        o.reset([init])
+        for t in range(25):
+            if t == 4 and H * W > 4:
+                pts = [(0, int(rng.integers(W)), int(rng.integers(H)), 3 + int(rng.integers(3))) for _ in range(3)]
+                eng.apply_mitigation(pts)
+                o.apply_mitigation(pts)
+            eng.step(1)
+            o.step(1)
+            assert (eng.fire_map(0) == o.fire_map(0)).all(), (shape, md, t)
+            assert (eng.burn(0) == o.burn(0)).all(), (shape, md, t)
+            st, el = eng.status()
+            so, eo = o.status()
+            assert (st == so).all() and (el == eo).all()
+
+
+def test_noop_calls():
+    from simfire_amd.engine import FireEngine
+    eng = FireEngine((8, 8))
+    eng.set_rtable(np.full((8, 8, 8), 100.0))
+    eng.reset([(3, 3)])
+    eng.step(0)
+    eng.apply_mitigation([])
+    st, el = eng.status()
+    assert st[0, 1] == 0 and el[0] == 0.0 and st[0, 3] == 1
+    assert eng.counters()["ignitions"] == 0
