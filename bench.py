@@ -43,7 +43,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-env measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--debug-cut", type=int, default=0, help="developer: SF_DEBUG_CUT during the timed steps")
     ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-sweep roofline measurement")
     return ap.parse_args()
@@ -202,11 +201,8 @@ def main():
 
     # ------------------------------------------------------------------ timed region
     fence()
-    if a.debug_cut:
-        os.environ["SF_DEBUG_CUT"] = str(a.debug_cut)
     t0 = time.perf_counter()
     kernel_ms = timed_steps(eng, w, a.steps, a.warmup, agent_pts)
-    os.environ.pop("SF_DEBUG_CUT", None)
     eng.copy_status_to(result.data_ptr())            # per-env result block (episode returns)
     if dist is not None:
         dist.all_gather_into_tensor(gathered, result)  # RCCL over xGMI, once per rollout
