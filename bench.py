@@ -220,9 +220,10 @@ def main():
     res = gathered.cpu().numpy()
 
     if rank == 0:
-        geo_tile_cells = 128 * 8 * (a.rows_per_band or 4) if W >= 128 else None
+        geo = eng.geometry()
+        geo_tile_cells = geo["tile_w"] * geo["tile_h"]
         kms, env_steps_local, cnt = measure(eng, w, a, agent_pts, a.dense)
-        tile_cells = geo_tile_cells or (H * W)
+        tile_cells = geo_tile_cells
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")
         traffic = traffic_dense = None
         if os.path.exists(pmc):
@@ -244,6 +245,7 @@ def main():
                        "envs_total": w.n_envs * world, "max_fire_duration": w.max_fire_duration,
                        "pixel_scale": w.pixel_scale, "ros_attenuation": w.attenuate_line_ros,
                        "agents_per_env": w.agents_per_env, "tile_skipping": not a.dense,
+                       "wave_tile": [geo["tile_h"], geo["tile_w"]],
                        "env_steps_executed": env_steps, "env_steps_requested": w.n_envs * world * a.steps,
                        "envs_running_at_end": int(res[:, 0].sum()),
                        "burned_cells_total": int(res[:, 4].sum())},

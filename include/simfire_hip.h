@@ -160,7 +160,10 @@ int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const floa
 int sf_get_counters(sf_sim *sim, int64_t *out /* [8] */, int32_t reset);
 /* The statistics cost a few atomics per active wavefront, so they are off by default. */
 int sf_enable_counters(sf_sim *sim, int32_t on);
-/* bytes of device memory held, and the launch geometry. */
+/* launch geometry: out[0..7] = wave-tile width and height in cells, tiles per environment in x and
+ * y, rows per lane band, row pitch, LDS bytes per wave, dense flag */
+int sf_get_geometry(sf_sim *sim, int32_t *out /* [8] */);
+/* bytes of device memory held */
 int sf_memory_bytes(sf_sim *sim, int64_t *bytes);
 int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step kernel */
 /* Overwrite the ignition threshold only (the reference's tests assign manager.pixel_scale after

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sf_enable_counters": [_VP, _I32],
     "sf_compute_ros": [_I64] + [_VP] * 18 + [_I32],
     "sf_memory_bytes": [_VP, C.POINTER(_I64)],
+    "sf_get_geometry": [_VP, _VP],
     "sf_set_rows_per_band": [_VP, _I32],
     "sf_set_dense": [_VP, _I32],
     "sf_set_threshold": [_VP, C.c_double],

@@ -151,6 +151,13 @@ class FireEngine:
         _lib.check(self._L.sf_memory_bytes(self._h, C.byref(v)))
         return int(v.value)
 
+    def geometry(self):
+        """dict(tile_w, tile_h, tiles_x, tiles_y, rows_per_band, pitch, lds_wave_bytes, dense)"""
+        out = np.zeros(8, dtype=np.int32)
+        _lib.check(self._L.sf_get_geometry(self._h, _ptr(out)))
+        keys = ("tile_w", "tile_h", "tiles_x", "tiles_y", "rows_per_band", "pitch", "lds_wave_bytes", "dense")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def set_rows_per_band(self, rows):
         _lib.check(self._L.sf_set_rows_per_band(self._h, int(rows)))
 
