@@ -454,18 +454,24 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             seam[k] = 0;
             if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
         }
+        // status rows: with the activity map nearly every visited tile is a live one, so they are
+        // requested together with the sprite rows (one memory round trip less); in the dense
+        // cross-check mode only after the quick reject (a quiescent tile costs its sprite rows only)
+        auto load_status = [&]() {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                sraw[i] = make_uint4(0, 0, 0, 0);
+                if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
+            }
+        };
+        if (!g.dense) load_status();
 
         // ---- quick reject: nothing alive, expiring or recyclable in or next to this tile
         uint32_t hot = 0;
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
         if (!g.att && __ballot(hot != 0) == 0ull) return;
-        // only now the status rows (a quiescent tile costs its sprite rows only)
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            sraw[i] = make_uint4(0, 0, 0, 0);
-            if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
-        }
+        if (g.dense) load_status();
 
         // tile activity for the next step, part 1: sprite bits that survive this step's recycling,
         // overall and along the four tile edges (a neighbour tile only has to look if they are set)
