@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--rows-per-band", type=int, default=0)
@@ -54,6 +54,8 @@ def make_workload(name, size, envs, env_offset):
         return workloads.c2(size, 1)
     if name == "c3":
         return workloads.c3(size, envs or 256, env_offset=env_offset)
+    if name == "c4":
+        return workloads.c4(2048 if size == 1024 else size, envs or 128, env_offset=env_offset)
     return workloads.c5(size, envs or 64, env_offset=env_offset)
 
 
@@ -175,7 +177,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    envs_local = a.envs or {"c2": 1, "c3": 256, "c5": 64}[a.workload]
+    envs_local = a.envs or {"c2": 1, "c3": 256, "c4": 128, "c5": 64}[a.workload]
     w = make_workload(a.workload, a.size, envs_local, env_offset=rank * envs_local)
     H, W = w.shape
     agent_pts = None

@@ -121,6 +121,9 @@ class DenseOracle:
         xy = np.ascontiguousarray(np.asarray(init_xy, dtype=np.int32).reshape(self.n_envs, 2))
         self._L.fo_reset(self._h, _p(xy))
 
+    def reset_env(self, env, x, y):
+        self._L.fo_reset_env(self._h, int(env), int(x), int(y))
+
     def apply_mitigation(self, pts):
         """pts: rows (env, x, y, type)."""
         q = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 4))

@@ -121,5 +121,35 @@ def c5(size=1024, n_envs=64, n_agents=64, env_offset=0):
     return w
 
 
+def octave_field(H, W, seed, scale, octaves, persistence, lacunarity, lo, hi):
+    """Smooth multi-octave field in [lo, hi] standing in for the reference's simplex-noise wind maps
+    (simfire/world/wind_mechanics/perlin_wind.py:83-98, ``noise.snoise2`` - a third-party wheel that
+    is not available offline; parity for that generator is unpinned in the reference itself).
+    Sum of randomly oriented sinusoids per octave, float32 like ``perlin_wind.py:69-75``."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    z = np.zeros((H, W))
+    amp, freq, norm = 1.0, 1.0 / scale, 0.0
+    for _ in range(octaves):
+        for _ in range(3):
+            th, ph = rng.uniform(0, 2 * np.pi, 2)
+            z += amp / 3 * np.sin(2 * np.pi * freq * (x * np.cos(th) + y * np.sin(th)) + ph)
+        norm += amp
+        amp *= persistence
+        freq *= lacunarity
+    z = (z / norm + 1) / 2
+    return (z * (hi - lo) + lo).astype(np.float32)
+
+
+def c4(size=2048, n_envs=128, env_offset=0):
+    """Section 8d C4: 2048^2 operational-style terrain, wind fields with the parameters of
+    configs/operational_config.yml:106-122 (speed 7-47 mph, direction 0-360 deg), 128 envs per GPU."""
+    w = c2(size, n_envs, name="c4_operational_%d_x%d" % (size, n_envs), env_offset=env_offset)
+    H, W = w.shape
+    w.U = octave_field(H, W, 2345, 400, 3, 0.7, 2.0, 7 * 88.0, 47 * 88.0).astype(np.float64)
+    w.U_dir = octave_field(H, W, 650, 1500, 2, 0.9, 1.0, 0.0, 360.0).astype(np.float64)
+    return w
+
+
 def build(name, **kw):
-    return {"c1": c1, "c2": c2, "c3": c3, "c5": c5}[name](**kw)
+    return {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}[name](**kw)

@@ -450,3 +450,52 @@ def test_noop_calls():
     st, el = eng.status()
     assert st[0, 1] == 0 and el[0] == 0.0 and st[0, 3] == 1
     assert eng.counters()["ignitions"] == 0
+
+
+def test_midrun_env_reset_and_geometry_change():
+    """RL auto-reset: one environment restarts while the others keep burning; then the launch
+    geometry is changed mid-run (the tile activity map is rebuilt from the cell planes)."""
+    d = _golden.load_traj("g3_lines_a1")
+    H, W = (int(v) for v in d["shape"])
+    E = 4
+    xy = np.array([[20, 18], [5, 5], [40, 30], [10, 35]], dtype=np.int32)
+    eng = _engine(d, n_envs=E)
+    eng.set_rtable(d["rtable"])
+    eng.reset(xy)
+    o = fire_dense.DenseOracle(n_envs=E, **_golden.engine_kwargs(d))
+    o.set_rtable(d["rtable"])
+    o.reset(xy)
+    rng = np.random.default_rng(3)
+
+    def both(fn):
+        fn(eng)
+        fn(o)
+
+    for t in range(45):
+        if t % 4 == 0:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(5)]
+            both(lambda s: s.apply_mitigation(pts))
+        if t == 12:
+            both(lambda s: s.reset_env(1, 30, 30))
+        if t == 20:
+            eng.set_rows_per_band(1)
+        if t == 30:
+            both(lambda s: s.reset_env(3, 2, 38))
+            eng.set_rows_per_band(8)
+        both(lambda s: s.step(1))
+        for e in range(E):
+            assert (eng.fire_map(e) == o.fire_map(e)).all(), (t, e)
+    for e in range(E):
+        assert (eng.burn(e) == o.burn(e)).all(), e
+    st, el = eng.status()
+    so, eo = o.status()
+    assert (st == so).all() and (el == eo).all()
+
+
+def test_c4_wind_field_workload():
+    """C4 shape at reduced batch: 2048x2048, spatially varying wind speed / direction."""
+    from simfire_amd import workloads
+    w = workloads.c4(2048, 2)
+    assert w.U.min() >= 7 * 88 and w.U.max() <= 47 * 88 and w.U_dir.min() >= 0 and w.U_dir.max() <= 360
+    _workload_pair(w, 120, 60)
