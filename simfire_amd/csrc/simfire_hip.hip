@@ -7,34 +7,34 @@
 //   compute_rate_of_spread                                       simfire/world/rothermel.py:4-136
 //   ControlLineManager.update + FireSimulation.update_mitigation mitigation.py:60-80, simulation.py:449-478
 //
-// Design (see DESIGN.md for the derivation):
+// Design (DESIGN.md has the derivation and the measurements):
 //   * State per environment, structure-of-arrays in HBM, row pitch P = roundup(W, 16) bytes:
 //       status u8 [H][P]      BurnStatus in bits 0-2 (bit 7 = "line attenuation already settled")
 //       age    u8 [H+2][P]    bitmask of the live sprites of a cell, indexed by ABSOLUTE ignition
 //                             step modulo N = max_fire_duration + 3 (one zero guard row above/below)
 //       burn   f64 [H][P]     RothermelFireManager.burn_amounts
-//     shared by all environments: rt f64 [8][H][P], the rate-of-spread table (ft/min).
+//     shared by all environments: rt f64 [8][H][P], the rate-of-spread table (ft/min), and a
+//     per-wave-tile activity map (u8 flags: sprites in tile / on which edges, control lines).
 //   * The reference's ordered sprite list is replaced by the order-free per-cell rule of
 //     SURVEY.md section 8a.  Ages are not shifted every step: a sprite ignited at step s owns
-//     bit (s mod N) until it is cleared at step s + max_fire_duration + 2, so the planes are
-//     only written where something happens, and a step can run IN PLACE: every concurrent
-//     writer of a step touches only the two slots (t and t - md - 2) that readers mask out.
-//   * One step = one launch.  Phase 1 (SWAR scan): every lane owns 16 cells of a row, slides a
-//     3-row register window down its band, and finds - 4 cells per VALU op - the cells that can
-//     matter: expiring sprites, cells next to a live sprite, control-line cells.  Horizontal
-//     neighbours come from the adjacent lanes by wavefront shuffles.  Those few cells are
-//     compacted into a per-wave LDS work list (ds_add_rtn allocation per lane).  Phase 2
-//     (frontier): the whole wave walks the compacted list, one cell per lane: winner source,
-//     R table lookup, float64 burn update, ignition.
-//   * The per-environment predicates of fire.py:637-652 (no sprite left -> QUIT, runtime
-//     exceeded -> QUIT, no candidate -> nothing happens) travel through a 3-deep ring of
-//     flag words: launch i reduces into ring[i % 3] with wave ballots + one atomicOr, launch
-//     i + 1 folds them into the environment state, so no extra launch sits between steps.
-//     The only consumer that needs a step's "any candidate" flag inside the same step - the
+//     bit (s mod N) until it is recycled at step s + max_fire_duration + 2, so the planes are
+//     only written where something happens, and a step runs IN PLACE: every concurrent writer of
+//     a step touches only the two slots (t and t - md - 2) that readers mask out.
+//   * One step = k_select + k_step.  k_select (one thread per 64 x 64 wave tile) folds the
+//     per-environment predicates of fire.py:637-652 of the previous step (3-deep ring of flag
+//     words), and compacts the tiles in which anything can change into a list (ballot + mbcnt +
+//     one atomic per workgroup).  k_step: persistent waves walk that list; a wave loads its tile
+//     (16 cells per lane, 16 B vectors) plus halo rows / seam columns, parks it in LDS, scans it
+//     SWAR (4 cells per VALU op) for expiring sprites and frontier cells (eligible status next
+//     to a live sprite), compacts those with one wave prefix sum into an LDS list and walks the
+//     list one cell per lane: winner source from the 3 x 3 LDS neighbourhood, one f64 table
+//     entry, f64 burn update, ignition.  Changed 16 B vectors are written back once.
+//   * The only consumer that needs a step's "any candidate" predicate inside the same step - the
 //     attenuation of control-line cells that are not next to the fire (fire.py:271-278) - is
 //     deferred by one step (applied first thing when the cell is next touched).
 //
-// No MFMA: there is no dense contraction anywhere on this path; it is HBM-bound byte work.
+// No MFMA: there is no dense contraction anywhere on this path; it is byte / integer work plus a
+// handful of float64 adds per frontier cell.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: burn_amounts and the
 // ignition test burn > pixel_scale must round exactly like IEEE float64 on the CPU).
 #include <hip/hip_runtime.h>
