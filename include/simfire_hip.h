@@ -169,6 +169,11 @@ int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step 
 /* Overwrite the ignition threshold only (the reference's tests assign manager.pixel_scale after
  * construction, test_fire.py:334; slopes keep the constructor value, fire.py:377). */
 int sf_set_threshold(sf_sim *sim, double pixel_scale);
+/* Asynchronous mode for rollout loops: sf_step / sf_apply_mitigation only enqueue work on the
+ * handle's stream; every call that hands data back (sf_get_*, sf_step_timed, sf_copy_status_to,
+ * sf_sync) synchronises.  Default: off (every call returns after its work is done). */
+int sf_set_async(sf_sim *sim, int32_t on);
+int sf_sync(sf_sim *sim);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);
 

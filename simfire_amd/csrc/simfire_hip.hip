@@ -926,45 +926,57 @@ __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 }
 
 // ------------------------------------------------------------------------- mitigation
-// One workgroup per environment that received points.  pts rows (env, x, y, type) are grouped
-// by environment on the host; seg[b] .. seg[b+1] is the row range of workgroup b.
-// Phase A (attenuation mode only): the first writer of a cell settles what the cell is still
-// owed for the last step under its OLD status.  Phases B1-B3: FIRELINE, SCRATCHLINE, WETLINE
-// writes in the reference's order (simulation.py:476-478), so for duplicates the later type wins.
-__global__ __launch_bounds__(256) void k_mitigate(Geo g, uint8_t *status, const uint8_t *age, double *burn,
-                                                  const EnvState *commit, const int32_t *pts, const int32_t *seg,
-                                                  uint8_t *tflags, int ring)
+// FireSimulation.update_mitigation (simulation.py:449-478) as two tiny launches, one thread per
+// point (env, x, y, type), no ordering of the points needed:
+//   k_mitigate_clear  one atomic CAS per point: the status byte becomes "no type yet | settled";
+//                     the thread that sees the OLD byte settles what the cell is still owed for
+//                     the last step under its old status (attenuation mode), duplicates see the
+//                     cleared byte and do nothing;
+//   k_mitigate_write  byte-wise atomic max of the line types: FIRELINE < SCRATCHLINE < WETLINE is
+//                     exactly the reference's "FIRELINE writes, then SCRATCHLINE, then WETLINE"
+//                     order for duplicates (simulation.py:476-478); each write is unconditional
+//                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.
+__global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+                                 const int32_t *pts, int n)
 {
-    const int b = blockIdx.x;
-    const int lo = seg[b], hi = seg[b + 1];
-    if (lo >= hi) return;
-    const int e = pts[4 * lo];
-    uint8_t *st_e = status + (long long)e * g.plane_env;
-    if (g.att) {
-        const EnvState s = commit[e];
-        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            const int x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
-            if (ty < SF_FIRELINE || ty > SF_WETLINE) continue;
-            const long long o = (long long)y * g.P + x;
-            uint32_t *word = reinterpret_cast<uint32_t *>(st_e + (o & ~3ll));
-            const int sh = (int)(o & 3) * 8;
-            const uint32_t old = atomicOr(word, 0x80u << sh);
-            const uint32_t sraw = (old >> sh) & 0xFFu;
-            if (!(sraw & 0x80u) && owes_attenuation(g, s, age + (long long)e * g.age_env, sraw, x, y)) {
-                const long long c = (long long)e * g.plane_env + o;
-                burn[c] = burn[c] - line_factor(sraw & 7u);
-            }
-            // the tile now holds a control line: it has to be visited every step from now on
-            uint8_t *tf = tflags + (((long long)ring * g.E + e) * g.TYp + y / (g.LR * g.RB) + 1) * g.TXp + (x / 16) / g.LC + 1;
-            if (!(*tf & 2u)) *tf = (uint8_t)(*tf | 2u);   // idempotent: every racer writes the same bit
-        }
-    }
-    const uint8_t mark = g.att ? 0x80u : 0u;
-    for (int kind = SF_FIRELINE; kind <= SF_WETLINE; ++kind) {
-        __syncthreads();
-        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x)
-            if (pts[4 * i + 3] == kind)
-                st_e[(long long)pts[4 * i + 2] * g.P + pts[4 * i + 1]] = (uint8_t)(kind | mark);   // mitigation.py:75-78
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = pts[4 * i], x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
+    if (ty < SF_FIRELINE || ty > SF_WETLINE) return;                 // simulation.py:469-473
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
+    const int sh = (int)(o & 3) * 8;
+    uint32_t old = *word, seen;
+    do {
+        seen = old;
+        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (0x80u << sh));
+    } while (old != seen);
+    const uint32_t sraw = (seen >> sh) & 0xFFu;
+    if (g.att && !(sraw & 0x80u) && owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y))
+        burn[o] = burn[o] - line_factor(sraw & 7u);
+}
+
+__global__ void k_mitigate_write(Geo g, uint8_t *status, const int32_t *pts, int n, uint8_t *tflags, int ring)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = pts[4 * i], x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
+    if (ty < SF_FIRELINE || ty > SF_WETLINE) return;
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
+    const int sh = (int)(o & 3) * 8;
+    const uint32_t mark = g.att ? 0x80u : 0u;                         // "nothing owed for the last step"
+    uint32_t old = *word, seen;
+    do {
+        seen = old;
+        const uint32_t cur = (seen >> sh) & 7u;
+        if (cur >= (uint32_t)ty && (((seen >> sh) & 0x80u) == mark)) break;
+        const uint32_t nb = (cur > (uint32_t)ty ? cur : (uint32_t)ty) | mark;
+        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (nb << sh));
+    } while (old != seen);
+    if (g.att) {   // the tile now holds a control line: it has to be visited every step from now on
+        uint8_t *tf = tflags + (((long long)ring * g.E + e) * g.TYp + y / (g.LR * g.RB) + 1) * g.TXp + (x / 16) / g.LC + 1;
+        if (!(*tf & 2u)) *tf = (uint8_t)(*tf | 2u);   // idempotent: every racer writes the same bit
     }
 }
 
@@ -1028,8 +1040,10 @@ struct sf_sim {
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
     size_t stage_bytes = 0;
-    int32_t *pts_dev = nullptr, *seg_dev = nullptr;
-    size_t pts_cap = 0, seg_cap = 0;
+    int32_t *pts_dev = nullptr, *pts_pinned = nullptr;
+    size_t pts_cap = 0;
+    hipEvent_t ev_pts = nullptr;
+    bool async = false;                // sf_set_async: calls that return no data do not synchronise
     bool have_rt = false, was_reset = false, counters_on = false;
     int64_t bytes = 0;
 };
@@ -1113,7 +1127,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     int rc;
 #define TRY(x) do { rc = (x); if (rc != SF_OK) { sf_destroy(s); return rc; } } while (0)
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(SF_EHIP, "hipStreamCreate failed"); }
-    hipEventCreate(&s->ev0); hipEventCreate(&s->ev1);
+    hipEventCreate(&s->ev0); hipEventCreate(&s->ev1); hipEventCreate(&s->ev_pts);
     const size_t cells = (size_t)g.E * g.plane_env;
     TRY(dev_alloc(s, &s->status, cells));
     TRY(dev_alloc(s, &s->age_alloc, (size_t)g.E * g.age_env + 2 * (size_t)g.P));
@@ -1155,7 +1169,9 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
                     s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
-                    s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->seg_dev};
+                    s->status_block, s->elapsed_dev, s->stage, s->pts_dev};
+    if (s->pts_pinned) (void)hipHostFree(s->pts_pinned);
+    if (s->ev_pts) (void)hipEventDestroy(s->ev_pts);
     for (void *p : ptrs) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
@@ -1211,6 +1227,23 @@ extern "C" int sf_set_threshold(sf_sim *s, double pixel_scale)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_threshold: null handle");
     s->g.pixel_scale = pixel_scale;
+    return SF_OK;
+}
+
+/* Asynchronous mode for rollout loops: sf_step / sf_apply_mitigation enqueue their work on the
+ * handle's stream and return; every call that hands data back (sf_get_*, sf_step_timed,
+ * sf_copy_status_to, sf_sync) synchronises. */
+extern "C" int sf_set_async(sf_sim *s, int32_t on)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_async: null handle");
+    s->async = on != 0;
+    return SF_OK;
+}
+extern "C" int sf_sync(sf_sim *s)
+{
+    if (!s) return fail(SF_EINVAL, "sf_sync: null handle");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
 
@@ -1338,45 +1371,35 @@ extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
     if (n < 0 || (n > 0 && !pts)) return fail(SF_EINVAL, "sf_apply_mitigation: bad point list");
     if (n == 0) return SF_OK;
     const Geo &g = s->g;
-    // validate, drop unknown types (simulation.py:469-473), group by environment (stable)
-    std::vector<int32_t> cnt(g.E + 1, 0);
     for (int i = 0; i < n; ++i) {
         const int32_t *q = pts + 4 * i;
         if (q[0] < 0 || q[0] >= g.E || q[1] < 0 || q[1] >= g.W || q[2] < 0 || q[2] >= g.H)
             return fail(SF_EINVAL, "sf_apply_mitigation: point %d = (env %d, x %d, y %d) is out of range", i, q[0], q[1], q[2]);
-        if (q[3] >= SF_FIRELINE && q[3] <= SF_WETLINE) cnt[q[0] + 1]++;
     }
-    std::vector<int32_t> start(g.E + 1, 0);
-    for (int e = 0; e < g.E; ++e) start[e + 1] = start[e] + cnt[e + 1];
-    const int m = start[g.E];
-    if (m == 0) return SF_OK;
-    std::vector<int32_t> sorted((size_t)4 * m), fill(start.begin(), start.end() - 1), seg;
-    for (int i = 0; i < n; ++i) {
-        const int32_t *q = pts + 4 * i;
-        if (q[3] < SF_FIRELINE || q[3] > SF_WETLINE) continue;
-        memcpy(&sorted[(size_t)4 * fill[q[0]]++], q, 4 * sizeof(int32_t));
-    }
-    for (int e = 0; e < g.E; ++e) if (start[e + 1] > start[e]) seg.push_back(start[e]);
-    const int nseg = (int)seg.size();
-    seg.push_back(m);
     HIPCHK(hipSetDevice(s->p.device));
-    if ((size_t)4 * m > s->pts_cap) {
+    const size_t bytes = (size_t)4 * n * sizeof(int32_t);
+    if ((size_t)4 * n > s->pts_cap) {
+        HIPCHK(hipStreamSynchronize(s->stream));
         if (s->pts_dev) HIPCHK(hipFree(s->pts_dev));
-        s->pts_cap = (size_t)4 * m * 2;
+        if (s->pts_pinned) HIPCHK(hipHostFree(s->pts_pinned));
+        s->pts_dev = nullptr; s->pts_pinned = nullptr;
+        s->pts_cap = (size_t)4 * n * 2;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->pts_dev), s->pts_cap * sizeof(int32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pts_pinned), s->pts_cap * sizeof(int32_t), hipHostMallocDefault));
+    } else {
+        // the pinned staging buffer may still feed the previous asynchronous upload
+        HIPCHK(hipEventSynchronize(s->ev_pts));
     }
-    if ((size_t)nseg + 1 > s->seg_cap) {
-        if (s->seg_dev) HIPCHK(hipFree(s->seg_dev));
-        s->seg_cap = ((size_t)nseg + 1) * 2;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->seg_dev), s->seg_cap * sizeof(int32_t)));
-    }
-    HIPCHK(hipMemcpyAsync(s->pts_dev, sorted.data(), (size_t)4 * m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->seg_dev, seg.data(), ((size_t)nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_mitigate, dim3(nseg), dim3(256), 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
-                       (const EnvState *)s->commit, (const int32_t *)s->pts_dev, (const int32_t *)s->seg_dev, s->tflags,
-                       s->ring);
+    memcpy(s->pts_pinned, pts, bytes);
+    HIPCHK(hipMemcpyAsync(s->pts_dev, s->pts_pinned, bytes, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipEventRecord(s->ev_pts, s->stream));
+    const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+                       (const EnvState *)s->commit, (const int32_t *)s->pts_dev, (int)n);
+    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, (const int32_t *)s->pts_dev, (int)n,
+                       s->tflags, s->ring);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s->stream));   // host vectors go out of scope
+    if (!s->async) HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
 
@@ -1437,7 +1460,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
                        (const EnvState *)s->tmp, s->flags, n_steps - 1, s->n_active);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s->stream));
+    if (ms || !s->async) HIPCHK(hipStreamSynchronize(s->stream));
     if (ms) HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
     return SF_OK;
 }

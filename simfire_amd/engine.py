@@ -166,6 +166,13 @@ class FireEngine:
         _lib.check(self._L.sf_set_threshold(self._h, float(pixel_scale)))
         self.params.pixel_scale = float(pixel_scale)
 
+    def set_async(self, on=True):
+        """Rollout mode: ``step`` / ``apply_mitigation`` only enqueue work; ``sync`` or any getter waits."""
+        _lib.check(self._L.sf_set_async(self._h, int(bool(on))))
+
+    def sync(self):
+        _lib.check(self._L.sf_sync(self._h))
+
     def set_dense(self, dense=True):
         """Visit every tile every step (cross-check of the tile activity map)."""
         _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))
