@@ -174,6 +174,9 @@ int sf_set_threshold(sf_sim *sim, double pixel_scale);
  * sf_sync) synchronises.  Default: off (every call returns after its work is done). */
 int sf_set_async(sf_sim *sim, int32_t on);
 int sf_sync(sf_sim *sim);
+/* Step launch structure: -1 = by problem size (default: one fused launch per step up to 4096 wave
+ * tiles, k_select + k_step above), 0 = always two launches, 1 = always fused. */
+int sf_set_fused(sf_sim *sim, int32_t mode);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);
 

@@ -727,14 +727,72 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     }
 }
 
+// Small problems (few wave tiles, e.g. a single 1024 x 1024 environment = 256 tiles): one launch
+// per step.  Every tile gets its own wave, which does k_select's job for that tile itself (fold the
+// environment state, look at the 3 x 3 tile flags, reset the tile's flag for the next step) and,
+// if the tile is live, the update.  Saves the second launch and the list round trip, which
+// dominate when a step is only a few microseconds of work.
+template <int RB>
+__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(StepArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
+    const int per_env = g.TY * g.TX;
+    const long long gid = (long long)blockIdx.x * kWaves + wave;
+    if (gid >= (long long)g.E * per_env) return;
+    const int e = (int)(gid / per_env);
+    const int tile = (int)(gid - (long long)e * per_env);
+    const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
+
+    EnvState st;
+    if (a.launch == 0) st = a.commit[e];
+    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    if (tile == 0 && lane == 0) {
+        a.tmp[(a.launch & 1) * g.E + e] = st;
+        a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
+    }
+    const long long fplane = (long long)g.TYp * g.TXp;
+    const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+    uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
+    const long long o = (long long)(tyw + 1) * g.TXp + (chunk + 1);
+    uint32_t fl = 0;
+    if (lane < 9) fl = f_rd[o + (lane / 3 - 1) * g.TXp + (lane % 3 - 1)];
+    // lanes 0..8 = ul up ur lf own rt dl dn dr; which flag bits make the centre tile live: see k_select
+    const uint32_t need[9] = {40u, 8u, 24u, 32u, 1u, 16u, 36u, 4u, 20u};
+    const uint32_t want = lane < 9 ? need[lane] : 0xFFu;
+    const bool near = __ballot(lane < 9 && (fl & want) == want) != 0ull;
+    const uint32_t own = __shfl(fl, 4);
+    if (lane == 0) f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
+    if (!(st.running && (g.dense || near || (g.att && (own & 2u))))) return;
+
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
+    step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2);
+    if (a.counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            n_active += __shfl_down(n_active, off);
+            n_ignite += __shfl_down(n_ignite, off);
+        }
+        if (lane == 0) {
+            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+            if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+            if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+            if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+            atomicAdd(&cs[3], 1ull);
+            if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);
+        }
+    }
+}
+
 typedef void (*StepKernel)(StepArgs);
-static StepKernel pick_step_kernel(int rb)
+static StepKernel pick_step_kernel(int rb, bool fused)
 {
     switch (rb) {
-    case 1: return k_step<1>;
-    case 2: return k_step<2>;
-    case 4: return k_step<4>;
-    default: return k_step<8>;
+    case 1: return fused ? k_step_fused<1> : k_step<1>;
+    case 2: return fused ? k_step_fused<2> : k_step<2>;
+    case 4: return fused ? k_step_fused<4> : k_step<4>;
+    default: return fused ? k_step_fused<8> : k_step<8>;
     }
 }
 
@@ -1036,6 +1094,7 @@ struct sf_sim {
     int ring = 0;                      // tile activity map the next step reads (0/1)
     uint32_t *tile_list = nullptr, *n_active = nullptr;
     int n_cu = 256;
+    int fused_mode = -1;               // -1 auto, 0 never, 1 always: one fused launch per step
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -1247,6 +1306,14 @@ extern "C" int sf_sync(sf_sim *s)
     return SF_OK;
 }
 
+/* -1 = choose by problem size (default), 0 = always k_select + k_step, 1 = always one fused launch */
+extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
+{
+    if (!s || mode < -1 || mode > 1) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0 or 1");
+    s->fused_mode = mode;
+    return SF_OK;
+}
+
 /* 1 = visit every tile every step (cross-check of the tile activity map), 0 = default */
 extern "C" int sf_set_dense(sf_sim *s, int32_t dense)
 {
@@ -1440,19 +1507,20 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     const dim3 block(kWaves * 64);
-    const StepKernel kern = pick_step_kernel(s->g.RB);
-    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active;
-    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     const long long n_wave_tiles = (long long)s->g.E * s->g.TY * s->g.TX;
+    // few tiles: one fused launch per step; many: select the live tiles first, then persistent waves
+    const bool fused = s->fused_mode == 1 || (s->fused_mode < 0 && n_wave_tiles <= 4096);
+    const StepKernel kern = pick_step_kernel(s->g.RB, fused);
+    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active;
     const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
-    // persistent step waves: enough workgroups to fill the chip, never more than there are tiles
-    long long want = (long long)s->n_cu * 16 / kWaves;
-    if (want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
+    long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * 16 / kWaves;
+    if (!fused && want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
     const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
+    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int i = 0; i < n_steps; ++i) {
         a.launch = i;
         a.ring = s->ring;
-        hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
+        if (!fused) hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
         hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
         s->ring ^= 1;
     }

@@ -173,6 +173,10 @@ class FireEngine:
     def sync(self):
         _lib.check(self._L.sf_sync(self._h))
 
+    def set_fused(self, mode=-1):
+        """-1 auto, 0 always k_select + k_step, 1 always one fused launch per step."""
+        _lib.check(self._L.sf_set_fused(self._h, int(mode)))
+
     def set_dense(self, dense=True):
         """Visit every tile every step (cross-check of the tile activity map)."""
         _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))

@@ -499,3 +499,36 @@ def test_c4_wind_field_workload():
     w = workloads.c4(2048, 2)
     assert w.U.min() >= 7 * 88 and w.U.max() <= 47 * 88 and w.U_dir.min() >= 0 and w.U_dir.max() <= 360
     _workload_pair(w, 120, 60)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("name", ["g3_lines_a1", "g4_lines_on_burning", "g7_early_return", "g6_runtime"])
+def test_launch_structures(name, fused):
+    """One fused launch per step (small problems) and k_select + persistent k_step (large ones)
+    are two schedules of the same update: force each on the golden trajectories."""
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    eng.set_fused(fused)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d)
+    assert (eng.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_c3_both_launch_structures(fused):
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c3(512, 6)
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_fused(fused)
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    eng.step(150)
+    o.step(150, 6)
+    for e in range(6):
+        assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
+    assert (eng.status()[0] == o.status()[0]).all()
