@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Manual soak test (not collected by pytest): many randomised worlds, HIP vs the dense C oracle,
+over random launch structures / geometries / modes.  python tests/soak_gpu.py [n_worlds] [seed0]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import fire_dense  # noqa: E402
+from simfire_amd.engine import FireEngine  # noqa: E402
+
+
+def world(seed):
+    rng = np.random.default_rng(seed)
+    big = rng.random() < 0.25
+    H, W = (int(rng.integers(60, 300)), int(rng.integers(60, 300))) if big else (int(rng.integers(1, 70)), int(rng.integers(1, 70)))
+    E = int(rng.integers(1, 5))
+    md = int(rng.integers(1, 6))
+    att, diag = bool(rng.integers(2)), bool(rng.integers(2))
+    ps = float(rng.choice([0.0, 5.0, 20.0, 50.0, 98.0]))
+    R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 99.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < rng.choice([0.0, 0.1, 0.4])] = 0.0
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=md, pixel_scale=ps,
+              update_rate=float(rng.choice([1.0, 0.5, 1.5, 3.0])),
+              max_time=(None if rng.random() < 0.6 else float(rng.integers(3, 40))),
+              attenuate_line_ros=att, diagonal_spread=diag)
+    xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
+    eng, o = FireEngine(**kw), fire_dense.DenseOracle(**kw)
+    eng.set_fused(int(rng.integers(-1, 2)))
+    eng.set_dense(bool(rng.random() < 0.2))
+    eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
+    eng.set_rtable(R8)
+    o.set_rtable(R8)
+    eng.reset(xy)
+    o.reset(xy)
+    steps = int(rng.integers(20, 90))
+    for t in range(steps):
+        r = rng.random()
+        if r < 0.35:
+            k = int(rng.integers(1, 30))
+            pts = np.column_stack([rng.integers(0, E, k), rng.integers(0, W, k), rng.integers(0, H, k), rng.integers(2, 7, k)])
+            cur = o.fire_map(0)
+            burning = np.argwhere(cur == 1)
+            if len(burning):
+                y, x = burning[rng.integers(len(burning))]
+                pts = np.vstack([pts, [[0, x, y, int(rng.integers(3, 6))], [0, x, y, int(rng.integers(3, 6))]]])
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        elif r < 0.40:
+            e = int(rng.integers(E))
+            new = o.fire_map(e).copy()
+            m = rng.random((H, W))
+            new[m < 0.05] = 0
+            new[m > 0.97] = rng.integers(3, 6)
+            eng.load_fire_map(e, new)
+            o.load_fire_map(e, new)
+        elif r < 0.44:
+            e = int(rng.integers(E))
+            x, y = int(rng.integers(W)), int(rng.integers(H))
+            eng.reset_env(e, x, y)
+            o.reset_env(e, x, y)
+        elif r < 0.47:
+            eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
+        n = int(rng.choice([1, 1, 1, 2, 5]))
+        eng.step(n)
+        o.step(n)
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), (seed, t, "status")
+        if rng.random() < 0.5 or t == steps - 1:
+            for e in range(E):
+                assert (eng.fire_map(e) == o.fire_map(e)).all(), (seed, t, e, "fire_map")
+                assert (eng.burn(e) == o.burn(e)).all(), (seed, t, e, "burn")
+    eng.close()
+    return H * W * E * steps
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    cells = 0
+    for s in range(s0, s0 + n):
+        cells += world(s)
+    print(f"soak ok: {n} worlds, {cells:.3g} cell-steps, {time.time()-t0:.1f} s")
