@@ -164,3 +164,36 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    """No CPU fallback: without the HIP library the product path raises, it does not degrade."""
+    from simfire_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsimfire_hip.so")
+    with pytest.raises(_lib.SimfireHipError):
+        _lib.load()
+    from simfire_amd.engine import FireEngine
+    with pytest.raises(_lib.SimfireHipError):
+        FireEngine((8, 8))
+
+
+def test_error_code_mapping():
+    from simfire_amd import _lib
+    lib = _lib.load()
+    # argument validation happens before any HIP call, so these work without a GPU
+    import ctypes as C
+    p = _lib.SfParams(n_envs=0, height=4, width=4, max_fire_duration=4, diagonal_spread=1, attenuate_line_ros=1,
+                      has_max_time=0, device=0, pixel_scale=1.0, update_rate=1.0, max_time=0.0, h=8000, S_T=0.0555,
+                      S_e=0.01, p_p=32, M_f=0.03)
+    h = C.c_void_p()
+    rc = lib.sf_create(C.byref(p), C.byref(h))
+    assert rc == _lib.SF_EINVAL
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    p.n_envs, p.max_fire_duration = 1, 9
+    rc = lib.sf_create(C.byref(p), C.byref(h))
+    assert rc == _lib.SF_ENOTSUP
+    with pytest.raises(NotImplementedError):
+        _lib.check(rc)
+    assert b"max_fire_duration" in lib.sf_last_error()
