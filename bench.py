@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-env measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the\n"
+                         "multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-sweep roofline measurement")
     return ap.parse_args()
 
@@ -184,13 +187,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    device = local_rank % n_dev                      # one process per GPU (gloo test runs may share one)
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = f"cuda:{device}" if (dist is None or a.backend == "nccl") else "cpu"
 
     envs_local = a.envs or {"c2": 1, "c3": 256, "c4": 128, "c5": 64}[a.workload]
     w = make_workload(a.workload, a.size, envs_local, env_offset=rank * envs_local)
@@ -200,10 +208,10 @@ def main():
         from simfire_amd import workloads
         agent_pts = workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup,
                                          env_offset=rank * envs_local)
-    eng = run_gpu(w, a.steps, a.warmup, local_rank, a.rows_per_band)
+    eng = run_gpu(w, a.steps, a.warmup, device, a.rows_per_band)
     eng.set_dense(a.dense)
-    result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{local_rank}")
-    gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else result
+    result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{device}")
+    gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
     if a.warmup:
         timed_steps(eng, w, a.warmup, 0, agent_pts)
@@ -222,13 +230,13 @@ def main():
     run_steps(eng, w, a.steps, a.warmup, agent_pts)
     eng.copy_status_to(result.data_ptr())            # per-env result block (episode returns)
     if dist is not None:
-        dist.all_gather_into_tensor(gathered, result)  # RCCL over xGMI, once per rollout
+        dist.all_gather_into_tensor(gathered, result.to(coll_dev))  # RCCL over xGMI, once per rollout
     fence()
     dt = time.perf_counter() - t0
     # ---------------------------------------------------------------------------------
     env_steps = result[:, 1].sum().item() - steps_before      # update() calls really made
     if dist is not None:
-        red = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        red = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=coll_dev)
         tmax = red[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = red[1:].clone()
@@ -283,7 +291,7 @@ def main():
             # secondary: BASELINE config C2 (1 env, 1024^2) - launch-latency bound
             eng.close()
             w2 = make_workload("c2", a.size, 1, 0)
-            e2 = run_gpu(w2, a.steps, a.warmup, local_rank)
+            e2 = run_gpu(w2, a.steps, a.warmup, device)
             e2.step(a.warmup)
             s0, _ = e2.status()
             torch.cuda.synchronize()
