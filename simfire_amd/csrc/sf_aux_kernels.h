@@ -1,0 +1,240 @@
+// Reset-time and boundary kernels: slopes, R table, rate-of-spread pairs, plane packing, mitigation scatter, result block.
+// Part of the single translation unit simfire_hip.hip (see its header comment for the design).
+// Replaces fire.py:436-449 (slopes), rothermel.py:4-136, mitigation.py:60-80 + simulation.py:425-478.
+#pragma once
+
+#include "sf_common.h"
+#include "rothermel_dev.h"
+
+namespace {
+
+// ------------------------------------------------------------------ layers -> R table
+// np.gradient(elevations, pixel_scale) (fire.py:446): centred 2nd-order differences inside,
+// one-sided 1st-order at the borders; slope_mag / slope_dir (fire.py:447-448) in float64.
+__global__ void k_slopes(int H, int W, const double *el, double ps, double *mag, double *dir)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const long long i = (long long)y * W + x;
+    double gy, gx;
+    if (H == 1) gy = 0.0;
+    else if (y == 0) gy = (el[i + W] - el[i]) / ps;
+    else if (y == H - 1) gy = (el[i] - el[i - W]) / ps;
+    else gy = (el[i + W] - el[i - W]) / (2.0 * ps);
+    if (W == 1) gx = 0.0;
+    else if (x == 0) gx = (el[i + 1] - el[i]) / ps;
+    else if (x == W - 1) gx = (el[i] - el[i - 1]) / ps;
+    else gx = (el[i + 1] - el[i - 1]) / (2.0 * ps);
+    mag[i] = sqrt(gx * gx + gy * gy);
+    dir[i] = atan2(gy, gx + 0.000001);
+}
+
+struct Thetas { float v[8]; };
+
+// One thread per cell: direction-independent terms once, then the 8 travel directions.
+__global__ void k_rtable(int H, int W, int P, const double *w0, const double *delta, const double *Mx,
+                         const double *sigma, const double *U, const double *Udir, const double *mag,
+                         const double *dir, float h, float S_T, float S_e, float p_p, float M_f,
+                         Thetas th, double *rt)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= P) return;
+    const long long o = (long long)y * P + x, plane = (long long)H * P;
+    if (x >= W) {
+        for (int k = 0; k < 8; ++k) rt[k * plane + o] = 0.0;
+        return;
+    }
+    const long long i = (long long)y * W + x;
+    // every input is rounded to float32 first (fire.py:537,546)
+    const sfdev::CellTerms t = sfdev::cell_terms((float)w0[i], (float)delta[i], (float)Mx[i], (float)sigma[i], h,
+                                                 S_T, S_e, p_p, M_f, (float)U[i], (float)Udir[i],
+                                                 (float)mag[i], (float)dir[i]);
+    for (int k = 0; k < 8; ++k) rt[k * plane + o] = sfdev::ros_dir(t, th.v[k]);
+}
+
+__global__ void k_compute_ros(long long n, const float *lx, const float *ly, const float *nx, const float *ny,
+                              const float *w0, const float *delta, const float *Mx, const float *sigma,
+                              const float *h, const float *S_T, const float *S_e, const float *p_p,
+                              const float *M_f, const float *U, const float *Udir, const float *mag,
+                              const float *dir, double *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float theta = (float)atan2((double)(ly[i] - ny[i]), (double)(nx[i] - lx[i]));   // rothermel.py:102
+    const sfdev::CellTerms t = sfdev::cell_terms(w0[i], delta[i], Mx[i], sigma[i], h[i], S_T[i], S_e[i], p_p[i],
+                                                 M_f[i], U[i], Udir[i], mag[i], dir[i]);
+    out[i] = sfdev::ros_dir(t, theta);
+}
+
+// pitched <-> dense plane copies
+__global__ void k_pack_rt(int H, int W, int P, const double *dense, double *pitched)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= P) return;
+    pitched[((long long)k * H + y) * P + x] = x < W ? dense[((long long)k * H + y) * W + x] : 0.0;
+}
+__global__ void k_unpack_f64(int H, int W, int P, const double *pitched, double *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= W) return;
+    dense[((long long)k * H + y) * W + x] = pitched[((long long)k * H + y) * P + x];
+}
+__global__ void k_unpack_status(Geo g, const uint8_t *status, int env0, uint8_t *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, i = blockIdx.z;
+    if (x >= g.W) return;
+    dense[((long long)i * g.H + y) * g.W + x] = status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x] & 7u;
+}
+
+// Is the attenuation of the last executed step still owed to this (line) cell?
+__device__ inline bool owes_attenuation(const Geo &g, const EnvState &s, const uint8_t *age_e, uint32_t sraw,
+                                        int x, int y)
+{
+    if (!g.att || !s.prev_flag || (sraw & 0x80u) || (sraw & 7u) < SF_FIRELINE) return false;
+    const Masks mk = make_masks(s.steps + 1, g.md, g.N);
+    const uint8_t *ap = age_e + (long long)y * g.P + x;
+    for (int k = 0; k < 8; ++k) {
+        const int dx = c_dx[k], dy = c_dy[k];
+        if (!g.diag && dx != 0 && dy != 0) continue;
+        const int xx = x + dx;
+        if (xx < 0 || xx >= g.W) continue;
+        if (ap[dy * g.P + dx] & mk.m_prev) return false;   // it was a candidate: already applied
+    }
+    return true;
+}
+
+// burn_amounts as the reference would hold them now (deferred attenuation resolved on the fly)
+__global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint8_t *age, const double *burn,
+                              const EnvState *commit, int e, double *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    double b = burn[o];
+    const uint32_t sraw = status[o];
+    if (owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y)) b = b - line_factor(sraw & 7u);
+    dense[(long long)y * g.W + x] = b;
+}
+
+// Make the deferred attenuation of one environment real and mark every line cell settled.
+// Used before fire_map / burn are overwritten wholesale (load_mitigation, set_burn).
+__global__ void k_settle_env(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+                             int e, int apply)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    const uint32_t sraw = status[o];
+    if ((sraw & 7u) < SF_FIRELINE) return;
+    if (apply && owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y))
+        burn[o] = burn[o] - line_factor(sraw & 7u);
+    status[o] = (uint8_t)(sraw | 0x80u);
+}
+
+__global__ void k_pack_status(Geo g, uint8_t *status, int e, const uint8_t *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const uint32_t v = dense[(long long)y * g.W + x];
+    // a freshly loaded line cell owes nothing for the step that ran before it existed
+    status[(long long)e * g.plane_env + (long long)y * g.P + x] = (uint8_t)((g.att && v >= SF_FIRELINE) ? (v | 0x80u) : v);
+}
+__global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    burn[(long long)e * g.plane_env + (long long)y * g.P + x] = dense[(long long)y * g.W + x];
+}
+
+// ------------------------------------------------------------------------- mitigation
+// FireSimulation.update_mitigation (simulation.py:449-478) as two tiny launches, one thread per
+// point (env, x, y, type), no ordering of the points needed:
+//   k_mitigate_clear  one atomic CAS per point: the status byte becomes "no type yet | settled";
+//                     the thread that sees the OLD byte settles what the cell is still owed for
+//                     the last step under its old status (attenuation mode), duplicates see the
+//                     cleared byte and do nothing;
+//   k_mitigate_write  byte-wise atomic max of the line types: FIRELINE < SCRATCHLINE < WETLINE is
+//                     exactly the reference's "FIRELINE writes, then SCRATCHLINE, then WETLINE"
+//                     order for duplicates (simulation.py:476-478); each write is unconditional
+//                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.
+__global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+                                 const int32_t *pts, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = pts[4 * i], x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
+    if (ty < SF_FIRELINE || ty > SF_WETLINE) return;                 // simulation.py:469-473
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
+    const int sh = (int)(o & 3) * 8;
+    uint32_t old = *word, seen;
+    do {
+        seen = old;
+        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (0x80u << sh));
+    } while (old != seen);
+    const uint32_t sraw = (seen >> sh) & 0xFFu;
+    if (g.att && !(sraw & 0x80u) && owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y))
+        burn[o] = burn[o] - line_factor(sraw & 7u);
+}
+
+__global__ void k_mitigate_write(Geo g, uint8_t *status, const int32_t *pts, int n, uint8_t *tflags, int ring)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = pts[4 * i], x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
+    if (ty < SF_FIRELINE || ty > SF_WETLINE) return;
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
+    const int sh = (int)(o & 3) * 8;
+    const uint32_t mark = g.att ? 0x80u : 0u;                         // "nothing owed for the last step"
+    uint32_t old = *word, seen;
+    do {
+        seen = old;
+        const uint32_t cur = (seen >> sh) & 7u;
+        if (cur >= (uint32_t)ty && (((seen >> sh) & 0x80u) == mark)) break;
+        const uint32_t nb = (cur > (uint32_t)ty ? cur : (uint32_t)ty) | mark;
+        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (nb << sh));
+    } while (old != seen);
+    if (g.att) {   // the tile now holds a control line: it has to be visited every step from now on
+        uint8_t *tf = tflags + (((long long)ring * g.E + e) * g.TYp + y / (g.LR * g.RB) + 1) * g.TXp + (x / 16) / g.LC + 1;
+        if (!(*tf & 2u)) *tf = (uint8_t)(*tf | 2u);   // idempotent: every racer writes the same bit
+    }
+}
+
+// ------------------------------------------------------------- per-environment results
+__global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, const EnvState *commit,
+                                                int32_t *out)
+{
+    __shared__ int32_t h[8];
+    const int e = blockIdx.y;
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    int32_t loc[6] = {0, 0, 0, 0, 0, 0};
+    const uint8_t *st_e = status + (long long)e * g.plane_env;
+    for (int y = blockIdx.x; y < g.H; y += gridDim.x)
+        for (int x = threadIdx.x; x < g.W; x += blockDim.x) {
+            const uint32_t v = st_e[(long long)y * g.P + x] & 7u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) loc[k] += (v == (uint32_t)k);
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int32_t v = loc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && h[threadIdx.x]) atomicAdd(&out[e * 8 + 2 + threadIdx.x], h[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[e * 8 + 0] = commit[e].running;
+        out[e * 8 + 1] = commit[e].steps;
+    }
+}
+
+__global__ void k_elapsed(int E, const EnvState *commit, double *out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) out[e] = commit[e].elapsed;
+}
+
+}  // namespace

@@ -1,0 +1,181 @@
+// Shared device/host types of the fire-spread stepper: geometry, environment state, sprite-mask algebra, SWAR helpers.
+// Part of the single translation unit simfire_hip.hip (see its header comment for the design).
+// Reference semantics: simfire/game/managers/fire.py:616-719 (per-step predicates), enums.py:72-85 (attenuation).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/simfire_hip.h"
+
+namespace {
+
+
+#ifndef SF_WAVES_PER_SIMD
+#define SF_WAVES_PER_SIMD 1
+#endif
+#ifndef SF_WAVES_PER_GROUP
+#define SF_WAVES_PER_GROUP 1
+#endif
+constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each wave works on its own tiles)
+constexpr int kListCap = 1024;     // per-wave frontier list: one row of a wave (64 lanes x 16 cells) always fits
+constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
+constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
+constexpr uint32_t FLAG_CAND = 2u; // some sprite has a cell to spread into     (fire.py:651)
+
+struct EnvState {
+    int32_t running;    // GameStatus.RUNNING
+    int32_t steps;      // update() calls made so far; the next step has index t = steps + 1
+    int32_t prev_flag;  // the last executed step was a complete one (had a candidate)
+    int32_t time_quit;  // the next update() will hit the runtime check (fire.py:641-643)
+    double elapsed;     // RothermelFireManager.elapsed_time
+};
+
+struct Geo {
+    int E, H, W, P, PV;          // P: row pitch (bytes / elements), PV = P / 16
+    int LC, logLC, LR;           // lanes across a row chunk, bands per wave (LC * LR = 64)
+    int RB;                      // rows per band
+    int chunks_x, tiles_per_env; // workgroup tiles
+    int md, N;                   // max_fire_duration, slot count md + 3
+    int diag, att, has_max_time;
+    double pixel_scale, update_rate, max_time;
+    long long age_env, plane_env; // element strides between environments
+    int lds_wave_bytes;           // dynamic LDS per wave: list + staged age tile
+    int TX, TY, TXp, TYp;         // wave tiles per environment (+ a zero guard ring in the flag maps)
+    int dense;                    // 1 = ignore the tile activity map (cross-check mode)
+};
+
+struct StepArgs {
+    Geo g;
+    uint8_t *status;
+    uint8_t *age;        // points at row 0 of env 0 (guard row is at -P)
+    double *burn;
+    const double *rt;
+    EnvState *commit;    // [E]   state between API calls
+    EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
+    uint32_t *flags;     // [3][E] ring
+    unsigned long long *counters;   // [kCounterShards][8]: active cell-updates, ignitions, frontier items; null = off
+    uint8_t *tflags;     // [2][E][TYp][TXp] tile activity maps: bit0 = tile holds sprites, bit1 = tile holds control lines
+    int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
+    uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
+    uint32_t *n_active;  // its length
+    int launch;          // index of this launch inside one sf_step call
+};
+
+struct Masks {
+    uint32_t b_new, b_exp, b_clr, m_live, m_prev;
+    int rot, N;
+};
+
+__host__ __device__ inline int slot_of(int s, int N)
+{
+    int r = s % N;
+    return r < 0 ? r + N : r;
+}
+
+// Bit layout of the age byte at step t (sprites are named by their ignition step s):
+//   live during step t (spread, fire.py:647):          s in [t - md, t - 1]
+//   live during step t - 1:                            s in [t - 1 - md, t - 2]
+//   pruned at step t (-> BURNED, fire.py:116-161):     s = t - md - 1
+//   bit cleared at step t (slot recycled for t + 1):   s = t - md - 2
+//   set at step t (new ignition, fire.py:571-587):     s = t
+__host__ __device__ inline Masks make_masks(int t, int md, int N)
+{
+    // N = md + 3, so relative to s0 = slot(t):  t-md-2 -> s0+1,  t-md-1 -> s0+2,  t-md -> s0+3
+    // (all mod N): one modulo, the rest are wrap-around adds and a rotate of a block of md ones.
+    Masks m;
+    m.N = N;
+    const int s0 = slot_of(t, N);
+    auto wrap = [N](int v) { return v >= N ? v - N : v; };
+    auto rotl = [N](uint32_t v, int k) { return ((v << k) | (v >> (N - k))) & ((1u << N) - 1u); };
+    const uint32_t ones = (1u << md) - 1u;
+    m.b_new = 1u << s0;
+    m.b_clr = 1u << wrap(s0 + 1);
+    m.b_exp = 1u << wrap(s0 + 2);
+    m.m_live = rotl(ones, wrap(s0 + 3));
+    m.m_prev = rotl(ones, wrap(s0 + 2));
+    m.rot = (N - 1) - wrap(s0 + N - 1);   // rotate left so that step t-1 lands on bit N-1
+    return m;
+}
+
+__device__ __forceinline__ uint32_t rep4(uint32_t b) { return b * 0x01010101u; }
+
+__device__ inline EnvState fold_state(EnvState s, uint32_t f, const Geo &g)
+{
+    if (!s.running) return s;                       // frozen: run() no longer calls update
+    s.steps += 1;
+    if (!(f & FLAG_LIVE)) { s.running = 0; s.prev_flag = 0; return s; }   // fire.py:637-638
+    if (s.time_quit) { s.running = 0; s.prev_flag = 0; return s; }        // fire.py:641-643
+    if (f & FLAG_CAND) { s.elapsed += g.update_rate; s.prev_flag = 1; }   // fire.py:717
+    else s.prev_flag = 0;                                                 // fire.py:651-652
+    s.time_quit = g.has_max_time && (g.update_rate > g.max_time || s.elapsed > g.max_time);
+    return s;
+}
+
+__device__ __forceinline__ double line_factor(uint32_t st)   // RoSAttenuation, enums.py:72-85
+{
+    return st == SF_FIRELINE ? 980.0 : (st == SF_SCRATCHLINE ? 490.0 : 245.0);
+}
+
+__device__ __forceinline__ uint32_t pick(const uint4 &v, int j)
+{
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ uint4 and4(uint4 a, uint32_t m) { return make_uint4(a.x & m, a.y & m, a.z & m, a.w & m); }
+__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+__device__ __forceinline__ uint32_t any4(uint4 a) { return a.x | a.y | a.z | a.w; }
+// 0/1 per byte: byte != 0
+__device__ __forceinline__ uint32_t nz01(uint32_t v)
+{
+    return ((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) >> 7) & 0x01010101u;
+}
+// 0/1 per byte for status bytes (0..7): status in {3,4,5,..}  (control line)
+__device__ __forceinline__ uint32_t ge3_01(uint32_t s7) { return ((s7 + 0x05050505u) >> 3) & 0x01010101u; }
+// 0/1 per byte: status == 0
+__device__ __forceinline__ uint32_t eq0_01(uint32_t s7) { return ~(s7 | (s7 >> 1) | (s7 >> 2)) & 0x01010101u; }
+// gather the 0/1 bytes of a dword into 4 bits
+__device__ __forceinline__ uint32_t pack4(uint32_t b01) { return (b01 * 0x01020408u) >> 24; }
+
+__constant__ int c_dx[8] = {+1, 0, -1, +1, -1, +1, 0, -1};
+__constant__ int c_dy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
+
+// value of lane-1 / lane+1 inside groups of LC lanes; lanes at a group edge get 0
+__device__ __forceinline__ uint32_t from_left(uint32_t v, int c, int LC)
+{
+    const uint32_t t = __shfl_up(v, 1, LC);
+    return c == 0 ? 0u : t;
+}
+__device__ __forceinline__ uint32_t from_right(uint32_t v, int c, int LC)
+{
+    const uint32_t t = __shfl_down(v, 1, LC);
+    return c == LC - 1 ? 0u : t;
+}
+
+// Winner source of a destination cell from its 3x3 neighbourhood (bytes 0..2
+// of up3 / mid3 / dn3 = cells x-1, x, x+1 of the rows y-1, y, y+1): the newest live sprite
+// wins, ties are broken by the priority order k = 0..7.  Also reports whether any neighbour
+// was live during the previous step.
+__device__ __forceinline__ int pick_winner(uint32_t up3, uint32_t mid3, uint32_t dn3, const Masks &mk, bool diag,
+                                           bool &prev_any)
+{
+    // k: 0 (+1,+1) 1 (0,+1) 2 (-1,+1) 3 (+1,0) 4 (-1,0) 5 (+1,-1) 6 (0,-1) 7 (-1,-1)
+    const uint32_t nbv[8] = {(dn3 >> 16) & 0xFFu, (dn3 >> 8) & 0xFFu, dn3 & 0xFFu, (mid3 >> 16) & 0xFFu,
+                             mid3 & 0xFFu, (up3 >> 16) & 0xFFu, (up3 >> 8) & 0xFFu, up3 & 0xFFu};
+    int best = -1, bestk = -1;
+    prev_any = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
+        uint32_t v = nbv[k];
+        if (diagonal_k && !diag) v = 0;
+        prev_any |= (v & mk.m_prev) != 0;
+        const uint32_t l = v & mk.m_live;
+        // newest sprite of the neighbour: rotate so that ignition step t-1 is the top bit
+        const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
+        const int msb = l ? 31 - __clz(r) : -1;
+        if (msb > best) { best = msb; bestk = k; }                  // ties: earlier k wins
+    }
+    return bestk;
+}
+
+}  // namespace

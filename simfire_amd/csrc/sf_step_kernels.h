@@ -1,0 +1,611 @@
+// The step itself: k_select (active-tile list), k_step / k_step_fused (tile update), k_commit, reset / flag-map kernels.
+// Part of the single translation unit simfire_hip.hip (see its header comment for the design).
+// Replaces RothermelFireManager.update and helpers, simfire/game/managers/fire.py:116-284, 550-589, 616-719.
+#pragma once
+
+#include "sf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// One step = two launches.
+//
+// k_select  (one thread per wave tile): folds the per-environment predicates of the previous
+//   step into the environment state, looks at the activity flags of the tile's 3 x 3 tile
+//   neighbourhood and appends the tile to the active list if anything in it can change in this
+//   step: some tile of the neighbourhood holds a sprite, or (attenuation on) the tile itself
+//   holds a control line.  A wave ballot + one atomic per workgroup allocate the list slots.
+//   It also zeroes the "next" flag map, which k_step then fills for the tiles it visits.
+// k_step    (persistent waves, grid-stride over the active list): the actual update of a tile.
+//   RB = rows per lane band (compile time: the RB + 2 age rows and RB status rows of a lane live
+//   in registers and are all requested before any of them is used).  A wave tile is LC x 16
+//   cells by LR x RB rows (128 x 32 for large grids).
+// Dynamic LDS of k_step, per wave: frontier list [kListCap] u32, then the staged age tile
+// [LR][RB + 2][LC * 16 + 32] bytes (16 pad bytes either side of a row hold the seam columns).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select(StepArgs a)
+{
+    __shared__ uint32_t s_base, s_wsum[4];
+    const Geo &g = a.g;
+    const int per_env = g.TY * g.TX;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = gid < (long long)g.E * per_env;
+    const int e = valid ? (int)(gid / per_env) : 0;
+    const int tile = valid ? (int)(gid - (long long)e * per_env) : 0;
+    const int tyw = tile / g.TX, tx = tile - tyw * g.TX;
+
+    // environment state entering this step (folded from the previous launch's flags)
+    EnvState st;
+    if (a.launch == 0) st = a.commit[e];
+    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    if (valid && tile == 0) {
+        a.tmp[(a.launch & 1) * g.E + e] = st;
+        a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
+    }
+
+    bool active = false;
+    if (valid) {
+        const long long fplane = (long long)g.TYp * g.TXp;
+        const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+        uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
+        const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
+        // flag bits: 0 sprites anywhere, 1 control lines, 2 / 3 sprites in the top / bottom row,
+        // 4 / 5 sprites in the left / right column of the tile
+        const uint32_t own = f_rd[o];
+        const uint32_t up = f_rd[o - g.TXp], dn = f_rd[o + g.TXp], lf = f_rd[o - 1], rt = f_rd[o + 1];
+        const uint32_t ul = f_rd[o - g.TXp - 1], ur = f_rd[o - g.TXp + 1], dl = f_rd[o + g.TXp - 1], dr = f_rd[o + g.TXp + 1];
+        const bool near = (own & 1u) || (up & 8u) || (dn & 4u) || (lf & 32u) || (rt & 16u) ||
+                          ((ul & 40u) == 40u) || ((ur & 24u) == 24u) || ((dl & 36u) == 36u) || ((dr & 20u) == 20u);
+        // frozen environments keep their flags (nothing reads them until the next reset)
+        f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
+        active = st.running && (g.dense || near || (g.att && (own & 2u)));
+    }
+    // compact: ballot -> rank inside the wave, one atomic per workgroup
+    const unsigned long long bal = __ballot(active);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        s_base = tot ? atomicAdd(&a.n_active[a.launch & 1], tot) : 0u;
+        if (blockIdx.x == 0) a.n_active[(a.launch + 1) & 1] = 0;   // counter of the next step
+    }
+    __syncthreads();
+    if (active) {
+        uint32_t off = s_base + rank;
+        for (int w = 0; w < wave; ++w) off += s_wsum[w];
+        a.tile_list[off] = (uint32_t)gid;
+    }
+}
+
+struct WalkAcc {
+    uint32_t n_active, n_ignite, cand, edges;   // edges: tile flag bits 0, 2..5 set by ignitions
+};
+__device__ __forceinline__ void acc_merge(WalkAcc &t, const WalkAcc &w)
+{
+    t.n_active += w.n_active; t.n_ignite += w.n_ignite; t.cand |= w.cand; t.edges |= w.edges;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// Phase 2: the whole wave walks the compacted frontier of its tile, one cell per lane.
+// item = row in band | owner lane << 5 | cell in vector << 11.  Everything about the cell is read
+// from the LDS copies of the tile (3 x 3 neighbourhood of sprite masks, status byte); an ignition
+// is written back into those copies - the cell planes in HBM are updated once, from LDS, at the end.
+template <int RB>
+__device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, bool spread,
+                                             int prev_flag, uint8_t *tile_lds, uint8_t *stat_lds, const uint16_t *s_list,
+                                             uint32_t pend, int lane)
+{
+    const Geo &g = a.g;
+    const int LC = g.LC, row_pitch = LC * 16 + 32;
+    WalkAcc acc = {0u, 0u, 0u, 0u};
+    for (uint32_t j = lane; j < pend; j += 64) {
+        const uint32_t it = s_list[j];
+        const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
+        const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
+        const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
+        const uint32_t idx = (uint32_t)(y * g.P + x);
+        const long long cell = (long long)e * g.plane_env + idx;
+        double bn = a.burn[cell];     // requested first: the LDS work below hides part of it
+        // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
+        uint8_t *own_age = tile_lds + (orr * (RB + 2) + i + 1) * row_pitch + 16 + oc * 16 + b;
+        const uint8_t *q = own_age - row_pitch - 1;
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
+        const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
+        const uint32_t *qb = reinterpret_cast<const uint32_t *>(q - sh + row_pitch);
+        const uint32_t *qc = reinterpret_cast<const uint32_t *>(q - sh + 2 * row_pitch);
+        const uint32_t up3 = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh);
+        const uint32_t mid3 = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh);
+        const uint32_t dn3 = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh);
+        uint8_t *own_st = stat_lds + ((orr * RB + i) * LC + oc) * 16 + b;
+        const uint32_t own = (mid3 >> 8) & 0xFFu;
+        // the status tile still holds the value from before this step's prune
+        const uint32_t raw = *own_st, s_pre = raw & 7u;
+        const bool settled = raw & 0x80u, expired = (own & mk.b_exp) != 0;
+        bool prev_any;
+        const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag, prev_any);
+        const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
+        const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
+        const bool is_cand = spread && eligible && bestk >= 0;
+        // attenuation of the previous step that was deferred (a line cell, not a candidate then)
+        const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && prev_flag && !prev_any;
+        uint32_t st_new = s_post;                        // S1 prune + settled bit cleared
+        if (is_cand || pending) {
+            acc.n_active++;
+            if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
+            if (is_cand) {
+                acc.cand = 1;
+                double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+                if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
+                    ros = g.att ? ros - line_factor(s_post) : 0.0;
+                bn = bn + ros;                                                   // fire.py:710
+                if (bn > g.pixel_scale) {                                        // fire.py:568
+                    acc.n_ignite++;
+                    acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
+                                 ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
+                    st_new = SF_BURNING;                                         // fire.py:587
+                    *own_age = (uint8_t)((own & ~mk.b_clr) | mk.b_new);          // fire.py:571-579
+                }
+            }
+            a.burn[cell] = bn;
+        }
+        *own_st = (uint8_t)st_new;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return acc;
+}
+
+template <int RB>
+__device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
+                                          uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
+                                          uint32_t &n_items_acc, uint32_t &n_phase2)
+{
+    const Geo &g = a.g;
+    const int LC = g.LC, LR = g.LR;
+    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
+    const int cv = chunk * LC + c;
+    const bool col_ok = cv < g.PV;
+    const int yw = tyw * LR * RB;                      // first row of this wave's tile
+    const int y0 = yw + r * RB;                        // first row of this lane's band
+
+    uint8_t *age_e = a.age + (long long)e * g.age_env;
+    uint8_t *st_e = a.status + (long long)e * g.plane_env;
+
+    const int t = st.steps + 1;
+    const Masks mk = make_masks(t, g.md, g.N);
+    const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
+    const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
+    const int exp_sh = __ffs(mk.b_exp) - 1;
+
+    // LDS of this wave: frontier list (u16) | age tile [LR][RB + 2][LC * 16 + 32] | status tile [LR][RB][LC * 16]
+    const int row_pitch = LC * 16 + 32;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(lds_wave);
+    uint8_t *tile_lds = lds_wave + kListCap * 2;
+    uint8_t *stat_lds = tile_lds + LR * (RB + 2) * row_pitch;
+    uint8_t *band_lds = tile_lds + r * (RB + 2) * row_pitch;
+    uint8_t *band_st = stat_lds + (r * RB) * (LC * 16);
+    uint32_t tile_flags;
+    {
+        // ---- request the RB + 2 age rows (zero guard rows at -1 and H) and the seam columns in
+        // one go; after the quick reject the RB status rows; then park it all in LDS
+        uint4 rows[RB + 2], sraw[RB];
+        const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            rows[k] = make_uint4(0, 0, 0, 0);
+            if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
+        }
+        // seams (rows wider than the wave tile): the column just outside the tile
+        uint32_t seam[RB + 2];
+        const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
+        const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            seam[k] = 0;
+            if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
+        }
+        // status rows: with the activity map nearly every visited tile is a live one, so they are
+        // requested together with the sprite rows (one memory round trip less); in the dense
+        // cross-check mode only after the quick reject (a quiescent tile costs its sprite rows only)
+        auto load_status = [&]() {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                sraw[i] = make_uint4(0, 0, 0, 0);
+                if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
+            }
+        };
+        if (!g.dense) load_status();
+
+        // ---- quick reject: nothing alive, expiring or recyclable in or next to this tile
+        uint32_t hot = 0;
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
+        if (!g.att && __ballot(hot != 0) == 0ull) return;
+        if (g.dense) load_status();
+
+        // tile activity for the next step, part 1: sprite bits that survive this step's recycling,
+        // overall and along the four tile edges (a neighbour tile only has to look if they are set)
+        uint32_t keep = 0, e_lft = 0, e_rgt = 0;
+#pragma unroll
+        for (int k = 1; k <= RB; ++k) {
+            keep |= any4(rows[k]);
+            e_lft |= rows[k].x & 0xFFu;
+            e_rgt |= rows[k].w >> 24;
+        }
+        keep &= ~CLR4;
+        const uint32_t e_top = (r == 0) ? (any4(rows[1]) & ~CLR4) : 0u;
+        const uint32_t e_bot = (r == LR - 1) ? (any4(rows[RB]) & ~CLR4) : 0u;
+        e_lft = (c == 0) ? (e_lft & ~mk.b_clr) : 0u;
+        e_rgt = (c == LC - 1) ? (e_rgt & ~mk.b_clr) : 0u;
+        tile_flags = (__ballot(keep != 0) ? 1u : 0u) | (__ballot(e_top != 0) ? 4u : 0u) |
+                     (__ballot(e_bot != 0) ? 8u : 0u) | (__ballot(e_lft != 0) ? 16u : 0u) |
+                     (__ballot(e_rgt != 0) ? 32u : 0u);
+
+        // ---- stage: everything below works out of LDS, so the registers above die here
+#pragma unroll
+        for (int k = 0; k < RB + 2; ++k) {
+            uint8_t *rp = band_lds + k * row_pitch;
+            *reinterpret_cast<uint4 *>(rp + 16 + c * 16) = rows[k];
+            if (c == 0) rp[15] = (uint8_t)(seam_l ? seam[k] : 0u);
+            if (c == LC - 1) rp[16 + LC * 16] = (uint8_t)(seam_r ? seam[k] : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = sraw[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase 1: per row, SWAR over the lane's 16 cells: which cells are frontier cells
+    // (eligible and next to a live sprite; all control-line cells when attenuation is on), which
+    // sprites expire / which slots are recycled.  A real loop: one copy of the row code, few
+    // live registers, operands from LDS.  fm[i / 2] collects the 16-bit cell masks of the rows.
+    uint32_t fm[(RB + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < (RB + 1) / 2; ++k) fm[k] = 0;
+    uint32_t live_acc = 0, line_acc = 0, dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
+#pragma unroll 1
+    for (int i = 0; i < RB; ++i) {
+        const int y = y0 + i;
+        uint8_t *rp = band_lds + i * row_pitch + 16 + c * 16;
+        const uint4 up = *reinterpret_cast<const uint4 *>(rp);
+        const uint4 mid = *reinterpret_cast<const uint4 *>(rp + row_pitch);
+        const uint4 dn = *reinterpret_cast<const uint4 *>(rp + 2 * row_pitch);
+        const uint4 midL = and4(mid, L4);
+        const uint4 vsrc = and4(or4(up, dn), L4);
+        const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+        live_acc |= any4(midL);
+        // horizontal neighbours: the bytes just left / right of the lane's 16 cells (the
+        // neighbour lane's data, or the seam column parked in the row padding)
+        uint32_t lin = rp[row_pitch - 1], rin = rp[row_pitch + 16];
+        if (g.diag) {
+            lin |= (uint32_t)rp[-1] | (uint32_t)rp[2 * row_pitch - 1];
+            rin |= (uint32_t)rp[16] | (uint32_t)rp[2 * row_pitch + 16];
+        }
+        lin &= mk.m_live;
+        rin &= mk.m_live;
+        uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
+        nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
+        nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
+        nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
+        nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
+
+        const uint4 ex4 = and4(mid, EXP4);
+        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+        const bool row_ok = col_ok && y < g.H;
+        if (row_ok && any_clr) {   // recycle the slot of sprites that were pruned one step ago
+            *reinterpret_cast<uint4 *>(rp + row_pitch) = and4(mid, ~CLR4);
+            dirty |= 0x10000u << i;
+        }
+        uint32_t m16 = 0;
+        if (row_ok && (any_exp | any_nb | (uint32_t)g.att)) {
+            const uint4 sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
+            const uint4 s7 = and4(sr, 0x07070707u);
+            // S1 prune: cells whose sprite reached max_fire_duration become BURNED
+            uint4 em;   // 0xFF per expiring byte
+            em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
+            em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
+            uint4 snew;
+            snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
+            snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
+            snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
+            snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
+            if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) dirty |= 1u << i;
+            // frontier cells: eligible & next to a live sprite; every line cell when attenuation
+            // is on (their burn changes even away from the fire)
+            const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+            const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+            const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+            const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            if (g.att) {
+                m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
+                       (pack4(ge3_01(s7.w)) << 12);
+                line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
+            }
+            // pitch padding (x >= W) never takes part
+            const int xs = cv * 16;
+            if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
+            // the frontier cells get their new status from the walk; the others here: the walk
+            // reads the OLD status from LDS, so only non-frontier bytes may be replaced now
+            // 0xFF where the cell is a frontier cell: 4 mask bits -> 4 byte LSBs -> full bytes
+            uint4 keepm;
+            keepm.x = (((m16 & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.y = ((((m16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.z = ((((m16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.w = ((((m16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            uint4 mix;
+            mix.x = (sr.x & keepm.x) | (snew.x & ~keepm.x);
+            mix.y = (sr.y & keepm.y) | (snew.y & ~keepm.y);
+            mix.z = (sr.z & keepm.z) | (snew.z & ~keepm.z);
+            mix.w = (sr.w & keepm.w) | (snew.w & ~keepm.w);
+            *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = mix;
+            if (m16) dirty |= (1u << i);       // the walk rewrites those bytes (settled bit, ignition)
+        }
+        if (i & 1) fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16 << 16; else fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16;
+    }
+
+    // ---- compact the frontier cells into the wave's list and walk it.  One prefix sum over the
+    // lanes gives every lane its slots.  If a tile has more frontier cells than the list holds
+    // (only with dense control lines) it is processed row by row.
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < (RB + 1) / 2; ++k) mine += (uint32_t)__popc(fm[k]);
+    WalkAcc tot_acc = {0u, 0u, 0u, 0u};
+    if (__ballot(mine != 0) != 0ull) {
+        const uint32_t incl_all = wave_scan_incl(mine, lane);
+        const uint32_t total = __shfl(incl_all, 63);
+        const int n_chunks = total <= (uint32_t)kListCap ? 1 : RB;
+#pragma unroll 1
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            // rows of this chunk: all of them, or just row ch
+            uint32_t cnt = 0, excl, tot;
+            if (n_chunks == 1) { cnt = mine; excl = incl_all - mine; tot = total; }
+            else {
+                const uint32_t w = fm[(ch >> 1) < (RB + 1) / 2 ? (ch >> 1) : 0];
+                cnt = (uint32_t)__popc((ch & 1) ? (w >> 16) : (w & 0xFFFFu));
+                const uint32_t inc = wave_scan_incl(cnt, lane);
+                excl = inc - cnt; tot = __shfl(inc, 63);
+            }
+            if (tot == 0) continue;
+            uint32_t pos = excl;
+#pragma unroll
+            for (int k = 0; k < (RB + 1) / 2; ++k) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * k + h;
+                    if (i >= RB || (n_chunks != 1 && i != ch)) continue;
+                    uint32_t m = h ? (fm[k] >> 16) : (fm[k] & 0xFFFFu);
+                    while (m) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        s_list[pos++] = (uint16_t)((uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.prev_flag, tile_lds, stat_lds, s_list, tot, lane);
+            acc_merge(tot_acc, w);
+            n_items_acc += (lane == 0) ? tot : 0u;
+            n_phase2++;
+        }
+    }
+    n_active += tot_acc.n_active;
+    n_ignite += tot_acc.n_ignite;
+
+    // ---- write the changed vectors of the tile back from LDS to the cell planes
+    if (dirty) {
+#pragma unroll 1
+        for (int i = 0; i < RB; ++i) {
+            const uint32_t voff = (uint32_t)((y0 + i) * g.P + cv * 16);
+            if (dirty & (1u << i)) {
+                uint4 v = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
+                v = and4(v, 0x07070707u);    // the settled marks end with this step
+                *reinterpret_cast<uint4 *>(st_e + voff) = v;
+            }
+            if (dirty & ((0x10000u | 1u) << i)) {
+                // bit i alone: an ignition may have set a sprite bit in this row
+                *reinterpret_cast<uint4 *>(age_e + voff) =
+                    *reinterpret_cast<const uint4 *>(band_lds + (i + 1) * row_pitch + 16 + c * 16);
+            }
+        }
+    }
+
+    // tile activity for the next step: sprites left in the tile or ignited in it (with their
+    // edge bits); control lines (a line cell that ignited this step is seen one step late -
+    // harmless, it is re-evaluated)
+    const long long fplane = (long long)g.TYp * g.TXp;
+    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
+    {
+        uint32_t ed = tot_acc.edges;
+        for (int off = 32; off > 0; off >>= 1) ed |= __shfl_xor(ed, off);
+        const bool lines = g.att && __ballot(line_acc != 0) != 0ull;
+        const uint32_t nf = tile_flags | ed | (lines ? 2u : 0u);
+        if (lane == 0 && nf) *f_own = (uint8_t)nf;
+    }
+    // per-environment predicates: wave ballot, then at most one atomic per wave
+    const bool w_live = __ballot(live_acc != 0) != 0ull;
+    const bool w_cand = __ballot(tot_acc.cand != 0) != 0ull;
+    if (lane == 0 && (w_live || w_cand)) {
+        uint32_t *f = a.flags + (a.launch % 3) * g.E + e;
+        const uint32_t want = (w_live ? FLAG_LIVE : 0u) | (w_cand ? FLAG_CAND : 0u);
+        const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((have & want) != want) atomicOr(f, want);
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
+    const uint32_t n_tiles = a.n_active[a.launch & 1];
+    const int per_env = g.TY * g.TX;
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_tiles_done = 0;
+    // list entries are taken round-robin: consecutive entries (neighbouring tiles of one fire, i.e.
+    // similar amounts of work) spread over all XCDs and CUs - measured 15 % faster than giving each
+    // XCD a contiguous run of the list (better L2 reuse of halos, but whole fires on one XCD)
+    for (uint32_t j = blockIdx.x * kWaves + wave; j < n_tiles; j += gridDim.x * kWaves) {
+        const uint32_t gid = a.tile_list[j];
+        const int e = gid / (uint32_t)per_env;
+        const int tile = gid - e * per_env;
+        const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
+        const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // already folded by k_select
+        step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2);
+        n_tiles_done++;
+    }
+    // optional statistics for the roofline accounting (active cell-updates = phi * cells)
+    if (a.counters && n_tiles_done) {
+        for (int off = 32; off > 0; off >>= 1) {
+            n_active += __shfl_down(n_active, off);
+            n_ignite += __shfl_down(n_ignite, off);
+        }
+        if (lane == 0) {
+            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+            if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+            if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+            if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+            atomicAdd(&cs[3], (unsigned long long)n_tiles_done);   // wave tiles visited
+            if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
+        }
+    }
+}
+
+// Small problems (few wave tiles, e.g. a single 1024 x 1024 environment = 256 tiles): one launch
+// per step.  Every tile gets its own wave, which does k_select's job for that tile itself (fold the
+// environment state, look at the 3 x 3 tile flags, reset the tile's flag for the next step) and,
+// if the tile is live, the update.  Saves the second launch and the list round trip, which
+// dominate when a step is only a few microseconds of work.
+template <int RB>
+__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(StepArgs a)
+{
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
+    const int per_env = g.TY * g.TX;
+    const long long gid = (long long)blockIdx.x * kWaves + wave;
+    if (gid >= (long long)g.E * per_env) return;
+    const int e = (int)(gid / per_env);
+    const int tile = (int)(gid - (long long)e * per_env);
+    const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
+
+    EnvState st;
+    if (a.launch == 0) st = a.commit[e];
+    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    if (tile == 0 && lane == 0) {
+        a.tmp[(a.launch & 1) * g.E + e] = st;
+        a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
+    }
+    const long long fplane = (long long)g.TYp * g.TXp;
+    const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+    uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
+    const long long o = (long long)(tyw + 1) * g.TXp + (chunk + 1);
+    uint32_t fl = 0;
+    if (lane < 9) fl = f_rd[o + (lane / 3 - 1) * g.TXp + (lane % 3 - 1)];
+    // lanes 0..8 = ul up ur lf own rt dl dn dr; which flag bits make the centre tile live: see k_select
+    const uint32_t need[9] = {40u, 8u, 24u, 32u, 1u, 16u, 36u, 4u, 20u};
+    const uint32_t want = lane < 9 ? need[lane] : 0xFFu;
+    const bool near = __ballot(lane < 9 && (fl & want) == want) != 0ull;
+    const uint32_t own = __shfl(fl, 4);
+    if (lane == 0) f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
+    if (!(st.running && (g.dense || near || (g.att && (own & 2u))))) return;
+
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
+    step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2);
+    if (a.counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            n_active += __shfl_down(n_active, off);
+            n_ignite += __shfl_down(n_ignite, off);
+        }
+        if (lane == 0) {
+            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+            if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+            if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+            if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+            atomicAdd(&cs[3], 1ull);
+            if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);
+        }
+    }
+}
+
+typedef void (*StepKernel)(StepArgs);
+static StepKernel pick_step_kernel(int rb, bool fused)
+{
+    switch (rb) {
+    case 1: return fused ? k_step_fused<1> : k_step<1>;
+    case 2: return fused ? k_step_fused<2> : k_step<2>;
+    case 4: return fused ? k_step_fused<4> : k_step<4>;
+    default: return fused ? k_step_fused<8> : k_step<8>;
+    }
+}
+
+// Fold the flags of the last launch of a sf_step call into the committed state, zero the ring.
+__global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t *flags, int last_launch, uint32_t *n_active)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) { n_active[0] = 0; n_active[1] = 0; }
+    if (e >= g.E) return;
+    commit[e] = fold_state(tmp[(last_launch & 1) * g.E + e], flags[(last_launch % 3) * g.E + e], g);
+    flags[e] = 0; flags[g.E + e] = 0; flags[2 * g.E + e] = 0;
+}
+
+__global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commit, uint8_t *tflags, int ring,
+                           const int32_t *xy, int env0, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = env0 + i;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
+    age[(long long)e * g.age_env + (long long)y * g.P + x] = 1u;                // ignition step 0
+    const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
+    tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
+    EnvState s;
+    s.running = 1; s.steps = 0; s.prev_flag = 0; s.elapsed = 0.0;
+    s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
+    commit[e] = s;
+}
+
+// Recompute the tile activity map of environments [env0, env0 + n) from the cell planes (after a
+// geometry change or a wholesale fire_map replacement).  One 64-lane workgroup per tile.
+__global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *status, const uint8_t *age,
+                                                       uint8_t *tflags, int ring, int env0)
+{
+    const int tx = blockIdx.x, tyw = blockIdx.y, e = env0 + blockIdx.z;
+    const int th = g.LR * g.RB, tw = g.LC * 16;
+    uint32_t has_age = 0, has_line = 0;
+    for (int i = threadIdx.x; i < th * tw; i += 64) {
+        const int y = tyw * th + i / tw, x = tx * tw + i % tw;
+        if (y >= g.H || x >= g.W) continue;
+        has_age |= age[(long long)e * g.age_env + (long long)y * g.P + x];
+        has_line |= (status[(long long)e * g.plane_env + (long long)y * g.P + x] & 7u) >= SF_FIRELINE;
+    }
+    const bool a_any = __ballot(has_age != 0) != 0ull, l_any = __ballot(has_line != 0) != 0ull;
+    if (threadIdx.x == 0) {
+        const long long o = (long long)(tyw + 1) * g.TXp + tx + 1, plane = (long long)g.TYp * g.TXp;
+        for (int k = 0; k < 2; ++k)
+            tflags[((long long)k * g.E + e) * plane + o] = (k == ring) ? (uint8_t)((a_any ? (1 | 4 | 8 | 16 | 32) : 0) | ((g.att && l_any) ? 2 : 0)) : 0;
+    }
+}
+
+}  // namespace
