@@ -181,6 +181,26 @@ class FireEngine:
         """Visit every tile every step (cross-check of the tile activity map)."""
         _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))
 
+    def fire_map_device(self):
+        """(device pointer, row pitch, env stride) of the uint8 status plane; bit 7 is internal."""
+        p, pitch, stride = C.c_void_p(), C.c_int64(), C.c_int64()
+        _lib.check(self._L.sf_fire_map_device(self._h, C.byref(p), C.byref(pitch), C.byref(stride)))
+        return p.value, int(pitch.value), int(stride.value)
+
+    def fire_maps_torch(self):
+        """Zero-copy view of all fire_maps as a torch uint8 tensor [n_envs, H, W] on this GPU (RL
+        observations without a PCIe round trip).  Values are BurnStatus | internal bit 7: apply
+        ``& 7`` (``torch.bitwise_and``) before use when rate-of-spread attenuation is on.  The view
+        aliases the library's state: read it between calls, do not write to it."""
+        import torch
+        ptr, pitch, stride = self.fire_map_device()
+        self.sync()
+
+        class _Plane:
+            __cuda_array_interface__ = {"shape": (self.n_envs, self.H, self.W), "typestr": "|u1",
+                                        "data": (ptr, False), "version": 2, "strides": (stride, pitch, 1)}
+        return torch.as_tensor(_Plane(), device=f"cuda:{self.params.device}")
+
     def status_device_ptr(self):
         """Device address of the int32 [E, 8] result block (after ``update_status_device``)."""
         p = C.c_void_p()

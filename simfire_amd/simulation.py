@@ -296,3 +296,16 @@ class BatchedFireSimulation:
 
     def fire_map(self, env: int) -> np.ndarray:
         return self._engine.fire_map(env)
+
+    def fire_maps_device(self):
+        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no copy); mask with 7."""
+        return self._engine.fire_maps_torch()
+
+    def gather_results(self):
+        """All ranks' result blocks (torch int32 [n_envs_total, 8]) - one all-gather over the
+        default process group (RCCL when initialised with backend ``nccl``)."""
+        import torch
+        from .parallel import gather_results
+        block = torch.zeros((self.n_envs, 8), dtype=torch.int32, device=f"cuda:{self._engine.params.device}")
+        self._engine.copy_status_to(block.data_ptr())
+        return gather_results(block)

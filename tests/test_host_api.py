@@ -207,3 +207,23 @@ def test_batched_simulation():
     assert (st[:, 1] == 5).all() and (el == 5.0).all()
     sim.reset([2])
     assert sim.fire_map(2).sum() == 1
+
+
+def test_zero_copy_observation_and_result_block():
+    import torch
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import BatchedFireSimulation
+    y = yaml.safe_load(open(os.path.join(CFG, "test_config_flat_simple.yml")))
+    y["area"]["screen_size"] = [40, 50]          # pitch 64 != width 50
+    sim = BatchedFireSimulation(Config(config_dict=y), 3)
+    sim.update_mitigation([(1, 7, 7, 3), (2, 8, 9, 5)])
+    maps, _ = sim.run(6)
+    view = sim.fire_maps_device()
+    assert view.shape == (3, 40, 50) and view.dtype == torch.uint8 and view.is_cuda
+    assert (torch.bitwise_and(view, 7).cpu().numpy() == maps).all()
+    sim.run(2, return_maps=False)                # the view aliases live state
+    assert (torch.bitwise_and(view, 7).cpu().numpy() == sim._engine.fire_maps()).all()
+    res = sim.gather_results()                   # no process group: the local block
+    st, _ = sim.results()
+    assert (res.cpu().numpy() == st).all()
