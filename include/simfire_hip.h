@@ -60,7 +60,7 @@ static const int SF_SRC_DY[SF_NDIR] = {+1, +1, +1, 0, 0, -1, -1, -1};
 typedef struct sf_params {
     int32_t n_envs;             /* independent simulations batched on this GPU (>= 1)          */
     int32_t height, width;      /* terrain.screen_size = (H, W)                                */
-    int32_t max_fire_duration;  /* fire.py:60; supported: 1..5 (reference configs use 4 and 5) */
+    int32_t max_fire_duration;  /* fire.py:60; 1..28 (1..5: tiled SWAR kernels; above: generic kernel) */
     int32_t diagonal_spread;    /* fire.py:306   0 = 4-connected, 1 = 8-connected              */
     int32_t attenuate_line_ros; /* fire.py:304                                                 */
     int32_t has_max_time;       /* 0 <=> max_time is None (fire.py:303)                        */
@@ -174,6 +174,9 @@ int sf_set_threshold(sf_sim *sim, double pixel_scale);
  * sf_sync) synchronises.  Default: off (every call returns after its work is done). */
 int sf_set_async(sf_sim *sim, int32_t on);
 int sf_sync(sf_sim *sim);
+/* 1 = step with the generic one-thread-per-cell kernel (the product path for max_fire_duration > 5,
+ * and an independent on-device cross-check of the tiled kernels otherwise), 0 = default. */
+int sf_set_generic(sf_sim *sim, int32_t on);
 /* Step launch structure: -1 = by problem size (default: one fused launch per step up to 4096 wave
  * tiles, k_select + k_step above), 0 = always two launches, 1 = always fused. */
 int sf_set_fused(sf_sim *sim, int32_t mode);

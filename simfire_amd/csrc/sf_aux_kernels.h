@@ -92,13 +92,13 @@ __device__ inline bool owes_attenuation(const Geo &g, const EnvState &s, const u
 {
     if (!g.att || !s.prev_flag || (sraw & 0x80u) || (sraw & 7u) < SF_FIRELINE) return false;
     const Masks mk = make_masks(s.steps + 1, g.md, g.N);
-    const uint8_t *ap = age_e + (long long)y * g.P + x;
+    const long long o = (long long)y * g.P + x;
     for (int k = 0; k < 8; ++k) {
         const int dx = c_dx[k], dy = c_dy[k];
         if (!g.diag && dx != 0 && dy != 0) continue;
         const int xx = x + dx;
         if (xx < 0 || xx >= g.W) continue;
-        if (ap[dy * g.P + dx] & mk.m_prev) return false;   // it was a candidate: already applied
+        if (age_load(g, age_e, o + dy * g.P + dx) & mk.m_prev) return false;   // it was a candidate: already applied
     }
     return true;
 }
@@ -112,7 +112,7 @@ __global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint8_t *age, 
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     double b = burn[o];
     const uint32_t sraw = status[o];
-    if (owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y)) b = b - line_factor(sraw & 7u);
+    if (owes_attenuation(g, commit[e], age + (long long)e * g.age_env * g.ab, sraw, x, y)) b = b - line_factor(sraw & 7u);
     dense[(long long)y * g.W + x] = b;
 }
 
@@ -126,7 +126,7 @@ __global__ void k_settle_env(Geo g, uint8_t *status, const uint8_t *age, double 
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     const uint32_t sraw = status[o];
     if ((sraw & 7u) < SF_FIRELINE) return;
-    if (apply && owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y))
+    if (apply && owes_attenuation(g, commit[e], age + (long long)e * g.age_env * g.ab, sraw, x, y))
         burn[o] = burn[o] - line_factor(sraw & 7u);
     status[o] = (uint8_t)(sraw | 0x80u);
 }
@@ -173,7 +173,7 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, dou
         old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (0x80u << sh));
     } while (old != seen);
     const uint32_t sraw = (seen >> sh) & 0xFFu;
-    if (g.att && !(sraw & 0x80u) && owes_attenuation(g, commit[e], age + (long long)e * g.age_env, sraw, x, y))
+    if (g.att && !(sraw & 0x80u) && owes_attenuation(g, commit[e], age + (long long)e * g.age_env * g.ab, sraw, x, y))
         burn[o] = burn[o] - line_factor(sraw & 7u);
 }
 

@@ -43,6 +43,7 @@ struct Geo {
     int lds_wave_bytes;           // dynamic LDS per wave: list + staged age tile
     int TX, TY, TXp, TYp;         // wave tiles per environment (+ a zero guard ring in the flag maps)
     int dense;                    // 1 = ignore the tile activity map (cross-check mode)
+    int ab;                       // bytes per cell of the sprite-mask plane: 1 (md <= 5), 2 (<= 13), 4 (<= 28)
 };
 
 struct StepArgs {
@@ -99,6 +100,22 @@ __host__ __device__ inline Masks make_masks(int t, int md, int N)
 }
 
 __device__ __forceinline__ uint32_t rep4(uint32_t b) { return b * 0x01010101u; }
+
+// Sprite mask of one cell for any plane width; base = row 0 of the environment, off = y * P + x
+// (may be negative: guard row).  Only the generic / boundary kernels use this; the fast step
+// kernels are written for the 1-byte plane.
+__device__ __forceinline__ uint32_t age_load(const Geo &g, const uint8_t *base, long long off)
+{
+    if (g.ab == 1) return base[off];
+    if (g.ab == 2) return reinterpret_cast<const uint16_t *>(base)[off];
+    return reinterpret_cast<const uint32_t *>(base)[off];
+}
+__device__ __forceinline__ void age_store(const Geo &g, uint8_t *base, long long off, uint32_t v)
+{
+    if (g.ab == 1) base[off] = (uint8_t)v;
+    else if (g.ab == 2) reinterpret_cast<uint16_t *>(base)[off] = (uint16_t)v;
+    else reinterpret_cast<uint32_t *>(base)[off] = v;
+}
 
 __device__ inline EnvState fold_state(EnvState s, uint32_t f, const Geo &g)
 {

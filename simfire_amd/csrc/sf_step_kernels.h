@@ -548,6 +548,86 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Generic step: one thread per cell, any sprite-plane width (AgeT = uint8_t / uint16_t /
+// uint32_t, i.e. max_fire_duration up to 5 / 13 / 28).  Same rules as k_select + k_step, written
+// the plain way (no tiles, no LDS, no activity map): every cell looks at its own status / mask /
+// burn and at the masks of its 8 neighbours.  It is the product path for max_fire_duration > 5
+// (the SWAR kernels are specialised for the 1-byte plane) and, forced through sf_set_generic,
+// an independent on-device cross-check of the fast path.  In place like the fast path: writers
+// only touch mask slots that every reader masks out.
+template <typename AgeT>
+__global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
+{
+    const Geo &g = a.g;
+    const int e = blockIdx.z, y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    // environment state entering this step (folded from the previous launch's flags)
+    EnvState st;
+    if (a.launch == 0) st = a.commit[e];
+    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    if (x == 0 && y == 0) {
+        a.tmp[(a.launch & 1) * g.E + e] = st;
+        a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
+    }
+    if (!st.running) return;
+    const Masks mk = make_masks(st.steps + 1, g.md, g.N);
+    const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
+    bool live = false, cand = false;
+    if (x < g.W) {
+        AgeT *age_e = reinterpret_cast<AgeT *>(a.age) + (long long)e * g.age_env;
+        const long long o = (long long)y * g.P + x, cell = (long long)e * g.plane_env + o;
+        const uint32_t own = age_e[o];
+        const uint32_t sraw = a.status[cell], s_pre = sraw & 7u;
+        const bool expired = (own & mk.b_exp) != 0;                              // S1 prune, fire.py:116-161
+        const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
+        live = (own & mk.m_live) != 0;
+        uint32_t nbv[8];   // k: 0 (+1,+1) 1 (0,+1) 2 (-1,+1) 3 (+1,0) 4 (-1,0) 5 (+1,-1) 6 (0,-1) 7 (-1,-1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int xx = x + c_dx[k];
+            nbv[k] = (xx >= 0 && xx < g.W) ? (uint32_t)age_e[o + c_dy[k] * g.P + c_dx[k]] : 0u;   // rows: zero guard rows
+        }
+        int best = -1, bestk = -1;
+        bool prev_any = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
+            const uint32_t v = (diagonal_k && !g.diag) ? 0u : nbv[k];
+            prev_any |= (v & mk.m_prev) != 0;
+            const uint32_t l = v & mk.m_live;
+            const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
+            const int msb = l ? 31 - __clz(r) : -1;
+            if (msb > best) { best = msb; bestk = k; }                             // ties: earlier k wins
+        }
+        const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);    // fire.py:192-205
+        const bool is_cand = spread && eligible && bestk >= 0;
+        const bool pending = g.att && s_pre >= SF_FIRELINE && !(sraw & 0x80u) && st.prev_flag && !prev_any;
+        uint32_t st_new = s_post, age_new = own & ~mk.b_clr;
+        if (is_cand || pending) {
+            double bn = a.burn[cell];
+            if (pending) bn = bn - line_factor(s_pre);                              // fire.py:278, one step late
+            if (is_cand) {
+                cand = true;
+                double ros = a.rt[(long long)bestk * g.H * g.P + o] * g.update_rate;  // fire.py:696,705
+                if (s_post >= SF_FIRELINE) ros = g.att ? ros - line_factor(s_post) : 0.0;   // fire.py:271-282
+                bn = bn + ros;                                                      // fire.py:710
+                if (bn > g.pixel_scale) { st_new = SF_BURNING; age_new |= mk.b_new; }   // fire.py:568-587
+            }
+            a.burn[cell] = bn;
+            if (a.counters) atomicAdd(&a.counters[(size_t)(blockIdx.x & (kCounterShards - 1)) * 8], 1ull);
+        }
+        if (st_new != sraw) a.status[cell] = (uint8_t)st_new;
+        if (age_new != own) age_e[o] = (AgeT)age_new;
+    }
+    const bool w_live = __ballot(live) != 0ull, w_cand = __ballot(cand) != 0ull;
+    if ((threadIdx.x & 63) == 0 && (w_live || w_cand)) {
+        uint32_t *f = a.flags + (a.launch % 3) * g.E + e;
+        const uint32_t want = (w_live ? FLAG_LIVE : 0u) | (w_cand ? FLAG_CAND : 0u);
+        const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((have & want) != want) atomicOr(f, want);
+    }
+}
+
 typedef void (*StepKernel)(StepArgs);
 static StepKernel pick_step_kernel(int rb, bool fused)
 {
@@ -577,7 +657,7 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     const int e = env0 + i;
     const int x = xy[2 * i], y = xy[2 * i + 1];
     status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
-    age[(long long)e * g.age_env + (long long)y * g.P + x] = 1u;                // ignition step 0
+    age_store(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x, 1u);   // ignition step 0
     const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
     tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
     EnvState s;
@@ -597,7 +677,7 @@ __global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *sta
     for (int i = threadIdx.x; i < th * tw; i += 64) {
         const int y = tyw * th + i / tw, x = tx * tw + i % tw;
         if (y >= g.H || x >= g.W) continue;
-        has_age |= age[(long long)e * g.age_env + (long long)y * g.P + x];
+        has_age |= age_load(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x);
         has_line |= (status[(long long)e * g.plane_env + (long long)y * g.P + x] & 7u) >= SF_FIRELINE;
     }
     const bool a_any = __ballot(has_age != 0) != 0ull, l_any = __ballot(has_line != 0) != 0ull;

@@ -97,6 +97,7 @@ struct sf_sim {
     uint32_t *tile_list = nullptr, *n_active = nullptr;
     int n_cu = 256;
     int fused_mode = -1;               // -1 auto, 0 never, 1 always: one fused launch per step
+    bool generic = false;              // sf_set_generic: per-cell kernel instead of the tiled SWAR kernels
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -152,8 +153,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
                     p->height, p->width);
     if (p->max_fire_duration < 1)
         return fail(SF_EINVAL, "sf_create: max_fire_duration must be >= 1 (got %d)", p->max_fire_duration);
-    if (p->max_fire_duration > 5)
-        return fail(SF_ENOTSUP, "sf_create: max_fire_duration %d > 5 is not supported by the 8-bit age plane",
+    if (p->max_fire_duration > 28)
+        return fail(SF_ENOTSUP, "sf_create: max_fire_duration %d > 28 does not fit the 32-bit sprite-mask plane",
                     p->max_fire_duration);
     if (!(p->update_rate > 0.0)) return fail(SF_EINVAL, "sf_create: update_rate must be > 0");
     const long long P = ((long long)p->width + 15) / 16 * 16;
@@ -176,6 +177,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.dense = 0;
     if (const char *v = getenv("SF_DENSE")) g.dense = atoi(v) != 0;
     g.md = p->max_fire_duration; g.N = g.md + 3;
+    g.ab = g.N <= 8 ? 1 : (g.N <= 16 ? 2 : 4);   // 1-byte plane: SWAR kernels; wider: generic per-cell kernel
     g.diag = p->diagonal_spread != 0; g.att = p->attenuate_line_ros != 0; g.has_max_time = p->has_max_time != 0;
     g.pixel_scale = p->pixel_scale; g.update_rate = p->update_rate; g.max_time = p->max_time;
     g.age_env = (long long)(g.H + 2) * g.P; g.plane_env = (long long)g.H * g.P;
@@ -191,8 +193,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     hipEventCreate(&s->ev0); hipEventCreate(&s->ev1); hipEventCreate(&s->ev_pts);
     const size_t cells = (size_t)g.E * g.plane_env;
     TRY(dev_alloc(s, &s->status, cells));
-    TRY(dev_alloc(s, &s->age_alloc, (size_t)g.E * g.age_env + 2 * (size_t)g.P));
-    s->age = s->age_alloc + g.P;   // row 0 of env 0; guard rows at -1 and H of every env
+    TRY(dev_alloc(s, &s->age_alloc, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab));
+    s->age = s->age_alloc + (size_t)g.P * g.ab;   // row 0 of env 0; guard rows at -1 and H of every env
     TRY(dev_alloc(s, &s->burn, cells));
     TRY(dev_alloc(s, &s->rt, (size_t)8 * g.plane_env));
     for (int i = 0; i < 7; ++i) TRY(dev_alloc(s, &s->lay[i], (size_t)g.H * g.W));
@@ -215,7 +217,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     HIPCHK(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
-    HIPCHK(hipMemsetAsync(s->age_alloc, 0, (size_t)g.E * g.age_env + 2 * (size_t)g.P, s->stream));
+    HIPCHK(hipMemsetAsync(s->age_alloc, 0, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab, s->stream));
     HIPCHK(hipMemsetAsync(s->status, 0, cells, s->stream));
     HIPCHK(hipMemsetAsync(s->burn, 0, cells * sizeof(double), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -305,6 +307,23 @@ extern "C" int sf_sync(sf_sim *s)
     if (!s) return fail(SF_EINVAL, "sf_sync: null handle");
     HIPCHK(hipSetDevice(s->p.device));
     HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+/* 1 = step with the generic per-cell kernel (always used when max_fire_duration > 5); switching
+ * back to the tiled kernels rebuilds their tile activity map from the cell planes. */
+extern "C" int sf_set_generic(sf_sim *s, int32_t on)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_generic: null handle");
+    HIPCHK(hipSetDevice(s->p.device));
+    const bool was = s->generic;
+    s->generic = on != 0;
+    if (was && !s->generic && s->was_reset && s->g.ab == 1) {
+        HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
+        int rc = rebuild_tflags(s, 0, s->g.E);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     return SF_OK;
 }
 
@@ -402,7 +421,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
                         xy[2 * i + 1], env0 + i, g.H, g.W);
     HIPCHK(hipSetDevice(s->p.device));
     HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
-    HIPCHK(hipMemsetAsync(s->age + (long long)env0 * g.age_env - g.P, 0, (size_t)n * g.age_env, s->stream));
+    HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
     int rc = ensure_stage(s, (size_t)n * 2 * sizeof(int32_t));
     if (rc) return rc;
@@ -519,9 +538,17 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     if (!fused && want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
     const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+    const bool generic = s->g.ab > 1 || s->generic;
+    const dim3 cell_grid((unsigned)((s->g.W + 255) / 256), (unsigned)s->g.H, (unsigned)s->g.E);
     for (int i = 0; i < n_steps; ++i) {
         a.launch = i;
         a.ring = s->ring;
+        if (generic) {
+            if (s->g.ab == 1) hipLaunchKernelGGL(k_step_cells<uint8_t>, cell_grid, dim3(256), 0, s->stream, a);
+            else if (s->g.ab == 2) hipLaunchKernelGGL(k_step_cells<uint16_t>, cell_grid, dim3(256), 0, s->stream, a);
+            else hipLaunchKernelGGL(k_step_cells<uint32_t>, cell_grid, dim3(256), 0, s->stream, a);
+            continue;
+        }
         if (!fused) hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
         hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
         s->ring ^= 1;

@@ -177,6 +177,10 @@ class FireEngine:
         """-1 auto, 0 always k_select + k_step, 1 always one fused launch per step."""
         _lib.check(self._L.sf_set_fused(self._h, int(mode)))
 
+    def set_generic(self, on=True):
+        """Per-cell kernel instead of the tiled SWAR kernels (always on for max_fire_duration > 5)."""
+        _lib.check(self._L.sf_set_generic(self._h, int(bool(on))))
+
     def set_dense(self, dense=True):
         """Visit every tile every step (cross-check of the tile activity map)."""
         _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))

@@ -17,7 +17,7 @@ def world(seed):
     big = rng.random() < 0.25
     H, W = (int(rng.integers(60, 300)), int(rng.integers(60, 300))) if big else (int(rng.integers(1, 70)), int(rng.integers(1, 70)))
     E = int(rng.integers(1, 5))
-    md = int(rng.integers(1, 6))
+    md = int(rng.integers(1, 6)) if rng.random() < 0.8 else int(rng.integers(6, 29))
     att, diag = bool(rng.integers(2)), bool(rng.integers(2))
     ps = float(rng.choice([0.0, 5.0, 20.0, 50.0, 98.0]))
     R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 99.0, 400.0, 1200.0], size=(8, H, W))
@@ -30,6 +30,7 @@ def world(seed):
     eng, o = FireEngine(**kw), fire_dense.DenseOracle(**kw)
     eng.set_fused(int(rng.integers(-1, 2)))
     eng.set_dense(bool(rng.random() < 0.2))
+    eng.set_generic(bool(rng.random() < 0.15))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
     eng.set_rtable(R8)
     o.set_rtable(R8)
@@ -63,6 +64,8 @@ def world(seed):
             o.reset_env(e, x, y)
         elif r < 0.47:
             eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
+        elif r < 0.50:
+            eng.set_generic(bool(rng.integers(2)))
         n = int(rng.choice([1, 1, 1, 2, 5]))
         eng.step(n)
         o.step(n)

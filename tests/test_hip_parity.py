@@ -273,7 +273,7 @@ def test_errors():
     with pytest.raises(ValueError):
         FireEngine((0, 5))
     with pytest.raises(NotImplementedError):
-        FireEngine((8, 8), max_fire_duration=9)
+        FireEngine((8, 8), max_fire_duration=29)
     eng = FireEngine((8, 8))
     with pytest.raises(RuntimeError):
         eng.step(1)                                   # no layers yet
@@ -532,3 +532,79 @@ def test_c3_both_launch_structures(fused):
     for e in range(6):
         assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
     assert (eng.status()[0] == o.status()[0]).all()
+
+
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_generic_kernel_golden(name):
+    """The plain one-thread-per-cell kernel (product path for max_fire_duration > 5) replays the
+    golden trajectories bit-exactly too - an independent on-device implementation of the rules."""
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    eng.set_generic(True)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d)
+    assert (eng.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("md", [6, 8, 13, 14, 20, 28])
+def test_long_fire_durations(md):
+    """max_fire_duration beyond the 8-bit sprite plane (16 / 32-bit planes, generic kernel)."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(900 + md)
+    H, W = int(rng.integers(20, 60)), int(rng.integers(20, 90))
+    R8 = rng.choice([0.0, 1.0, 2.5, 6.0, 30.0, 400.0], size=(8, H, W))
+    kw = dict(shape=(H, W), n_envs=2, max_fire_duration=md, pixel_scale=40.0, update_rate=1.0, max_time=None,
+              attenuate_line_ros=bool(md % 2), diagonal_spread=True)
+    eng = FireEngine(**kw)
+    o = fire_dense.DenseOracle(**kw)
+    eng.set_rtable(R8)
+    o.set_rtable(R8)
+    xy = [(W // 2, H // 2), (2, 3)]
+    eng.reset(xy)
+    o.reset(xy)
+    small = H * W <= 2500
+    if small:
+        s = fire_sprites.SpriteFire((H, W), xy[0], md, 40.0, 1.0, rtable=R8, attenuate_line_ros=bool(md % 2))
+        fm = np.zeros((H, W), dtype=np.int64)
+        fm[xy[0][1], xy[0][0]] = 1
+    for t in range(3 * md + 20):
+        if t % 5 == 2:
+            pts = [(0, int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(4)]
+            cur = o.fire_map(0)
+            b = np.argwhere(cur == 1)
+            if len(b):
+                y, x = b[rng.integers(len(b))]
+                pts.append((0, int(x), int(y), 4))
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+            if small:
+                fire_sprites.apply_mitigation(fm, [(x, y, ty) for (_, x, y, ty) in pts])
+        eng.step(1)
+        o.step(1)
+        for e in range(2):
+            assert (eng.fire_map(e) == o.fire_map(e)).all(), (md, t, e)
+            assert (eng.burn(e) == o.burn(e)).all(), (md, t, e)
+        assert (eng.status()[0] == o.status()[0]).all()
+        if small:
+            fm, _ = s.update(fm) if o.status()[0][0, 0] or t == 0 else (fm, None)
+            if o.status()[0][0, 0]:
+                assert (o.fire_map(0) == fm).all() and (o.burn(0) == s.burn).all(), (md, t)
+
+
+def test_generic_and_tiled_agree_midrun():
+    """Switching between the tiled kernels and the generic kernel mid-run (the tile activity map
+    is rebuilt) does not change anything."""
+    d = _golden.load_traj("g3_lines_a1")
+    eng = _engine(d)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    sched = d["schedule"]
+    for s_ in range(len(d["status"])):
+        eng.set_generic((s_ // 7) % 2 == 1)
+        pts = sched[sched[:, 0] == s_]
+        if len(pts):
+            eng.apply_mitigation(np.column_stack([np.zeros(len(pts), int), pts[:, 1], pts[:, 2], pts[:, 3]]))
+        eng.step(1)
+        assert (eng.fire_map(0) == d["fire_maps"][s_]).all(), s_
+    assert (eng.burn(0) == d["burn"]).all()

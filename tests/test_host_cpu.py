@@ -191,7 +191,7 @@ def test_error_code_mapping():
     assert rc == _lib.SF_EINVAL
     with pytest.raises(ValueError):
         _lib.check(rc)
-    p.n_envs, p.max_fire_duration = 1, 9
+    p.n_envs, p.max_fire_duration = 1, 29
     rc = lib.sf_create(C.byref(p), C.byref(h))
     assert rc == _lib.SF_ENOTSUP
     with pytest.raises(NotImplementedError):
