@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-env measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
+    ap.add_argument("--generic", action="store_true", help="plain one-thread-per-cell kernel instead of the tiled kernels")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the\n"
                          "multi-rank code path on a box with fewer GPUs than ranks)")
@@ -210,6 +211,7 @@ def main():
                                          env_offset=rank * envs_local)
     eng = run_gpu(w, a.steps, a.warmup, device, a.rows_per_band)
     eng.set_dense(a.dense)
+    eng.set_generic(a.generic)
     result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{device}")
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
