@@ -174,6 +174,12 @@ int sf_set_threshold(sf_sim *sim, double pixel_scale);
  * sf_sync) synchronises.  Default: off (every call returns after its work is done). */
 int sf_set_async(sf_sim *sim, int32_t on);
 int sf_sync(sf_sim *sim);
+/* Spread graph by-product - FireSpreadGraph.add_edges_from_manager (simfire/utils/graph.py:84-150,
+ * called at fire.py:584): when enabled, every ignition records which of its 8 neighbours were
+ * BURNING at that moment.  parents = uint8 [H*W]; bit j <=> edge from neighbour j of graph.py's
+ * adj_locs order (x+1,y) (x+1,y+1) (x,y+1) (x-1,y+1) (x-1,y) (x-1,y-1) (x,y-1) (x+1,y-1). */
+int sf_enable_spread_graph(sf_sim *sim, int32_t on);
+int sf_get_spread_parents(sf_sim *sim, int32_t env, uint8_t *parents_out);
 /* 1 = step with the generic one-thread-per-cell kernel (the product path for max_fire_duration > 5,
  * and an independent on-device cross-check of the tiled kernels otherwise), 0 = default. */
 int sf_set_generic(sf_sim *sim, int32_t on);

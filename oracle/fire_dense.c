@@ -43,6 +43,7 @@ typedef struct {
     int32_t *running;    /* [E] 1 = GameStatus.RUNNING */
     int32_t *steps;      /* [E] update() calls made */
     int32_t *ign;        /* [E][H*W] scratch: cells igniting this step */
+    uint8_t *parents;    /* [E][H][W] spread graph: bit j set <=> edge from neighbour j (order E,SE,S,SW,W,NW,N,NE) */
 } fo_sim;
 
 /* source offsets (sx-cx, sy-cy) in winner priority order: larger source y, then larger x.
@@ -134,6 +135,7 @@ void *fo_create(const fo_params *p)
     s->running = (int32_t *)calloc(E, sizeof(int32_t));
     s->steps = (int32_t *)calloc(E, sizeof(int32_t));
     s->ign = (int32_t *)malloc(E * n * sizeof(int32_t));
+    s->parents = (uint8_t *)calloc(E * n, 1);
     return s;
 }
 
@@ -141,7 +143,7 @@ void fo_destroy(void *v)
 {
     fo_sim *s = (fo_sim *)v;
     free(s->rt); free(s->status); free(s->age); free(s->burn);
-    free(s->elapsed); free(s->running); free(s->steps); free(s->ign); free(s);
+    free(s->elapsed); free(s->running); free(s->steps); free(s->ign); free(s->parents); free(s);
 }
 
 void fo_set_rtable(void *v, const double *R8)
@@ -184,6 +186,7 @@ static void reset_env(fo_sim *s, int e, int x, int y)
     memset(s->status + e * n, UNBURNED, n);
     memset(s->age + e * n, 0, n * sizeof(uint32_t));
     memset(s->burn + e * n, 0, n * sizeof(double));
+    memset(s->parents + e * n, 0, n);
     s->status[e * n + (size_t)y * s->p.W + x] = BURNING;   /* simulation.py:555-566 */
     s->age[e * n + (size_t)y * s->p.W + x] = 1u;           /* fire.py:101-103: duration 0 */
     s->elapsed[e] = 0.0; s->running[e] = 1; s->steps[e] = 0;
@@ -232,6 +235,13 @@ void fo_get_burn(void *v, int e, double *out)
     fo_sim *s = (fo_sim *)v;
     size_t n = (size_t)s->p.H * s->p.W;
     memcpy(out, s->burn + e * n, n * sizeof(double));
+}
+
+void fo_get_parents(void *v, int e, uint8_t *out)
+{
+    fo_sim *s = (fo_sim *)v;
+    size_t n = (size_t)s->p.H * s->p.W;
+    memcpy(out, s->parents + e * n, n);
 }
 
 void fo_set_burn(void *v, int e, const double *in)
@@ -340,6 +350,20 @@ static void step_env(fo_sim *s, int e)
             }
             burn[i] = burn[i] + ros;                                                  /* fire.py:710 */
             if (best_k >= 0 && burn[i] > p->pixel_scale) ign[n_ign++] = (int32_t)i;   /* fire.py:568 */
+        }
+    }
+    /* spread graph (utils/graph.py:84-150, called at fire.py:584 before the BURNING writes): an edge
+     * from every 8-neighbour (always 8-connected, graph.py:125-134) that is BURNING right now */
+    {
+        static const int GX[8] = {+1, +1, 0, -1, -1, -1, 0, +1}, GY[8] = {0, +1, +1, +1, 0, -1, -1, -1};
+        uint8_t *par = s->parents + e * n;
+        for (int j = 0; j < n_ign; ++j) {
+            int x = ign[j] % W, y = ign[j] / W;
+            for (int k = 0; k < 8; ++k) {
+                int nx = x + GX[k], ny = y + GY[k];
+                if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+                if (st[(size_t)ny * W + nx] == BURNING) par[ign[j]] |= (uint8_t)(1u << k);
+            }
         }
     }
     for (int j = 0; j < n_ign; ++j) {                                                 /* fire.py:571-587 */

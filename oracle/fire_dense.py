@@ -37,7 +37,7 @@ def lib():
         L.fo_create.argtypes = [C.POINTER(_Params)]
         for name in ("fo_destroy", "fo_set_rtable", "fo_get_rtable", "fo_reset", "fo_reset_env",
                      "fo_apply_mitigation", "fo_load_fire_map", "fo_get_fire_map", "fo_get_burn",
-                     "fo_set_burn", "fo_get_status", "fo_step", "fo_build_rtable",
+                     "fo_set_burn", "fo_get_parents", "fo_get_status", "fo_step", "fo_build_rtable",
                      "fo_compute_ros", "fo_slopes"):
             getattr(L, name).restype = None
         vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
@@ -51,6 +51,7 @@ def lib():
         L.fo_get_fire_map.argtypes = [vp, i32, vp]
         L.fo_get_burn.argtypes = [vp, i32, vp]
         L.fo_set_burn.argtypes = [vp, i32, vp]
+        L.fo_get_parents.argtypes = [vp, i32, vp]
         L.fo_get_status.argtypes = [vp, vp, vp]
         L.fo_step.argtypes = [vp, i32, i32]
         L.fo_build_rtable.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, vp]
@@ -148,6 +149,12 @@ class DenseOracle:
         self._L.fo_get_burn(self._h, env, _p(out))
         return out
 
+    def parents(self, env=0):
+        """uint8 [H, W]: spread-graph parent mask (bit j: edge from neighbour j, order E,SE,S,SW,W,NW,N,NE)."""
+        out = np.empty((self.H, self.W), dtype=np.uint8)
+        self._L.fo_get_parents(self._h, env, _p(out))
+        return out
+
     def set_burn(self, env, burn):
         b = np.ascontiguousarray(burn, dtype=np.float64)
         self._L.fo_set_burn(self._h, env, _p(b))
@@ -158,3 +165,19 @@ class DenseOracle:
         el = np.zeros(self.n_envs)
         self._L.fo_get_status(self._h, _p(out), _p(el))
         return out, el
+
+
+# neighbour order of the spread-graph parent mask = adj_locs of simfire/utils/graph.py:125-134
+GRAPH_DX = (+1, +1, 0, -1, -1, -1, 0, +1)
+GRAPH_DY = (0, +1, +1, +1, 0, -1, -1, -1)
+
+
+def edges_from_parents(parents):
+    """parent-mask plane -> sorted list of edges (sx, sy, x, y)."""
+    out = []
+    ys, xs = np.nonzero(parents)
+    for y, x in zip(ys, xs):
+        for k in range(8):
+            if parents[y, x] >> k & 1:
+                out.append((int(x) + GRAPH_DX[k], int(y) + GRAPH_DY[k], int(x), int(y)))
+    return sorted(out)

@@ -53,6 +53,7 @@ class SpriteFire:
         self.durations = [0]
         self.elapsed_time = 0.0
         self.burn = np.zeros(shape, dtype=np.float64)
+        self.edges = set()                                    # FireSpreadGraph edges ((sx, sy), (x, y))
 
     # fire.py:116-161
     def _prune(self, fire_map):
@@ -122,11 +123,18 @@ class SpriteFire:
                 ros[fire_map == status] = 0
         self.burn = self.burn + ros                                             # :710
         # fire.py:550-589: unique (y, x) in lexicographic order, strict threshold
-        for (y, x) in sorted({(y, x) for (x, y) in dst}):
-            if self.burn[y, x] > self.pixel_scale:
-                self.sprites.append((x, y))
-                self.durations.append(0)
-                fire_map[y, x] = BURNING
+        new = [(x, y) for (y, x) in sorted({(y, x) for (x, y) in dst}) if self.burn[y, x] > self.pixel_scale]
+        # spread graph (utils/graph.py:84-150, called at fire.py:584 BEFORE the BURNING writes at :587):
+        # an edge from every 8-neighbour that is BURNING in fire_map right now
+        for (x, y) in new:
+            for dx, dy in _NB8:
+                nx, ny = x + dx, y + dy
+                if 0 <= nx < self.W and 0 <= ny < self.H and fire_map[ny, nx] == BURNING:
+                    self.edges.add(((nx, ny), (x, y)))
+        for (x, y) in new:
+            self.sprites.append((x, y))
+            self.durations.append(0)
+            fire_map[y, x] = BURNING
         self.elapsed_time += self.update_rate                                   # :717
         return fire_map, RUNNING
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     "sf_get_geometry": [_VP, _VP],
     "sf_set_rows_per_band": [_VP, _I32],
     "sf_set_dense": [_VP, _I32],
+    "sf_enable_spread_graph": [_VP, _I32],
+    "sf_get_spread_parents": [_VP, _I32, _VP],
     "sf_set_generic": [_VP, _I32],
     "sf_set_fused": [_VP, _I32],
     "sf_set_async": [_VP, _I32],

@@ -60,6 +60,7 @@ struct StepArgs {
     int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
     uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
     uint32_t *n_active;  // its length
+    uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
     int launch;          // index of this launch inside one sf_step call
 };
 

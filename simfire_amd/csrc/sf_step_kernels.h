@@ -628,6 +628,39 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Spread graph as a by-product: FireSpreadGraph.add_edges_from_manager
+// (simfire/utils/graph.py:84-150) is called at fire.py:584, before the BURNING writes of the
+// step, and adds an edge from every 8-neighbour (always 8-connected, graph.py:125-134) whose
+// fire_map value is BURNING at that moment.  Done here as a read-only pass right after the
+// step: a cell that ignited at step t carries sprite bit slot(t); its neighbour n was BURNING
+// "at that moment" iff n is BURNING now and did not itself ignite at step t (an ignition needs an
+// eligible, i.e. non-BURNING, status).  Bit j of the mask = neighbour j of graph.py's adj_locs
+// (E, SE, S, SW, W, NW, N, NE); masks are OR-ed over re-ignitions like edges in a DiGraph.
+__global__ __launch_bounds__(256) void k_graph_pass(StepArgs a)
+{
+    const Geo &g = a.g;
+    const int e = blockIdx.z, y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= g.W) return;
+    const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // state with which this step was entered
+    if (!st.running) return;
+    const Masks mk = make_masks(st.steps + 1, g.md, g.N);
+    const uint8_t *age_e = a.age + (long long)e * g.age_env * g.ab;
+    const long long o = (long long)y * g.P + x, cell = (long long)e * g.plane_env + o;
+    if (!(age_load(g, age_e, o) & mk.b_new)) return;        // did not ignite in this step
+    const int GX[8] = {+1, +1, 0, -1, -1, -1, 0, +1}, GY[8] = {0, +1, +1, +1, 0, -1, -1, -1};
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int nx = x + GX[k], ny = y + GY[k];
+        if (nx < 0 || nx >= g.W || ny < 0 || ny >= g.H) continue;
+        const long long no = (long long)ny * g.P + nx;
+        if ((a.status[(long long)e * g.plane_env + no] & 7u) == SF_BURNING && !(age_load(g, age_e, no) & mk.b_new))
+            mask |= 1u << k;
+    }
+    if (mask) a.parents[cell] |= (uint8_t)mask;
+}
+
 typedef void (*StepKernel)(StepArgs);
 static StepKernel pick_step_kernel(int rb, bool fused)
 {

@@ -98,6 +98,8 @@ struct sf_sim {
     int n_cu = 256;
     int fused_mode = -1;               // -1 auto, 0 never, 1 always: one fused launch per step
     bool generic = false;              // sf_set_generic: per-cell kernel instead of the tiled SWAR kernels
+    uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
+    bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -232,7 +234,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
                     s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
-                    s->status_block, s->elapsed_dev, s->stage, s->pts_dev};
+                    s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->parents};
     if (s->pts_pinned) (void)hipHostFree(s->pts_pinned);
     if (s->ev_pts) (void)hipEventDestroy(s->ev_pts);
     for (void *p : ptrs) if (p) hipFree(p);
@@ -306,6 +308,37 @@ extern "C" int sf_sync(sf_sim *s)
 {
     if (!s) return fail(SF_EINVAL, "sf_sync: null handle");
     HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+/* Spread graph (FireSpreadGraph, simfire/utils/graph.py): record for every ignition which of the 8
+ * neighbours were BURNING at that moment.  Off by default (one more small launch per step and one
+ * more byte per cell). */
+extern "C" int sf_enable_spread_graph(sf_sim *s, int32_t on)
+{
+    if (!s) return fail(SF_EINVAL, "sf_enable_spread_graph: null handle");
+    HIPCHK(hipSetDevice(s->p.device));
+    if (on && !s->parents) {
+        const size_t n = (size_t)s->g.E * s->g.plane_env;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->parents), n));
+        s->bytes += (int64_t)n;
+        HIPCHK(hipMemsetAsync(s->parents, 0, n, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    s->graph_on = on != 0;
+    return SF_OK;
+}
+
+extern "C" int sf_get_spread_parents(sf_sim *s, int32_t env, uint8_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_spread_parents: null argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_spread_parents: environment %d out of range", env);
+    if (!s->parents) return fail(SF_ESTATE, "sf_get_spread_parents: call sf_enable_spread_graph first");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)g.W, s->parents + (size_t)env * g.plane_env, (size_t)g.P, (size_t)g.W,
+                            (size_t)g.H, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
@@ -423,6 +456,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
     HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
+    if (s->parents) HIPCHK(hipMemsetAsync(s->parents + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
     int rc = ensure_stage(s, (size_t)n * 2 * sizeof(int32_t));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->stage, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
@@ -527,6 +561,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     StepArgs a;
     a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
+    a.parents = s->graph_on ? s->parents : nullptr;
     const dim3 block(kWaves * 64);
     const long long n_wave_tiles = (long long)s->g.E * s->g.TY * s->g.TX;
     // few tiles: one fused launch per step; many: select the live tiles first, then persistent waves
@@ -547,11 +582,12 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
             if (s->g.ab == 1) hipLaunchKernelGGL(k_step_cells<uint8_t>, cell_grid, dim3(256), 0, s->stream, a);
             else if (s->g.ab == 2) hipLaunchKernelGGL(k_step_cells<uint16_t>, cell_grid, dim3(256), 0, s->stream, a);
             else hipLaunchKernelGGL(k_step_cells<uint32_t>, cell_grid, dim3(256), 0, s->stream, a);
-            continue;
+        } else {
+            if (!fused) hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
+            hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
+            s->ring ^= 1;
         }
-        if (!fused) hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
-        hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
-        s->ring ^= 1;
+        if (a.parents) hipLaunchKernelGGL(k_graph_pass, cell_grid, dim3(256), 0, s->stream, a);
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,

@@ -177,6 +177,31 @@ class FireEngine:
         """-1 auto, 0 always k_select + k_step, 1 always one fused launch per step."""
         _lib.check(self._L.sf_set_fused(self._h, int(mode)))
 
+    # neighbour order of the parent masks = adj_locs of simfire/utils/graph.py:125-134
+    GRAPH_DX = (+1, +1, 0, -1, -1, -1, 0, +1)
+    GRAPH_DY = (0, +1, +1, +1, 0, -1, -1, -1)
+
+    def enable_spread_graph(self, on=True):
+        """Record the fire-spread graph (FireSpreadGraph, simfire/utils/graph.py) as parent masks."""
+        _lib.check(self._L.sf_enable_spread_graph(self._h, int(bool(on))))
+
+    def spread_parents(self, env=0):
+        """uint8 [H, W]: bit j set <=> graph edge from neighbour j (GRAPH_DX/DY) into the cell."""
+        out = np.zeros((self.H, self.W), dtype=np.uint8)
+        _lib.check(self._L.sf_get_spread_parents(self._h, int(env), _ptr(out)))
+        return out
+
+    def spread_edges(self, env=0):
+        """Sorted list of graph edges (source_x, source_y, x, y) like ``FireSpreadGraph.graph.edges``."""
+        par = self.spread_parents(env)
+        out = []
+        ys, xs = np.nonzero(par)
+        for y, x in zip(ys, xs):
+            for k in range(8):
+                if (par[y, x] >> k) & 1:
+                    out.append((int(x) + self.GRAPH_DX[k], int(y) + self.GRAPH_DY[k], int(x), int(y)))
+        return sorted(out)
+
     def set_generic(self, on=True):
         """Per-cell kernel instead of the tiled SWAR kernels (always on for max_fire_duration > 5)."""
         _lib.check(self._L.sf_set_generic(self._h, int(bool(on))))

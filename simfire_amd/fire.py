@@ -5,9 +5,9 @@ contract as ``simfire.game.managers.fire.RothermelFireManager``
 (simfire/game/managers/fire.py:287-719); the per-step work happens in the ``k_select`` /
 ``k_step`` kernels through the C ABI (``simfire_amd/engine.py``).  There is no CPU fallback.
 
-What is *not* reproduced: the pygame ``Fire`` sprites (display only, sprites.py:198-245) and
-the networkx ``FireSpreadGraph`` (utils/graph.py) - a side effect of the path that does not
-feed back into ``fire_map``.
+What is *not* reproduced: the pygame ``Fire`` sprites (display only, sprites.py:198-245).  The
+``FireSpreadGraph`` side effect (utils/graph.py) is available as an opt-in device by-product
+(``enable_spread_graph`` / ``spread_graph_edges``), not as a per-pixel networkx object.
 """
 from typing import Optional, Sequence, Tuple, Union
 
@@ -157,5 +157,26 @@ class RothermelFireManager:
         self._status = GameStatus.RUNNING if st[0, 0] else GameStatus.QUIT
         return fire_map, self._status
 
+    # ------------------------------------------------------------------------ spread graph
+    def enable_spread_graph(self, on: bool = True) -> None:
+        """Record the fire-spread graph from now on (the reference always does, fire.py:380,584;
+        here it is opt-in: one extra byte per cell and one more small launch per step)."""
+        self._engine.enable_spread_graph(on)
+
+    @property
+    def spread_graph_edges(self):
+        """Edges ((sx, sy), (x, y)) of ``FireSpreadGraph.graph`` (simfire/utils/graph.py:84-150)."""
+        return [((a, b), (c, d)) for (a, b, c, d) in self._engine.spread_edges(0)]
+
+    def get_spread_graph(self):
+        """networkx.DiGraph with one node per pixel and the recorded edges, like ``fs_graph.graph``."""
+        import networkx as nx
+        graph = nx.DiGraph()
+        H, W = self.screen_size
+        graph.add_nodes_from((x, y) for x in range(W) for y in range(H))      # graph.py:46-48
+        graph.add_edges_from(self.spread_graph_edges)
+        return graph
+
     def draw_spread_graph(self, game_screen=None):
-        raise NotImplementedError("the fire-spread graph (simfire/utils/graph.py) is outside simfire_amd's scope")
+        raise NotImplementedError("drawing the spread graph over the terrain image is display code, outside "
+                                  "simfire_amd's scope; use get_spread_graph() / spread_graph_edges")

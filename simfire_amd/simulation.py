@@ -65,6 +65,8 @@ class FireSimulation:
         self.fuel_particle = FuelParticle()
         self.environment = Environment(cfg.environment.moisture, cfg.wind.speed, cfg.wind.direction)
         x, y = cfg.fire.fire_initial_position
+        if cfg.simulation.draw_spread_graph:
+            self._engine.enable_spread_graph(True)
         self._engine.reset([(x, y)])
         self.fire_map = np.full(cfg.area.screen_size, int(BurnStatus.UNBURNED))      # int64, simulation.py:561-566
         self.fire_map[y, x] = int(BurnStatus.BURNING)
@@ -246,8 +248,18 @@ class FireSimulation:
     def save_gif(self, path=None):
         raise NotImplementedError("display / GIF export is outside simfire_amd's scope")
 
+    def enable_spread_graph(self, on: bool = True) -> None:
+        """Record the fire-spread graph (``simulation.draw_spread_graph: true`` in the config does
+        the same at reset)."""
+        self._engine.enable_spread_graph(on)
+
+    def spread_graph_edges(self):
+        """Edges ((sx, sy), (x, y)) of the reference's ``fire_manager.fs_graph.graph``."""
+        return [((a, b), (c, d)) for (a, b, c, d) in self._engine.spread_edges(0)]
+
     def save_spread_graph(self, path=None):
-        raise NotImplementedError("the fire-spread graph is outside simfire_amd's scope")
+        raise NotImplementedError("rendering the spread graph to a PNG is display code, outside simfire_amd's "
+                                  "scope; use spread_graph_edges()")
 
 
 class BatchedFireSimulation:

@@ -148,10 +148,15 @@ def run_trajectory(case, selfcheck=False):
             assert orc.elapsed_time == mgr.elapsed_time
         if st != GameStatus.RUNNING:
             break
+    if orc is not None:
+        ref_edges = {((int(a[0]), int(a[1])), (int(b[0]), int(b[1]))) for a, b in mgr.fs_graph.graph.edges()}
+        assert ref_edges == orc.edges, f"{case['name']}: spread-graph edges differ"
     return dict(
         fire_maps=np.stack(maps), status=np.array(status, dtype=np.int8),
         elapsed=np.array(elapsed), burn=np.array(mgr.burn_amounts, dtype=np.float64),
         rtable=rt, tie_margin=np.float64(margin),
+        edges=np.array(sorted((a[0], a[1], b[0], b[1]) for a, b in mgr.fs_graph.graph.edges()),
+                       dtype=np.int32).reshape(-1, 4),
         slope_mag=np.asarray(mgr.slope_mag, dtype=np.float64),
         slope_dir=np.asarray(mgr.slope_dir, dtype=np.float64),
     )

@@ -608,3 +608,41 @@ def test_generic_and_tiled_agree_midrun():
         eng.step(1)
         assert (eng.fire_map(0) == d["fire_maps"][s_]).all(), s_
     assert (eng.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("mode", ["tiled", "fused0", "generic"])
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_spread_graph_edges(name, mode):
+    """The spread graph recorded on the device equals the reference's FireSpreadGraph edges."""
+    d = _golden.load_traj(name)
+    eng = _engine(d)
+    eng.enable_spread_graph(True)
+    if mode == "generic":
+        eng.set_generic(True)
+    if mode == "fused0":
+        eng.set_fused(0)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d, check_each_step=False)
+    assert eng.spread_edges(0) == [tuple(int(v) for v in r) for r in d["edges"]]
+
+
+def test_spread_graph_multi_step_and_batch():
+    """sf_step(n) records the graph of every intermediate step; envs are independent."""
+    d = _golden.load_traj("g2_mixed_a1d1")
+    H, W = (int(v) for v in d["shape"])
+    xy = [(20, 18), (5, 30), (40, 8)]
+    eng = _engine(d, n_envs=3)
+    eng.enable_spread_graph(True)
+    eng.set_rtable(d["rtable"])
+    eng.reset(xy)
+    o = fire_dense.DenseOracle(n_envs=3, **_golden.engine_kwargs(d))
+    o.set_rtable(d["rtable"])
+    o.reset(xy)
+    eng.step(17)
+    eng.step(13)
+    o.step(30)
+    for e in range(3):
+        assert (eng.spread_parents(e) == o.parents(e)).all(), e
+    eng.reset_env(1, 7, 7)
+    assert not eng.spread_parents(1).any() and eng.spread_parents(0).any()

@@ -227,3 +227,21 @@ def test_zero_copy_observation_and_result_block():
     res = sim.gather_results()                   # no process group: the local block
     st, _ = sim.results()
     assert (res.cpu().numpy() == st).all()
+
+
+def test_spread_graph_host_api():
+    """simfire/utils/_tests/test_graph.py:99-117 shape: one burning cell -> edges into the cells it
+    ignites; here via FireSimulation with draw_spread_graph enabled in the config."""
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    y = yaml.safe_load(open(os.path.join(CFG, "test_config_flat_simple.yml")))
+    y["simulation"]["draw_spread_graph"] = True
+    sim = FireSimulation(Config(config_dict=y))
+    sim.run(2)
+    edges = sim.spread_graph_edges()
+    x0, y0 = sim.config.fire.fire_initial_position
+    assert edges and all(src == (x0, y0) or abs(src[0] - x0) <= 1 for src, dst in edges)
+    newly = {dst for src, dst in edges if src == (x0, y0)}
+    burning_or_burned = {(int(x), int(yy)) for yy, x in np.argwhere(sim.fire_map >= 1)}
+    assert newly <= burning_or_burned

@@ -202,3 +202,20 @@ def test_dense_equals_sprite_list_random(seed):
         assert (o.burn(0) == s.burn).all(), (seed, t)
         stt, el = o.status()
         assert bool(stt[0, 0]) == running and el[0] == s.elapsed_time
+
+
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_spread_graph_edges_oracles(name):
+    """FireSpreadGraph edges (simfire/utils/graph.py:84-150) of the real reference run vs the
+    parent masks of the dense oracle and the edge set of the sprite-list oracle."""
+    d = _golden.load_traj(name)
+    ref = [tuple(int(v) for v in r) for r in d["edges"]]
+    o = fire_dense.DenseOracle(**_golden.engine_kwargs(d))
+    o.set_rtable(d["rtable"])
+    o.reset([d["init_pos"]])
+    _golden.replay(o, d, check_each_step=False)
+    assert fire_dense.edges_from_parents(o.parents(0)) == ref
+    if name in ("g1_flat32", "g4_lines_on_burning", "g7_early_return"):
+        eng = _SpriteEngine(d, d["rtable"])
+        _golden.replay(eng, d, check_each_step=False)
+        assert sorted((a[0], a[1], b[0], b[1]) for a, b in eng.f.edges) == ref
