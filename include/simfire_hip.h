@@ -70,6 +70,8 @@ typedef struct sf_params {
     double max_time;            /* fire.py:303 (minutes)                                       */
     double h, S_T, S_e, p_p;    /* FuelParticle; rounded to float32 like fire.py:537,546        */
     double M_f;                 /* Environment.M_f                                              */
+    int32_t per_env_terrain;    /* 0 = all environments share terrain and wind (one R table);    */
+                                /* 1 = every environment has its own layers (sf_set_layers_env)  */
 } sf_params;
 
 typedef struct sf_sim sf_sim; /* opaque */
@@ -95,6 +97,13 @@ int sf_set_layers(sf_sim *sim, const double *w_0, const double *delta, const dou
 int sf_set_rtable(sf_sim *sim, const double *R8);
 int sf_get_rtable(sf_sim *sim, double *R8_out);
 int sf_get_slopes(sf_sim *sim, double *slope_mag_out, double *slope_dir_out);
+/* Per-environment terrain (handles created with per_env_terrain = 1): independent FireSimulation
+ * instances with different fuel / topography / wind in one batch.  sf_set_layers / sf_set_rtable
+ * then address every environment at once; sf_get_rtable returns environment 0. */
+int sf_set_layers_env(sf_sim *sim, int32_t env, const double *w_0, const double *delta, const double *M_x,
+                      const double *sigma, const double *elevation, const double *U, const double *U_dir);
+int sf_set_rtable_env(sf_sim *sim, int32_t env, const double *R8);
+int sf_get_rtable_env(sf_sim *sim, int32_t env, double *R8_out);
 
 /* FireSimulation.reset for every environment (simulation.py:202-214, 555-566): fire_map all
  * UNBURNED except the ignition cell, burn_amounts 0, one sprite of duration 0, elapsed_time 0.

@@ -23,7 +23,7 @@ class SfParams(C.Structure):
                 ("attenuate_line_ros", C.c_int32), ("has_max_time", C.c_int32), ("device", C.c_int32),
                 ("pixel_scale", C.c_double), ("update_rate", C.c_double), ("max_time", C.c_double),
                 ("h", C.c_double), ("S_T", C.c_double), ("S_e", C.c_double), ("p_p", C.c_double),
-                ("M_f", C.c_double)]
+                ("M_f", C.c_double), ("per_env_terrain", C.c_int32)]
 
 
 # name -> argtypes; every function returns int except the two string getters
@@ -35,6 +35,9 @@ SIGNATURES = {
     "sf_set_rtable": [_VP, _VP],
     "sf_get_rtable": [_VP, _VP],
     "sf_get_slopes": [_VP, _VP, _VP],
+    "sf_set_layers_env": [_VP, _I32] + [_VP] * 7,
+    "sf_set_rtable_env": [_VP, _I32, _VP],
+    "sf_get_rtable_env": [_VP, _I32, _VP],
     "sf_reset": [_VP, _VP],
     "sf_reset_env": [_VP, _I32, _I32, _I32],
     "sf_apply_mitigation": [_VP, _VP, _I32],

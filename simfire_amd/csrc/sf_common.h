@@ -44,6 +44,7 @@ struct Geo {
     int TX, TY, TXp, TYp;         // wave tiles per environment (+ a zero guard ring in the flag maps)
     int dense;                    // 1 = ignore the tile activity map (cross-check mode)
     int ab;                       // bytes per cell of the sprite-mask plane: 1 (md <= 5), 2 (<= 13), 4 (<= 28)
+    long long rt_env;             // element stride between the R tables of two environments (0 = one shared table)
 };
 
 struct StepArgs {

@@ -146,7 +146,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
             if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
             if (is_cand) {
                 acc.cand = 1;
-                double ros = a.rt[(long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+                double ros = a.rt[(long long)e * g.rt_env + (long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
                 if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
                     ros = g.att ? ros - line_factor(s_post) : 0.0;
                 bn = bn + ros;                                                   // fire.py:710
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
             if (pending) bn = bn - line_factor(s_pre);                              // fire.py:278, one step late
             if (is_cand) {
                 cand = true;
-                double ros = a.rt[(long long)bestk * g.H * g.P + o] * g.update_rate;  // fire.py:696,705
+                double ros = a.rt[(long long)e * g.rt_env + (long long)bestk * g.H * g.P + o] * g.update_rate;  // fire.py:696,705
                 if (s_post >= SF_FIRELINE) ros = g.att ? ros - line_factor(s_post) : 0.0;   // fire.py:271-282
                 bn = bn + ros;                                                      // fire.py:710
                 if (bn > g.pixel_scale) { st_new = SF_BURNING; age_new |= mk.b_new; }   // fire.py:568-587

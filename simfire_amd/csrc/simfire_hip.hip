@@ -109,6 +109,7 @@ struct sf_sim {
     hipEvent_t ev_pts = nullptr;
     bool async = false;                // sf_set_async: calls that return no data do not synchronise
     bool have_rt = false, was_reset = false, counters_on = false;
+    std::vector<char> rt_set;          // per table: layers / R table supplied?
     int64_t bytes = 0;
 };
 
@@ -179,7 +180,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.dense = 0;
     if (const char *v = getenv("SF_DENSE")) g.dense = atoi(v) != 0;
     g.md = p->max_fire_duration; g.N = g.md + 3;
-    g.ab = g.N <= 8 ? 1 : (g.N <= 16 ? 2 : 4);   // 1-byte plane: SWAR kernels; wider: generic per-cell kernel
+    g.ab = g.N <= 8 ? 1 : (g.N <= 16 ? 2 : 4);
+    g.rt_env = p->per_env_terrain ? (long long)8 * g.H * P : 0;   // 1-byte plane: SWAR kernels; wider: generic per-cell kernel
     g.diag = p->diagonal_spread != 0; g.att = p->attenuate_line_ros != 0; g.has_max_time = p->has_max_time != 0;
     g.pixel_scale = p->pixel_scale; g.update_rate = p->update_rate; g.max_time = p->max_time;
     g.age_env = (long long)(g.H + 2) * g.P; g.plane_env = (long long)g.H * g.P;
@@ -198,7 +200,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->age_alloc, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab));
     s->age = s->age_alloc + (size_t)g.P * g.ab;   // row 0 of env 0; guard rows at -1 and H of every env
     TRY(dev_alloc(s, &s->burn, cells));
-    TRY(dev_alloc(s, &s->rt, (size_t)8 * g.plane_env));
+    TRY(dev_alloc(s, &s->rt, (size_t)8 * g.plane_env * (p->per_env_terrain ? g.E : 1)));
+    s->rt_set.assign(p->per_env_terrain ? g.E : 1, 0);
     for (int i = 0; i < 7; ++i) TRY(dev_alloc(s, &s->lay[i], (size_t)g.H * g.W));
     TRY(dev_alloc(s, &s->smag, (size_t)g.H * g.W));
     TRY(dev_alloc(s, &s->sdir, (size_t)g.H * g.W));
@@ -376,11 +379,28 @@ extern "C" int sf_set_dense(sf_sim *s, int32_t dense)
     return SF_OK;
 }
 
-extern "C" int sf_set_layers(sf_sim *s, const double *w_0, const double *delta, const double *M_x,
-                             const double *sigma, const double *elevation, const double *U, const double *U_dir)
+// which R tables an env argument addresses: env < 0 = all of them
+static int table_range(sf_sim *s, int env, const char *who, int *lo, int *hi)
 {
-    if (!s) return fail(SF_EINVAL, "sf_set_layers: null handle");
-    const double *src[7] = {w_0, delta, M_x, sigma, elevation, U, U_dir};
+    const int n_tab = (int)s->rt_set.size();
+    if (env < 0) { *lo = 0; *hi = n_tab; return SF_OK; }
+    if (n_tab == 1) return fail(SF_ESTATE, "%s: this handle shares one terrain between all environments "
+                                "(create it with per_env_terrain = 1)", who);
+    if (env >= n_tab) return fail(SF_EINVAL, "%s: environment %d out of range", who, env);
+    *lo = env; *hi = env + 1;
+    return SF_OK;
+}
+static void mark_tables(sf_sim *s, int lo, int hi)
+{
+    for (int i = lo; i < hi; ++i) s->rt_set[i] = 1;
+    s->have_rt = true;
+    for (char c : s->rt_set) if (!c) s->have_rt = false;
+}
+
+static int set_layers_impl(sf_sim *s, int env, const double *const src[7])
+{
+    int lo, hi, rc = table_range(s, env, "sf_set_layers", &lo, &hi);
+    if (rc) return rc;
     for (int i = 0; i < 7; ++i) if (!src[i]) return fail(SF_EINVAL, "sf_set_layers: null layer pointer (#%d)", i);
     HIPCHK(hipSetDevice(s->p.device));
     const Geo &g = s->g;
@@ -392,46 +412,98 @@ extern "C" int sf_set_layers(sf_sim *s, const double *w_0, const double *delta, 
     for (int k = 0; k < 8; ++k)   // theta = arctan2(src_y - dst_y, dst_x - src_x), float32 (rothermel.py:102)
         th.v[k] = atan2f((float)SF_SRC_DY[k], (float)(-SF_SRC_DX[k]));
     dim3 grd2((g.P + 255) / 256, g.H);
+    const size_t tab = (size_t)8 * g.plane_env;
     hipLaunchKernelGGL(k_rtable, grd2, blk, 0, s->stream, g.H, g.W, g.P, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
                        s->lay[5], s->lay[6], s->smag, s->sdir, (float)s->p.h, (float)s->p.S_T, (float)s->p.S_e,
-                       (float)s->p.p_p, (float)s->p.M_f, th, s->rt);
+                       (float)s->p.p_p, (float)s->p.M_f, th, s->rt + (size_t)lo * tab);
+    HIPCHK(hipGetLastError());
+    for (int i = lo + 1; i < hi; ++i)   // same terrain for several environments: replicate the table
+        HIPCHK(hipMemcpyAsync(s->rt + (size_t)i * tab, s->rt + (size_t)lo * tab, tab * sizeof(double),
+                              hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    mark_tables(s, lo, hi);
+    return SF_OK;
+}
+
+extern "C" int sf_set_layers(sf_sim *s, const double *w_0, const double *delta, const double *M_x,
+                             const double *sigma, const double *elevation, const double *U, const double *U_dir)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_layers: null handle");
+    const double *src[7] = {w_0, delta, M_x, sigma, elevation, U, U_dir};
+    return set_layers_impl(s, -1, src);
+}
+
+extern "C" int sf_set_layers_env(sf_sim *s, int32_t env, const double *w_0, const double *delta, const double *M_x,
+                                 const double *sigma, const double *elevation, const double *U, const double *U_dir)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_layers_env: null handle");
+    if (env < 0) return fail(SF_EINVAL, "sf_set_layers_env: environment %d out of range", env);
+    const double *src[7] = {w_0, delta, M_x, sigma, elevation, U, U_dir};
+    return set_layers_impl(s, env, src);
+}
+
+static int set_rtable_impl(sf_sim *s, int env, const double *R8)
+{
+    int lo, hi, rc = table_range(s, env, "sf_set_rtable", &lo, &hi);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
+    rc = ensure_stage(s, n);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->stage, R8, n, hipMemcpyHostToDevice, s->stream));
+    dim3 blk(256), grd((g.P + 255) / 256, g.H, 8);
+    const size_t tab = (size_t)8 * g.plane_env;
+    for (int i = lo; i < hi; ++i)
+        hipLaunchKernelGGL(k_pack_rt, grd, blk, 0, s->stream, g.H, g.W, g.P, (const double *)s->stage, s->rt + (size_t)i * tab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->have_rt = true;
+    mark_tables(s, lo, hi);
     return SF_OK;
 }
 
 extern "C" int sf_set_rtable(sf_sim *s, const double *R8)
 {
     if (!s || !R8) return fail(SF_EINVAL, "sf_set_rtable: null argument");
-    HIPCHK(hipSetDevice(s->p.device));
-    const Geo &g = s->g;
-    const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
-    int rc = ensure_stage(s, n);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s->stage, R8, n, hipMemcpyHostToDevice, s->stream));
-    dim3 blk(256), grd((g.P + 255) / 256, g.H, 8);
-    hipLaunchKernelGGL(k_pack_rt, grd, blk, 0, s->stream, g.H, g.W, g.P, (const double *)s->stage, s->rt);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s->stream));
-    s->have_rt = true;
-    return SF_OK;
+    return set_rtable_impl(s, -1, R8);
 }
 
-extern "C" int sf_get_rtable(sf_sim *s, double *out)
+extern "C" int sf_set_rtable_env(sf_sim *s, int32_t env, const double *R8)
 {
-    if (!s || !out) return fail(SF_EINVAL, "sf_get_rtable: null argument");
-    if (!s->have_rt) return fail(SF_ESTATE, "sf_get_rtable: no layers / table set");
+    if (!s || !R8) return fail(SF_EINVAL, "sf_set_rtable_env: null argument");
+    if (env < 0) return fail(SF_EINVAL, "sf_set_rtable_env: environment %d out of range", env);
+    return set_rtable_impl(s, env, R8);
+}
+
+static int get_rtable_impl(sf_sim *s, int env, double *out)
+{
+    const int n_tab = (int)s->rt_set.size();
+    const int t = n_tab == 1 ? 0 : env;
+    if (t < 0 || t >= n_tab) return fail(SF_EINVAL, "sf_get_rtable: environment %d out of range", env);
+    if (!s->rt_set[t]) return fail(SF_ESTATE, "sf_get_rtable: no layers / table set");
     HIPCHK(hipSetDevice(s->p.device));
     const Geo &g = s->g;
     const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
     int rc = ensure_stage(s, n);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H, 8);
-    hipLaunchKernelGGL(k_unpack_f64, grd, blk, 0, s->stream, g.H, g.W, g.P, (const double *)s->rt, (double *)s->stage);
+    hipLaunchKernelGGL(k_unpack_f64, grd, blk, 0, s->stream, g.H, g.W, g.P,
+                       (const double *)(s->rt + (size_t)t * 8 * g.plane_env), (double *)s->stage);
     HIPCHK(hipMemcpyAsync(out, s->stage, n, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
+}
+
+extern "C" int sf_get_rtable(sf_sim *s, double *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_rtable: null argument");
+    return get_rtable_impl(s, 0, out);
+}
+
+extern "C" int sf_get_rtable_env(sf_sim *s, int32_t env, double *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_rtable_env: null argument");
+    return get_rtable_impl(s, env, out);
 }
 
 extern "C" int sf_get_slopes(sf_sim *s, double *mag, double *dir)

@@ -23,7 +23,7 @@ class FireEngine:
 
     def __init__(self, shape, n_envs=1, max_fire_duration=4, pixel_scale=50.0, update_rate=1.0,
                  max_time=None, attenuate_line_ros=True, diagonal_spread=True, M_f=0.03,
-                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0):
+                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0, per_env_terrain=False):
         self._L = _lib.load()
         self.H, self.W = int(shape[0]), int(shape[1])
         self.n_envs = int(n_envs)
@@ -33,7 +33,8 @@ class FireEngine:
             diagonal_spread=int(bool(diagonal_spread)), attenuate_line_ros=int(bool(attenuate_line_ros)),
             has_max_time=int(max_time is not None), device=int(device), pixel_scale=float(pixel_scale),
             update_rate=float(update_rate), max_time=float(0.0 if max_time is None else max_time),
-            h=float(h), S_T=float(S_T), S_e=float(S_e), p_p=float(p_p), M_f=float(M_f))
+            h=float(h), S_T=float(S_T), S_e=float(S_e), p_p=float(p_p), M_f=float(M_f),
+            per_env_terrain=int(bool(per_env_terrain)))
         self._h = C.c_void_p()
         _lib.check(self._L.sf_create(C.byref(self.params), C.byref(self._h)))
 
@@ -58,21 +59,28 @@ class FireEngine:
                              f"shape of {(self.H, self.W)} ({name})")
         return np.ascontiguousarray(a)
 
-    def set_layers(self, w_0, delta, M_x, sigma, elevation, U, U_dir):
+    def set_layers(self, w_0, delta, M_x, sigma, elevation, U, U_dir, env=None):
+        """``env=None``: all environments; an index: that environment only (``per_env_terrain``)."""
         arrs = [self._plane(a, n) for a, n in zip(
             (w_0, delta, M_x, sigma, elevation, U, U_dir),
             ("w_0", "delta", "M_x", "sigma", "elevation", "U", "U_dir"))]
-        _lib.check(self._L.sf_set_layers(self._h, *[_ptr(a) for a in arrs]))
+        if env is None:
+            _lib.check(self._L.sf_set_layers(self._h, *[_ptr(a) for a in arrs]))
+        else:
+            _lib.check(self._L.sf_set_layers_env(self._h, int(env), *[_ptr(a) for a in arrs]))
 
-    def set_rtable(self, R8):
+    def set_rtable(self, R8, env=None):
         R8 = np.ascontiguousarray(R8, dtype=np.float64)
         if R8.shape != (8, self.H, self.W):
             raise ValueError(f"R table shape {R8.shape} != {(8, self.H, self.W)}")
-        _lib.check(self._L.sf_set_rtable(self._h, _ptr(R8)))
+        if env is None:
+            _lib.check(self._L.sf_set_rtable(self._h, _ptr(R8)))
+        else:
+            _lib.check(self._L.sf_set_rtable_env(self._h, int(env), _ptr(R8)))
 
-    def get_rtable(self):
+    def get_rtable(self, env=0):
         out = np.empty((8, self.H, self.W), dtype=np.float64)
-        _lib.check(self._L.sf_get_rtable(self._h, _ptr(out)))
+        _lib.check(self._L.sf_get_rtable_env(self._h, int(env), _ptr(out)))
         return out
 
     def get_slopes(self):

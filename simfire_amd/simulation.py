@@ -35,18 +35,31 @@ class _TerrainView:
         self.fuels, self.elevations, self.screen_size = fuels, elevations, screen_size
 
 
-def _engine_from_config(config: Config, n_envs: int, device: int) -> Tuple[FireEngine, _TerrainView]:
-    fp = FuelParticle()
+def _config_layers(config: Config):
     fuels = config.terrain.fuel_layer.data.squeeze()
     elev = np.asarray(config.terrain.topography_layer.data.squeeze(), dtype=np.float64)
+    return fuels, elev
+
+
+def _engine_from_config(config: Config, n_envs: int, device: int,
+                        per_env_terrain: bool = False) -> Tuple[FireEngine, _TerrainView]:
+    fp = FuelParticle()
+    fuels, elev = _config_layers(config)
     H, W = config.area.screen_size
     eng = FireEngine((H, W), n_envs=n_envs, max_fire_duration=config.fire.max_fire_duration,
                      pixel_scale=config.area.pixel_scale, update_rate=config.simulation.update_rate,
                      max_time=config.simulation.runtime, attenuate_line_ros=config.mitigation.ros_attenuation,
                      diagonal_spread=config.fire.diagonal_spread, M_f=config.environment.moisture,
-                     particle=(fp.h, fp.S_T, fp.S_e, fp.p_p), device=device)
-    eng.set_layers(*fuel_planes(fuels), elev, config.wind.speed, config.wind.direction)
+                     particle=(fp.h, fp.S_T, fp.S_e, fp.p_p), device=device, per_env_terrain=per_env_terrain)
+    if not per_env_terrain:
+        eng.set_layers(*fuel_planes(fuels), elev, config.wind.speed, config.wind.direction)
     return eng, _TerrainView(fuels, elev, (H, W))
+
+
+# the scalars one device handle shares between its environments (sf_params)
+_SHARED_FIELDS = (("area", "screen_size"), ("area", "pixel_scale"), ("fire", "max_fire_duration"),
+                  ("fire", "diagonal_spread"), ("simulation", "update_rate"), ("simulation", "runtime"),
+                  ("mitigation", "ros_attenuation"), ("environment", "moisture"))
 
 
 class FireSimulation:
@@ -263,7 +276,13 @@ class FireSimulation:
 
 
 class BatchedFireSimulation:
-    """``n_envs`` independent fire simulations on one GPU that share the config's terrain and wind.
+    """``n_envs`` independent fire simulations on one GPU.
+
+    ``config`` is either one ``Config`` - every environment shares its terrain and wind and only the
+    ignition differs - or a sequence of ``n_envs`` configs with their own fuel / topography / wind
+    layers (what ``n_envs`` separate reference ``FireSimulation`` objects would hold); those must
+    agree on the scalars of ``sf_params`` (screen size, pixel scale, update rate, runtime, fire
+    duration, diagonal spread, line attenuation, moisture).
 
     ``ignitions``: int [n_envs, 2] (x, y), or None to draw them like the reference's ``random``
     fire position (``rng = default_rng(seed); x = rng.integers(W); y = rng.integers(H)``,
@@ -271,8 +290,20 @@ class BatchedFireSimulation:
 
     def __init__(self, config: Config, n_envs: int, ignitions=None, seeds: Optional[Sequence[int]] = None,
                  device: int = 0) -> None:
-        self.config = config
         self.n_envs = int(n_envs)
+        self.configs = None
+        if not isinstance(config, Config):
+            self.configs = list(config)
+            if len(self.configs) != self.n_envs:
+                raise ValueError(f"{len(self.configs)} configs for {self.n_envs} environments")
+            config = self.configs[0]
+            for e, c in enumerate(self.configs[1:], start=1):
+                for sec, name in _SHARED_FIELDS:
+                    a, b = getattr(getattr(config, sec), name), getattr(getattr(c, sec), name)
+                    if a != b:
+                        raise ValueError(f"config of environment {e}: {sec}.{name} = {b!r} differs from "
+                                         f"environment 0 ({a!r}); one device handle shares this value")
+        self.config = config
         H, W = config.area.screen_size
         if ignitions is None:
             seeds = list(seeds) if seeds is not None else [1234 + e for e in range(self.n_envs)]
@@ -281,7 +312,14 @@ class BatchedFireSimulation:
                 rng = np.random.default_rng(sd)
                 ignitions[e] = (rng.integers(W, dtype=int), rng.integers(H, dtype=int))
         self.ignitions = np.asarray(ignitions, dtype=np.int32).reshape(self.n_envs, 2)
-        self._engine, self.terrain = _engine_from_config(config, self.n_envs, device)
+        self._engine, self.terrain = _engine_from_config(config, self.n_envs, device,
+                                                         per_env_terrain=self.configs is not None)
+        if self.configs is not None:
+            self.terrains = []
+            for e, c in enumerate(self.configs):
+                fuels, elev = _config_layers(c)
+                self._engine.set_layers(*fuel_planes(fuels), elev, c.wind.speed, c.wind.direction, env=e)
+                self.terrains.append(_TerrainView(fuels, elev, (H, W)))
         self.reset()
 
     def reset(self, envs: Optional[Sequence[int]] = None) -> None:

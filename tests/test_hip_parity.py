@@ -646,3 +646,82 @@ def test_spread_graph_multi_step_and_batch():
         assert (eng.spread_parents(e) == o.parents(e)).all(), e
     eng.reset_env(1, 7, 7)
     assert not eng.spread_parents(1).any() and eng.spread_parents(0).any()
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_per_env_terrain_vs_single_env_oracles(generic):
+    """Handles created with per_env_terrain: every environment spreads over its own R table (its own
+    fuel / topography / wind), i.e. E separate reference FireSimulation objects in one batch.  Each
+    environment must equal a one-environment oracle run on that environment's table."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(99)
+    H, W, E = 45, 70, 5
+    kw = dict(shape=(H, W), max_fire_duration=3, pixel_scale=20.0, update_rate=1.0)
+    eng = FireEngine(n_envs=E, per_env_terrain=True, **kw)
+    eng.set_generic(generic)
+    tabs = [rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 400.0], size=(8, H, W)) * (1 + e) for e in range(E)]
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng.reset(inits)
+    with pytest.raises(RuntimeError):
+        eng.step(1)                                        # no table yet
+    for e in range(E - 1):
+        eng.set_rtable(tabs[e], env=e)
+    with pytest.raises(RuntimeError):
+        eng.step(1)                                        # environment E-1 still has none
+    eng.set_rtable(tabs[E - 1], env=E - 1)
+    for e in range(E):
+        assert (eng.get_rtable(env=e) == tabs[e]).all()
+    eng.reset(inits)
+    oracles = []
+    for e in range(E):
+        o = fire_dense.DenseOracle(**kw)
+        o.set_rtable(tabs[e])
+        o.reset([inits[e]])
+        oracles.append(o)
+    for t in range(40):
+        if t % 7 == 3:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(12)]
+            eng.apply_mitigation(pts)
+            for (e, x, y, ty) in pts:
+                oracles[e].apply_mitigation([(0, x, y, ty)])
+        eng.step(1)
+        st, el = eng.status()
+        for e, o in enumerate(oracles):
+            o.step(1)
+            assert (eng.fire_map(e) == o.fire_map(0)).all(), (t, e)
+            ost, oel = o.status()
+            assert (st[e] == ost[0]).all() and el[e] == oel[0], (t, e)
+    for e, o in enumerate(oracles):
+        assert (eng.burn(e) == o.burn(0)).all()
+
+
+def test_per_env_layers_equal_single_env_tables():
+    """sf_set_layers_env builds the same table bits as sf_set_layers on a one-environment handle, and
+    sf_set_layers on a per-env handle fills every environment."""
+    from simfire_amd.engine import FireEngine
+    from simfire_amd.parameters import Fuel
+    rng = np.random.default_rng(7)
+    H, W = 33, 50
+    kw = dict(shape=(H, W), max_fire_duration=4, pixel_scale=50.0, update_rate=1.0)
+
+    def layers(seed):
+        r = np.random.default_rng(seed)
+        return (r.uniform(0.01, 0.3, (H, W)), r.uniform(0.5, 6.0, (H, W)), r.uniform(0.12, 0.4, (H, W)),
+                r.uniform(1000, 3500, (H, W)), r.uniform(0, 400, (H, W)), r.uniform(0, 900, (H, W)),
+                r.uniform(0, 360, (H, W)))
+    multi = FireEngine(n_envs=3, per_env_terrain=True, **kw)
+    for e in range(3):
+        multi.set_layers(*layers(100 + e), env=e)
+    for e in range(3):
+        one = FireEngine(n_envs=1, **kw)
+        one.set_layers(*layers(100 + e))
+        assert (one.get_rtable() == multi.get_rtable(env=e)).all()
+    multi.set_layers(*layers(555))
+    ref = multi.get_rtable(env=0)
+    assert (multi.get_rtable(env=1) == ref).all() and (multi.get_rtable(env=2) == ref).all()
+    shared = FireEngine(n_envs=3, **kw)
+    with pytest.raises(RuntimeError):
+        shared.set_layers(*layers(1), env=1)               # shared-terrain handle has one table
+    with pytest.raises(ValueError):
+        multi.set_layers(*layers(1), env=3)

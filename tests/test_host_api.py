@@ -245,3 +245,39 @@ def test_spread_graph_host_api():
     newly = {dst for src, dst in edges if src == (x0, y0)}
     burning_or_burned = {(int(x), int(yy)) for yy, x in np.argwhere(sim.fire_map >= 1)}
     assert newly <= burning_or_burned
+
+
+def test_batched_simulation_one_config_per_env():
+    """A list of configs = separate reference FireSimulation objects (own fuel, topography, wind) in
+    one device batch; each environment must equal that config run on its own."""
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import BatchedFireSimulation, FireSimulation
+    from simfire_amd.parameters import FuelModelToFuel
+    y = yaml.safe_load(open(os.path.join(CFG, "test_config_flat_simple.yml")))
+    H, W = 40, 56
+    rng = np.random.default_rng(3)
+    cfgs = []
+    for e in range(3):
+        codes = rng.choice([1, 2, 4, 5, 10], size=(H, W))
+        elev = rng.uniform(0, 30.0 * (e + 1), (H, W))
+        speed = np.full((H, W), 300.0 * (e + 1))
+        direction = np.full((H, W), 90.0 * e)
+        yy = yaml.safe_load(yaml.safe_dump(y))
+        yy["fire"]["fire_initial_position"] = {"type": "static", "static": {"position": f"({10 + 5 * e}, {12 + 3 * e})"}}
+        cfgs.append(Config.from_arrays(yy, codes, elev, speed, direction))
+    ign = [c.fire.fire_initial_position for c in cfgs]
+    batch = BatchedFireSimulation(cfgs, 3, ignitions=ign)
+    batch.update_mitigation([(e, 20, r, 3) for e in range(3) for r in range(5, 30)])
+    maps, _ = batch.run(25)
+    for e, c in enumerate(cfgs):
+        solo = FireSimulation(c)
+        solo.update_mitigation([(20, r, 3) for r in range(5, 30)])
+        fm, _ = solo.run(25)
+        assert (maps[e] == fm).all(), e
+    assert not (maps[0] == maps[1]).all()
+    bad = yaml.safe_load(yaml.safe_dump(y))
+    bad["area"]["pixel_scale"] = 77
+    with pytest.raises(ValueError):
+        BatchedFireSimulation([cfgs[0], Config.from_arrays(bad, rng.choice([1, 2], size=(H, W)), np.zeros((H, W)),
+                                                            np.zeros((H, W)), np.zeros((H, W)))], 2, ignitions=ign[:2])
