@@ -105,6 +105,27 @@ int sf_set_layers_env(sf_sim *sim, int32_t env, const double *w_0, const double 
 int sf_set_rtable_env(sf_sim *sim, int32_t env, const double *R8);
 int sf_get_rtable_env(sf_sim *sim, int32_t env, double *R8_out);
 
+/* Layers from an FBFM13 fuel-model raster, expanded on the device: FuelLayer._get_data
+ * (simfire/utils/layers.py:670-676) with the caller's FuelModelToFuel table (simfire/enums.py:176-198):
+ * lut_codes int32 [n_lut], lut_fuel float64 [n_lut][4] = (w_0, delta, M_x, sigma).  codes int32 [H*W];
+ * env = -1 addresses every environment.  A code missing from the table is SF_EINVAL (KeyError there). */
+int sf_set_layers_fbfm(sf_sim *sim, int32_t env, const int32_t *codes, int32_t n_lut, const int32_t *lut_codes,
+                       const double *lut_fuel, const double *elevation, const double *U, const double *U_dir);
+/* FireSimulation.get_attribute_data (simfire/sim/simulation.py:376-403) from the layers held in HBM:
+ * w_0, delta, M_x as float32, sigma as uint32, elevation / wind as supplied (float64), each [H*W];
+ * null pointers are skipped.  device_pointers != 0: the outputs are device buffers. */
+int sf_get_attribute_data(sf_sim *sim, int32_t env, float *w_0, uint32_t *sigma, float *delta, float *M_x,
+                          double *elevation, double *wind_speed, double *wind_direction, int32_t device_pointers);
+
+/* History of FireSimulation._save_data (simulation.py:548-549, 887-959): the fire map after every
+ * executed update, a ring int8 [n_envs][capacity][H][W] in HBM: update number u (0-based, counted from
+ * the last reset of that environment = elapsed_steps before it) lands in slot u mod capacity.
+ * sf_get_history copies updates first .. first+count-1 (count <= capacity; the caller fetches before
+ * the ring wraps over them).  capacity 0 frees it. */
+int sf_enable_history(sf_sim *sim, int32_t capacity);
+int sf_get_history(sf_sim *sim, int32_t env, int32_t first, int32_t count, int8_t *out);
+int sf_history_device(sf_sim *sim, void **ptr, int32_t *capacity);
+
 /* FireSimulation.reset for every environment (simulation.py:202-214, 555-566): fire_map all
  * UNBURNED except the ignition cell, burn_amounts 0, one sprite of duration 0, elapsed_time 0.
  * init_xy = int32 [n_envs][2] = (x, y). */

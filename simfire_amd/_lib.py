@@ -38,6 +38,11 @@ SIGNATURES = {
     "sf_set_layers_env": [_VP, _I32] + [_VP] * 7,
     "sf_set_rtable_env": [_VP, _I32, _VP],
     "sf_get_rtable_env": [_VP, _I32, _VP],
+    "sf_set_layers_fbfm": [_VP, _I32, _VP, _I32, _VP, _VP, _VP, _VP, _VP],
+    "sf_get_attribute_data": [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32],
+    "sf_enable_history": [_VP, _I32],
+    "sf_get_history": [_VP, _I32, _I32, _I32, _VP],
+    "sf_history_device": [_VP, _VP, _VP],
     "sf_reset": [_VP, _VP],
     "sf_reset_env": [_VP, _I32, _I32, _I32],
     "sf_apply_mitigation": [_VP, _VP, _I32],

@@ -162,6 +162,7 @@ class Config:
         if cfd_precompute:
             raise ConfigError("CFD wind pre-computation is outside the scope of simfire_amd")
         self._arrays: Dict[str, np.ndarray] = {}
+        self.fuel_codes: Optional[np.ndarray] = None
         self._build()
 
     # ------------------------------------------------------------------ alternative ctor
@@ -249,7 +250,9 @@ class Config:
             fuel = self._arrays["fuel"]
             if fuel.shape != (H, W):
                 raise ConfigError(f"fuel shape {fuel.shape} != screen_size {(H, W)}")
+            self.fuel_codes = None
             if fuel.dtype != object:
+                self.fuel_codes = np.ascontiguousarray(fuel, dtype=np.int32)    # kept for the device-side lookup
                 lut = {int(c): FuelModelToFuel[int(c)] for c in np.unique(fuel)}
                 obj = np.empty((H, W), dtype=object)
                 for c, f in lut.items():

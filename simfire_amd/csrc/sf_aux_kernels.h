@@ -67,6 +67,45 @@ __global__ void k_compute_ros(long long n, const float *lx, const float *ly, con
 }
 
 // pitched <-> dense plane copies
+// FBFM13 code -> Fuel (w_0, delta, M_x, sigma); the table travels as a kernel argument
+constexpr int kMaxFuelLut = 48;
+struct FuelLut {
+    int n;
+    int32_t code[kMaxFuelLut];
+    double fuel[kMaxFuelLut][4];
+};
+__global__ void k_fuel_lut(long long n, const int32_t *codes, FuelLut lut, double *w0, double *delta, double *mx,
+                           double *sigma, int32_t *bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = codes[i];
+    int hit = -1;
+    for (int k = 0; k < lut.n; ++k) if (lut.code[k] == c) hit = k;
+    if (hit < 0) { *bad = c; return; }      // any offending code will do for the message
+    w0[i] = lut.fuel[hit][0]; delta[i] = lut.fuel[hit][1]; mx[i] = lut.fuel[hit][2]; sigma[i] = lut.fuel[hit][3];
+}
+
+// observation planes in the dtypes of get_attribute_data (simulation.py:395-399)
+__global__ void k_attribute_planes(long long n, const double *w0, const double *delta, const double *mx, const double *sigma,
+                                   float *o_w0, uint32_t *o_sigma, float *o_delta, float *o_mx)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_w0[i] = (float)w0[i]; o_sigma[i] = (uint32_t)sigma[i]; o_delta[i] = (float)delta[i]; o_mx[i] = (float)mx[i];
+}
+
+// fire map after the update this launch executed, for the environments that executed one
+__global__ void k_record(Geo g, const uint8_t *status, const EnvState *st, int8_t *hist, int cap)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
+    if (x >= g.W) return;
+    const EnvState s = st[e];
+    if (!s.running) return;
+    hist[(((long long)e * cap + s.steps % cap) * g.H + y) * g.W + x] =
+        (int8_t)(status[(long long)e * g.plane_env + (long long)y * g.P + x] & 7u);
+}
+
 __global__ void k_pack_rt(int H, int W, int P, const double *dense, double *pitched)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;

@@ -86,7 +86,10 @@ struct sf_sim {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *status = nullptr, *age_alloc = nullptr, *age = nullptr;
     double *burn = nullptr, *rt = nullptr;
-    double *lay[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // w0 delta Mx sigma elev U Udir (dense)
+    double *lay_all = nullptr;         // [tables][7][H*W] dense: w0 delta Mx sigma elev U Udir (kept for the observation planes)
+    double *layer(int table, int i) const { return lay_all + ((size_t)table * 7 + i) * (size_t)g.H * g.W; }
+    int8_t *history = nullptr;         // sf_enable_history: [E][history_cap][H][W] fire maps after each update
+    int history_cap = 0;
     double *smag = nullptr, *sdir = nullptr;
     EnvState *commit = nullptr, *tmp = nullptr;
     uint32_t *flags = nullptr;
@@ -202,7 +205,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->burn, cells));
     TRY(dev_alloc(s, &s->rt, (size_t)8 * g.plane_env * (p->per_env_terrain ? g.E : 1)));
     s->rt_set.assign(p->per_env_terrain ? g.E : 1, 0);
-    for (int i = 0; i < 7; ++i) TRY(dev_alloc(s, &s->lay[i], (size_t)g.H * g.W));
+    TRY(dev_alloc(s, &s->lay_all, (size_t)7 * g.H * g.W * (p->per_env_terrain ? g.E : 1)));
     TRY(dev_alloc(s, &s->smag, (size_t)g.H * g.W));
     TRY(dev_alloc(s, &s->sdir, (size_t)g.H * g.W));
     TRY(dev_alloc(s, &s->commit, (size_t)g.E));
@@ -235,8 +238,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
-                    s->lay[4], s->lay[5], s->lay[6], s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
                     s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->parents};
     if (s->pts_pinned) (void)hipHostFree(s->pts_pinned);
     if (s->ev_pts) (void)hipEventDestroy(s->ev_pts);
@@ -397,29 +399,32 @@ static void mark_tables(sf_sim *s, int lo, int hi)
     for (char c : s->rt_set) if (!c) s->have_rt = false;
 }
 
+// src[i] == nullptr: plane i of table `lo` is already on the device (filled from a fuel-code raster)
 static int set_layers_impl(sf_sim *s, int env, const double *const src[7])
 {
     int lo, hi, rc = table_range(s, env, "sf_set_layers", &lo, &hi);
     if (rc) return rc;
-    for (int i = 0; i < 7; ++i) if (!src[i]) return fail(SF_EINVAL, "sf_set_layers: null layer pointer (#%d)", i);
     HIPCHK(hipSetDevice(s->p.device));
     const Geo &g = s->g;
     const size_t n = (size_t)g.H * g.W;
-    for (int i = 0; i < 7; ++i) HIPCHK(hipMemcpyAsync(s->lay[i], src[i], n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    for (int i = 0; i < 7; ++i)
+        if (src[i]) HIPCHK(hipMemcpyAsync(s->layer(lo, i), src[i], n * sizeof(double), hipMemcpyHostToDevice, s->stream));
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
-    hipLaunchKernelGGL(k_slopes, grd, blk, 0, s->stream, g.H, g.W, s->lay[4], g.pixel_scale, s->smag, s->sdir);
+    hipLaunchKernelGGL(k_slopes, grd, blk, 0, s->stream, g.H, g.W, s->layer(lo, 4), g.pixel_scale, s->smag, s->sdir);
     Thetas th;
     for (int k = 0; k < 8; ++k)   // theta = arctan2(src_y - dst_y, dst_x - src_x), float32 (rothermel.py:102)
         th.v[k] = atan2f((float)SF_SRC_DY[k], (float)(-SF_SRC_DX[k]));
     dim3 grd2((g.P + 255) / 256, g.H);
     const size_t tab = (size_t)8 * g.plane_env;
-    hipLaunchKernelGGL(k_rtable, grd2, blk, 0, s->stream, g.H, g.W, g.P, s->lay[0], s->lay[1], s->lay[2], s->lay[3],
-                       s->lay[5], s->lay[6], s->smag, s->sdir, (float)s->p.h, (float)s->p.S_T, (float)s->p.S_e,
-                       (float)s->p.p_p, (float)s->p.M_f, th, s->rt + (size_t)lo * tab);
+    hipLaunchKernelGGL(k_rtable, grd2, blk, 0, s->stream, g.H, g.W, g.P, s->layer(lo, 0), s->layer(lo, 1), s->layer(lo, 2),
+                       s->layer(lo, 3), s->layer(lo, 5), s->layer(lo, 6), s->smag, s->sdir, (float)s->p.h, (float)s->p.S_T,
+                       (float)s->p.S_e, (float)s->p.p_p, (float)s->p.M_f, th, s->rt + (size_t)lo * tab);
     HIPCHK(hipGetLastError());
-    for (int i = lo + 1; i < hi; ++i)   // same terrain for several environments: replicate the table
+    for (int i = lo + 1; i < hi; ++i) {   // same terrain for several environments: replicate layers and table
+        HIPCHK(hipMemcpyAsync(s->layer(i, 0), s->layer(lo, 0), 7 * n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->rt + (size_t)i * tab, s->rt + (size_t)lo * tab, tab * sizeof(double),
                               hipMemcpyDeviceToDevice, s->stream));
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     mark_tables(s, lo, hi);
     return SF_OK;
@@ -440,6 +445,81 @@ extern "C" int sf_set_layers_env(sf_sim *s, int32_t env, const double *w_0, cons
     if (env < 0) return fail(SF_EINVAL, "sf_set_layers_env: environment %d out of range", env);
     const double *src[7] = {w_0, delta, M_x, sigma, elevation, U, U_dir};
     return set_layers_impl(s, env, src);
+}
+
+// FuelLayer._get_data (simfire/utils/layers.py:670-676): FBFM13 code raster -> Fuel through the
+// FuelModelToFuel table (simfire/enums.py:176-198), done on the device.  The table is the caller's.
+extern "C" int sf_set_layers_fbfm(sf_sim *s, int32_t env, const int32_t *codes, int32_t n_lut, const int32_t *lut_codes,
+                                  const double *lut_fuel, const double *elevation, const double *U, const double *U_dir)
+{
+    if (!s || !codes || !lut_codes || !lut_fuel || !elevation || !U || !U_dir)
+        return fail(SF_EINVAL, "sf_set_layers_fbfm: null argument");
+    if (n_lut < 1 || n_lut > kMaxFuelLut) return fail(SF_EINVAL, "sf_set_layers_fbfm: n_lut must be 1..%d", kMaxFuelLut);
+    int lo, hi, rc = table_range(s, env, "sf_set_layers_fbfm", &lo, &hi);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t n = (size_t)g.H * g.W;
+    rc = ensure_stage(s, n * sizeof(int32_t) + sizeof(int32_t));
+    if (rc) return rc;
+    int32_t *codes_dev = (int32_t *)s->stage, *bad_dev = codes_dev + n;
+    HIPCHK(hipMemcpyAsync(codes_dev, codes, n * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    const int32_t none = INT32_MIN;
+    HIPCHK(hipMemcpyAsync(bad_dev, &none, sizeof none, hipMemcpyHostToDevice, s->stream));
+    FuelLut lut;
+    lut.n = n_lut;
+    for (int i = 0; i < n_lut; ++i) {
+        lut.code[i] = lut_codes[i];
+        for (int k = 0; k < 4; ++k) lut.fuel[i][k] = lut_fuel[4 * i + k];
+    }
+    hipLaunchKernelGGL(k_fuel_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (long long)n,
+                       (const int32_t *)codes_dev, lut, s->layer(lo, 0), s->layer(lo, 1), s->layer(lo, 2), s->layer(lo, 3), bad_dev);
+    HIPCHK(hipGetLastError());
+    int32_t bad = none;
+    HIPCHK(hipMemcpyAsync(&bad, bad_dev, sizeof bad, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (bad != none) return fail(SF_EINVAL, "sf_set_layers_fbfm: fuel model code %d is not in the table", bad);
+    const double *src[7] = {nullptr, nullptr, nullptr, nullptr, elevation, U, U_dir};
+    return set_layers_impl(s, env, src);
+}
+
+// FireSimulation.get_attribute_data (simfire/sim/simulation.py:376-403): w_0 / delta / M_x as float32,
+// sigma as uint32 (astype truncation), elevation and wind as supplied (float64).  Null pointers are
+// skipped; device_pointers != 0: the outputs are device buffers (observation tensors stay in HBM).
+extern "C" int sf_get_attribute_data(sf_sim *s, int32_t env, float *w_0, uint32_t *sigma, float *delta, float *M_x,
+                                     double *elevation, double *wind_speed, double *wind_direction, int32_t device_pointers)
+{
+    if (!s) return fail(SF_EINVAL, "sf_get_attribute_data: null handle");
+    const int n_tab = (int)s->rt_set.size();
+    if (env < 0 || env >= s->g.E) return fail(SF_EINVAL, "sf_get_attribute_data: environment %d out of range", env);
+    const int t = n_tab == 1 ? 0 : env;
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t n = (size_t)g.H * g.W;
+    const hipMemcpyKind kind = device_pointers ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (w_0 || sigma || delta || M_x) {
+        int rc = ensure_stage(s, 4 * n * sizeof(float));
+        if (rc) return rc;
+        float *st = (float *)s->stage;
+        float *d_w0 = device_pointers && w_0 ? w_0 : st, *d_de = device_pointers && delta ? delta : st + 2 * n,
+              *d_mx = device_pointers && M_x ? M_x : st + 3 * n;
+        uint32_t *d_si = device_pointers && sigma ? sigma : (uint32_t *)(st + n);
+        hipLaunchKernelGGL(k_attribute_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (long long)n,
+                           (const double *)s->layer(t, 0), (const double *)s->layer(t, 1), (const double *)s->layer(t, 2),
+                           (const double *)s->layer(t, 3), d_w0, d_si, d_de, d_mx);
+        HIPCHK(hipGetLastError());
+        if (!device_pointers) {
+            if (w_0) HIPCHK(hipMemcpyAsync(w_0, st, n * 4, kind, s->stream));
+            if (sigma) HIPCHK(hipMemcpyAsync(sigma, st + n, n * 4, kind, s->stream));
+            if (delta) HIPCHK(hipMemcpyAsync(delta, st + 2 * n, n * 4, kind, s->stream));
+            if (M_x) HIPCHK(hipMemcpyAsync(M_x, st + 3 * n, n * 4, kind, s->stream));
+        }
+    }
+    if (elevation) HIPCHK(hipMemcpyAsync(elevation, s->layer(t, 4), n * sizeof(double), kind, s->stream));
+    if (wind_speed) HIPCHK(hipMemcpyAsync(wind_speed, s->layer(t, 5), n * sizeof(double), kind, s->stream));
+    if (wind_direction) HIPCHK(hipMemcpyAsync(wind_direction, s->layer(t, 6), n * sizeof(double), kind, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
 }
 
 static int set_rtable_impl(sf_sim *s, int env, const double *R8)
@@ -660,6 +740,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
             s->ring ^= 1;
         }
         if (a.parents) hipLaunchKernelGGL(k_graph_pass, cell_grid, dim3(256), 0, s->stream, a);
+        if (s->history) hipLaunchKernelGGL(k_record, cell_grid, dim3(256), 0, s->stream, s->g, (const uint8_t *)s->status,
+                                           (const EnvState *)(s->tmp + (size_t)(i & 1) * s->g.E), s->history, s->history_cap);
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
@@ -667,6 +749,51 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     HIPCHK(hipGetLastError());
     if (ms || !s->async) HIPCHK(hipStreamSynchronize(s->stream));
     if (ms) HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return SF_OK;
+}
+
+// The per-update history FireSimulation._save_data appends to fire_map.npy (simulation.py:548-549,
+// 887-959: int8 [T, H, W], one map after every executed update), recorded on the device.
+extern "C" int sf_enable_history(sf_sim *s, int32_t capacity)
+{
+    if (!s) return fail(SF_EINVAL, "sf_enable_history: null handle");
+    if (capacity < 0) return fail(SF_EINVAL, "sf_enable_history: capacity must be >= 0");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const size_t per = (size_t)s->g.E * s->g.H * s->g.W;
+    if (s->history) { HIPCHK(hipFree(s->history)); s->bytes -= (int64_t)(per * s->history_cap); }
+    s->history = nullptr; s->history_cap = 0;
+    if (capacity == 0) return SF_OK;
+    HIPCHK(hipMalloc((void **)&s->history, per * capacity));
+    s->bytes += (int64_t)(per * capacity);
+    s->history_cap = capacity;
+    HIPCHK(hipMemsetAsync(s->history, 0, per * capacity, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_get_history(sf_sim *s, int32_t env, int32_t first, int32_t count, int8_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_history: null argument");
+    if (!s->history) return fail(SF_ESTATE, "sf_get_history: call sf_enable_history first");
+    if (env < 0 || env >= s->g.E) return fail(SF_EINVAL, "sf_get_history: environment %d out of range", env);
+    if (first < 0 || count < 0 || count > s->history_cap)
+        return fail(SF_EINVAL, "sf_get_history: %d updates from %d do not fit the capacity %d", count, first, s->history_cap);
+    HIPCHK(hipSetDevice(s->p.device));
+    const size_t map = (size_t)s->g.H * s->g.W;
+    const int8_t *base = s->history + (size_t)env * s->history_cap * map;
+    const int slot = first % s->history_cap;
+    const int n1 = count < s->history_cap - slot ? count : s->history_cap - slot;    // up to the end of the ring
+    if (n1) HIPCHK(hipMemcpyAsync(out, base + (size_t)slot * map, (size_t)n1 * map, hipMemcpyDeviceToHost, s->stream));
+    if (count > n1) HIPCHK(hipMemcpyAsync(out + (size_t)n1 * map, base, (size_t)(count - n1) * map, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_history_device(sf_sim *s, void **ptr, int32_t *capacity)
+{
+    if (!s || !ptr || !capacity) return fail(SF_EINVAL, "sf_history_device: null argument");
+    *ptr = s->history; *capacity = s->history_cap;
     return SF_OK;
 }
 

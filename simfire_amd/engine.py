@@ -210,6 +210,71 @@ class FireEngine:
                     out.append((int(x) + self.GRAPH_DX[k], int(y) + self.GRAPH_DY[k], int(x), int(y)))
         return sorted(out)
 
+    # ---------------------------------------------------------------- layers held in HBM
+    def set_layers_fbfm(self, codes, elevation, U, U_dir, env=None, table=None):
+        """Layers from an FBFM13 fuel-model raster; the code -> Fuel lookup
+        (``FuelLayer._get_data``, simfire/utils/layers.py:670-676) runs on the device.
+        ``table``: {code: Fuel}, default ``parameters.FuelModelToFuel``.  Unknown code: ValueError."""
+        from .parameters import FuelModelToFuel
+        table = FuelModelToFuel if table is None else table
+        codes = np.ascontiguousarray(codes, dtype=np.int32)
+        if codes.shape != (self.H, self.W):
+            raise ValueError(f"fuel code raster shape {codes.shape} != {(self.H, self.W)}")
+        lut_codes = np.array(sorted(table), dtype=np.int32)
+        lut_fuel = np.array([[table[int(c)].w_0, table[int(c)].delta, table[int(c)].M_x, table[int(c)].sigma]
+                             for c in lut_codes], dtype=np.float64)
+        arrs = [self._plane(a, n) for a, n in zip((elevation, U, U_dir), ("elevation", "U", "U_dir"))]
+        _lib.check(self._L.sf_set_layers_fbfm(self._h, -1 if env is None else int(env), _ptr(codes), len(lut_codes),
+                                              _ptr(lut_codes), _ptr(lut_fuel), *[_ptr(a) for a in arrs]))
+
+    def attribute_data(self, env=0):
+        """``FireSimulation.get_attribute_data`` (simfire/sim/simulation.py:376-403) from the layers
+        in GPU memory: w_0 / delta / M_x float32, sigma uint32, elevation / wind float64."""
+        shp = (self.H, self.W)
+        out = {"w_0": np.empty(shp, np.float32), "sigma": np.empty(shp, np.uint32), "delta": np.empty(shp, np.float32),
+               "M_x": np.empty(shp, np.float32), "elevation": np.empty(shp, np.float64),
+               "wind_speed": np.empty(shp, np.float64), "wind_direction": np.empty(shp, np.float64)}
+        _lib.check(self._L.sf_get_attribute_data(self._h, int(env), *[_ptr(out[k]) for k in (
+            "w_0", "sigma", "delta", "M_x", "elevation", "wind_speed", "wind_direction")], 0))
+        return out
+
+    def attribute_data_torch(self, envs=None):
+        """The same planes as torch tensors [len(envs), H, W] on this GPU (no host round trip);
+        sigma as int32 (torch has no uint32 arithmetic; the values are < 2^31)."""
+        import torch
+        envs = list(range(self.n_envs)) if envs is None else [int(e) for e in envs]
+        dev = f"cuda:{self.params.device}"
+        n = len(envs)
+        out = {"w_0": torch.empty((n, self.H, self.W), dtype=torch.float32, device=dev),
+               "sigma": torch.empty((n, self.H, self.W), dtype=torch.int32, device=dev),
+               "delta": torch.empty((n, self.H, self.W), dtype=torch.float32, device=dev),
+               "M_x": torch.empty((n, self.H, self.W), dtype=torch.float32, device=dev),
+               "elevation": torch.empty((n, self.H, self.W), dtype=torch.float64, device=dev),
+               "wind_speed": torch.empty((n, self.H, self.W), dtype=torch.float64, device=dev),
+               "wind_direction": torch.empty((n, self.H, self.W), dtype=torch.float64, device=dev)}
+        torch.cuda.synchronize(dev)
+        for i, e in enumerate(envs):
+            _lib.check(self._L.sf_get_attribute_data(self._h, e, *[C.c_void_p(out[k][i].data_ptr()) for k in (
+                "w_0", "sigma", "delta", "M_x", "elevation", "wind_speed", "wind_direction")], 1))
+        return out
+
+    # ---------------------------------------------------------------- per-update history
+    def enable_history(self, capacity):
+        """Record the fire map after every executed update (what ``_save_data`` appends to
+        ``fire_map.npy``, simfire/sim/simulation.py:548-549) in GPU memory: a ring int8
+        [n_envs, capacity, H, W] (update u in slot u mod capacity); 0 switches it off."""
+        _lib.check(self._L.sf_enable_history(self._h, int(capacity)))
+
+    def history(self, env=0, first=0, count=None):
+        """int8 [count, H, W]: maps after updates ``first .. first+count-1`` of ``env`` since its reset."""
+        if count is None:
+            st, _ = self.status()
+            count = int(st[env, 1]) - int(first)
+        out = np.empty((max(int(count), 0), self.H, self.W), dtype=np.int8)
+        if out.shape[0]:
+            _lib.check(self._L.sf_get_history(self._h, int(env), int(first), int(count), _ptr(out)))
+        return out
+
     def set_generic(self, on=True):
         """Per-cell kernel instead of the tiled SWAR kernels (always on for max_fire_duration > 5)."""
         _lib.check(self._L.sf_set_generic(self._h, int(bool(on))))

@@ -9,6 +9,8 @@ is a device scatter, ``fire_map`` is copied out when ``run`` returns.
 share terrain and wind) - the form the hardware wants.
 """
 import warnings
+from datetime import datetime
+from pathlib import Path
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -52,8 +54,18 @@ def _engine_from_config(config: Config, n_envs: int, device: int,
                      diagonal_spread=config.fire.diagonal_spread, M_f=config.environment.moisture,
                      particle=(fp.h, fp.S_T, fp.S_e, fp.p_p), device=device, per_env_terrain=per_env_terrain)
     if not per_env_terrain:
-        eng.set_layers(*fuel_planes(fuels), elev, config.wind.speed, config.wind.direction)
+        _set_config_layers(eng, config, fuels, elev, None)
     return eng, _TerrainView(fuels, elev, (H, W))
+
+
+def _set_config_layers(eng: FireEngine, config: Config, fuels, elev, env) -> None:
+    """An FBFM13 code raster (``Config.from_arrays``) is expanded on the device; an object array of
+    ``Fuel`` (functional fuel layers) on the host."""
+    codes = getattr(config, "fuel_codes", None)
+    if codes is not None:
+        eng.set_layers_fbfm(codes, elev, config.wind.speed, config.wind.direction, env=env)
+    else:
+        eng.set_layers(*fuel_planes(fuels), elev, config.wind.speed, config.wind.direction, env=env)
 
 
 # the scalars one device handle shares between its environments (sf_params)
@@ -68,6 +80,8 @@ class FireSimulation:
         self._device = device
         self._rendering = False
         self.agents: Dict[int, Tuple[int, int]] = {}
+        self.start_time = datetime.now().strftime("%Y-%m-%d_%H-%M-%S")          # simulation.py:56
+        self.sf_home = Path(config.simulation.sf_home).expanduser()             # simulation.py:1015
         self.reset()
 
     # ------------------------------------------------------------------------- life cycle
@@ -75,6 +89,7 @@ class FireSimulation:
         """simulation.py:202-214: fire_map, agents, terrain, fire manager state, mitigations."""
         cfg = self.config
         self._engine, self.terrain = _engine_from_config(cfg, 1, self._device)
+        self._history_cap = 0
         self.fuel_particle = FuelParticle()
         self.environment = Environment(cfg.environment.moisture, cfg.wind.speed, cfg.wind.direction)
         x, y = cfg.fire.fire_initial_position
@@ -119,7 +134,10 @@ class FireSimulation:
         self._sync_to_device()
         if self.fire_status == GameStatus.RUNNING and total > 0:
             before = int(self._engine.status()[0][0, 1])
-            self._engine.step(total)
+            if self.config.simulation.save_data:
+                self._run_saving(before, total)
+            else:
+                self._engine.step(total)
             st, el = self._engine.status()
             self.elapsed_steps += int(st[0, 1]) - before
             self.elapsed_time = float(el[0])
@@ -128,6 +146,59 @@ class FireSimulation:
             self._device_map = self.fire_map.copy()
         self.active = self.fire_status == GameStatus.RUNNING
         return self.fire_map, self.active
+
+    # ----------------------------------------------------------------------- data saving
+    _HISTORY_CHUNK = 64      # updates recorded on the device between two fetches
+
+    def _run_saving(self, before: int, total: int) -> None:
+        """``simulation.save_data``: the reference appends ``fire_map`` to ``fire_map.npy`` after
+        every update (simulation.py:548-549).  Here the maps are recorded in GPU memory by the step
+        loop and fetched once per chunk."""
+        if self._history_cap == 0:
+            self._history_cap = self._HISTORY_CHUNK
+            self._engine.enable_history(self._history_cap)
+        done, maps = 0, []
+        while done < total:
+            n = min(self._history_cap, total - done)
+            self._engine.step(n)
+            st, _ = self._engine.status()
+            executed = int(st[0, 1]) - before - sum(m.shape[0] for m in maps)
+            if executed:
+                maps.append(self._engine.history(0, before + sum(m.shape[0] for m in maps), executed))
+            done += n
+            if not st[0, 0]:
+                break
+        if maps:
+            self._save_data(np.concatenate(maps, axis=0))
+
+    def _save_data(self, new_maps: np.ndarray) -> None:
+        """On-disk layout of simulation.py:887-959, 1059-1104 for ``data_type: npy``:
+        ``<sf_home>/data/<start_time>/`` with ``fire_map.npy`` (int8 [T, H, W], appended to by every
+        run), one ``<name>.npy`` per observation plane and ``metadata.json``."""
+        import json
+        dtype = self.config.simulation.data_type
+        if dtype != "npy":
+            raise NotImplementedError(f"data_type '{dtype}' needs h5py / jsonlines, which this build does not "
+                                      "depend on; use 'npy'")
+        datapath = self.sf_home / "data" / self.start_time
+        datapath.mkdir(parents=True, exist_ok=True)
+        data = self.get_attribute_data()
+        locs = {k: f"{k}.npy" for k in data}
+        for k, loc in locs.items():
+            if not (datapath / loc).is_file():
+                np.save(datapath / loc, data[k])
+        shape = list(next(iter(data.values())).shape)
+        metadata = {"config": self.config.yaml_data, "seeds": self.get_seeds(), "layer_types": self.get_layer_types(),
+                    "shape": shape, "static_data": {"data": locs, "shape": shape}, "fire_map": "fire_map.npy"}
+        with open(datapath / "metadata.json", "w") as f:
+            json.dump(metadata, f, indent=2, default=str)
+        path = datapath / "fire_map.npy"
+        if path.is_file():
+            old = np.load(path)
+            if old.ndim == 2:
+                old = old[None]
+            new_maps = np.append(old, new_maps, axis=0)
+        np.save(path, new_maps.astype(np.int8))
 
     # ------------------------------------------------------------------------ mitigation
     def update_mitigation(self, points: Iterable[Tuple[int, int, int]]) -> None:
@@ -199,11 +270,13 @@ class FireSimulation:
         }
 
     def get_attribute_data(self) -> Dict[str, np.ndarray]:
-        """simulation.py:376-403 (same dtypes; built without the per-pixel Python loop)."""
-        w_0, delta, M_x, sigma = fuel_planes(self.terrain.fuels)
-        return {"w_0": w_0.astype(np.float32), "sigma": sigma.astype(np.uint32), "delta": delta.astype(np.float32),
-                "M_x": M_x.astype(np.float32), "elevation": self.terrain.elevations,
-                "wind_speed": self.config.wind.speed, "wind_direction": self.config.wind.direction}
+        """simulation.py:376-403 (same dtypes): the fuel planes are cast on the device from the
+        layers held in GPU memory (no per-pixel Python loop); elevation and wind are the config's
+        own arrays, as in the reference."""
+        dev = self._engine.attribute_data(0)
+        return {"w_0": dev["w_0"], "sigma": dev["sigma"], "delta": dev["delta"], "M_x": dev["M_x"],
+                "elevation": self.terrain.elevations, "wind_speed": self.config.wind.speed,
+                "wind_direction": self.config.wind.direction}
 
     # -------------------------------------------------------------------- seeds / layers
     def get_seeds(self) -> Dict[str, Optional[int]]:
@@ -318,7 +391,7 @@ class BatchedFireSimulation:
             self.terrains = []
             for e, c in enumerate(self.configs):
                 fuels, elev = _config_layers(c)
-                self._engine.set_layers(*fuel_planes(fuels), elev, c.wind.speed, c.wind.direction, env=e)
+                _set_config_layers(self._engine, c, fuels, elev, e)
                 self.terrains.append(_TerrainView(fuels, elev, (H, W)))
         self.reset()
 

@@ -725,3 +725,110 @@ def test_per_env_layers_equal_single_env_tables():
         shared.set_layers(*layers(1), env=1)               # shared-terrain handle has one table
     with pytest.raises(ValueError):
         multi.set_layers(*layers(1), env=3)
+
+
+def test_fbfm_lookup_and_attribute_planes_on_device():
+    """sf_set_layers_fbfm (FuelLayer._get_data, layers.py:670-676, through FuelModelToFuel) gives the
+    table bits of host-expanded planes; sf_get_attribute_data returns the casts of
+    get_attribute_data (simulation.py:395-399); per-environment variants; unknown code refused."""
+    import torch
+    from simfire_amd.engine import FireEngine
+    from simfire_amd.parameters import FuelModelToFuel, fuel_planes
+    rng = np.random.default_rng(11)
+    H, W = 37, 53
+    kw = dict(shape=(H, W), max_fire_duration=4, pixel_scale=30.0, update_rate=1.0)
+    all_codes = np.array(sorted(FuelModelToFuel), dtype=np.int32)
+
+    def world(seed):
+        r = np.random.default_rng(seed)
+        return (r.choice(all_codes, size=(H, W)).astype(np.int32), r.uniform(0, 500, (H, W)), r.uniform(0, 2000, (H, W)),
+                r.uniform(0, 360, (H, W)))
+    codes, elev, U, Ud = world(1)
+    a = FireEngine(**kw)
+    a.set_layers_fbfm(codes, elev, U, Ud)
+    b = FireEngine(**kw)
+    b.set_layers(*fuel_planes(codes), elev, U, Ud)
+    assert (a.get_rtable() == b.get_rtable()).all()
+    w0, delta, mx, sigma = fuel_planes(codes)
+    for eng in (a, b):
+        at = eng.attribute_data(0)
+        assert at["w_0"].dtype == np.float32 and (at["w_0"] == w0.astype(np.float32)).all()
+        assert at["sigma"].dtype == np.uint32 and (at["sigma"] == sigma.astype(np.uint32)).all()
+        assert (at["delta"] == delta.astype(np.float32)).all() and (at["M_x"] == mx.astype(np.float32)).all()
+        assert (at["elevation"] == elev).all() and (at["wind_speed"] == U).all() and (at["wind_direction"] == Ud).all()
+    bad = codes.copy()
+    bad[5, 7] = 77
+    with pytest.raises(ValueError, match="77"):
+        a.set_layers_fbfm(bad, elev, U, Ud)
+    # one raster per environment; observation tensors stay on the GPU
+    multi = FireEngine(n_envs=3, per_env_terrain=True, **kw)
+    worlds = [world(20 + e) for e in range(3)]
+    for e, wd in enumerate(worlds):
+        multi.set_layers_fbfm(*wd, env=e)
+    t = multi.attribute_data_torch()
+    assert t["w_0"].shape == (3, H, W) and t["w_0"].is_cuda
+    for e, wd in enumerate(worlds):
+        one = FireEngine(**kw)
+        one.set_layers_fbfm(*wd)
+        assert (multi.get_rtable(env=e) == one.get_rtable()).all()
+        pw0, pde, pmx, psi = fuel_planes(wd[0])
+        assert (t["w_0"][e].cpu().numpy() == pw0.astype(np.float32)).all()
+        assert (t["sigma"][e].cpu().numpy() == psi.astype(np.uint32).astype(np.int32)).all()
+        assert (t["delta"][e].cpu().numpy() == pde.astype(np.float32)).all()
+        assert (t["M_x"][e].cpu().numpy() == pmx.astype(np.float32)).all()
+        assert (t["elevation"][e].cpu().numpy() == wd[1]).all() and (t["wind_direction"][e].cpu().numpy() == wd[3]).all()
+
+
+@pytest.mark.parametrize("mode", ["tiled", "fused", "generic"])
+def test_history_ring_equals_per_update_maps(mode):
+    """sf_enable_history: slot u mod capacity holds the fire map after update u of that environment;
+    environments that stopped (QUIT) record nothing further."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(5)
+    H, W, E, cap = 40, 72, 3, 6
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0], size=(8, H, W))
+    R8[:, :, 30:] = 0.0                       # fires die against the barren half
+    inits = [(3, 3), (20, 30), (10, 12)]
+    eng = FireEngine(**kw)
+    if mode == "generic":
+        eng.set_generic(True)
+    else:
+        eng.set_fused(mode == "fused")
+    eng.set_rtable(R8)
+    eng.reset(inits)
+    eng.enable_history(cap)
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(R8)
+    o.reset(inits)
+    expect = [[] for _ in range(E)]
+    fetched = [[] for _ in range(E)]
+    for chunk in range(30):
+        n = int(rng.integers(1, cap + 1))
+        before = eng.status()[0][:, 1].copy()
+        if chunk == 4:
+            pts = [(e, 25, y, 3) for e in range(E) for y in range(H)]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        for _ in range(n):
+            was_running = o.status()[0][:, 0].copy()
+            o.step(1)
+            for e in range(E):
+                if was_running[e]:
+                    expect[e].append(o.fire_map(e).astype(np.int8))
+        eng.step(n)
+        after = eng.status()[0][:, 1]
+        for e in range(E):
+            if after[e] > before[e]:
+                fetched[e].append(eng.history(e, int(before[e]), int(after[e] - before[e])))
+    st, _ = eng.status()
+    assert not st[:, 0].all()                 # at least one environment reached QUIT inside the test
+    for e in range(E):
+        got = np.concatenate(fetched[e], axis=0)
+        assert got.shape[0] == len(expect[e]) == st[e, 1]
+        assert (got == np.stack(expect[e])).all(), e
+    with pytest.raises(ValueError):
+        eng.history(0, 0, cap + 1)
+    eng.enable_history(0)
+    with pytest.raises(RuntimeError):
+        eng.history(0, 0, 1)

@@ -281,3 +281,42 @@ def test_batched_simulation_one_config_per_env():
     with pytest.raises(ValueError):
         BatchedFireSimulation([cfgs[0], Config.from_arrays(bad, rng.choice([1, 2], size=(H, W)), np.zeros((H, W)),
                                                             np.zeros((H, W)), np.zeros((H, W)))], 2, ignitions=ign[:2])
+
+
+def test_save_data_matches_reference(tmp_path):
+    """``simulation.save_data: true``: the files a reference run leaves under
+    ``<sf_home>/data/<start_time>/`` (simulation.py:887-959, 1059-1104), recorded from the reference
+    itself by tests/golden/make_golden_savedata.py.  The per-update maps are recorded in GPU memory
+    (history ring) and written once per run() call."""
+    import json
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    d = _golden.load("save_data_c1_32.npz")
+    y = yaml.safe_load(open(os.path.join(CFG, "functional_config.yml")))
+    y["area"]["screen_size"] = [32, 32]
+    y["terrain"]["topography"]["functional"]["function"] = "flat"
+    y["simulation"].update(headless=True, save_data=True, data_type="npy", sf_home=str(tmp_path))
+    y["fire"]["fire_initial_position"]["static"]["position"] = "(8, 9)"
+    sim = FireSimulation(Config(config_dict=y))
+    sim._HISTORY_CHUNK = 4                       # several fetches per run(), ring wraps
+    sim.update_mitigation([tuple(int(v) for v in p) for p in d["points"]])
+    sim.run(7)
+    sim.run(5)
+    datadir = tmp_path / "data" / sim.start_time
+    assert sorted(os.listdir(datadir)) == [str(f) for f in d["files"]]
+    hist = np.load(datadir / "fire_map.npy")
+    assert hist.dtype == np.int8 and hist.shape == d["history"].shape
+    assert (hist == d["history"]).all()
+    assert (sim.fire_map == d["final"]).all()
+    meta = json.load(open(datadir / "metadata.json"))
+    assert sorted(meta) == [str(k) for k in d["metadata_keys"]]
+    assert meta["static_data"] == json.loads(str(d["metadata_static"]))
+    assert meta["shape"] == [int(v) for v in d["metadata_shape"]] and meta["fire_map"] == str(d["metadata_fire_map"])
+    attr = sim.get_attribute_data()
+    for name, dt in zip(d["static_names"], d["static_dtypes"]):
+        ref = d[f"attr_{name}"]
+        mine = np.load(datadir / f"{name}.npy")
+        assert (mine == ref).all() and (np.asarray(attr[str(name)]) == ref).all(), name
+        if str(name) in ("w_0", "sigma", "delta", "M_x", "wind_speed", "wind_direction"):
+            assert str(mine.dtype) == str(dt), name

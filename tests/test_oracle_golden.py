@@ -219,3 +219,23 @@ def test_spread_graph_edges_oracles(name):
         eng = _SpriteEngine(d, d["rtable"])
         _golden.replay(eng, d, check_each_step=False)
         assert sorted((a[0], a[1], b[0], b[1]) for a, b in eng.f.edges) == ref
+
+
+def test_save_data_history_fixture():
+    """The per-update maps the reference's ``_save_data`` wrote (tests/golden/save_data_c1_32.npz,
+    a FIRELINE drawn before the run): the dense oracle reproduces every one of the 12 maps."""
+    d = _golden.load("save_data_c1_32.npz")
+    w0, de, mx, sg = _golden.load("sim_c1_128.npz")["fuel"]
+    H = W = 32
+    o = fire_dense.DenseOracle((H, W), max_fire_duration=4, pixel_scale=50.0, update_rate=1.0,
+                               max_time=1440, attenuate_line_ros=True, diagonal_spread=True)
+    o.build_rtable(np.full((H, W), w0), np.full((H, W), de), np.full((H, W), mx), np.full((H, W), sg),
+                   np.zeros((H, W)), np.full((H, W), 7 * 88.0), np.full((H, W), 90.0), 0.03)
+    o.reset([tuple(int(v) for v in d["position"])])
+    o.apply_mitigation([(0, int(x), int(y), int(t)) for x, y, t in d["points"]])
+    for u in range(d["history"].shape[0]):
+        o.step(1)
+        assert (o.fire_map(0) == d["history"][u]).all(), u
+    # the observation planes are the float32 / uint32 casts of the uniform fuel
+    assert (d["attr_w_0"] == np.float32(w0)).all() and (d["attr_sigma"] == np.uint32(sg)).all()
+    assert (d["attr_delta"] == np.float32(de)).all() and (d["attr_M_x"] == np.float32(mx)).all()
