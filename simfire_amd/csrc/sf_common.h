@@ -21,7 +21,8 @@ constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each
 constexpr int kListCap = 1024;     // per-wave frontier list: one row of a wave (64 lanes x 16 cells) always fits
 constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
-constexpr uint32_t FLAG_CAND = 2u; // some sprite has a cell to spread into     (fire.py:651)
+constexpr uint32_t FLAG_CAND = 0x100u; // (own byte of the flag word, so the tiled kernels can set it with a plain byte store)
+// some sprite has a cell to spread into     (fire.py:651)
 
 struct EnvState {
     int32_t running;    // GameStatus.RUNNING

@@ -87,16 +87,19 @@ __device__ __forceinline__ void acc_merge(WalkAcc &t, const WalkAcc &w)
     t.n_active += w.n_active; t.n_ignite += w.n_ignite; t.cand |= w.cand; t.edges |= w.edges;
 }
 
-// inclusive prefix sum over the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
+// inclusive prefix sum over the 64 lanes of a wave, on the DPP cross-lane path (no LDS round trips):
+// Hillis-Steele inside each row of 16 lanes, then the row totals are carried with the two row broadcasts
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int /*lane*/)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 // Phase 2: the whole wave walks the compacted frontier of its tile, one cell per lane.
 // item = row in band | owner lane << 5 | cell in vector << 11.  Everything about the cell is read
@@ -117,7 +120,6 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
         const uint32_t idx = (uint32_t)(y * g.P + x);
         const long long cell = (long long)e * g.plane_env + idx;
-        double bn = a.burn[cell];     // requested first: the LDS work below hides part of it
         // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
         uint8_t *own_age = tile_lds + (orr * (RB + 2) + i + 1) * row_pitch + 16 + oc * 16 + b;
         const uint8_t *q = own_age - row_pitch - 1;
@@ -143,10 +145,15 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         uint32_t st_new = s_post;                        // S1 prune + settled bit cleared
         if (is_cand || pending) {
             acc.n_active++;
+            // both operands are requested before either is used: one memory round trip, not two
+            const double *rt_p = a.rt + ((long long)e * g.rt_env + (long long)(is_cand ? bestk : 0) * g.H * g.P + idx);
+            double bn = a.burn[cell];
+            double r_tab = *rt_p;
+            asm volatile("" : "+v"(bn), "+v"(r_tab));     // keeps the table read from being sunk behind the first use of bn
             if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
             if (is_cand) {
                 acc.cand = 1;
-                double ros = a.rt[(long long)e * g.rt_env + (long long)bestk * g.H * g.P + idx] * g.update_rate;   // fire.py:696,705
+                double ros = r_tab * g.update_rate;                              // fire.py:696,705
                 if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
                     ros = g.att ? ros - line_factor(s_post) : 0.0;
                 bn = bn + ros;                                                   // fire.py:710
@@ -369,7 +376,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     WalkAcc tot_acc = {0u, 0u, 0u, 0u};
     if (__ballot(mine != 0) != 0ull) {
         const uint32_t incl_all = wave_scan_incl(mine, lane);
-        const uint32_t total = __shfl(incl_all, 63);
+        const uint32_t total = wave_last(incl_all);
         const int n_chunks = total <= (uint32_t)kListCap ? 1 : RB;
 #pragma unroll 1
         for (int ch = 0; ch < n_chunks; ++ch) {
@@ -380,7 +387,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
                 const uint32_t w = fm[(ch >> 1) < (RB + 1) / 2 ? (ch >> 1) : 0];
                 cnt = (uint32_t)__popc((ch & 1) ? (w >> 16) : (w & 0xFFFFu));
                 const uint32_t inc = wave_scan_incl(cnt, lane);
-                excl = inc - cnt; tot = __shfl(inc, 63);
+                excl = inc - cnt; tot = wave_last(inc);
             }
             if (tot == 0) continue;
             uint32_t pos = excl;
@@ -434,8 +441,10 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     const long long fplane = (long long)g.TYp * g.TXp;
     uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
     {
-        uint32_t ed = tot_acc.edges;
-        for (int off = 32; off > 0; off >>= 1) ed |= __shfl_xor(ed, off);
+        const uint32_t le = tot_acc.edges;
+        const uint32_t ed = (__ballot((le & 1u) != 0) ? 1u : 0u) | (__ballot((le & 4u) != 0) ? 4u : 0u) |
+                            (__ballot((le & 8u) != 0) ? 8u : 0u) | (__ballot((le & 16u) != 0) ? 16u : 0u) |
+                            (__ballot((le & 32u) != 0) ? 32u : 0u);
         const bool lines = g.att && __ballot(line_acc != 0) != 0ull;
         const uint32_t nf = tile_flags | ed | (lines ? 2u : 0u);
         if (lane == 0 && nf) *f_own = (uint8_t)nf;
@@ -444,10 +453,10 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     const bool w_live = __ballot(live_acc != 0) != 0ull;
     const bool w_cand = __ballot(tot_acc.cand != 0) != 0ull;
     if (lane == 0 && (w_live || w_cand)) {
-        uint32_t *f = a.flags + (a.launch % 3) * g.E + e;
-        const uint32_t want = (w_live ? FLAG_LIVE : 0u) | (w_cand ? FLAG_CAND : 0u);
-        const uint32_t have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((have & want) != want) atomicOr(f, want);
+        // idempotent byte stores (byte 0 = FLAG_LIVE, byte 1 = FLAG_CAND): no read, no atomic, nothing to wait for
+        uint8_t *f = reinterpret_cast<uint8_t *>(a.flags + (a.launch % 3) * g.E + e);
+        if (w_live) f[0] = 1;
+        if (w_cand) f[1] = 1;
     }
 }
 
@@ -464,8 +473,12 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     // list entries are taken round-robin: consecutive entries (neighbouring tiles of one fire, i.e.
     // similar amounts of work) spread over all XCDs and CUs - measured 15 % faster than giving each
     // XCD a contiguous run of the list (better L2 reuse of halos, but whole fires on one XCD)
-    for (uint32_t j = blockIdx.x * kWaves + wave; j < n_tiles; j += gridDim.x * kWaves) {
-        const uint32_t gid = a.tile_list[j];
+    // the first list entry is requested together with the list length (the slot exists even if the
+    // list is shorter: the list is allocated for every tile)
+    const uint32_t j0 = blockIdx.x * kWaves + wave;
+    const uint32_t gid0 = a.tile_list[j0];
+    for (uint32_t j = j0; j < n_tiles; j += gridDim.x * kWaves) {
+        const uint32_t gid = j == j0 ? gid0 : a.tile_list[j];
         const int e = gid / (uint32_t)per_env;
         const int tile = gid - e * per_env;
         const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
