@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsimfire_hip.so")
+# SIMFIRE_HIP_LIB: another build of the same library (e.g. the phase-clock build of profiles/phase_profile.sh)
+LIB_PATH = os.environ.get("SIMFIRE_HIP_LIB") or os.path.join(_HERE, "csrc", "libsimfire_hip.so")
 
 SF_OK, SF_EINVAL, SF_ESHAPE, SF_EHIP, SF_ENOTSUP, SF_ESTATE = 0, -1, -2, -3, -4, -5
 

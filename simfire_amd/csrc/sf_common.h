@@ -18,7 +18,7 @@ namespace {
 #define SF_WAVES_PER_GROUP 1
 #endif
 constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each wave works on its own tiles)
-constexpr int kListCap = 1024;     // per-wave frontier list: one row of a wave (64 lanes x 16 cells) always fits
+constexpr int kListCap = 384;        // frontier cells per walk window (u16 entries in LDS); larger frontiers take several windows
 constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
 constexpr uint32_t FLAG_CAND = 0x100u; // (own byte of the flag word, so the tiled kernels can set it with a plain byte store)

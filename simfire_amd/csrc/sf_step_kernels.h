@@ -20,8 +20,10 @@ namespace {
 //   RB = rows per lane band (compile time: the RB + 2 age rows and RB status rows of a lane live
 //   in registers and are all requested before any of them is used).  A wave tile is LC x 16
 //   cells by LR x RB rows (128 x 32 for large grids).
-// Dynamic LDS of k_step, per wave: frontier list [kListCap] u32, then the staged age tile
-// [LR][RB + 2][LC * 16 + 32] bytes (16 pad bytes either side of a row hold the seam columns).
+// Dynamic LDS of k_step, per wave: frontier list [kListCap] u16, then the staged sprite-mask tile
+// [LR * RB + 2][LC * 16 + 16] bytes (tile row 0 = the row above the tile; byte 15 of a row's pad holds its
+// left seam cell, byte 0 of the NEXT row's pad its right seam cell) + 16, then the status tile
+// [LR * RB][LC * 16].  10 KB per wave at LC = 4, RB = 4: 16 waves per CU.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_select(StepArgs a)
 {
@@ -79,6 +81,19 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     }
 }
 
+// Development aid (build with -DSF_PHASES, see profiles/phase_profile.sh): lane 0 of every wave sums
+// the shader clocks it spends in each phase of step_tile into the statistics counters.
+struct PhaseClock {
+#ifdef SF_PHASES
+    unsigned long long t, ph[7];
+    __device__ __forceinline__ void start() { t = __builtin_readcyclecounter(); for (int k = 0; k < 7; ++k) ph[k] = 0; }
+    __device__ __forceinline__ void mark(int k) { const unsigned long long n = __builtin_readcyclecounter(); ph[k] += n - t; t = n; }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+
 struct WalkAcc {
     uint32_t n_active, n_ignite, cand, edges;   // edges: tile flag bits 0, 2..5 set by ignitions
 };
@@ -111,7 +126,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
                                              uint32_t pend, int lane)
 {
     const Geo &g = a.g;
-    const int LC = g.LC, row_pitch = LC * 16 + 32;
+    const int LC = g.LC, row_pitch = LC * 16 + 16;
     WalkAcc acc = {0u, 0u, 0u, 0u};
     for (uint32_t j = lane; j < pend; j += 64) {
         const uint32_t it = s_list[j];
@@ -121,7 +136,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         const uint32_t idx = (uint32_t)(y * g.P + x);
         const long long cell = (long long)e * g.plane_env + idx;
         // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
-        uint8_t *own_age = tile_lds + (orr * (RB + 2) + i + 1) * row_pitch + 16 + oc * 16 + b;
+        uint8_t *own_age = tile_lds + (orr * RB + i + 1) * row_pitch + 16 + oc * 16 + b;
         const uint8_t *q = own_age - row_pitch - 1;
         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
         const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
@@ -178,7 +193,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
 template <int RB>
 __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
                                           uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
-                                          uint32_t &n_items_acc, uint32_t &n_phase2)
+                                          uint32_t &n_items_acc, uint32_t &n_phase2, PhaseClock &pc)
 {
     const Geo &g = a.g;
     const int LC = g.LC, LR = g.LR;
@@ -197,23 +212,27 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
     const int exp_sh = __ffs(mk.b_exp) - 1;
 
-    // LDS of this wave: frontier list (u16) | age tile [LR][RB + 2][LC * 16 + 32] | status tile [LR][RB][LC * 16]
-    const int row_pitch = LC * 16 + 32;
+    // LDS of this wave: frontier list (u16) | sprite-mask tile [LR * RB + 2][LC * 16 + 16] (+ 16) | status tile [LR * RB][LC * 16]
+    const int row_pitch = LC * 16 + 16;
     uint16_t *s_list = reinterpret_cast<uint16_t *>(lds_wave);
     uint8_t *tile_lds = lds_wave + kListCap * 2;
-    uint8_t *stat_lds = tile_lds + LR * (RB + 2) * row_pitch;
-    uint8_t *band_lds = tile_lds + r * (RB + 2) * row_pitch;
+    uint8_t *stat_lds = tile_lds + (LR * RB + 2) * row_pitch + 16;
+    uint8_t *band_lds = tile_lds + r * RB * row_pitch;      // row k of the band = tile row r * RB + k (halo rows shared)
     uint8_t *band_st = stat_lds + (r * RB) * (LC * 16);
     uint32_t tile_flags;
     {
         // ---- request the RB + 2 age rows (zero guard rows at -1 and H) and the seam columns in
         // one go; after the quick reject the RB status rows; then park it all in LDS
+        // a lane requests its own RB rows; the row above / below the tile only the first / last band
+        // (the rows between two bands are the neighbour band's own rows, shared through LDS)
         uint4 rows[RB + 2], sraw[RB];
         const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
+        const bool k_lo = r == 0, k_hi = r == LR - 1;
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) {
             rows[k] = make_uint4(0, 0, 0, 0);
-            if (col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
+            const bool mine = (k >= 1 && k <= RB) || (k == 0 && k_lo) || (k == RB + 1 && k_hi);
+            if (mine && col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
         }
         // seams (rows wider than the wave tile): the column just outside the tile
         uint32_t seam[RB + 2];
@@ -222,7 +241,8 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) {
             seam[k] = 0;
-            if ((seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
+            const bool mine = (k >= 1 && k <= RB) || (k == 0 && k_lo) || (k == RB + 1 && k_hi);
+            if (mine && (seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
         }
         // status rows: with the activity map nearly every visited tile is a live one, so they are
         // requested together with the sprite rows (one memory round trip less); in the dense
@@ -261,13 +281,16 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
                      (__ballot(e_bot != 0) ? 8u : 0u) | (__ballot(e_lft != 0) ? 16u : 0u) |
                      (__ballot(e_rgt != 0) ? 32u : 0u);
 
+        pc.mark(1);          // sprite / status rows arrived, quick reject, tile flags
         // ---- stage: everything below works out of LDS, so the registers above die here
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) {
+            const bool mine = (k >= 1 && k <= RB) || (k == 0 && k_lo) || (k == RB + 1 && k_hi);
+            if (!mine) continue;
             uint8_t *rp = band_lds + k * row_pitch;
             *reinterpret_cast<uint4 *>(rp + 16 + c * 16) = rows[k];
             if (c == 0) rp[15] = (uint8_t)(seam_l ? seam[k] : 0u);
-            if (c == LC - 1) rp[16 + LC * 16] = (uint8_t)(seam_r ? seam[k] : 0u);
+            if (c == LC - 1) rp[row_pitch] = (uint8_t)(seam_r ? seam[k] : 0u);    // pad byte 0 of the next row
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = sraw[i];
@@ -367,9 +390,10 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         if (i & 1) fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16 << 16; else fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16;
     }
 
+    pc.mark(2);              // staging + row loop
     // ---- compact the frontier cells into the wave's list and walk it.  One prefix sum over the
-    // lanes gives every lane its slots.  If a tile has more frontier cells than the list holds
-    // (only with dense control lines) it is processed row by row.
+    // lanes gives every lane the ranks of its cells.  If a tile has more frontier cells than the list
+    // holds (only with dense control lines) it is walked in windows of kListCap ranks.
     uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < (RB + 1) / 2; ++k) mine += (uint32_t)__popc(fm[k]);
@@ -377,38 +401,35 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     if (__ballot(mine != 0) != 0ull) {
         const uint32_t incl_all = wave_scan_incl(mine, lane);
         const uint32_t total = wave_last(incl_all);
-        const int n_chunks = total <= (uint32_t)kListCap ? 1 : RB;
+        const uint32_t excl = incl_all - mine;          // rank of this lane's first frontier cell
+        // one window unless the tile has more frontier cells than the list holds (dense control lines)
 #pragma unroll 1
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            // rows of this chunk: all of them, or just row ch
-            uint32_t cnt = 0, excl, tot;
-            if (n_chunks == 1) { cnt = mine; excl = incl_all - mine; tot = total; }
-            else {
-                const uint32_t w = fm[(ch >> 1) < (RB + 1) / 2 ? (ch >> 1) : 0];
-                cnt = (uint32_t)__popc((ch & 1) ? (w >> 16) : (w & 0xFFFFu));
-                const uint32_t inc = wave_scan_incl(cnt, lane);
-                excl = inc - cnt; tot = wave_last(inc);
-            }
-            if (tot == 0) continue;
+        for (uint32_t win = 0; win < total; win += (uint32_t)kListCap) {
             uint32_t pos = excl;
 #pragma unroll
             for (int k = 0; k < (RB + 1) / 2; ++k) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * k + h;
-                    if (i >= RB || (n_chunks != 1 && i != ch)) continue;
+                    if (i >= RB) continue;
                     uint32_t m = h ? (fm[k] >> 16) : (fm[k] & 0xFFFFu);
                     while (m) {
                         const int b = __ffs(m) - 1;
                         m &= m - 1;
-                        s_list[pos++] = (uint16_t)((uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11));
+                        const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
+                        if (slot < (uint32_t)kListCap)
+                            s_list[slot] = (uint16_t)((uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11));
+                        pos++;
                     }
                 }
             }
+            const uint32_t tot = total - win < (uint32_t)kListCap ? total - win : (uint32_t)kListCap;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            pc.mark(3);      // prefix sum + list building
             const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.prev_flag, tile_lds, stat_lds, s_list, tot, lane);
+            pc.mark(4);      // walk
             acc_merge(tot_acc, w);
             n_items_acc += (lane == 0) ? tot : 0u;
             n_phase2++;
@@ -435,6 +456,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         }
     }
 
+    pc.mark(5);              // write-back
     // tile activity for the next step: sprites left in the tile or ignited in it (with their
     // edge bits); control lines (a line cell that ignited this step is seen one step late -
     // harmless, it is re-evaluated)
@@ -467,6 +489,8 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     const Geo &g = a.g;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t *lds_wave = reinterpret_cast<uint8_t *>(s_dyn) + (size_t)wave * g.lds_wave_bytes;
+    PhaseClock pc;
+    pc.start();
     const uint32_t n_tiles = a.n_active[a.launch & 1];
     const int per_env = g.TY * g.TX;
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_tiles_done = 0;
@@ -483,7 +507,8 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
         const int tile = gid - e * per_env;
         const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
         const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // already folded by k_select
-        step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2);
+        pc.mark(0);          // list entry + environment state received
+        step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2, pc);
         n_tiles_done++;
     }
     // optional statistics for the roofline accounting (active cell-updates = phi * cells)
@@ -494,11 +519,18 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
         }
         if (lane == 0) {
             unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+#ifndef SF_PHASES
             if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
             if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
             if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
             atomicAdd(&cs[3], (unsigned long long)n_tiles_done);   // wave tiles visited
             if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
+#else
+            pc.mark(6);
+            atomicAdd(&cs[3], (unsigned long long)n_tiles_done);
+            atomicAdd(&cs[0], pc.ph[0]); atomicAdd(&cs[1], pc.ph[1]); atomicAdd(&cs[2], pc.ph[2]); atomicAdd(&cs[4], pc.ph[3]);
+            atomicAdd(&cs[5], pc.ph[4]); atomicAdd(&cs[6], pc.ph[5]); atomicAdd(&cs[7], pc.ph[6]);
+#endif
         }
     }
 }
@@ -544,7 +576,9 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
     if (!(st.running && (g.dense || near || (g.att && (own & 2u))))) return;
 
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
-    step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2);
+    PhaseClock pc;
+    pc.start();
+    step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2, pc);
     if (a.counters) {
         for (int off = 32; off > 0; off >>= 1) {
             n_active += __shfl_down(n_active, off);

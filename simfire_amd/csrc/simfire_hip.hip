@@ -138,8 +138,8 @@ static void choose_rows_per_band(Geo &g, int rows)
 {
     int rb = 1;
     while (rb * 2 <= rows && rb < 8) rb *= 2;    // the kernel is instantiated for 1, 2, 4, 8
-    // staged tile per wave = LR x (RB + 2) x (LC * 16 + 32) bytes; keep a workgroup below ~60 KB
-    auto wave_bytes = [&](int r) { return kListCap * 2 + g.LR * (r + 2) * (g.LC * 16 + 32) + g.LR * r * g.LC * 16; };
+    // per wave: list + sprite-mask tile [LR * RB + 2][LC * 16 + 16] + 16 + status tile [LR * RB][LC * 16]
+    auto wave_bytes = [&](int r) { return kListCap * 2 + (g.LR * r + 2) * (g.LC * 16 + 16) + 16 + g.LR * r * g.LC * 16; };
     while (rb > 1 && wave_bytes(rb) > 40 * 1024) rb /= 2;
     g.RB = rb;
     g.lds_wave_bytes = (wave_bytes(rb) + 15) / 16 * 16;
@@ -918,7 +918,7 @@ extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
     HIPCHK(hipMemcpy(h.data(), s->counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) out[k] = 0;
     for (int i = 0; i < kCounterShards; ++i)
-        for (int k = 0; k < 5; ++k) out[k] += (int64_t)h[(size_t)i * 8 + k];
+        for (int k = 0; k < 8; ++k) out[k] += (int64_t)h[(size_t)i * 8 + k];
     if (reset) HIPCHK(hipMemset(s->counters, 0, h.size() * sizeof(unsigned long long)));
     return SF_OK;
 }

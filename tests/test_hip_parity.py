@@ -832,3 +832,36 @@ def test_history_ring_equals_per_update_maps(mode):
     eng.enable_history(0)
     with pytest.raises(RuntimeError):
         eng.history(0, 0, 1)
+
+
+@pytest.mark.parametrize("fill", [0.5, 1.0])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_frontier_larger_than_list_window(fill, fused):
+    """With rate-of-spread attenuation every control-line cell is a frontier cell of every step.  A
+    64 x 64 wave tile then holds up to 4096 of them, far more than one walk window of the per-wave
+    list (kListCap): the windows must together cover every cell exactly once."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(17)
+    H, W = 130, 200
+    kw = dict(shape=(H, W), max_fire_duration=4, pixel_scale=30.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([12.0, 30.0, 400.0, 1500.0, 2500.0], size=(8, H, W))
+    eng = FireEngine(**kw)
+    eng.set_fused(fused)
+    eng.set_rtable(R8)
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(R8)
+    init = [(100, 64)]
+    eng.reset(init)
+    o.reset(init)
+    ys, xs = np.nonzero(rng.random((H, W)) < fill)
+    pts = [(0, int(x), int(y), int(3 + (x + 2 * y) % 3)) for y, x in zip(ys, xs) if (x, y) != init[0]]
+    eng.apply_mitigation(pts)
+    o.apply_mitigation(pts)
+    for t in range(40):
+        eng.step(1)
+        o.step(1)
+        assert (eng.fire_map(0) == o.fire_map(0)).all(), t
+    assert (eng.burn(0) == o.burn(0)).all()
+    st, el = eng.status()
+    ost, oel = o.status()
+    assert (st == ost).all() and (el == oel).all()
