@@ -15,7 +15,7 @@ namespace {
 #define SF_WAVES_PER_SIMD 1
 #endif
 #ifndef SF_WAVES_PER_GROUP
-#define SF_WAVES_PER_GROUP 1
+#define SF_WAVES_PER_GROUP 4
 #endif
 constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each wave works on its own tiles)
 constexpr int kListCap = 384;        // frontier cells per walk window (u16 entries in LDS); larger frontiers take several windows
@@ -148,6 +148,13 @@ __device__ __forceinline__ uint32_t any4(uint4 a) { return a.x | a.y | a.z | a.w
 __device__ __forceinline__ uint32_t nz01(uint32_t v)
 {
     return ((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) >> 7) & 0x01010101u;
+}
+// 0/1 per byte -> 0x00/0xFF per byte
+__device__ __forceinline__ uint32_t spread01(uint32_t m01) { return (m01 << 8) - m01; }
+// 0/1 per byte for the first n (<= 0: none, >= 4: all) bytes
+__device__ __forceinline__ uint32_t first01(int n)
+{
+    return n >= 4 ? 0x01010101u : (n <= 0 ? 0u : (0x01010101u >> (8 * (4 - n))));
 }
 // 0/1 per byte for status bytes (0..7): status in {3,4,5,..}  (control line)
 __device__ __forceinline__ uint32_t ge3_01(uint32_t s7) { return ((s7 + 0x05050505u) >> 3) & 0x01010101u; }

@@ -345,40 +345,38 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             const uint4 sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
             const uint4 s7 = and4(sr, 0x07070707u);
             // S1 prune: cells whose sprite reached max_fire_duration become BURNED
-            uint4 em;   // 0xFF per expiring byte
-            em.x = ((ex4.x >> exp_sh) & 0x01010101u) * 0xFFu;
-            em.y = ((ex4.y >> exp_sh) & 0x01010101u) * 0xFFu;
-            em.z = ((ex4.z >> exp_sh) & 0x01010101u) * 0xFFu;
-            em.w = ((ex4.w >> exp_sh) & 0x01010101u) * 0xFFu;
+            uint4 em;   // 0xFF per expiring byte (x * 255 == (x << 8) - x: no 32-bit multiply)
+            em.x = spread01((ex4.x >> exp_sh) & 0x01010101u);
+            em.y = spread01((ex4.y >> exp_sh) & 0x01010101u);
+            em.z = spread01((ex4.z >> exp_sh) & 0x01010101u);
+            em.w = spread01((ex4.w >> exp_sh) & 0x01010101u);
             uint4 snew;
             snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
             snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
             snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
             snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
             if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) dirty |= 1u << i;
-            // frontier cells: eligible & next to a live sprite; every line cell when attenuation
-            // is on (their burn changes even away from the fire)
-            const uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
-            const uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
-            const uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
-            const uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
-            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            // frontier cells (0 / 1 per byte): eligible & next to a live sprite; every line cell when
+            // attenuation is on (their burn changes even away from the fire)
+            uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+            uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+            uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+            uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
             if (g.att) {
-                m16 |= pack4(ge3_01(s7.x)) | (pack4(ge3_01(s7.y)) << 4) | (pack4(ge3_01(s7.z)) << 8) |
-                       (pack4(ge3_01(s7.w)) << 12);
+                p0 |= ge3_01(s7.x); p1 |= ge3_01(s7.y); p2 |= ge3_01(s7.z); p3 |= ge3_01(s7.w);
                 line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
             }
             // pitch padding (x >= W) never takes part
             const int xs = cv * 16;
-            if (xs + 16 > g.W) m16 &= (xs >= g.W) ? 0u : ((1u << (g.W - xs)) - 1u);
-            // the frontier cells get their new status from the walk; the others here: the walk
-            // reads the OLD status from LDS, so only non-frontier bytes may be replaced now
-            // 0xFF where the cell is a frontier cell: 4 mask bits -> 4 byte LSBs -> full bytes
+            if (xs + 16 > g.W) {
+                const int nv = g.W - xs;          // valid cells of this vector (may be <= 0)
+                p0 &= first01(nv); p1 &= first01(nv - 4); p2 &= first01(nv - 8); p3 &= first01(nv - 12);
+            }
+            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            // the frontier cells get their new status from the walk, which reads the OLD status from
+            // LDS: only the other bytes may be replaced now.  0xFF where the cell is a frontier cell
             uint4 keepm;
-            keepm.x = (((m16 & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
-            keepm.y = ((((m16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
-            keepm.z = ((((m16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
-            keepm.w = ((((m16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            keepm.x = spread01(p0); keepm.y = spread01(p1); keepm.z = spread01(p2); keepm.w = spread01(p3);
             uint4 mix;
             mix.x = (sr.x & keepm.x) | (snew.x & ~keepm.x);
             mix.y = (sr.y & keepm.y) | (snew.y & ~keepm.y);

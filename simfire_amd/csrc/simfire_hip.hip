@@ -214,7 +214,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->counters, (size_t)kCounterShards * 8));
     s->tflags_bytes = (size_t)2 * g.E * ((size_t)(g.H + g.LR - 1) / g.LR + 2) * (g.chunks_x + 2) + 64;
     TRY(dev_alloc(s, &s->tflags, s->tflags_bytes));
-    TRY(dev_alloc(s, &s->tile_list, (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x));
+    // + 64: every wave of k_step requests its first list entry before it knows the list length
+    TRY(dev_alloc(s, &s->tile_list, (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x + 64));
     TRY(dev_alloc(s, &s->n_active, (size_t)16));
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) s->n_cu = prop.multiProcessorCount; }
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
@@ -721,7 +722,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     const StepKernel kern = pick_step_kernel(s->g.RB, fused);
     a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active;
     const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
-    long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * 16 / kWaves;
+    static const int waves_per_cu = getenv("SF_WAVES_PER_CU") ? atoi(getenv("SF_WAVES_PER_CU")) : 24;   // persistent grid of k_step
+    long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * waves_per_cu / kWaves;
     if (!fused && want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
     const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
