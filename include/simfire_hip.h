@@ -138,6 +138,9 @@ int sf_reset_env(sf_sim *sim, int32_t env, int32_t x, int32_t y);
  * first, then SCRATCHLINE, then WETLINE (simulation.py:476-478); each write is unconditional
  * (mitigation.py:75-78).  Out-of-range rows -> SF_EINVAL (the reference would raise IndexError). */
 int sf_apply_mitigation(sf_sim *sim, const int32_t *pts, int32_t n);
+/* The same scatter for a point list that already lives in GPU memory (e.g. the action tensor of a
+ * policy): rows (env, column, row, type) int32; rows with an out-of-range field are skipped. */
+int sf_apply_mitigation_device(sf_sim *sim, const int32_t *device_pts, int32_t n);
 
 /* FireSimulation.load_mitigation (simulation.py:425-447): fire_map of one environment is
  * replaced wholesale (uint8 [H*W], values 0..5 else SF_EINVAL); burning sprites persist. */

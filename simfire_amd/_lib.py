@@ -47,6 +47,7 @@ SIGNATURES = {
     "sf_reset": [_VP, _VP],
     "sf_reset_env": [_VP, _I32, _I32, _I32],
     "sf_apply_mitigation": [_VP, _VP, _I32],
+    "sf_apply_mitigation_device": [_VP, _VP, _I32],
     "sf_load_fire_map": [_VP, _I32, _VP],
     "sf_step": [_VP, _I32],
     "sf_step_timed": [_VP, _I32, C.POINTER(C.c_float)],

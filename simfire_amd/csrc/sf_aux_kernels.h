@@ -203,6 +203,7 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, dou
     if (i >= n) return;
     const int e = pts[4 * i], x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
     if (ty < SF_FIRELINE || ty > SF_WETLINE) return;                 // simulation.py:469-473
+    if (e < 0 || e >= g.E || x < 0 || x >= g.W || y < 0 || y >= g.H) return;   // device-side lists are not pre-checked
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
     const int sh = (int)(o & 3) * 8;
@@ -222,6 +223,7 @@ __global__ void k_mitigate_write(Geo g, uint8_t *status, const int32_t *pts, int
     if (i >= n) return;
     const int e = pts[4 * i], x = pts[4 * i + 1], y = pts[4 * i + 2], ty = pts[4 * i + 3];
     if (ty < SF_FIRELINE || ty > SF_WETLINE) return;
+    if (e < 0 || e >= g.E || x < 0 || x >= g.W || y < 0 || y >= g.H) return;
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
     const int sh = (int)(o & 3) * 8;

@@ -107,9 +107,14 @@ struct sf_sim {
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
     size_t stage_bytes = 0;
-    int32_t *pts_dev = nullptr, *pts_pinned = nullptr;
+    // control-line points: one device buffer (uploads are stream-ordered behind the kernels that read the
+    // previous batch) and a ring of pinned staging buffers, so that in async mode the host can run
+    // several scatter + step pairs ahead of the GPU
+    static constexpr int kPtsRing = 8;
+    int32_t *pts_dev = nullptr, *pts_pinned[kPtsRing] = {};
     size_t pts_cap = 0;
-    hipEvent_t ev_pts = nullptr;
+    hipEvent_t ev_pts[kPtsRing] = {};
+    int pts_slot = 0;
     bool async = false;                // sf_set_async: calls that return no data do not synchronise
     bool have_rt = false, was_reset = false, counters_on = false;
     std::vector<char> rt_set;          // per table: layers / R table supplied?
@@ -197,7 +202,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     int rc;
 #define TRY(x) do { rc = (x); if (rc != SF_OK) { sf_destroy(s); return rc; } } while (0)
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(SF_EHIP, "hipStreamCreate failed"); }
-    hipEventCreate(&s->ev0); hipEventCreate(&s->ev1); hipEventCreate(&s->ev_pts);
+    hipEventCreate(&s->ev0); hipEventCreate(&s->ev1);
+    for (int i = 0; i < sf_sim::kPtsRing; ++i) hipEventCreate(&s->ev_pts[i]);
     const size_t cells = (size_t)g.E * g.plane_env;
     TRY(dev_alloc(s, &s->status, cells));
     TRY(dev_alloc(s, &s->age_alloc, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab));
@@ -241,8 +247,10 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
                     s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->parents};
-    if (s->pts_pinned) (void)hipHostFree(s->pts_pinned);
-    if (s->ev_pts) (void)hipEventDestroy(s->ev_pts);
+    for (int i = 0; i < sf_sim::kPtsRing; ++i) {
+        if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
+        if (s->ev_pts[i]) (void)hipEventDestroy(s->ev_pts[i]);
+    }
     for (void *p : ptrs) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
@@ -640,6 +648,20 @@ extern "C" int sf_reset_env(sf_sim *s, int32_t env, int32_t x, int32_t y)
     return reset_range(s, env, 1, xy);
 }
 
+// rows (env, column, row, type) in device memory -> the two scatter kernels (clear, then write with the
+// type precedence of simulation.py:449-478); rows with an out-of-range field are skipped by the kernels
+static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n)
+{
+    const Geo &g = s->g;
+    const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+                       (const EnvState *)s->commit, pts_dev, n);
+    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, pts_dev, n, s->tflags, s->ring);
+    HIPCHK(hipGetLastError());
+    if (!s->async) HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
+}
+
 extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
 {
     if (!s) return fail(SF_EINVAL, "sf_apply_mitigation: null handle");
@@ -656,26 +678,33 @@ extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
     if ((size_t)4 * n > s->pts_cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if (s->pts_dev) HIPCHK(hipFree(s->pts_dev));
-        if (s->pts_pinned) HIPCHK(hipHostFree(s->pts_pinned));
-        s->pts_dev = nullptr; s->pts_pinned = nullptr;
+        s->pts_dev = nullptr;
+        for (int i = 0; i < sf_sim::kPtsRing; ++i) {
+            if (s->pts_pinned[i]) HIPCHK(hipHostFree(s->pts_pinned[i]));
+            s->pts_pinned[i] = nullptr;
+        }
         s->pts_cap = (size_t)4 * n * 2;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->pts_dev), s->pts_cap * sizeof(int32_t)));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pts_pinned), s->pts_cap * sizeof(int32_t), hipHostMallocDefault));
-    } else {
-        // the pinned staging buffer may still feed the previous asynchronous upload
-        HIPCHK(hipEventSynchronize(s->ev_pts));
+        for (int i = 0; i < sf_sim::kPtsRing; ++i)
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pts_pinned[i]), s->pts_cap * sizeof(int32_t), hipHostMallocDefault));
     }
-    memcpy(s->pts_pinned, pts, bytes);
-    HIPCHK(hipMemcpyAsync(s->pts_dev, s->pts_pinned, bytes, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipEventRecord(s->ev_pts, s->stream));
-    const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
-                       (const EnvState *)s->commit, (const int32_t *)s->pts_dev, (int)n);
-    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, (const int32_t *)s->pts_dev, (int)n,
-                       s->tflags, s->ring);
-    HIPCHK(hipGetLastError());
-    if (!s->async) HIPCHK(hipStreamSynchronize(s->stream));
-    return SF_OK;
+    const int slot = s->pts_slot;
+    s->pts_slot = (slot + 1) % sf_sim::kPtsRing;
+    // this staging buffer may still feed an upload enqueued kPtsRing calls ago
+    HIPCHK(hipEventSynchronize(s->ev_pts[slot]));
+    memcpy(s->pts_pinned[slot], pts, bytes);
+    HIPCHK(hipMemcpyAsync(s->pts_dev, s->pts_pinned[slot], bytes, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipEventRecord(s->ev_pts[slot], s->stream));
+    return scatter_points(s, s->pts_dev, n);
+}
+
+extern "C" int sf_apply_mitigation_device(sf_sim *s, const int32_t *device_pts, int32_t n)
+{
+    if (!s) return fail(SF_EINVAL, "sf_apply_mitigation_device: null handle");
+    if (n < 0 || (n > 0 && !device_pts)) return fail(SF_EINVAL, "sf_apply_mitigation_device: bad point list");
+    if (n == 0) return SF_OK;
+    HIPCHK(hipSetDevice(s->p.device));
+    return scatter_points(s, device_pts, n);
 }
 
 extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)

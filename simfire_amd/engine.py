@@ -107,6 +107,19 @@ class FireEngine:
         if len(q):
             _lib.check(self._L.sf_apply_mitigation(self._h, _ptr(q), len(q)))
 
+    def apply_mitigation_torch(self, pts):
+        """The same scatter for a torch int32 tensor [n, 4] (env, x, y, type) that already lives on this
+        GPU (e.g. the actions of a policy): no host round trip; rows with an out-of-range field are
+        skipped.  The caller orders its own stream before this call (``torch.cuda.synchronize`` or an
+        event), the library then works on its own stream."""
+        import torch
+        if pts.dtype != torch.int32 or pts.dim() != 2 or pts.shape[1] != 4 or not pts.is_cuda:
+            raise ValueError("expected a CUDA int32 tensor of shape [n, 4]")
+        pts = pts.contiguous()
+        if pts.shape[0]:
+            _lib.check(self._L.sf_apply_mitigation_device(self._h, C.c_void_p(pts.data_ptr()), int(pts.shape[0])))
+            self._keep_alive = pts          # until the next call: the scatter may still be queued (async mode)
+
     def load_fire_map(self, env, fire_map):
         m = np.asarray(fire_map)
         if m.shape != (self.H, self.W):

@@ -865,3 +865,36 @@ def test_frontier_larger_than_list_window(fill, fused):
     st, el = eng.status()
     ost, oel = o.status()
     assert (st == ost).all() and (el == oel).all()
+
+
+def test_mitigation_from_device_tensor_and_async_ring():
+    """sf_apply_mitigation_device (point list in GPU memory) == sf_apply_mitigation == oracle, rows with
+    out-of-range fields skipped; and more scatter + step pairs enqueued in async mode than the
+    pinned staging ring has slots."""
+    import torch
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(23)
+    H, W, E = 50, 90, 3
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([3.0, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    inits = [(10, 10), (45, 25), (80, 40)]
+    a, b = FireEngine(**kw), FireEngine(**kw)
+    o = fire_dense.DenseOracle(**kw)
+    for x in (a, b, o):
+        x.set_rtable(R8)
+        x.reset(inits)
+    a.set_async(True)
+    for t in range(30):
+        pts = np.array([(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                        for _ in range(20)], dtype=np.int32)
+        junk = np.array([(E, 1, 1, 3), (0, W, 1, 4), (0, 1, -1, 5), (-1, 0, 0, 3), (0, 2, 2, 9)], dtype=np.int32)
+        a.apply_mitigation(pts)                                   # host list, async: runs ahead of the GPU
+        a.step(1)
+        b.apply_mitigation_torch(torch.from_numpy(np.concatenate([pts, junk])).cuda())
+        b.step(1)
+        o.apply_mitigation(pts)
+        o.step(1)
+    a.sync()
+    for e in range(E):
+        assert (a.fire_map(e) == o.fire_map(e)).all() and (b.fire_map(e) == o.fire_map(e)).all(), e
+        assert (a.burn(e) == o.burn(e)).all() and (b.burn(e) == o.burn(e)).all(), e
