@@ -177,7 +177,9 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, traffic):
             "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "cells_scanned_per_launch": performed, "active_cell_updates_per_launch": active,
             "tiles_visited_per_launch": cnt["active_waves"] / a.steps,
-            "frontier_walks_per_launch": cnt["frontier_walks"] / a.steps}
+            "frontier_walks_per_launch": cnt["frontier_walks"] / a.steps,
+            # bytes the PMC pass really saw on the fabric per launch / this launch time
+            "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None}
 
 
 def main():
@@ -284,7 +286,11 @@ def main():
         if world == 1 and not a.dense and not a.no_dense_leg:
             kd, _, cd = measure(eng, w, a, agent_pts, True)
             out["roofline_dense"] = roofline_block(w, a, kd, cd, tile_cells, traffic_dense)
-            out["roofline_dense"]["note"] = "same workload with tile skipping off: every cell scanned every step"
+            out["roofline_dense"]["note"] = ("same workload with tile skipping off: every cell scanned every step.  The "
+                                             "4 B per cell-update of the algorithmic model (status and sprite mask, "
+                                             "read + write) is more than this kernel moves for a quiescent cell (1 B: "
+                                             "the sprite-mask rows, then a wave-level reject), so 'achieved' is a "
+                                             "rate in model bytes; the bytes really moved are 'traffic' / 'traffic_gbs'")
             out["roofline_dense"]["value_cell_updates_per_s"] = H * W * env_steps_local / (kd * 1e-3)
             eng.set_dense(False)
         if world == 1 and not a.no_cpu_baseline:

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r01
 mkdir -p $O
-B="python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extra --no-dense-leg"
+B="python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-extra --no-dense-leg"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/sf_mb profiles/streaming_microbench.hip
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o sparse -- $B > $O/bench_sparse.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o dense -- $B --dense > $O/bench_dense.json 2>/dev/null
@@ -35,7 +35,7 @@ for tag in ("sparse","dense"):
         s=0.0
         for (k,c),v in acc.items():
             if k in ("k_step","k_select"):
-                v=v[20:320]          # the timed 300 steps (after 20 warm-up launches)
+                v=v[20:1020]         # the timed 1000 steps (after 20 warm-up launches)
                 s+=sum(v)/len(v)
         tot[cn]=s
     out[tag]=tot
@@ -47,7 +47,7 @@ with open(f"{O}/sq_counters_sparse.csv","w") as f:
     f.write("kernel,counter,mean_over_timed_steps\n")
     for (k,c),v in sorted(acc.items()):
         if k in ("k_step","k_select"):
-            v=v[20:320]; f.write(f"{k},{c},{sum(v)/len(v):.1f}\n")
+            v=v[20:1020]; f.write(f"{k},{c},{sum(v)/len(v):.1f}\n")
 print(json.dumps(out, indent=1))
 for f in glob.glob(f"{O}/pmc/*.csv"): os.remove(f)
 PY
