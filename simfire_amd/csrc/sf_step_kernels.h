@@ -36,32 +36,34 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     const int tile = valid ? (int)(gid - (long long)e * per_env) : 0;
     const int tyw = tile / g.TX, tx = tile - tyw * g.TX;
 
+    // Everything this thread reads is requested before anything is used or stored (one memory round
+    // trip instead of five: the kernel is a latency chain, not a bandwidth problem).
+    // flag bits: 0 sprites anywhere, 1 control lines, 2 / 3 sprites in the top / bottom row,
+    // 4 / 5 sprites in the left / right column of the tile
+    const long long fplane = (long long)g.TYp * g.TXp;
+    const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+    uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
+    const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
+    const EnvState *sp = a.launch == 0 ? a.commit + e : a.tmp + ((a.launch - 1) & 1) * g.E + e;
+    const uint32_t *fp = a.flags + ((a.launch + 2) % 3) * g.E + e;     // ring slot of the previous launch
+    int32_t s_run = sp->running, s_steps = sp->steps, s_prev = sp->prev_flag, s_tq = sp->time_quit;
+    double s_el = sp->elapsed;
+    uint32_t fl = *fp;
+    uint32_t own = f_rd[o], up = f_rd[o - g.TXp], dn = f_rd[o + g.TXp], lf = f_rd[o - 1], rt = f_rd[o + 1];
+    uint32_t ul = f_rd[o - g.TXp - 1], ur = f_rd[o - g.TXp + 1], dl = f_rd[o + g.TXp - 1], dr = f_rd[o + g.TXp + 1];
+    asm volatile("" : "+v"(s_run), "+v"(s_steps), "+v"(s_prev), "+v"(s_tq), "+v"(s_el), "+v"(fl), "+v"(own), "+v"(up),
+                      "+v"(dn), "+v"(lf), "+v"(rt), "+v"(ul), "+v"(ur), "+v"(dl), "+v"(dr));
+
     // environment state entering this step (folded from the previous launch's flags)
     EnvState st;
-    if (a.launch == 0) st = a.commit[e];
-    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
-    if (valid && tile == 0) {
-        a.tmp[(a.launch & 1) * g.E + e] = st;
-        a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
-    }
+    st.running = s_run; st.steps = s_steps; st.prev_flag = s_prev; st.time_quit = s_tq; st.elapsed = s_el;
+    if (a.launch != 0) st = fold_state(st, fl, g);
 
-    bool active = false;
-    if (valid) {
-        const long long fplane = (long long)g.TYp * g.TXp;
-        const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
-        uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
-        const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
-        // flag bits: 0 sprites anywhere, 1 control lines, 2 / 3 sprites in the top / bottom row,
-        // 4 / 5 sprites in the left / right column of the tile
-        const uint32_t own = f_rd[o];
-        const uint32_t up = f_rd[o - g.TXp], dn = f_rd[o + g.TXp], lf = f_rd[o - 1], rt = f_rd[o + 1];
-        const uint32_t ul = f_rd[o - g.TXp - 1], ur = f_rd[o - g.TXp + 1], dl = f_rd[o + g.TXp - 1], dr = f_rd[o + g.TXp + 1];
-        const bool near = (own & 1u) || (up & 8u) || (dn & 4u) || (lf & 32u) || (rt & 16u) ||
-                          ((ul & 40u) == 40u) || ((ur & 24u) == 24u) || ((dl & 36u) == 36u) || ((dr & 20u) == 20u);
-        // frozen environments keep their flags (nothing reads them until the next reset)
-        f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
-        active = st.running && (g.dense || near || (g.att && (own & 2u)));
-    }
+    // (bitwise, not short-circuit: nothing to skip, the flags are all here)
+    const bool near = ((own & 1u) | (up & 8u) | (dn & 4u) | (lf & 32u) | (rt & 16u)) != 0 ||
+                      ((ul & 40u) == 40u) | ((ur & 24u) == 24u) | ((dl & 36u) == 36u) | ((dr & 20u) == 20u);
+    const bool active = valid && st.running && (g.dense || near || (g.att && (own & 2u)));
+
     // compact: ballot -> rank inside the wave, one atomic per workgroup
     const unsigned long long bal = __ballot(active);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,6 +80,15 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
         uint32_t off = s_base + rank;
         for (int w = 0; w < wave; ++w) off += s_wsum[w];
         a.tile_list[off] = (uint32_t)gid;
+    }
+    // stores last (nothing above waits for them)
+    if (valid) {
+        // frozen environments keep their flags (nothing reads them until the next reset)
+        f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
+        if (tile == 0) {
+            a.tmp[(a.launch & 1) * g.E + e] = st;
+            a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
+        }
     }
 }
 
