@@ -197,6 +197,7 @@ __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 //                     order for duplicates (simulation.py:476-478); each write is unconditional
 //                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.
 __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+                                 const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
                                  const int32_t *pts, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +214,8 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, dou
         old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (0x80u << sh));
     } while (old != seen);
     const uint32_t sraw = (seen >> sh) & 0xFFu;
-    if (g.att && !(sraw & 0x80u) && owes_attenuation(g, commit[e], age + (long long)e * g.age_env * g.ab, sraw, x, y))
+    if (g.att && !(sraw & 0x80u) &&
+        owes_attenuation(g, entering_state(commit, tmp, flags, launch, from_commit, e, g), age + (long long)e * g.age_env * g.ab, sraw, x, y))
         burn[o] = burn[o] - line_factor(sraw & 7u);
 }
 

@@ -63,7 +63,8 @@ struct StepArgs {
     uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
     uint32_t *n_active;  // its length
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
-    int launch;          // index of this launch inside one sf_step call
+    int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
+    int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };
 
 struct Masks {
@@ -130,6 +131,15 @@ __device__ inline EnvState fold_state(EnvState s, uint32_t f, const Geo &g)
     else s.prev_flag = 0;                                                 // fire.py:651-652
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || s.elapsed > g.max_time);
     return s;
+}
+
+// State of environment e entering step launch `launch`: commit[e], or the previous launch's state folded
+// with the predicates that launch collected.
+__device__ __forceinline__ EnvState entering_state(const EnvState *commit, const EnvState *tmp, const uint32_t *flags,
+                                                   int launch, int from_commit, int e, const Geo &g)
+{
+    if (from_commit) return commit[e];
+    return fold_state(tmp[((launch + 1) & 1) * g.E + e], flags[((launch + 2) % 3) * g.E + e], g);
 }
 
 __device__ __forceinline__ double line_factor(uint32_t st)   // RoSAttenuation, enums.py:72-85

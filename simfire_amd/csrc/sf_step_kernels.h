@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
     uint8_t *f_wr = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane;
     const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
-    const EnvState *sp = a.launch == 0 ? a.commit + e : a.tmp + ((a.launch - 1) & 1) * g.E + e;
+    const EnvState *sp = a.from_commit ? a.commit + e : a.tmp + ((a.launch + 1) & 1) * g.E + e;
     const uint32_t *fp = a.flags + ((a.launch + 2) % 3) * g.E + e;     // ring slot of the previous launch
     int32_t s_run = sp->running, s_steps = sp->steps, s_prev = sp->prev_flag, s_tq = sp->time_quit;
     double s_el = sp->elapsed;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     // environment state entering this step (folded from the previous launch's flags)
     EnvState st;
     st.running = s_run; st.steps = s_steps; st.prev_flag = s_prev; st.time_quit = s_tq; st.elapsed = s_el;
-    if (a.launch != 0) st = fold_state(st, fl, g);
+    if (!a.from_commit) st = fold_state(st, fl, g);
 
     // (bitwise, not short-circuit: nothing to skip, the flags are all here)
     const bool near = ((own & 1u) | (up & 8u) | (dn & 4u) | (lf & 32u) | (rt & 16u)) != 0 ||
@@ -564,8 +564,7 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
     const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
 
     EnvState st;
-    if (a.launch == 0) st = a.commit[e];
-    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    st = entering_state(a.commit, a.tmp, a.flags, a.launch, a.from_commit, e, g);
     if (tile == 0 && lane == 0) {
         a.tmp[(a.launch & 1) * g.E + e] = st;
         a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch
@@ -619,8 +618,7 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
     const int e = blockIdx.z, y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
     // environment state entering this step (folded from the previous launch's flags)
     EnvState st;
-    if (a.launch == 0) st = a.commit[e];
-    else st = fold_state(a.tmp[((a.launch - 1) & 1) * g.E + e], a.flags[((a.launch - 1) % 3) * g.E + e], g);
+    st = entering_state(a.commit, a.tmp, a.flags, a.launch, a.from_commit, e, g);
     if (x == 0 && y == 0) {
         a.tmp[(a.launch & 1) * g.E + e] = st;
         a.flags[((a.launch + 1) % 3) * g.E + e] = 0;   // ring slot of the next launch

@@ -107,19 +107,22 @@ struct sf_sim {
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
     size_t stage_bytes = 0;
-    // control-line points: one device buffer (uploads are stream-ordered behind the kernels that read the
-    // previous batch) and a ring of pinned staging buffers, so that in async mode the host can run
-    // several scatter + step pairs ahead of the GPU
-    static constexpr int kPtsRing = 8;
-    int32_t *pts_dev = nullptr, *pts_pinned[kPtsRing] = {};
+    // control-line points: a ring of pinned, device-mapped staging buffers which the scatter kernels read
+    // directly, so that in async mode the host can run several scatter + step pairs ahead of the GPU
+    static constexpr int kPtsRing = 16;
+    int32_t *pts_pinned[kPtsRing] = {}, *pts_mapped[kPtsRing] = {};
     size_t pts_cap = 0;
     hipEvent_t ev_pts[kPtsRing] = {};
     int pts_slot = 0;
     bool async = false;                // sf_set_async: calls that return no data do not synchronise
     bool have_rt = false, was_reset = false, counters_on = false;
+    int seq = 0;                       // index (mod 6) of the next step launch
+    bool committed = true;             // commit[] is current (no step launch since the last k_commit / reset)
     std::vector<char> rt_set;          // per table: layers / R table supplied?
     int64_t bytes = 0;
 };
+
+static int ensure_commit(sf_sim *s);
 
 static int ensure_stage(sf_sim *s, size_t bytes)
 {
@@ -246,7 +249,7 @@ extern "C" int sf_destroy(sf_sim *s)
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
-                    s->status_block, s->elapsed_dev, s->stage, s->pts_dev, s->parents};
+                    s->status_block, s->elapsed_dev, s->stage, s->parents};
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
         if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
         if (s->ev_pts[i]) (void)hipEventDestroy(s->ev_pts[i]);
@@ -288,6 +291,7 @@ extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
 {
     if (!s || rows < 1 || rows > 4096) return fail(SF_EINVAL, "sf_set_rows_per_band: rows must be in [1, 4096]");
     HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // also clears the list counters of the tiled path
     choose_rows_per_band(s->g, rows);
     // the tile activity map is laid out per wave tile: rebuild it for the new geometry
     HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
@@ -363,6 +367,7 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_generic: null handle");
     HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the list counters of the tiled path restart clean
     const bool was = s->generic;
     s->generic = on != 0;
     if (was && !s->generic && s->was_reset && s->g.ab == 1) {
@@ -378,6 +383,8 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
 extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 {
     if (!s || mode < -1 || mode > 1) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0 or 1");
+    HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
     return SF_OK;
 }
@@ -386,6 +393,8 @@ extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 extern "C" int sf_set_dense(sf_sim *s, int32_t dense)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_dense: null handle");
+    HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->g.dense = dense != 0;
     return SF_OK;
 }
@@ -606,6 +615,18 @@ extern "C" int sf_get_slopes(sf_sim *s, double *mag, double *dir)
     return SF_OK;
 }
 
+// The environment states live in the tmp / flags rings while steps are being enqueued; they are folded
+// into commit[] only when something needs them (status queries, resets, burn_amounts transfers).
+static int ensure_commit(sf_sim *s)
+{
+    if (s->committed) return SF_OK;
+    hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
+                       (const EnvState *)s->tmp, s->flags, (s->seq + 5) % 6, s->n_active);
+    HIPCHK(hipGetLastError());
+    s->committed = true;
+    return SF_OK;
+}
+
 static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
 {
     const Geo &g = s->g;
@@ -614,6 +635,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
             return fail(SF_EINVAL, "reset: ignition (%d, %d) of environment %d is outside the %dx%d grid", xy[2 * i],
                         xy[2 * i + 1], env0 + i, g.H, g.W);
     HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
     HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
     HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
@@ -650,15 +672,16 @@ extern "C" int sf_reset_env(sf_sim *s, int32_t env, int32_t x, int32_t y)
 
 // rows (env, column, row, type) in device memory -> the two scatter kernels (clear, then write with the
 // type precedence of simulation.py:449-478); rows with an out-of-range field are skipped by the kernels
-static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n)
+static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n, bool sync)
 {
     const Geo &g = s->g;
     const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
-                       (const EnvState *)s->commit, pts_dev, n);
+                       (const EnvState *)s->commit, (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq,
+                       s->committed ? 1 : 0, pts_dev, n);
     hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, pts_dev, n, s->tflags, s->ring);
     HIPCHK(hipGetLastError());
-    if (!s->async) HIPCHK(hipStreamSynchronize(s->stream));
+    if (sync && !s->async) HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
 
@@ -677,25 +700,27 @@ extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
     const size_t bytes = (size_t)4 * n * sizeof(int32_t);
     if ((size_t)4 * n > s->pts_cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
-        if (s->pts_dev) HIPCHK(hipFree(s->pts_dev));
-        s->pts_dev = nullptr;
         for (int i = 0; i < sf_sim::kPtsRing; ++i) {
             if (s->pts_pinned[i]) HIPCHK(hipHostFree(s->pts_pinned[i]));
             s->pts_pinned[i] = nullptr;
         }
         s->pts_cap = (size_t)4 * n * 2;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->pts_dev), s->pts_cap * sizeof(int32_t)));
-        for (int i = 0; i < sf_sim::kPtsRing; ++i)
-            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pts_pinned[i]), s->pts_cap * sizeof(int32_t), hipHostMallocDefault));
+        for (int i = 0; i < sf_sim::kPtsRing; ++i) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->pts_pinned[i]), s->pts_cap * sizeof(int32_t), hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->pts_mapped[i]), s->pts_pinned[i], 0));
+        }
     }
     const int slot = s->pts_slot;
     s->pts_slot = (slot + 1) % sf_sim::kPtsRing;
-    // this staging buffer may still feed an upload enqueued kPtsRing calls ago
+    // The scatter kernels read the points straight from this pinned, device-mapped buffer (a few
+    // KB over the host link; no copy to enqueue).  It may still feed kernels enqueued kPtsRing calls ago.
     HIPCHK(hipEventSynchronize(s->ev_pts[slot]));
     memcpy(s->pts_pinned[slot], pts, bytes);
-    HIPCHK(hipMemcpyAsync(s->pts_dev, s->pts_pinned[slot], bytes, hipMemcpyHostToDevice, s->stream));
+    int rc = scatter_points(s, s->pts_mapped[slot], n, /*sync=*/false);
+    if (rc) return rc;
     HIPCHK(hipEventRecord(s->ev_pts[slot], s->stream));
-    return scatter_points(s, s->pts_dev, n);
+    if (!s->async) HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
 }
 
 extern "C" int sf_apply_mitigation_device(sf_sim *s, const int32_t *device_pts, int32_t n)
@@ -704,7 +729,7 @@ extern "C" int sf_apply_mitigation_device(sf_sim *s, const int32_t *device_pts, 
     if (n < 0 || (n > 0 && !device_pts)) return fail(SF_EINVAL, "sf_apply_mitigation_device: bad point list");
     if (n == 0) return SF_OK;
     HIPCHK(hipSetDevice(s->p.device));
-    return scatter_points(s, device_pts, n);
+    return scatter_points(s, device_pts, n, true);
 }
 
 extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
@@ -719,6 +744,8 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     int rc = ensure_stage(s, n);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    rc = ensure_commit(s);
+    if (rc) return rc;
     if (g.att)
         hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
                            (const EnvState *)s->commit, env, 1);
@@ -759,7 +786,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     const bool generic = s->g.ab > 1 || s->generic;
     const dim3 cell_grid((unsigned)((s->g.W + 255) / 256), (unsigned)s->g.H, (unsigned)s->g.E);
     for (int i = 0; i < n_steps; ++i) {
-        a.launch = i;
+        a.launch = s->seq;
+        a.from_commit = s->committed ? 1 : 0;
         a.ring = s->ring;
         if (generic) {
             if (s->g.ab == 1) hipLaunchKernelGGL(k_step_cells<uint8_t>, cell_grid, dim3(256), 0, s->stream, a);
@@ -772,11 +800,12 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
         }
         if (a.parents) hipLaunchKernelGGL(k_graph_pass, cell_grid, dim3(256), 0, s->stream, a);
         if (s->history) hipLaunchKernelGGL(k_record, cell_grid, dim3(256), 0, s->stream, s->g, (const uint8_t *)s->status,
-                                           (const EnvState *)(s->tmp + (size_t)(i & 1) * s->g.E), s->history, s->history_cap);
+                                           (const EnvState *)(s->tmp + (size_t)(a.launch & 1) * s->g.E), s->history, s->history_cap);
+        s->seq = (s->seq + 1) % 6;
+        s->committed = false;
     }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
-    hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
-                       (const EnvState *)s->tmp, s->flags, n_steps - 1, s->n_active);
+    // no commit here: the states stay in the rings until something asks for them (ensure_commit)
     HIPCHK(hipGetLastError());
     if (ms || !s->async) HIPCHK(hipStreamSynchronize(s->stream));
     if (ms) HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
@@ -879,6 +908,8 @@ extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    rc = ensure_commit(s);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_unpack_burn, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)s->age,
                        (const double *)s->burn, (const EnvState *)s->commit, env, (double *)s->stage);
     HIPCHK(hipGetLastError());
@@ -897,6 +928,8 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
+    rc = ensure_commit(s);
+    if (rc) return rc;
     if (g.att)   // the caller's values are the truth now: nothing is owed any more
         hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
                            (const EnvState *)s->commit, env, 0);
@@ -912,6 +945,7 @@ extern "C" int sf_update_status_device(sf_sim *s)
     if (!s) return fail(SF_EINVAL, "sf_update_status_device: null handle");
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
     int bx = g.H < 64 ? g.H : 64;
     hipLaunchKernelGGL(k_counts, dim3(bx, g.E), dim3(256), 0, s->stream, g, (const uint8_t *)s->status,

@@ -898,3 +898,69 @@ def test_mitigation_from_device_tensor_and_async_ring():
     for e in range(E):
         assert (a.fire_map(e) == o.fire_map(e)).all() and (b.fire_map(e) == o.fire_map(e)).all(), e
         assert (a.burn(e) == o.burn(e)).all() and (b.burn(e) == o.burn(e)).all(), e
+
+
+@pytest.mark.parametrize("read_back", [False, True])
+def test_state_rings_across_calls_and_mode_switches(read_back):
+    """Environment states stay in the device rings between sf_step calls and are folded into the
+    committed block only on demand.  A sequence of calls that never reads anything back (steps,
+    mitigation, kernel switches, a mid-run environment reset, a wholesale fire_map replacement) must
+    end in the same state as the oracle driven through the same sequence - with or without status
+    reads in between."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(31)
+    H, W, E = 70, 150, 4
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0,
+              attenuate_line_ros=True, max_time=25.0)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
+    R8[:, :, 100:] = 0.0
+    inits = [(5, 5), (60, 30), (90, 60), (140, 10)]       # the last one sits in barren ground: QUIT early
+    eng = FireEngine(**kw)
+    o = fire_dense.DenseOracle(**kw)
+    for x in (eng, o):
+        x.set_rtable(R8)
+        x.reset(inits)
+    eng.set_async(True)
+
+    def both(fn):
+        fn(eng)
+        fn(o)
+        if read_back:
+            st, el = eng.status()
+            ost, oel = o.status()
+            assert (st == ost).all() and (el == oel).all()
+
+    def pts(n):
+        return [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(n)]
+    both(lambda x: x.step(3))
+    p = pts(40)
+    both(lambda x: x.apply_mitigation(p))
+    both(lambda x: x.step(2))
+    eng.set_generic(True)
+    both(lambda x: x.step(2))
+    p2 = pts(40)
+    both(lambda x: x.apply_mitigation(p2))
+    both(lambda x: x.step(1))
+    eng.set_generic(False)
+    both(lambda x: x.step(4))
+    both(lambda x: x.reset_env(1, 20, 20))
+    both(lambda x: x.step(3))
+    eng.set_fused(1)
+    both(lambda x: x.step(2))
+    eng.set_fused(0)
+    fm = o.fire_map(2).copy()
+    fm[10:14, 50:90] = 4
+    both(lambda x: x.load_fire_map(2, fm))
+    both(lambda x: x.step(7))
+    eng.set_dense(True)
+    both(lambda x: x.step(3))
+    eng.set_dense(False)
+    both(lambda x: x.step(6))
+    eng.sync()
+    st, el = eng.status()
+    ost, oel = o.status()
+    assert (st == ost).all() and (el == oel).all()
+    assert not st[:, 0].all()
+    for e in range(E):
+        assert (eng.fire_map(e) == o.fire_map(e)).all(), e
+        assert (eng.burn(e) == o.burn(e)).all(), e
