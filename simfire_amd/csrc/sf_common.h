@@ -19,6 +19,7 @@ namespace {
 #endif
 constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each wave works on its own tiles)
 constexpr int kListCap = 384;        // frontier cells per walk window (u16 entries in LDS); larger frontiers take several windows
+constexpr int kSeamPad = 8;          // row y of a seam column sits at index y + kSeamPad (zero guard, keeps 8-byte loads aligned)
 constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
 constexpr uint32_t FLAG_CAND = 0x100u; // (own byte of the flag word, so the tiled kernels can set it with a plain byte store)
@@ -46,6 +47,8 @@ struct Geo {
     int dense;                    // 1 = ignore the tile activity map (cross-check mode)
     int ab;                       // bytes per cell of the sprite-mask plane: 1 (md <= 5), 2 (<= 13), 4 (<= 28)
     long long rt_env;             // element stride between the R tables of two environments (0 = one shared table)
+    int Hs;                       // bytes per seam column (row y at index y + kSeamPad; zero guards; covers partial tiles)
+    long long seam_env;           // bytes of seam columns per environment = (chunks_x + 1) * 2 * Hs
 };
 
 struct StepArgs {
@@ -62,6 +65,7 @@ struct StepArgs {
     int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
     uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
     uint32_t *n_active;  // its length
+    uint8_t *seam;       // [E][chunks_x + 1][2][Hs] copies of the sprite-mask columns either side of every chunk boundary
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)

@@ -201,6 +201,16 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
     return acc;
 }
 
+// RB consecutive bytes (RB = 1, 2, 4, 8; the address is RB-aligned)
+template <int RB>
+__device__ __forceinline__ unsigned long long load_rows(const uint8_t *p)
+{
+    if (RB == 1) return *p;
+    if (RB == 2) return *reinterpret_cast<const uint16_t *>(p);
+    if (RB == 4) return *reinterpret_cast<const uint32_t *>(p);
+    return *reinterpret_cast<const unsigned long long *>(p);
+}
+
 template <int RB>
 __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
                                           uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
@@ -245,15 +255,27 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             const bool mine = (k >= 1 && k <= RB) || (k == 0 && k_lo) || (k == RB + 1 && k_hi);
             if (mine && col_ok && y0 - 1 + k <= g.H) rows[k] = *reinterpret_cast<const uint4 *>(win + k * g.P);
         }
-        // seams (rows wider than the wave tile): the column just outside the tile
+        // seams (rows wider than the wave tile): the column just outside the tile.  They come from the
+        // seam planes - contiguous copies of the two sprite-mask columns at every chunk boundary - so
+        // a lane gets the seam cells of its RB rows with one load from one cache line, instead of one
+        // byte per row out of the neighbour tile's rows (a different 128 B line each).
         uint32_t seam[RB + 2];
         const bool seam_l = g.chunks_x > 1 && c == 0 && cv > 0 && col_ok;
         const bool seam_r = g.chunks_x > 1 && c == LC - 1 && cv + 1 < g.PV;
+        {
+            // left seam: column chunk * LC * 16 - 1 = boundary `chunk`, side 0; right seam: boundary chunk + 1, side 1
+            const uint8_t *scol = a.seam + (long long)e * g.seam_env +
+                                  (long long)((chunk + (seam_r ? 1 : 0)) * 2 + (seam_r ? 1 : 0)) * g.Hs + kSeamPad + y0;
+            unsigned long long packed = 0;
+            uint32_t s_lo = 0, s_hi = 0;
+            if (seam_l || seam_r) {
+                packed = load_rows<RB>(scol);                  // rows y0 .. y0 + RB - 1 (aligned: y0 is a multiple of RB)
+                if (k_lo) s_lo = scol[-1];
+                if (k_hi) s_hi = scol[RB];
+            }
+            seam[0] = s_lo; seam[RB + 1] = s_hi;
 #pragma unroll
-        for (int k = 0; k < RB + 2; ++k) {
-            seam[k] = 0;
-            const bool mine = (k >= 1 && k <= RB) || (k == 0 && k_lo) || (k == RB + 1 && k_hi);
-            if (mine && (seam_l || seam_r) && y0 - 1 + k <= g.H) seam[k] = win[k * g.P + (seam_l ? -1 : 16)];
+            for (int k = 1; k <= RB; ++k) seam[k] = (uint32_t)(packed >> (8 * (k - 1))) & 0xFFu;
         }
         // status rows: with the activity map nearly every visited tile is a live one, so they are
         // requested together with the sprite rows (one memory round trip less); in the dense
@@ -459,8 +481,14 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             }
             if (dirty & ((0x10000u | 1u) << i)) {
                 // bit i alone: an ignition may have set a sprite bit in this row
-                *reinterpret_cast<uint4 *>(age_e + voff) =
-                    *reinterpret_cast<const uint4 *>(band_lds + (i + 1) * row_pitch + 16 + c * 16);
+                const uint4 av = *reinterpret_cast<const uint4 *>(band_lds + (i + 1) * row_pitch + 16 + c * 16);
+                *reinterpret_cast<uint4 *>(age_e + voff) = av;
+                // keep the seam planes in step: first / last column of the chunk
+                if (g.chunks_x > 1) {
+                    uint8_t *sp = a.seam + (long long)e * g.seam_env + kSeamPad + (y0 + i);
+                    if (c == 0 && chunk > 0) sp[(long long)(chunk * 2 + 1) * g.Hs] = (uint8_t)(av.x & 0xFFu);
+                    if (c == LC - 1 && chunk + 1 < g.chunks_x) sp[(long long)((chunk + 1) * 2) * g.Hs] = (uint8_t)(av.w >> 24);
+                }
             }
         }
     }
@@ -751,6 +779,21 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     s.running = 1; s.steps = 0; s.prev_flag = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
     commit[e] = s;
+}
+
+// Recompute the seam planes of environments [env0, env0 + n) from the sprite-mask plane (after a reset,
+// or when the per-cell kernel, which does not maintain them, hands over to the tiled kernels).
+__global__ void k_rebuild_seams(Geo g, const uint8_t *age, uint8_t *seam, int env0)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index in the seam column
+    const int bs = blockIdx.y, e = env0 + blockIdx.z;         // boundary * 2 + side
+    if (i >= g.Hs) return;
+    const int b = bs >> 1, side = bs & 1;
+    const int x = b * g.LC * 16 - 1 + side, y = i - kSeamPad;
+    uint8_t v = 0;
+    if (b >= 1 && b < g.chunks_x && x < g.P && y >= 0 && y < g.H)
+        v = age[(long long)e * g.age_env + (long long)y * g.P + x];
+    seam[(long long)e * g.seam_env + (long long)bs * g.Hs + i] = v;
 }
 
 // Recompute the tile activity map of environments [env0, env0 + n) from the cell planes (after a

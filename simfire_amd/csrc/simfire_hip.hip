@@ -101,6 +101,7 @@ struct sf_sim {
     int n_cu = 256;
     int fused_mode = -1;               // -1 auto, 0 never, 1 always: one fused launch per step
     bool generic = false;              // sf_set_generic: per-cell kernel instead of the tiled SWAR kernels
+    uint8_t *seam = nullptr;           // seam planes (tiled kernels, 1-byte sprite plane)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -226,6 +227,9 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     // + 64: every wave of k_step requests its first list entry before it knows the list length
     TRY(dev_alloc(s, &s->tile_list, (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x + 64));
     TRY(dev_alloc(s, &s->n_active, (size_t)16));
+    g.Hs = (g.H + 512 + 2 * kSeamPad + 7) / 8 * 8;      // a tile may reach up to 512 rows past H
+    g.seam_env = (long long)(g.chunks_x + 1) * 2 * g.Hs;
+    TRY(dev_alloc(s, &s->seam, (size_t)g.E * g.seam_env));
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) s->n_cu = prop.multiProcessorCount; }
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
@@ -233,6 +237,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
+    HIPCHK(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->age_alloc, 0, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab, s->stream));
@@ -248,7 +253,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active,
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
         if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
@@ -283,6 +288,16 @@ static int rebuild_tflags(sf_sim *s, int env0, int n)
     const Geo &g = s->g;
     hipLaunchKernelGGL(k_rebuild_tflags, dim3(g.TX, g.TY, n), dim3(64), 0, s->stream, g, (const uint8_t *)s->status,
                        (const uint8_t *)s->age, s->tflags, s->ring, env0);
+    HIPCHK(hipGetLastError());
+    return SF_OK;
+}
+
+static int rebuild_seams(sf_sim *s, int env0, int n)
+{
+    const Geo &g = s->g;
+    if (g.ab != 1) return SF_OK;       // wider sprite planes always run in the per-cell kernel
+    hipLaunchKernelGGL(k_rebuild_seams, dim3((g.Hs + 255) / 256, (g.chunks_x + 1) * 2, n), dim3(256), 0, s->stream, g,
+                       (const uint8_t *)s->age, s->seam, env0);
     HIPCHK(hipGetLastError());
     return SF_OK;
 }
@@ -373,6 +388,8 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
     if (was && !s->generic && s->was_reset && s->g.ab == 1) {
         HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
         int rc = rebuild_tflags(s, 0, s->g.E);
+        if (rc) return rc;
+        rc = rebuild_seams(s, 0, s->g.E);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(s->stream));
     }
@@ -649,6 +666,8 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
                        s->tflags, s->ring, (const int32_t *)s->stage, env0, n);
     HIPCHK(hipGetLastError());
+    rc = rebuild_seams(s, env0, n);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
@@ -776,7 +795,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     // few tiles: one fused launch per step; many: select the live tiles first, then persistent waves
     const bool fused = s->fused_mode == 1 || (s->fused_mode < 0 && n_wave_tiles <= 4096);
     const StepKernel kern = pick_step_kernel(s->g.RB, fused);
-    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active;
+    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active; a.seam = s->seam;
     const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
     static const int waves_per_cu = getenv("SF_WAVES_PER_CU") ? atoi(getenv("SF_WAVES_PER_CU")) : 24;   // persistent grid of k_step
     long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * waves_per_cu / kWaves;
