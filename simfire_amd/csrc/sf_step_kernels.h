@@ -96,14 +96,21 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
 // the shader clocks it spends in each phase of step_tile into the statistics counters.
 struct PhaseClock {
 #ifdef SF_PHASES
-    unsigned long long t, ph[7];
-    __device__ __forceinline__ void start() { t = __builtin_readcyclecounter(); for (int k = 0; k < 7; ++k) ph[k] = 0; }
+    unsigned long long t, t0, ph[7];
+    __device__ __forceinline__ void start() { t = t0 = __builtin_readcyclecounter(); for (int k = 0; k < 7; ++k) ph[k] = 0; }
     __device__ __forceinline__ void mark(int k) { const unsigned long long n = __builtin_readcyclecounter(); ph[k] += n - t; t = n; }
 #else
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
 #endif
 };
+
+#ifdef SF_PHASES
+// per-wave timeline of one k_step launch: [wave][0] first clock, [1] last clock,
+// [2] tiles | frontier cells << 16 | walk windows << 40, [3] HW_ID | XCC_ID << 32
+__device__ unsigned long long g_wave_log[16384 * 4];
+__device__ int g_wave_log_launch = -1;       // -2: record (armed from the host through sf_debug_wave_log)
+#endif
 
 struct WalkAcc {
     uint32_t n_active, n_ignite, cand, edges;   // edges: tile flag bits 0, 2..5 set by ignitions
@@ -548,6 +555,17 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
         step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2, pc);
         n_tiles_done++;
     }
+#ifdef SF_PHASES
+    if (lane == 0 && g_wave_log_launch == -2) {
+        const unsigned w = blockIdx.x * kWaves + wave;
+        if (w < 16384) {
+            g_wave_log[w * 4 + 0] = pc.t0; g_wave_log[w * 4 + 1] = __builtin_readcyclecounter();
+            g_wave_log[w * 4 + 2] = n_tiles_done | ((unsigned long long)n_items_acc << 16) | ((unsigned long long)n_phase2 << 40);
+            g_wave_log[w * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                    ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+        }
+    }
+#endif
     // optional statistics for the roofline accounting (active cell-updates = phi * cells)
     if (a.counters && n_tiles_done) {
         for (int off = 32; off > 0; off >>= 1) {

@@ -876,6 +876,17 @@ extern "C" int sf_history_device(sf_sim *s, void **ptr, int32_t *capacity)
     return SF_OK;
 }
 
+#ifdef SF_PHASES
+// development build only: arm / read the per-wave timeline of k_step (see profiles/phase_profile.py)
+extern "C" int sf_debug_wave_log(int32_t arm, unsigned long long *out)
+{
+    if (arm) { int v = -2; return hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log_launch), &v, sizeof v) == hipSuccess ? 0 : -1; }
+    int v = -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log_launch), &v, sizeof v);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_log), sizeof(unsigned long long) * 16384 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int sf_step(sf_sim *s, int32_t n_steps) { return step_impl(s, n_steps, nullptr); }
 extern "C" int sf_step_timed(sf_sim *s, int32_t n_steps, float *ms_out)
 {
