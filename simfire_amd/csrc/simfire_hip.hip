@@ -197,10 +197,10 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.diag = p->diagonal_spread != 0; g.att = p->attenuate_line_ros != 0; g.has_max_time = p->has_max_time != 0;
     g.pixel_scale = p->pixel_scale; g.update_rate = p->update_rate; g.max_time = p->max_time;
     g.age_env = (long long)(g.H + 2) * g.P; g.plane_env = (long long)g.H * g.P;
-    // rows per band: enough workgroups to fill 256 CUs several times over when the batch is
-    // large, short bands when a single environment has to spread over the chip
-    long long rows_total = (long long)g.E * g.H;
-    int rb = rows_total >= 4096 ? 4 : 2;
+    // rows per lane band: 2, i.e. wave tiles of 64 x 32 cells.  Measured on C3 / C4 / C5 once a wave needed
+    // only 5.5 KB of LDS: shorter per-tile latency chains beat the fewer, larger 64 x 64 tiles by 6 / 14 / 17 %
+    // (a step lasts as long as its slowest wave); 64 x 16 loses again to the halo overhead.
+    int rb = 2;
     choose_rows_per_band(g, rb);
 
     int rc;
