@@ -166,8 +166,8 @@ int sf_set_burn(sf_sim *sim, int32_t env, const double *burn);
 int sf_get_status(sf_sim *sim, int32_t *status /* [n_envs][8] */, double *elapsed_time);
 
 /* Device-side views for zero-copy consumers (RL observation tensors): pointer to the uint8
- * status plane of environment 0, row pitch and environment stride in bytes.  Bit 7 of a byte
- * is internal bookkeeping: mask with 0x07. */
+ * status plane of environment 0, row pitch and environment stride in bytes; the bytes are the
+ * BurnStatus values 0..5. */
 int sf_fire_map_device(sf_sim *sim, void **ptr, int64_t *row_pitch, int64_t *env_stride);
 /* Device buffer int32 [n_envs][8] filled by sf_update_status_device (same content as
  * sf_get_status) - the block that is all-gathered over RCCL by the multi-GPU host code. */

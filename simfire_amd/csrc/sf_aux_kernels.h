@@ -125,58 +125,44 @@ __global__ void k_unpack_status(Geo g, const uint8_t *status, int env0, uint8_t 
     dense[((long long)i * g.H + y) * g.W + x] = status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x] & 7u;
 }
 
-// Is the attenuation of the last executed step still owed to this (line) cell?
-__device__ inline bool owes_attenuation(const Geo &g, const EnvState &s, const uint8_t *age_e, uint32_t sraw,
-                                        int x, int y)
-{
-    if (!g.att || !s.prev_flag || (sraw & 0x80u) || (sraw & 7u) < SF_FIRELINE) return false;
-    const Masks mk = make_masks(s.steps + 1, g.md, g.N);
-    const long long o = (long long)y * g.P + x;
-    for (int k = 0; k < 8; ++k) {
-        const int dx = c_dx[k], dy = c_dy[k];
-        if (!g.diag && dx != 0 && dy != 0) continue;
-        const int xx = x + dx;
-        if (xx < 0 || xx >= g.W) continue;
-        if (age_load(g, age_e, o + dy * g.P + dx) & mk.m_prev) return false;   // it was a candidate: already applied
-    }
-    return true;
-}
-
-// burn_amounts as the reference would hold them now (deferred attenuation resolved on the fly)
-__global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint8_t *age, const double *burn,
+// burn_amounts as the reference would hold them now: the attenuation a control-line cell is still owed
+// (see lazy_sub) is resolved on the fly
+__global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint32_t *settled, const double *burn,
                               const EnvState *commit, int e, double *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= g.W) return;
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     double b = burn[o];
-    const uint32_t sraw = status[o];
-    if (owes_attenuation(g, commit[e], age + (long long)e * g.age_env * g.ab, sraw, x, y)) b = b - line_factor(sraw & 7u);
+    const uint32_t st = status[o] & 7u;
+    if (g.att && st >= SF_FIRELINE) b = lazy_sub(b, line_factor(st), (uint32_t)commit[e].complete - settled[o]);
     dense[(long long)y * g.W + x] = b;
 }
 
-// Make the deferred attenuation of one environment real and mark every line cell settled.
+// Make the owed attenuation of one environment real (apply) and mark every line cell as up to date.
 // Used before fire_map / burn are overwritten wholesale (load_mitigation, set_burn).
-__global__ void k_settle_env(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+__global__ void k_settle_env(Geo g, const uint8_t *status, uint32_t *settled, double *burn, const EnvState *commit,
                              int e, int apply)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= g.W) return;
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
-    const uint32_t sraw = status[o];
-    if ((sraw & 7u) < SF_FIRELINE) return;
-    if (apply && owes_attenuation(g, commit[e], age + (long long)e * g.age_env * g.ab, sraw, x, y))
-        burn[o] = burn[o] - line_factor(sraw & 7u);
-    status[o] = (uint8_t)(sraw | 0x80u);
+    const uint32_t st = status[o] & 7u;
+    if (st < SF_FIRELINE) return;
+    const uint32_t now = (uint32_t)commit[e].complete;
+    if (apply) burn[o] = lazy_sub(burn[o], line_factor(st), now - settled[o]);
+    settled[o] = now;
 }
 
-__global__ void k_pack_status(Geo g, uint8_t *status, int e, const uint8_t *dense)
+__global__ void k_pack_status(Geo g, uint8_t *status, uint32_t *settled, const EnvState *commit, int e, const uint8_t *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= g.W) return;
     const uint32_t v = dense[(long long)y * g.W + x];
-    // a freshly loaded line cell owes nothing for the step that ran before it existed
-    status[(long long)e * g.plane_env + (long long)y * g.P + x] = (uint8_t)((g.att && v >= SF_FIRELINE) ? (v | 0x80u) : v);
+    const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
+    status[o] = (uint8_t)v;
+    // a freshly loaded line cell owes nothing for the updates that ran before it existed
+    if (g.att && v >= SF_FIRELINE) settled[o] = (uint32_t)commit[e].complete;
 }
 __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 {
@@ -188,15 +174,15 @@ __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 // ------------------------------------------------------------------------- mitigation
 // FireSimulation.update_mitigation (simulation.py:449-478) as two tiny launches, one thread per
 // point (env, x, y, type), no ordering of the points needed:
-//   k_mitigate_clear  one atomic CAS per point: the status byte becomes "no type yet | settled";
-//                     the thread that sees the OLD byte settles what the cell is still owed for
-//                     the last step under its old status (attenuation mode), duplicates see the
-//                     cleared byte and do nothing;
+//   k_mitigate_clear  one atomic AND per point clears the cell's status byte; the one thread that
+//                     gets the OLD byte back (duplicates get 0) makes up the attenuation the cell
+//                     is still owed under its old line type (attenuation mode, lazy_sub);
 //   k_mitigate_write  byte-wise atomic max of the line types: FIRELINE < SCRATCHLINE < WETLINE is
 //                     exactly the reference's "FIRELINE writes, then SCRATCHLINE, then WETLINE"
 //                     order for duplicates (simulation.py:476-478); each write is unconditional
-//                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.
-__global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, double *burn, const EnvState *commit,
+//                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.  The
+//                     new line cell owes attenuation from the next update on.
+__global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint32_t *settled, double *burn, const EnvState *commit,
                                  const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
                                  const int32_t *pts, int n)
 {
@@ -208,18 +194,15 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint8_t *age, dou
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
     const int sh = (int)(o & 3) * 8;
-    uint32_t old = *word, seen;
-    do {
-        seen = old;
-        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (0x80u << sh));
-    } while (old != seen);
-    const uint32_t sraw = (seen >> sh) & 0xFFu;
-    if (g.att && !(sraw & 0x80u) &&
-        owes_attenuation(g, entering_state(commit, tmp, flags, launch, from_commit, e, g), age + (long long)e * g.age_env * g.ab, sraw, x, y))
-        burn[o] = burn[o] - line_factor(sraw & 7u);
+    const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
+    if (g.att && old >= SF_FIRELINE) {
+        const uint32_t now = (uint32_t)entering_state(commit, tmp, flags, launch, from_commit, e, g).complete;
+        burn[o] = lazy_sub(burn[o], line_factor(old), now - settled[o]);
+    }
 }
 
-__global__ void k_mitigate_write(Geo g, uint8_t *status, const int32_t *pts, int n, uint8_t *tflags, int ring)
+__global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, const EnvState *commit, const EnvState *tmp,
+                                 const uint32_t *flags, int launch, int from_commit, const int32_t *pts, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -229,19 +212,15 @@ __global__ void k_mitigate_write(Geo g, uint8_t *status, const int32_t *pts, int
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
     uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
     const int sh = (int)(o & 3) * 8;
-    const uint32_t mark = g.att ? 0x80u : 0u;                         // "nothing owed for the last step"
     uint32_t old = *word, seen;
     do {
         seen = old;
-        const uint32_t cur = (seen >> sh) & 7u;
-        if (cur >= (uint32_t)ty && (((seen >> sh) & 0x80u) == mark)) break;
-        const uint32_t nb = (cur > (uint32_t)ty ? cur : (uint32_t)ty) | mark;
-        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | (nb << sh));
+        const uint32_t cur = (seen >> sh) & 0xFFu;
+        if (cur >= (uint32_t)ty) break;
+        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
     } while (old != seen);
-    if (g.att) {   // the tile now holds a control line: it has to be visited every step from now on
-        uint8_t *tf = tflags + (((long long)ring * g.E + e) * g.TYp + y / (g.LR * g.RB) + 1) * g.TXp + (x / 16) / g.LC + 1;
-        if (!(*tf & 2u)) *tf = (uint8_t)(*tf | 2u);   // idempotent: every racer writes the same bit
-    }
+    if (g.att)      // idempotent: every point of this call on this cell stores the same count
+        settled[o] = (uint32_t)entering_state(commit, tmp, flags, launch, from_commit, e, g).complete;
 }
 
 // ------------------------------------------------------------- per-environment results

@@ -28,7 +28,7 @@ constexpr uint32_t FLAG_CAND = 0x100u; // (own byte of the flag word, so the til
 struct EnvState {
     int32_t running;    // GameStatus.RUNNING
     int32_t steps;      // update() calls made so far; the next step has index t = steps + 1
-    int32_t prev_flag;  // the last executed step was a complete one (had a candidate)
+    int32_t complete;   // updates so far that ran to the end (had a candidate: fire.py:651-652 not taken)
     int32_t time_quit;  // the next update() will hit the runtime check (fire.py:641-643)
     double elapsed;     // RothermelFireManager.elapsed_time
 };
@@ -65,6 +65,8 @@ struct StepArgs {
     int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
     uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
     uint32_t *n_active;  // its length
+    uint32_t *settled;   // [E][H][P], attenuation mode only: complete-update count up to which a control-line cell's
+                         // attenuation is contained in burn (see lazy_sub)
     uint8_t *seam;       // [E][chunks_x + 1][2][Hs] copies of the sprite-mask columns either side of every chunk boundary
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
@@ -72,7 +74,7 @@ struct StepArgs {
 };
 
 struct Masks {
-    uint32_t b_new, b_exp, b_clr, m_live, m_prev;
+    uint32_t b_new, b_exp, b_clr, m_live;
     int rot, N;
 };
 
@@ -84,7 +86,6 @@ __host__ __device__ inline int slot_of(int s, int N)
 
 // Bit layout of the age byte at step t (sprites are named by their ignition step s):
 //   live during step t (spread, fire.py:647):          s in [t - md, t - 1]
-//   live during step t - 1:                            s in [t - 1 - md, t - 2]
 //   pruned at step t (-> BURNED, fire.py:116-161):     s = t - md - 1
 //   bit cleared at step t (slot recycled for t + 1):   s = t - md - 2
 //   set at step t (new ignition, fire.py:571-587):     s = t
@@ -102,7 +103,6 @@ __host__ __device__ inline Masks make_masks(int t, int md, int N)
     m.b_clr = 1u << wrap(s0 + 1);
     m.b_exp = 1u << wrap(s0 + 2);
     m.m_live = rotl(ones, wrap(s0 + 3));
-    m.m_prev = rotl(ones, wrap(s0 + 2));
     m.rot = (N - 1) - wrap(s0 + N - 1);   // rotate left so that step t-1 lands on bit N-1
     return m;
 }
@@ -129,10 +129,9 @@ __device__ inline EnvState fold_state(EnvState s, uint32_t f, const Geo &g)
 {
     if (!s.running) return s;                       // frozen: run() no longer calls update
     s.steps += 1;
-    if (!(f & FLAG_LIVE)) { s.running = 0; s.prev_flag = 0; return s; }   // fire.py:637-638
-    if (s.time_quit) { s.running = 0; s.prev_flag = 0; return s; }        // fire.py:641-643
-    if (f & FLAG_CAND) { s.elapsed += g.update_rate; s.prev_flag = 1; }   // fire.py:717
-    else s.prev_flag = 0;                                                 // fire.py:651-652
+    if (!(f & FLAG_LIVE)) { s.running = 0; return s; }                    // fire.py:637-638
+    if (s.time_quit) { s.running = 0; return s; }                         // fire.py:641-643
+    if (f & FLAG_CAND) { s.elapsed += g.update_rate; s.complete += 1; }   // fire.py:717; else fire.py:651-652
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || s.elapsed > g.max_time);
     return s;
 }
@@ -149,6 +148,31 @@ __device__ __forceinline__ EnvState entering_state(const EnvState *commit, const
 __device__ __forceinline__ double line_factor(uint32_t st)   // RoSAttenuation, enums.py:72-85
 {
     return st == SF_FIRELINE ? 980.0 : (st == SF_SCRATCHLINE ? 490.0 : 245.0);
+}
+
+// Lazy rate-of-spread attenuation.  With attenuate_line_ros the reference subtracts 980 / 490 / 245 from
+// the burn amount of EVERY control-line cell in every update that runs to the end (fire.py:271-278, 710).
+// Here a line cell is only touched when something happens to it (it becomes an ignition candidate, it
+// is overwritten, burn_amounts is read back); the k subtractions it is owed by then are made up in one
+// go - bit for bit: `k` times x = fl(x - f).
+// f is a small positive integer, so a subtraction is exact unless the result needs a coarser ulp than
+// x has, which only happens when |x| grows past a power of two (or x is tiny next to f).  Inside one
+// binade n steps collapse into the exact x - n * f; each binade crossing is one real IEEE step.
+__device__ inline double lazy_sub(double x, double f, uint32_t k)
+{
+    while (k) {
+        if (x == 0.0) return -(double)k * f;                  // integers: exact
+        // |x| in [2^E, 2^(E+1)); every x - j * f above -2^(E+1) is representable (a multiple of ulp(x))
+        const int ex = (int)((__double_as_longlong(x) >> 52) & 0x7FF);
+        if (ex == 0 || ex == 0x7FF) { x = x - f; --k; continue; }          // subnormal / not finite: plain steps
+        const double limit = __longlong_as_double((long long)(ex + 1) << 52);   // 2^(E+1)
+        const double room = (x + limit) / f;                  // j * f < x + limit; rounded, hence the margin of 2
+        long long n = (room < 4.0e9 ? (long long)room : 4000000000ll) - 2;
+        if (n > (long long)k) n = k;
+        if (n >= 1) { x = x - (double)n * f; k -= (uint32_t)n; }
+        if (k) { x = x - f; --k; }                            // a real step (rounds if it has to)
+    }
+    return x;
 }
 
 __device__ __forceinline__ uint32_t pick(const uint4 &v, int j)
@@ -194,22 +218,18 @@ __device__ __forceinline__ uint32_t from_right(uint32_t v, int c, int LC)
 
 // Winner source of a destination cell from its 3x3 neighbourhood (bytes 0..2
 // of up3 / mid3 / dn3 = cells x-1, x, x+1 of the rows y-1, y, y+1): the newest live sprite
-// wins, ties are broken by the priority order k = 0..7.  Also reports whether any neighbour
-// was live during the previous step.
-__device__ __forceinline__ int pick_winner(uint32_t up3, uint32_t mid3, uint32_t dn3, const Masks &mk, bool diag,
-                                           bool &prev_any)
+// wins, ties are broken by the priority order k = 0..7.
+__device__ __forceinline__ int pick_winner(uint32_t up3, uint32_t mid3, uint32_t dn3, const Masks &mk, bool diag)
 {
     // k: 0 (+1,+1) 1 (0,+1) 2 (-1,+1) 3 (+1,0) 4 (-1,0) 5 (+1,-1) 6 (0,-1) 7 (-1,-1)
     const uint32_t nbv[8] = {(dn3 >> 16) & 0xFFu, (dn3 >> 8) & 0xFFu, dn3 & 0xFFu, (mid3 >> 16) & 0xFFu,
                              mid3 & 0xFFu, (up3 >> 16) & 0xFFu, (up3 >> 8) & 0xFFu, up3 & 0xFFu};
     int best = -1, bestk = -1;
-    prev_any = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
         uint32_t v = nbv[k];
         if (diagonal_k && !diag) v = 0;
-        prev_any |= (v & mk.m_prev) != 0;
         const uint32_t l = v & mk.m_live;
         // newest sprite of the neighbour: rotate so that ignition step t-1 is the top bit
         const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);

@@ -46,23 +46,23 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     const long long o = (long long)(tyw + 1) * g.TXp + (tx + 1);
     const EnvState *sp = a.from_commit ? a.commit + e : a.tmp + ((a.launch + 1) & 1) * g.E + e;
     const uint32_t *fp = a.flags + ((a.launch + 2) % 3) * g.E + e;     // ring slot of the previous launch
-    int32_t s_run = sp->running, s_steps = sp->steps, s_prev = sp->prev_flag, s_tq = sp->time_quit;
+    int32_t s_run = sp->running, s_steps = sp->steps, s_cmp = sp->complete, s_tq = sp->time_quit;
     double s_el = sp->elapsed;
     uint32_t fl = *fp;
     uint32_t own = f_rd[o], up = f_rd[o - g.TXp], dn = f_rd[o + g.TXp], lf = f_rd[o - 1], rt = f_rd[o + 1];
     uint32_t ul = f_rd[o - g.TXp - 1], ur = f_rd[o - g.TXp + 1], dl = f_rd[o + g.TXp - 1], dr = f_rd[o + g.TXp + 1];
-    asm volatile("" : "+v"(s_run), "+v"(s_steps), "+v"(s_prev), "+v"(s_tq), "+v"(s_el), "+v"(fl), "+v"(own), "+v"(up),
+    asm volatile("" : "+v"(s_run), "+v"(s_steps), "+v"(s_cmp), "+v"(s_tq), "+v"(s_el), "+v"(fl), "+v"(own), "+v"(up),
                       "+v"(dn), "+v"(lf), "+v"(rt), "+v"(ul), "+v"(ur), "+v"(dl), "+v"(dr));
 
     // environment state entering this step (folded from the previous launch's flags)
     EnvState st;
-    st.running = s_run; st.steps = s_steps; st.prev_flag = s_prev; st.time_quit = s_tq; st.elapsed = s_el;
+    st.running = s_run; st.steps = s_steps; st.complete = s_cmp; st.time_quit = s_tq; st.elapsed = s_el;
     if (!a.from_commit) st = fold_state(st, fl, g);
 
     // (bitwise, not short-circuit: nothing to skip, the flags are all here)
     const bool near = ((own & 1u) | (up & 8u) | (dn & 4u) | (lf & 32u) | (rt & 16u)) != 0 ||
                       ((ul & 40u) == 40u) | ((ur & 24u) == 24u) | ((dl & 36u) == 36u) | ((dr & 20u) == 20u);
-    const bool active = valid && st.running && (g.dense || near || (g.att && (own & 2u)));
+    const bool active = valid && st.running && (g.dense || near);
 
     // compact: ballot -> rank inside the wave, one atomic per workgroup
     const unsigned long long bal = __ballot(active);
@@ -140,7 +140,7 @@ __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__b
 // is written back into those copies - the cell planes in HBM are updated once, from LDS, at the end.
 template <int RB>
 __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, bool spread,
-                                             int prev_flag, uint8_t *tile_lds, uint8_t *stat_lds, const uint16_t *s_list,
+                                             int complete, uint8_t *tile_lds, uint8_t *stat_lds, const uint16_t *s_list,
                                              uint32_t pend, int lane)
 {
     const Geo &g = a.g;
@@ -166,37 +166,42 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         uint8_t *own_st = stat_lds + ((orr * RB + i) * LC + oc) * 16 + b;
         const uint32_t own = (mid3 >> 8) & 0xFFu;
         // the status tile still holds the value from before this step's prune
-        const uint32_t raw = *own_st, s_pre = raw & 7u;
-        const bool settled = raw & 0x80u, expired = (own & mk.b_exp) != 0;
-        bool prev_any;
-        const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag, prev_any);
+        const uint32_t s_pre = *own_st & 7u;
+        const bool expired = (own & mk.b_exp) != 0;
+        const int bestk = pick_winner(up3, mid3, dn3, mk, g.diag);
         const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
         const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
         const bool is_cand = spread && eligible && bestk >= 0;
-        // attenuation of the previous step that was deferred (a line cell, not a candidate then)
-        const bool pending = g.att && s_pre >= SF_FIRELINE && !settled && prev_flag && !prev_any;
-        uint32_t st_new = s_post;                        // S1 prune + settled bit cleared
-        if (is_cand || pending) {
+        uint32_t st_new = s_post;                        // S1 prune
+        if (g.att && expired && s_pre >= SF_FIRELINE)     // a line on a burning cell, overwritten by the prune (fire.py:140)
+            a.burn[cell] = lazy_sub(a.burn[cell], line_factor(s_pre), (uint32_t)complete - a.settled[cell]);
+        if (is_cand) {
             acc.n_active++;
+            acc.cand = 1;
             // both operands are requested before either is used: one memory round trip, not two
-            const double *rt_p = a.rt + ((long long)e * g.rt_env + (long long)(is_cand ? bestk : 0) * g.H * g.P + idx);
+            const double *rt_p = a.rt + ((long long)e * g.rt_env + (long long)bestk * g.H * g.P + idx);
+            const bool line = s_post >= SF_FIRELINE;
             double bn = a.burn[cell];
             double r_tab = *rt_p;
-            asm volatile("" : "+v"(bn), "+v"(r_tab));     // keeps the table read from being sunk behind the first use of bn
-            if (pending) bn = bn - line_factor(s_pre);                          // fire.py:278 with ros = 0
-            if (is_cand) {
-                acc.cand = 1;
-                double ros = r_tab * g.update_rate;                              // fire.py:696,705
-                if (s_post >= SF_FIRELINE)                                       // fire.py:271-282
-                    ros = g.att ? ros - line_factor(s_post) : 0.0;
-                bn = bn + ros;                                                   // fire.py:710
-                if (bn > g.pixel_scale) {                                        // fire.py:568
-                    acc.n_ignite++;
-                    acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
-                                 ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
-                    st_new = SF_BURNING;                                         // fire.py:587
-                    *own_age = (uint8_t)((own & ~mk.b_clr) | mk.b_new);          // fire.py:571-579
-                }
+            uint32_t owed = 0;
+            if (line && g.att) owed = (uint32_t)complete - a.settled[cell];
+            asm volatile("" : "+v"(bn), "+v"(r_tab), "+v"(owed));     // keeps the loads from being sunk behind the first use of bn
+            double ros = r_tab * g.update_rate;                                  // fire.py:696,705
+            if (line) {                                                          // fire.py:271-282
+                if (g.att) {
+                    const double f = line_factor(s_post);
+                    bn = lazy_sub(bn, f, owed);          // the updates since this cell was last touched (fire.py:278, ros = 0)
+                    ros = ros - f;
+                    a.settled[cell] = (uint32_t)complete + 1u;                   // this update runs to the end: it has a candidate
+                } else ros = 0.0;
+            }
+            bn = bn + ros;                                                       // fire.py:710
+            if (bn > g.pixel_scale) {                                            // fire.py:568
+                acc.n_ignite++;
+                acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
+                             ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
+                st_new = SF_BURNING;                                             // fire.py:587
+                *own_age = (uint8_t)((own & ~mk.b_clr) | mk.b_new);              // fire.py:571-579
             }
             a.burn[cell] = bn;
         }
@@ -300,7 +305,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         uint32_t hot = 0;
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
-        if (!g.att && __ballot(hot != 0) == 0ull) return;
+        if (__ballot(hot != 0) == 0ull) return;
         if (g.dense) load_status();
 
         // tile activity for the next step, part 1: sprite bits that survive this step's recycling,
@@ -346,7 +351,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     uint32_t fm[(RB + 1) / 2];
 #pragma unroll
     for (int k = 0; k < (RB + 1) / 2; ++k) fm[k] = 0;
-    uint32_t live_acc = 0, line_acc = 0, dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
+    uint32_t live_acc = 0, dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
 #pragma unroll 1
     for (int i = 0; i < RB; ++i) {
         const int y = y0 + i;
@@ -381,7 +386,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             dirty |= 0x10000u << i;
         }
         uint32_t m16 = 0;
-        if (row_ok && (any_exp | any_nb | (uint32_t)g.att)) {
+        if (row_ok && (any_exp | any_nb)) {
             const uint4 sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
             const uint4 s7 = and4(sr, 0x07070707u);
             // S1 prune: cells whose sprite reached max_fire_duration become BURNED
@@ -396,15 +401,16 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
             snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
             if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) dirty |= 1u << i;
-            // frontier cells (0 / 1 per byte): eligible & next to a live sprite; every line cell when
-            // attenuation is on (their burn changes even away from the fire)
+            // frontier cells (0 / 1 per byte): eligible & next to a live sprite
             uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
             uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
             uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
             uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+            // attenuation mode: a control line drawn on a burning cell ends when that sprite expires (the
+            // prune overwrites it with BURNED); the walk then makes up the attenuation it is still owed
             if (g.att) {
-                p0 |= ge3_01(s7.x); p1 |= ge3_01(s7.y); p2 |= ge3_01(s7.z); p3 |= ge3_01(s7.w);
-                line_acc |= ge3_01(snew.x) | ge3_01(snew.y) | ge3_01(snew.z) | ge3_01(snew.w);
+                p0 |= ge3_01(s7.x) & em.x & 0x01010101u; p1 |= ge3_01(s7.y) & em.y & 0x01010101u;
+                p2 |= ge3_01(s7.z) & em.z & 0x01010101u; p3 |= ge3_01(s7.w) & em.w & 0x01010101u;
             }
             // pitch padding (x >= W) never takes part
             const int xs = cv * 16;
@@ -423,7 +429,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             mix.z = (sr.z & keepm.z) | (snew.z & ~keepm.z);
             mix.w = (sr.w & keepm.w) | (snew.w & ~keepm.w);
             *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = mix;
-            if (m16) dirty |= (1u << i);       // the walk rewrites those bytes (settled bit, ignition)
+            if (m16) dirty |= (1u << i);       // the walk rewrites those bytes (ignition)
         }
         if (i & 1) fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16 << 16; else fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16;
     }
@@ -466,7 +472,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             pc.mark(3);      // prefix sum + list building
-            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.prev_flag, tile_lds, stat_lds, s_list, tot, lane);
+            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.complete, tile_lds, stat_lds, s_list, tot, lane);
             pc.mark(4);      // walk
             acc_merge(tot_acc, w);
             n_items_acc += (lane == 0) ? tot : 0u;
@@ -483,7 +489,6 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             const uint32_t voff = (uint32_t)((y0 + i) * g.P + cv * 16);
             if (dirty & (1u << i)) {
                 uint4 v = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
-                v = and4(v, 0x07070707u);    // the settled marks end with this step
                 *reinterpret_cast<uint4 *>(st_e + voff) = v;
             }
             if (dirty & ((0x10000u | 1u) << i)) {
@@ -501,9 +506,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     }
 
     pc.mark(5);              // write-back
-    // tile activity for the next step: sprites left in the tile or ignited in it (with their
-    // edge bits); control lines (a line cell that ignited this step is seen one step late -
-    // harmless, it is re-evaluated)
+    // tile activity for the next step: sprites left in the tile or ignited in it (with their edge bits)
     const long long fplane = (long long)g.TYp * g.TXp;
     uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
     {
@@ -511,8 +514,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         const uint32_t ed = (__ballot((le & 1u) != 0) ? 1u : 0u) | (__ballot((le & 4u) != 0) ? 4u : 0u) |
                             (__ballot((le & 8u) != 0) ? 8u : 0u) | (__ballot((le & 16u) != 0) ? 16u : 0u) |
                             (__ballot((le & 32u) != 0) ? 32u : 0u);
-        const bool lines = g.att && __ballot(line_acc != 0) != 0ull;
-        const uint32_t nf = tile_flags | ed | (lines ? 2u : 0u);
+        const uint32_t nf = tile_flags | ed;
         if (lane == 0 && nf) *f_own = (uint8_t)nf;
     }
     // per-environment predicates: wave ballot, then at most one atomic per wave
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
     const bool near = __ballot(lane < 9 && (fl & want) == want) != 0ull;
     const uint32_t own = __shfl(fl, 4);
     if (lane == 0) f_wr[o] = st.running ? (uint8_t)0 : (uint8_t)own;
-    if (!(st.running && (g.dense || near || (g.att && (own & 2u))))) return;
+    if (!(st.running && (g.dense || near))) return;
 
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
     PhaseClock pc;
@@ -688,12 +690,10 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
             nbv[k] = (xx >= 0 && xx < g.W) ? (uint32_t)age_e[o + c_dy[k] * g.P + c_dx[k]] : 0u;   // rows: zero guard rows
         }
         int best = -1, bestk = -1;
-        bool prev_any = false;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
             const uint32_t v = (diagonal_k && !g.diag) ? 0u : nbv[k];
-            prev_any |= (v & mk.m_prev) != 0;
             const uint32_t l = v & mk.m_live;
             const uint32_t r = ((l << mk.rot) | (l >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
             const int msb = l ? 31 - __clz(r) : -1;
@@ -701,18 +701,23 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
         }
         const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);    // fire.py:192-205
         const bool is_cand = spread && eligible && bestk >= 0;
-        const bool pending = g.att && s_pre >= SF_FIRELINE && !(sraw & 0x80u) && st.prev_flag && !prev_any;
         uint32_t st_new = s_post, age_new = own & ~mk.b_clr;
-        if (is_cand || pending) {
+        if (g.att && expired && s_pre >= SF_FIRELINE)     // a line on a burning cell, overwritten by the prune (fire.py:140)
+            a.burn[cell] = lazy_sub(a.burn[cell], line_factor(s_pre), (uint32_t)st.complete - a.settled[cell]);
+        if (is_cand) {
+            cand = true;
             double bn = a.burn[cell];
-            if (pending) bn = bn - line_factor(s_pre);                              // fire.py:278, one step late
-            if (is_cand) {
-                cand = true;
-                double ros = a.rt[(long long)e * g.rt_env + (long long)bestk * g.H * g.P + o] * g.update_rate;  // fire.py:696,705
-                if (s_post >= SF_FIRELINE) ros = g.att ? ros - line_factor(s_post) : 0.0;   // fire.py:271-282
-                bn = bn + ros;                                                      // fire.py:710
-                if (bn > g.pixel_scale) { st_new = SF_BURNING; age_new |= mk.b_new; }   // fire.py:568-587
+            double ros = a.rt[(long long)e * g.rt_env + (long long)bestk * g.H * g.P + o] * g.update_rate;  // fire.py:696,705
+            if (s_post >= SF_FIRELINE) {                                            // fire.py:271-282
+                if (g.att) {
+                    const double f = line_factor(s_post);
+                    bn = lazy_sub(bn, f, (uint32_t)st.complete - a.settled[cell]);  // the updates since the cell was last touched
+                    ros = ros - f;
+                    a.settled[cell] = (uint32_t)st.complete + 1u;
+                } else ros = 0.0;
             }
+            bn = bn + ros;                                                          // fire.py:710
+            if (bn > g.pixel_scale) { st_new = SF_BURNING; age_new |= mk.b_new; }   // fire.py:568-587
             a.burn[cell] = bn;
             if (a.counters) atomicAdd(&a.counters[(size_t)(blockIdx.x & (kCounterShards - 1)) * 8], 1ull);
         }
@@ -794,7 +799,7 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
     tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
     EnvState s;
-    s.running = 1; s.steps = 0; s.prev_flag = 0; s.elapsed = 0.0;
+    s.running = 1; s.steps = 0; s.complete = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
     commit[e] = s;
 }

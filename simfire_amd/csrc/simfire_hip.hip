@@ -102,6 +102,7 @@ struct sf_sim {
     int fused_mode = -1;               // -1 auto, 0 never, 1 always: one fused launch per step
     bool generic = false;              // sf_set_generic: per-cell kernel instead of the tiled SWAR kernels
     uint8_t *seam = nullptr;           // seam planes (tiled kernels, 1-byte sprite plane)
+    uint32_t *settled = nullptr;       // attenuation bookkeeping per cell (attenuate_line_ros only)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -230,6 +231,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.Hs = (g.H + 512 + 2 * kSeamPad + 7) / 8 * 8;      // a tile may reach up to 512 rows past H
     g.seam_env = (long long)(g.chunks_x + 1) * 2 * g.Hs;
     TRY(dev_alloc(s, &s->seam, (size_t)g.E * g.seam_env));
+    if (g.att) TRY(dev_alloc(s, &s->settled, cells));
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) s->n_cu = prop.multiProcessorCount; }
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
@@ -238,6 +240,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
+    if (s->settled) HIPCHK(hipMemsetAsync(s->settled, 0, cells * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     HIPCHK(hipMemsetAsync(s->age_alloc, 0, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab, s->stream));
@@ -253,7 +256,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam,
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
         if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
@@ -657,6 +660,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
     if (s->parents) HIPCHK(hipMemsetAsync(s->parents + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
+    if (s->settled) HIPCHK(hipMemsetAsync(s->settled + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(uint32_t), s->stream));
     int rc = ensure_stage(s, (size_t)n * 2 * sizeof(int32_t));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->stage, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
@@ -695,10 +699,11 @@ static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n, bool sync)
 {
     const Geo &g = s->g;
     const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint32_t *)s->settled, s->burn,
                        (const EnvState *)s->commit, (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq,
                        s->committed ? 1 : 0, pts_dev, n);
-    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, pts_dev, n, s->tflags, s->ring);
+    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, s->settled, (const EnvState *)s->commit,
+                       (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq, s->committed ? 1 : 0, pts_dev, n);
     HIPCHK(hipGetLastError());
     if (sync && !s->async) HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
@@ -766,10 +771,11 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     rc = ensure_commit(s);
     if (rc) return rc;
     if (g.att)
-        hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+        hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, s->settled, s->burn,
                            (const EnvState *)s->commit, env, 1);
     HIPCHK(hipMemcpyAsync(s->stage, map, n, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_pack_status, grd, blk, 0, s->stream, g, s->status, env, (const uint8_t *)s->stage);
+    hipLaunchKernelGGL(k_pack_status, grd, blk, 0, s->stream, g, s->status, s->settled, (const EnvState *)s->commit, env,
+                       (const uint8_t *)s->stage);
     HIPCHK(hipGetLastError());
     rc = rebuild_tflags(s, env, 1);   // control lines may now sit in any tile
     if (rc) return rc;
@@ -795,7 +801,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     // few tiles: one fused launch per step; many: select the live tiles first, then persistent waves
     const bool fused = s->fused_mode == 1 || (s->fused_mode < 0 && n_wave_tiles <= 4096);
     const StepKernel kern = pick_step_kernel(s->g.RB, fused);
-    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active; a.seam = s->seam;
+    a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active; a.seam = s->seam; a.settled = s->settled;
     const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
     static const int waves_per_cu = getenv("SF_WAVES_PER_CU") ? atoi(getenv("SF_WAVES_PER_CU")) : 24;   // persistent grid of k_step
     long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * waves_per_cu / kWaves;
@@ -940,7 +946,7 @@ extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
     rc = ensure_commit(s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_unpack_burn, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)s->age,
+    hipLaunchKernelGGL(k_unpack_burn, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint32_t *)s->settled,
                        (const double *)s->burn, (const EnvState *)s->commit, env, (double *)s->stage);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
@@ -961,7 +967,7 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
     rc = ensure_commit(s);
     if (rc) return rc;
     if (g.att)   // the caller's values are the truth now: nothing is owed any more
-        hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, s->status, (const uint8_t *)s->age, s->burn,
+        hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, s->settled, s->burn,
                            (const EnvState *)s->commit, env, 0);
     HIPCHK(hipMemcpyAsync(s->stage, burn, bytes, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_pack_burn, grd, blk, 0, s->stream, g, s->burn, env, (const double *)s->stage);

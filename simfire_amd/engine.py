@@ -297,15 +297,14 @@ class FireEngine:
         _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))
 
     def fire_map_device(self):
-        """(device pointer, row pitch, env stride) of the uint8 status plane; bit 7 is internal."""
+        """(device pointer, row pitch, env stride) of the uint8 status plane (BurnStatus values)."""
         p, pitch, stride = C.c_void_p(), C.c_int64(), C.c_int64()
         _lib.check(self._L.sf_fire_map_device(self._h, C.byref(p), C.byref(pitch), C.byref(stride)))
         return p.value, int(pitch.value), int(stride.value)
 
     def fire_maps_torch(self):
         """Zero-copy view of all fire_maps as a torch uint8 tensor [n_envs, H, W] on this GPU (RL
-        observations without a PCIe round trip).  Values are BurnStatus | internal bit 7: apply
-        ``& 7`` (``torch.bitwise_and``) before use when rate-of-spread attenuation is on.  The view
+        observations without a PCIe round trip).  The bytes are the BurnStatus values.  The view
         aliases the library's state: read it between calls, do not write to it."""
         import torch
         ptr, pitch, stride = self.fire_map_device()

@@ -421,7 +421,7 @@ class BatchedFireSimulation:
         return self._engine.fire_map(env)
 
     def fire_maps_device(self):
-        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no copy); mask with 7."""
+        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no copy)."""
         return self._engine.fire_maps_torch()
 
     def gather_results(self):
