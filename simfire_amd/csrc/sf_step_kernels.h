@@ -25,9 +25,10 @@ namespace {
 // left seam cell, byte 0 of the NEXT row's pad its right seam cell) + 16, then the status tile
 // [LR * RB][LC * 16].  10 KB per wave at LC = 4, RB = 4: 16 waves per CU.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_select(StepArgs a)
+constexpr int kSelectThreads = 1024;     // few, large workgroups: one list-slot atomic each, and they all hit one address
+__global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
 {
-    __shared__ uint32_t s_base, s_wsum[4];
+    __shared__ uint32_t s_base, s_wsum[kSelectThreads / 64];
     const Geo &g = a.g;
     const int per_env = g.TY * g.TX;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256) void k_select(StepArgs a)
     if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(bal);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t tot = 0;
+        for (int w = 0; w < kSelectThreads / 64; ++w) tot += s_wsum[w];
         s_base = tot ? atomicAdd(&a.n_active[a.launch & 1], tot) : 0u;
         if (blockIdx.x == 0) a.n_active[(a.launch + 1) & 1] = 0;   // counter of the next step
     }

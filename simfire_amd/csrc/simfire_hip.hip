@@ -802,7 +802,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     const bool fused = s->fused_mode == 1 || (s->fused_mode < 0 && n_wave_tiles <= 4096);
     const StepKernel kern = pick_step_kernel(s->g.RB, fused);
     a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active; a.seam = s->seam; a.settled = s->settled;
-    const dim3 sel_grid((unsigned)((n_wave_tiles + 255) / 256));
+    const dim3 sel_grid((unsigned)((n_wave_tiles + kSelectThreads - 1) / kSelectThreads));
     static const int waves_per_cu = getenv("SF_WAVES_PER_CU") ? atoi(getenv("SF_WAVES_PER_CU")) : 24;   // persistent grid of k_step
     long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * waves_per_cu / kWaves;
     if (!fused && want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
@@ -819,7 +819,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
             else if (s->g.ab == 2) hipLaunchKernelGGL(k_step_cells<uint16_t>, cell_grid, dim3(256), 0, s->stream, a);
             else hipLaunchKernelGGL(k_step_cells<uint32_t>, cell_grid, dim3(256), 0, s->stream, a);
         } else {
-            if (!fused) hipLaunchKernelGGL(k_select, sel_grid, dim3(256), 0, s->stream, a);
+            if (!fused) hipLaunchKernelGGL(k_select, sel_grid, dim3(kSelectThreads), 0, s->stream, a);
             hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
             s->ring ^= 1;
         }
