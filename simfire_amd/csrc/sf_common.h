@@ -61,7 +61,7 @@ struct StepArgs {
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
     uint32_t *flags;     // [3][E] ring
     unsigned long long *counters;   // [kCounterShards][8]: active cell-updates, ignitions, frontier items; null = off
-    uint8_t *tflags;     // [2][E][TYp][TXp] tile activity maps: bit0 = tile holds sprites, bit1 = tile holds control lines
+    uint8_t *tflags;     // [2][E][TYp][TXp] tile activity maps: bit0 = tile holds sprites, bits 2-5 = on its top / bottom / left / right edge
     int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
     uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)
     uint32_t *n_active;  // its length

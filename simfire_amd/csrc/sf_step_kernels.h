@@ -13,17 +13,17 @@ namespace {
 // k_select  (one thread per wave tile): folds the per-environment predicates of the previous
 //   step into the environment state, looks at the activity flags of the tile's 3 x 3 tile
 //   neighbourhood and appends the tile to the active list if anything in it can change in this
-//   step: some tile of the neighbourhood holds a sprite, or (attenuation on) the tile itself
-//   holds a control line.  A wave ballot + one atomic per workgroup allocate the list slots.
+//   step: the tile holds a sprite or a neighbour tile holds one on the shared edge.  A wave
+//   ballot + one atomic per workgroup allocate the list slots.
 //   It also zeroes the "next" flag map, which k_step then fills for the tiles it visits.
 // k_step    (persistent waves, grid-stride over the active list): the actual update of a tile.
 //   RB = rows per lane band (compile time: the RB + 2 age rows and RB status rows of a lane live
 //   in registers and are all requested before any of them is used).  A wave tile is LC x 16
-//   cells by LR x RB rows (128 x 32 for large grids).
+//   cells by LR x RB rows (64 x 32 by default).
 // Dynamic LDS of k_step, per wave: frontier list [kListCap] u16, then the staged sprite-mask tile
 // [LR * RB + 2][LC * 16 + 16] bytes (tile row 0 = the row above the tile; byte 15 of a row's pad holds its
 // left seam cell, byte 0 of the NEXT row's pad its right seam cell) + 16, then the status tile
-// [LR * RB][LC * 16].  10 KB per wave at LC = 4, RB = 4: 16 waves per CU.
+// [LR * RB][LC * 16].  5.5 KB per wave at LC = 4, RB = 2.
 // ------------------------------------------------------------------------------------------
 constexpr int kSelectThreads = 1024;     // few, large workgroups: one list-slot atomic each, and they all hit one address
 __global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
 
     // Everything this thread reads is requested before anything is used or stored (one memory round
     // trip instead of five: the kernel is a latency chain, not a bandwidth problem).
-    // flag bits: 0 sprites anywhere, 1 control lines, 2 / 3 sprites in the top / bottom row,
+    // flag bits: 0 sprites anywhere, 2 / 3 sprites in the top / bottom row,
     // 4 / 5 sprites in the left / right column of the tile
     const long long fplane = (long long)g.TYp * g.TXp;
     const uint8_t *f_rd = a.tflags + ((long long)a.ring * g.E + e) * fplane;
@@ -828,18 +828,17 @@ __global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *sta
 {
     const int tx = blockIdx.x, tyw = blockIdx.y, e = env0 + blockIdx.z;
     const int th = g.LR * g.RB, tw = g.LC * 16;
-    uint32_t has_age = 0, has_line = 0;
+    uint32_t has_age = 0;
     for (int i = threadIdx.x; i < th * tw; i += 64) {
         const int y = tyw * th + i / tw, x = tx * tw + i % tw;
         if (y >= g.H || x >= g.W) continue;
         has_age |= age_load(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x);
-        has_line |= (status[(long long)e * g.plane_env + (long long)y * g.P + x] & 7u) >= SF_FIRELINE;
     }
-    const bool a_any = __ballot(has_age != 0) != 0ull, l_any = __ballot(has_line != 0) != 0ull;
+    const bool a_any = __ballot(has_age != 0) != 0ull;
     if (threadIdx.x == 0) {
         const long long o = (long long)(tyw + 1) * g.TXp + tx + 1, plane = (long long)g.TYp * g.TXp;
         for (int k = 0; k < 2; ++k)
-            tflags[((long long)k * g.E + e) * plane + o] = (k == ring) ? (uint8_t)((a_any ? (1 | 4 | 8 | 16 | 32) : 0) | ((g.att && l_any) ? 2 : 0)) : 0;
+            tflags[((long long)k * g.E + e) * plane + o] = (k == ring && a_any) ? (uint8_t)(1 | 4 | 8 | 16 | 32) : (uint8_t)0;
     }
 }
 

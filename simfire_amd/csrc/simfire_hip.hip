@@ -9,18 +9,20 @@
 //
 // Design (DESIGN.md has the derivation and the measurements):
 //   * State per environment, structure-of-arrays in HBM, row pitch P = roundup(W, 16) bytes:
-//       status u8 [H][P]      BurnStatus in bits 0-2 (bit 7 = "line attenuation already settled")
+//       status u8 [H][P]      BurnStatus (the plane is fire_map as uint8)
 //       age    u8 [H+2][P]    bitmask of the live sprites of a cell, indexed by ABSOLUTE ignition
 //                             step modulo N = max_fire_duration + 3 (one zero guard row above/below)
 //       burn   f64 [H][P]     RothermelFireManager.burn_amounts
+//       settled u32 [H][P]    (attenuate_line_ros only) complete-update count a control-line cell is paid up to
+//       seam   u8 [P/64+1][2][H+pad]  copies of the sprite-mask columns at the chunk boundaries
 //     shared by all environments: rt f64 [8][H][P], the rate-of-spread table (ft/min), and a
-//     per-wave-tile activity map (u8 flags: sprites in tile / on which edges, control lines).
+//     per-wave-tile activity map (u8 flags: sprites in tile / on which edges).
 //   * The reference's ordered sprite list is replaced by the order-free per-cell rule of
 //     SURVEY.md section 8a.  Ages are not shifted every step: a sprite ignited at step s owns
 //     bit (s mod N) until it is recycled at step s + max_fire_duration + 2, so the planes are
 //     only written where something happens, and a step runs IN PLACE: every concurrent writer of
 //     a step touches only the two slots (t and t - md - 2) that readers mask out.
-//   * One step = k_select + k_step.  k_select (one thread per 64 x 64 wave tile) folds the
+//   * One step = k_select + k_step.  k_select (one thread per 64 x 32 wave tile) folds the
 //     per-environment predicates of fire.py:637-652 of the previous step (3-deep ring of flag
 //     words), and compacts the tiles in which anything can change into a list (ballot + mbcnt +
 //     one atomic per workgroup).  k_step: persistent waves walk that list; a wave loads its tile
@@ -29,9 +31,11 @@
 //     to a live sprite), compacts those with one wave prefix sum into an LDS list and walks the
 //     list one cell per lane: winner source from the 3 x 3 LDS neighbourhood, one f64 table
 //     entry, f64 burn update, ignition.  Changed 16 B vectors are written back once.
-//   * The only consumer that needs a step's "any candidate" predicate inside the same step - the
-//     attenuation of control-line cells that are not next to the fire (fire.py:271-278) - is
-//     deferred by one step (applied first thing when the cell is next touched).
+//   * The whole-grid attenuation of control-line cells (fire.py:271-278) is lazy: a line cell is
+//     touched only when it becomes a candidate, is overwritten or burn_amounts is read back; the
+//     subtractions it is owed by then are made up bit for bit (lazy_sub, sf_common.h).
+//   * A step lasts as long as its slowest wave (all live tiles are resident at once), so the
+//     kernels are organised around a short per-tile dependency chain, not around throughput.
 //
 // No MFMA: there is no dense contraction anywhere on this path; it is byte / integer work plus a
 // handful of float64 adds per frontier cell.
@@ -777,7 +781,7 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     hipLaunchKernelGGL(k_pack_status, grd, blk, 0, s->stream, g, s->status, s->settled, (const EnvState *)s->commit, env,
                        (const uint8_t *)s->stage);
     HIPCHK(hipGetLastError());
-    rc = rebuild_tflags(s, env, 1);   // control lines may now sit in any tile
+    rc = rebuild_tflags(s, env, 1);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
