@@ -221,6 +221,9 @@ def main():
         timed_steps(eng, w, a.warmup, 0, agent_pts)
     eng.copy_status_to(result.data_ptr())
     steps_before = result[:, 1].sum().item()
+    if dist is not None:
+        # untimed warm-up of the one collective of the rollout (communicator set-up, first-use kernel load)
+        dist.all_gather_into_tensor(gathered, result.to(coll_dev))
 
     def fence():
         torch.cuda.synchronize()
