@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
     ap.add_argument("--generic", action="store_true", help="plain one-thread-per-cell kernel instead of the tiled kernels")
+    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1],
+                    help="-1 automatic, 0 always k_select + k_step, 1 always one fused launch per step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the\n"
                          "multi-rank code path on a box with fewer GPUs than ranks)")
@@ -214,6 +216,7 @@ def main():
     eng = run_gpu(w, a.steps, a.warmup, device, a.rows_per_band)
     eng.set_dense(a.dense)
     eng.set_generic(a.generic)
+    eng.set_fused(a.fused)
     result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{device}")
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
