@@ -550,7 +550,9 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
     const uint32_t j0 = blockIdx.x * kWaves + wave;
     const uint32_t gid0 = a.tile_list[j0];
     for (uint32_t j = j0; j < n_tiles; j += gridDim.x * kWaves) {
-        const uint32_t gid = j == j0 ? gid0 : a.tile_list[j];
+        // wave-uniform, so in an SGPR: what is derived from it (environment, tile origin, plane offsets) is scalar
+        // arithmetic and the row loads take a scalar base - 85 instead of 111 VGPRs at RB = 2 (5 waves per SIMD)
+        const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j == j0 ? gid0 : a.tile_list[j]));
         const int e = gid / (uint32_t)per_env;
         const int tile = gid - e * per_env;
         const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
