@@ -115,7 +115,8 @@ __device__ int g_wave_log_launch = -1;       // -2: record (armed from the host 
 #endif
 
 struct WalkAcc {
-    uint32_t n_active, n_ignite, cand, edges;   // edges: tile flag bits 0, 2..5 set by ignitions
+    uint32_t n_active, n_ignite, cand;   // wave totals / wave-wide predicate (uniform: they live in SGPRs)
+    uint32_t edges;                      // per lane: tile flag bits 0, 2..5 set by ignitions
 };
 __device__ __forceinline__ void acc_merge(WalkAcc &t, const WalkAcc &w)
 {
@@ -177,9 +178,13 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         uint32_t st_new = s_post;                        // S1 prune
         if (g.att && expired && s_pre >= SF_FIRELINE)     // a line on a burning cell, overwritten by the prune (fire.py:140)
             a.burn[cell] = lazy_sub(a.burn[cell], line_factor(s_pre), (uint32_t)complete - a.settled[cell]);
+        {
+            const unsigned long long cb = __ballot(is_cand);
+            acc.n_active += (uint32_t)__popcll(cb);
+            acc.cand |= cb != 0ull;
+        }
+        bool ignited = false;
         if (is_cand) {
-            acc.n_active++;
-            acc.cand = 1;
             // both operands are requested before either is used: one memory round trip, not two
             const double *rt_p = a.rt + ((long long)e * g.rt_env + (long long)bestk * g.H * g.P + idx);
             const bool line = s_post >= SF_FIRELINE;
@@ -199,7 +204,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
             }
             bn = bn + ros;                                                       // fire.py:710
             if (bn > g.pixel_scale) {                                            // fire.py:568
-                acc.n_ignite++;
+                ignited = true;
                 acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
                              ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
                 st_new = SF_BURNING;                                             // fire.py:587
@@ -207,6 +212,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
             }
             a.burn[cell] = bn;
         }
+        acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
         *own_st = (uint8_t)st_new;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -353,7 +359,8 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     uint32_t fm[(RB + 1) / 2];
 #pragma unroll
     for (int k = 0; k < (RB + 1) / 2; ++k) fm[k] = 0;
-    uint32_t live_acc = 0, dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
+    bool live_any = false;              // wave-wide (SGPR): some cell of the tile holds a live sprite
+    uint32_t dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
 #pragma unroll 1
     for (int i = 0; i < RB; ++i) {
         const int y = y0 + i;
@@ -364,7 +371,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         const uint4 midL = and4(mid, L4);
         const uint4 vsrc = and4(or4(up, dn), L4);
         const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
-        live_acc |= any4(midL);
+        live_any |= __ballot(any4(midL) != 0) != 0ull;
         // horizontal neighbours: the bytes just left / right of the lane's 16 cells (the
         // neighbour lane's data, or the seam column parked in the row padding)
         uint32_t lin = rp[row_pitch - 1], rin = rp[row_pitch + 16];
@@ -520,8 +527,8 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         if (lane == 0 && nf) *f_own = (uint8_t)nf;
     }
     // per-environment predicates: wave ballot, then at most one atomic per wave
-    const bool w_live = __ballot(live_acc != 0) != 0ull;
-    const bool w_cand = __ballot(tot_acc.cand != 0) != 0ull;
+    const bool w_live = live_any;
+    const bool w_cand = tot_acc.cand != 0;
     if (lane == 0 && (w_live || w_cand)) {
         // idempotent byte stores (byte 0 = FLAG_LIVE, byte 1 = FLAG_CAND): no read, no atomic, nothing to wait for
         uint8_t *f = reinterpret_cast<uint8_t *>(a.flags + (a.launch % 3) * g.E + e);
@@ -530,8 +537,11 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     }
 }
 
+#ifndef SF_WAVES_SMALL_TILES
+#define SF_WAVES_SMALL_TILES 1
+#endif
 template <int RB>
-__global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArgs a)
+__global__ __launch_bounds__(kWaves * 64, (RB <= 2 ? SF_WAVES_SMALL_TILES : SF_WAVES_PER_SIMD)) void k_step(StepArgs a)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
@@ -574,10 +584,6 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step(StepArg
 #endif
     // optional statistics for the roofline accounting (active cell-updates = phi * cells)
     if (a.counters && n_tiles_done) {
-        for (int off = 32; off > 0; off >>= 1) {
-            n_active += __shfl_down(n_active, off);
-            n_ignite += __shfl_down(n_ignite, off);
-        }
         if (lane == 0) {
             unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
 #ifndef SF_PHASES
@@ -640,10 +646,6 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
     pc.start();
     step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2, pc);
     if (a.counters) {
-        for (int off = 32; off > 0; off >>= 1) {
-            n_active += __shfl_down(n_active, off);
-            n_ignite += __shfl_down(n_ignite, off);
-        }
         if (lane == 0) {
             unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
             if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
