@@ -224,6 +224,8 @@ __global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, cons
 }
 
 // ------------------------------------------------------------- per-environment results
+// 16 cells per load, byte-parallel compares; the pitch padding (x >= W) always holds UNBURNED, so the
+// UNBURNED count is derived from the others.
 __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, const EnvState *commit,
                                                 int32_t *out)
 {
@@ -231,25 +233,39 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
     const int e = blockIdx.y;
     if (threadIdx.x < 8) h[threadIdx.x] = 0;
     __syncthreads();
-    int32_t loc[6] = {0, 0, 0, 0, 0, 0};
-    const uint8_t *st_e = status + (long long)e * g.plane_env;
-    for (int y = blockIdx.x; y < g.H; y += gridDim.x)
-        for (int x = threadIdx.x; x < g.W; x += blockDim.x) {
-            const uint32_t v = st_e[(long long)y * g.P + x] & 7u;
+    int32_t loc[6] = {0, 0, 0, 0, 0, 0};            // loc[0] unused
+    const uint4 *st_e = reinterpret_cast<const uint4 *>(status + (long long)e * g.plane_env);
+    const long long n_vec = (long long)g.H * g.PV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 v = st_e[i];
+        if ((v.x | v.y | v.z | v.w) == 0u) continue;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) loc[k] += (v == (uint32_t)k);
+        for (int k = 1; k < 6; ++k) {
+            int32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t m = w[j] ^ ((uint32_t)k * 0x01010101u);       // bytes are 0..7: zero byte <=> status == k
+                c += 4 - __popc((m + 0x7F7F7F7Fu) & 0x80808080u);
+            }
+            loc[k] += c;
         }
+    }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 1; k < 6; ++k) {
         int32_t v = loc[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[k], v);
     }
     __syncthreads();
-    if (threadIdx.x < 6 && h[threadIdx.x]) atomicAdd(&out[e * 8 + 2 + threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x >= 1 && threadIdx.x < 6 && h[threadIdx.x]) {
+        atomicAdd(&out[e * 8 + 2 + threadIdx.x], h[threadIdx.x]);
+        atomicSub(&out[e * 8 + 2], h[threadIdx.x]);                          // UNBURNED = H * W - the others
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[e * 8 + 0] = commit[e].running;
         out[e * 8 + 1] = commit[e].steps;
+        atomicAdd(&out[e * 8 + 2], g.H * g.W);
     }
 }
 
