@@ -748,14 +748,9 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
 // "at that moment" iff n is BURNING now and did not itself ignite at step t (an ignition needs an
 // eligible, i.e. non-BURNING, status).  Bit j of the mask = neighbour j of graph.py's adj_locs
 // (E, SE, S, SW, W, NW, N, NE); masks are OR-ed over re-ignitions like edges in a DiGraph.
-__global__ __launch_bounds__(256) void k_graph_pass(StepArgs a)
+__device__ __forceinline__ void graph_cell(const StepArgs &a, const Masks &mk, int e, int x, int y)
 {
     const Geo &g = a.g;
-    const int e = blockIdx.z, y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= g.W) return;
-    const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // state with which this step was entered
-    if (!st.running) return;
-    const Masks mk = make_masks(st.steps + 1, g.md, g.N);
     const uint8_t *age_e = a.age + (long long)e * g.age_env * g.ab;
     const long long o = (long long)y * g.P + x, cell = (long long)e * g.plane_env + o;
     if (!(age_load(g, age_e, o) & mk.b_new)) return;        // did not ignite in this step
@@ -770,6 +765,38 @@ __global__ __launch_bounds__(256) void k_graph_pass(StepArgs a)
             mask |= 1u << k;
     }
     if (mask) a.parents[cell] |= (uint8_t)mask;
+}
+
+// every cell (fused / per-cell step kernels: no tile list)
+__global__ __launch_bounds__(256) void k_graph_pass(StepArgs a)
+{
+    const Geo &g = a.g;
+    const int e = blockIdx.z, y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= g.W) return;
+    const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // state with which this step was entered
+    if (!st.running) return;
+    graph_cell(a, make_masks(st.steps + 1, g.md, g.N), e, x, y);
+}
+
+// only the tiles k_step has just visited (an ignition can only have happened there): grid-stride over
+// the tile list of this step, one workgroup per tile
+__global__ __launch_bounds__(256) void k_graph_pass_tiles(StepArgs a)
+{
+    const Geo &g = a.g;
+    const uint32_t n_tiles = a.n_active[a.launch & 1];
+    const int per_env = g.TY * g.TX, tw = g.LC * 16, th = g.LR * g.RB;
+    for (uint32_t j = blockIdx.x; j < n_tiles; j += gridDim.x) {
+        const uint32_t gid = a.tile_list[j];
+        const int e = gid / (uint32_t)per_env, tile = gid - e * per_env;
+        const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
+        const EnvState st = a.tmp[(a.launch & 1) * g.E + e];
+        if (!st.running) continue;
+        const Masks mk = make_masks(st.steps + 1, g.md, g.N);
+        for (int c = threadIdx.x; c < tw * th; c += blockDim.x) {
+            const int x = chunk * tw + c % tw, y = tyw * th + c / tw;
+            if (x < g.W && y < g.H) graph_cell(a, mk, e, x, y);
+        }
+    }
 }
 
 typedef void (*StepKernel)(StepArgs);

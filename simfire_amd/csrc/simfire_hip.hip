@@ -828,7 +828,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
             hipLaunchKernelGGL(kern, step_grid, block, (size_t)kWaves * s->g.lds_wave_bytes, s->stream, a);
             s->ring ^= 1;
         }
-        if (a.parents) hipLaunchKernelGGL(k_graph_pass, cell_grid, dim3(256), 0, s->stream, a);
+        if (a.parents) {
+            if (generic || fused) hipLaunchKernelGGL(k_graph_pass, cell_grid, dim3(256), 0, s->stream, a);
+            else hipLaunchKernelGGL(k_graph_pass_tiles, dim3((unsigned)(s->n_cu * 8)), dim3(256), 0, s->stream, a);
+        }
         if (s->history) hipLaunchKernelGGL(k_record, cell_grid, dim3(256), 0, s->stream, s->g, (const uint8_t *)s->status,
                                            (const EnvState *)(s->tmp + (size_t)(a.launch & 1) * s->g.E), s->history, s->history_cap);
         s->seq = (s->seq + 1) % 6;
