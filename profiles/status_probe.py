@@ -11,3 +11,8 @@ t0 = time.perf_counter()
 for _ in range(50):
     e.status()
 print("status(): %.1f us per call (256 x 1024^2)" % ((time.perf_counter() - t0) / 50 * 1e6))
+t0 = time.perf_counter()
+for _ in range(200):
+    e.step(1)
+    e.status()
+print("step(1) + status(): %.1f us per pair" % ((time.perf_counter() - t0) / 200 * 1e6))

@@ -201,8 +201,9 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint32_t *settled
     }
 }
 
-__global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, const EnvState *commit, const EnvState *tmp,
-                                 const uint32_t *flags, int launch, int from_commit, const int32_t *pts, int n)
+__global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, uint8_t *tdirty, const EnvState *commit,
+                                 const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
+                                 const int32_t *pts, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -221,6 +222,7 @@ __global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, cons
     } while (old != seen);
     if (g.att)      // idempotent: every point of this call on this cell stores the same count
         settled[o] = (uint32_t)entering_state(commit, tmp, flags, launch, from_commit, e, g).complete;
+    tdirty[((long long)e * g.TY + y / (g.LR * g.RB)) * g.TX + (x / 16) / g.LC] = 1;
 }
 
 // ------------------------------------------------------------- per-environment results
@@ -266,6 +268,68 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
         out[e * 8 + 0] = commit[e].running;
         out[e * 8 + 1] = commit[e].steps;
         atomicAdd(&out[e * 8 + 2], g.H * g.W);
+    }
+}
+
+// The same counts from per-tile histograms: only tiles whose status bytes changed since the last query
+// (marked by the step kernels and the mitigation scatter) are recounted, the others come from the
+// cache.  A status query then costs a few MB of traffic instead of a sweep over every fire map.
+// thist: u16 [E * TY * TX][8], entries 1..5 = cells of that BurnStatus in the tile.
+constexpr int kCountTilesPerWave = 16;
+__global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *status, uint8_t *tdirty, uint16_t *thist,
+                                                      const EnvState *commit, int32_t *out)
+{
+    const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_env = g.TY * g.TX;
+    const int c = lane & (g.LC - 1), r = lane >> g.logLC;
+    int32_t tot[6] = {0, 0, 0, 0, 0, 0};
+    const int t0 = (blockIdx.x * 4 + wave) * kCountTilesPerWave;
+    for (int t = t0; t < t0 + kCountTilesPerWave && t < per_env; ++t) {
+        const long long idx = (long long)e * per_env + t;
+        if (tdirty[idx]) {
+            const int tyw = t / g.TX, chunk = t - tyw * g.TX;
+            const int cv = chunk * g.LC + c, y0 = (tyw * g.LR + r) * g.RB;
+            int32_t loc[6] = {0, 0, 0, 0, 0, 0};
+            if (cv < g.PV)
+                for (int i = 0; i < g.RB; ++i) {
+                    if (y0 + i >= g.H) break;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(status + (long long)e * g.plane_env + (long long)(y0 + i) * g.P + cv * 16);
+                    if ((v.x | v.y | v.z | v.w) == 0u) continue;
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 1; k < 6; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            loc[k] += 4 - __popc(((w[j] ^ ((uint32_t)k * 0x01010101u)) + 0x7F7F7F7Fu) & 0x80808080u);
+                }
+#pragma unroll
+            for (int k = 1; k < 6; ++k) {
+                int32_t v = loc[k];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                loc[k] = v;
+                tot[k] += v;
+            }
+            if (lane >= 1 && lane < 6) thist[idx * 8 + lane] = (uint16_t)(lane == 1 ? loc[1] : lane == 2 ? loc[2] : lane == 3 ? loc[3] : lane == 4 ? loc[4] : loc[5]);
+            if (lane == 0) tdirty[idx] = 0;
+        } else {
+            const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
+            tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
+            tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+        }
+    }
+    if (lane == 0) {
+        int32_t others = 0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            if (tot[k]) atomicAdd(&out[e * 8 + 2 + k], tot[k]);
+            others += tot[k];
+        }
+        if (others) atomicSub(&out[e * 8 + 2], others);                              // UNBURNED = H * W - the others
+        if (blockIdx.x == 0 && wave == 0) {
+            out[e * 8 + 0] = commit[e].running;
+            out[e * 8 + 1] = commit[e].steps;
+            atomicAdd(&out[e * 8 + 2], g.H * g.W);
+        }
     }
 }
 

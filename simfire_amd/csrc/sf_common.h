@@ -68,6 +68,7 @@ struct StepArgs {
     uint32_t *settled;   // [E][H][P], attenuation mode only: complete-update count up to which a control-line cell's
                          // attenuation is contained in burn (see lazy_sub)
     uint8_t *seam;       // [E][chunks_x + 1][2][Hs] copies of the sprite-mask columns either side of every chunk boundary
+    uint8_t *tdirty;     // [E][TY][TX] 1 = the tile's status bytes changed since its histogram was last taken (result block)
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)

@@ -514,6 +514,9 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         }
     }
 
+    // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
+    if (__ballot((dirty & 0xFFFFu) != 0) != 0ull && lane == 0)
+        a.tdirty[((long long)e * g.TY + tyw) * g.TX + chunk] = 1;
     pc.mark(5);              // write-back
     // tile activity for the next step: sprites left in the tile or ignited in it (with their edge bits)
     const long long fplane = (long long)g.TYp * g.TXp;
