@@ -216,8 +216,13 @@ int sf_get_spread_parents(sf_sim *sim, int32_t env, uint8_t *parents_out);
 /* 1 = step with the generic one-thread-per-cell kernel (the product path for max_fire_duration > 5,
  * and an independent on-device cross-check of the tiled kernels otherwise), 0 = default. */
 int sf_set_generic(sf_sim *sim, int32_t on);
-/* Step launch structure: -1 = by problem size (default: one fused launch per step up to 4096 wave
- * tiles, k_select + k_step above), 0 = always two launches, 1 = always fused. */
+/* Step launch structure.  -1 = automatic (default): sf_step(n >= 2) on a batch of >= 64 environments is ONE
+ * environment-resident launch (k_run: a workgroup owns an environment for all n steps; environments are
+ * independent FireSimulation objects, simulation.py:202-214, so nothing is synchronised between them);
+ * otherwise one fused launch per step up to 12288 wave tiles, k_select + k_step above.
+ * 0 = always two launches per step, 1 = always one fused launch per step, 2 = always the resident launch
+ * (falls back to the per-step launches while the spread graph / history by-products are on or
+ * max_fire_duration > 5). */
 int sf_set_fused(sf_sim *sim, int32_t mode);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);

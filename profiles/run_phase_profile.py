@@ -1,0 +1,59 @@
+"""Development aid: where the waves of k_run (environment-resident launch) spend their shader clocks, and how the
+work is spread over the environments (C3 workload; library built with -DSF_PHASES, see run_phase_profile.sh)."""
+import ctypes
+import json
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from simfire_amd import workloads            # noqa: E402
+from simfire_amd.engine import FireEngine    # noqa: E402
+from simfire_amd import _lib                 # noqa: E402
+
+NAMES = ["outside step_tile (select, barriers, waiting for the slowest wave)", "rows arrive, quick reject, tile flags",
+         "staging + row loop", "prefix sum + list building", "walk (burn / R-table round trip)", "write-back",
+         "flags + statistics"]
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    envs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    w = workloads.c3(1024, envs)
+    eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    eng.reset(w.init_xy)
+    eng.set_fused(2)
+    eng.step(20)
+    eng.enable_counters(True)
+    out = np.zeros(8, dtype=np.int64)
+    _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
+    fn = eng._L.sf_debug_wave_log
+    fn.argtypes = [ctypes.c_int32, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    log = np.zeros((16384, 4), dtype=np.uint64)
+    fn(0, log.ctypes.data_as(ctypes.c_void_p))      # clears nothing, but makes sure the symbol is there
+    fn(1, None)
+    ms = eng.step_timed(steps)
+    _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
+    fn(0, log.ctypes.data_as(ctypes.c_void_p))
+    tiles = int(out[3])
+    ph = [int(out[i]) for i in (0, 1, 2, 4, 5, 6, 7)]
+    res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "tiles_per_step": tiles / steps,
+           "clocks_per_tile": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},
+           "clocks_per_tile_total": round(sum(ph) / tiles, 1)}
+    clk = log[:envs, 0].astype(np.float64)
+    til = log[:envs, 1].astype(np.float64)
+    stp = log[:envs, 2].astype(np.float64)
+    order = np.argsort(-clk)
+    res["per_env"] = {
+        "clocks_pct_0_50_90_99_100": [float(np.percentile(clk, p)) for p in (0, 50, 90, 99, 100)],
+        "tiles_pct_0_50_90_99_100": [float(np.percentile(til, p)) for p in (0, 50, 90, 99, 100)],
+        "sum_clocks_over_max": float(clk.sum() / max(clk.max(), 1.0)),
+        "slowest_10": [{"env": int(e), "clocks": float(clk[e]), "tiles": float(til[e]), "steps_at_end": float(stp[e]),
+                        "clocks_per_tile": float(clk[e] / max(til[e], 1))} for e in order[:10]]}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -233,8 +233,8 @@ __device__ __forceinline__ unsigned long long load_rows(const uint8_t *p)
 
 template <int RB>
 __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
-                                          uint8_t *lds_wave, uint32_t &n_active, uint32_t &n_ignite,
-                                          uint32_t &n_items_acc, uint32_t &n_phase2, PhaseClock &pc)
+                                          uint8_t *lds_wave, uint8_t *f_own, uint8_t *pred, uint32_t &n_active,
+                                          uint32_t &n_ignite, uint32_t &n_items_acc, uint32_t &n_phase2, PhaseClock &pc)
 {
     const Geo &g = a.g;
     const int LC = g.LC, LR = g.LR;
@@ -519,8 +519,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         a.tdirty[((long long)e * g.TY + tyw) * g.TX + chunk] = 1;
     pc.mark(5);              // write-back
     // tile activity for the next step: sprites left in the tile or ignited in it (with their edge bits)
-    const long long fplane = (long long)g.TYp * g.TXp;
-    uint8_t *f_own = a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * fplane + (long long)(tyw + 1) * g.TXp + (chunk + 1);
+    // (f_own: this tile's entry in the flag map of the next step - global for k_step, LDS for k_run)
     {
         const uint32_t le = tot_acc.edges;
         const uint32_t ed = (__ballot((le & 1u) != 0) ? 1u : 0u) | (__ballot((le & 4u) != 0) ? 4u : 0u) |
@@ -534,9 +533,8 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     const bool w_cand = tot_acc.cand != 0;
     if (lane == 0 && (w_live || w_cand)) {
         // idempotent byte stores (byte 0 = FLAG_LIVE, byte 1 = FLAG_CAND): no read, no atomic, nothing to wait for
-        uint8_t *f = reinterpret_cast<uint8_t *>(a.flags + (a.launch % 3) * g.E + e);
-        if (w_live) f[0] = 1;
-        if (w_cand) f[1] = 1;
+        if (w_live) pred[0] = 1;
+        if (w_cand) pred[1] = 1;
     }
 }
 
@@ -571,7 +569,9 @@ __global__ __launch_bounds__(kWaves * 64, (RB <= 2 ? SF_WAVES_SMALL_TILES : SF_W
         const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
         const EnvState st = a.tmp[(a.launch & 1) * g.E + e];   // already folded by k_select
         pc.mark(0);          // list entry + environment state received
-        step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2, pc);
+        step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave,
+                      a.tflags + ((long long)(a.ring ^ 1) * g.E + e) * ((long long)g.TYp * g.TXp) + (long long)(tyw + 1) * g.TXp + (chunk + 1),
+                      reinterpret_cast<uint8_t *>(a.flags + (a.launch % 3) * g.E + e), n_active, n_ignite, n_items_acc, n_phase2, pc);
         n_tiles_done++;
     }
 #ifdef SF_PHASES
@@ -647,7 +647,8 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0;
     PhaseClock pc;
     pc.start();
-    step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, n_active, n_ignite, n_items_acc, n_phase2, pc);
+    step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, f_wr + o, reinterpret_cast<uint8_t *>(a.flags + (a.launch % 3) * g.E + e),
+                  n_active, n_ignite, n_items_acc, n_phase2, pc);
     if (a.counters) {
         if (lane == 0) {
             unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
@@ -657,6 +658,132 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
             atomicAdd(&cs[3], 1ull);
             if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Environment-resident stepping: sf_step(n) as ONE launch.  Environments never read each other's
+// state (simulation.py:202-214), so a workgroup owns one environment for all n steps and nothing
+// has to be synchronised across workgroups: no per-step launch (and with it no L2 write-back /
+// invalidate between steps - an environment's tiles stay in the L2 of the XCD its workgroup sits on),
+// no k_select sweep over the flags of every tile of every environment, no list / state round trips
+// through HBM, and a fast environment never waits for a slow one.  Per step and workgroup:
+//   select   the tile activity map of the environment lives in LDS (two maps [TYp][TXp], a few hundred
+//            bytes); every thread looks at the 3 x 3 flags of its tiles and appends the live ones to an
+//            LDS list (ballot + mbcnt + one LDS atomic per wave)
+//   update   the waves take list entries off a shared cursor and run step_tile on them - the same
+//            code as k_step; what one wave writes to the cell planes is read by its neighbours in the
+//            next step through the CU's own L1 / L2 (workgroup-scope ordering is enough: one CU)
+//   fold     the predicates of fire.py:637-652 are two LDS bytes; every thread folds them into its
+//            copy of the environment state
+// Two workgroup barriers per step.  LDS: waves x lds_wave_bytes + 2 flag maps + u16 list + 9 control words.
+constexpr int kRunCtl = 12;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] list cursor (rings of 3 steps)
+__host__ __device__ inline int run_shared_bytes(const Geo &g)
+{
+    const int fplane = (g.TYp * g.TXp + 15) / 16 * 16, per_env = (g.TY * g.TX + 7) / 8 * 8;
+    return 2 * fplane + 2 * per_env + kRunCtl * 4;
+}
+
+constexpr int run_max_waves(int rb) { return rb <= 4 ? 16 : 8; }      // 64 x 128 tiles need more than 128 VGPRs per lane
+template <int RB>
+__global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run(StepArgs a, int n_steps)
+{
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(s_dyn);
+    uint8_t *lds_wave = lds + (size_t)wave * g.lds_wave_bytes;
+    uint8_t *shared = lds + (size_t)n_waves * g.lds_wave_bytes;
+    const int fplane = g.TYp * g.TXp, fplane_p = (fplane + 15) / 16 * 16;
+    const int per_env = g.TY * g.TX, per_env_p = (per_env + 7) / 8 * 8;
+    uint8_t *fcur = shared, *fnext = shared + fplane_p;
+    uint16_t *list = reinterpret_cast<uint16_t *>(shared + 2 * fplane_p);
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(shared + 2 * fplane_p + 2 * per_env_p);
+    const int e = blockIdx.x;
+
+    EnvState st = a.commit[e];
+    if (!st.running) return;                    // frozen: run() no longer calls update (uniform over the workgroup)
+    uint8_t *f_glob = a.tflags + ((long long)a.ring * g.E + e) * fplane;
+    for (int i = tid; i < fplane; i += blockDim.x) { fcur[i] = f_glob[i]; fnext[i] = 0; }
+    if (tid < kRunCtl) ctl[tid] = 0;
+    __syncthreads();
+
+    PhaseClock pc;
+    pc.start();
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_tiles_done = 0;
+    for (int s = 0; s < n_steps && st.running; ++s) {
+        const int k = s % 3, kn = (s + 1) % 3;
+        // ---- select (everything it overwrites was last read before the barrier that ended the previous step)
+        if (tid < 3) ctl[3 * tid + kn] = 0;     // ring slots of the next step
+        for (int base = 0; base < per_env; base += blockDim.x) {
+            const int tile = base + tid;
+            const bool valid = tile < per_env;
+            const int tyw = valid ? tile / g.TX : 0, tx = valid ? tile - tyw * g.TX : 0;
+            const int o = (tyw + 1) * g.TXp + (tx + 1);
+            const uint32_t own = fcur[o], up = fcur[o - g.TXp], dn = fcur[o + g.TXp], lf = fcur[o - 1], rt = fcur[o + 1];
+            const uint32_t ul = fcur[o - g.TXp - 1], ur = fcur[o - g.TXp + 1], dl = fcur[o + g.TXp - 1], dr = fcur[o + g.TXp + 1];
+            // which flag bits make the centre tile live: see k_select
+            const bool near = ((own & 1u) | (up & 8u) | (dn & 4u) | (lf & 32u) | (rt & 16u)) != 0 ||
+                              ((ul & 40u) == 40u) | ((ur & 24u) == 24u) | ((dl & 36u) == 36u) | ((dr & 20u) == 20u);
+            const bool active = valid && (g.dense || near);
+            const unsigned long long bal = __ballot(active);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            uint32_t wbase = 0;
+            if (lane == 0 && bal) wbase = atomicAdd(&ctl[k], (uint32_t)__popcll(bal));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (active) list[wbase + rank] = (uint16_t)tile;
+            if (valid) fnext[o] = 0;
+        }
+        __syncthreads();
+        // ---- update: list entries off a shared cursor (tiles differ a lot in work)
+        const uint32_t n_list = ctl[k];
+        for (;;) {
+            uint32_t j = 0;
+            if (lane == 0) j = atomicAdd(&ctl[6 + k], 1u);
+            j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+            if (j >= n_list) break;
+            const int tile = __builtin_amdgcn_readfirstlane((int)list[j]);
+            const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
+            pc.mark(0);
+            step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, fnext + (tyw + 1) * g.TXp + (chunk + 1),
+                          reinterpret_cast<uint8_t *>(ctl + 3 + k), n_active, n_ignite, n_items_acc, n_phase2, pc);
+            n_tiles_done++;
+        }
+        __syncthreads();
+        // ---- fold (every thread the same arithmetic on the same values)
+        st = fold_state(st, ctl[3 + k], g);
+        st.running = __builtin_amdgcn_readfirstlane(st.running);
+        st.steps = __builtin_amdgcn_readfirstlane(st.steps);
+        st.complete = __builtin_amdgcn_readfirstlane(st.complete);
+        st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
+        uint8_t *t = fcur; fcur = fnext; fnext = t;
+    }
+#ifdef SF_PHASES
+    if (lane == 0 && g_wave_log_launch == -2 && e < 4096) {      // per environment: clocks of the workgroup, tiles, steps
+        if (wave == 0) { g_wave_log[e * 4 + 0] = __builtin_readcyclecounter() - pc.t0; g_wave_log[e * 4 + 2] = (unsigned long long)st.steps; }
+        atomicAdd(&g_wave_log[e * 4 + 1], (unsigned long long)n_tiles_done);
+    }
+#endif
+    // ---- hand the environment back: state, tile activity map (the map the next step reads)
+    if (tid == 0) a.commit[e] = st;
+    for (int i = tid; i < per_env; i += blockDim.x) {
+        const int tyw = i / g.TX, tx = i - tyw * g.TX, o = (tyw + 1) * g.TXp + (tx + 1);
+        f_glob[o] = fcur[o];
+    }
+    if (a.counters && n_tiles_done && lane == 0) {
+        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
+#ifndef SF_PHASES
+        if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+        if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+        if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+        atomicAdd(&cs[3], (unsigned long long)n_tiles_done);   // wave tiles visited
+        if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
+#else
+        pc.mark(6);
+        atomicAdd(&cs[3], (unsigned long long)n_tiles_done);
+        atomicAdd(&cs[0], pc.ph[0]); atomicAdd(&cs[1], pc.ph[1]); atomicAdd(&cs[2], pc.ph[2]); atomicAdd(&cs[4], pc.ph[3]);
+        atomicAdd(&cs[5], pc.ph[4]); atomicAdd(&cs[6], pc.ph[5]); atomicAdd(&cs[7], pc.ph[6]);
+#endif
     }
 }
 

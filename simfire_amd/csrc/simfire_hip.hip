@@ -103,7 +103,7 @@ struct sf_sim {
     int ring = 0;                      // tile activity map the next step reads (0/1)
     uint32_t *tile_list = nullptr, *n_active = nullptr;
     int n_cu = 256;
-    int fused_mode = -1;               // -1 auto, 0 never, 1 always: one fused launch per step
+    int fused_mode = -1;               // -1 auto, 0 k_select + k_step, 1 one fused launch per step, 2 one resident launch per sf_step call
     bool generic = false;              // sf_set_generic: per-cell kernel instead of the tiled SWAR kernels
     uint8_t *seam = nullptr;           // seam planes (tiled kernels, 1-byte sprite plane)
     uint32_t *settled = nullptr;       // attenuation bookkeeping per cell (attenuate_line_ros only)
@@ -414,10 +414,11 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
     return SF_OK;
 }
 
-/* -1 = choose by problem size (default), 0 = always k_select + k_step, 1 = always one fused launch */
+/* -1 = choose by problem size (default), 0 = always k_select + k_step, 1 = always one fused launch per step,
+ * 2 = one environment-resident launch per sf_step call (k_run) whenever the handle's options allow it */
 extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 {
-    if (!s || mode < -1 || mode > 1) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0 or 1");
+    if (!s || mode < -1 || mode > 2) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0, 1 or 2");
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
@@ -826,8 +827,34 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * waves_per_cu / kWaves;
     if (!fused && want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
     const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
-    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     const bool generic = s->g.ab > 1 || s->generic;
+    // Environment-resident launch (k_run): all n steps of an environment in one workgroup.  Not with the
+    // per-step by-products (spread graph, history) and not for the wide sprite planes.
+    int run_waves = 0;
+    size_t run_lds = 0;
+    if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1) {
+        static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
+        static const int envs_knob = getenv("SF_RUN_MIN_ENVS") ? atoi(getenv("SF_RUN_MIN_ENVS")) : 64;
+        const int per_env = s->g.TY * s->g.TX;
+        int nw = waves_knob < 1 ? 1 : waves_knob;
+        if (nw > run_max_waves(s->g.RB)) nw = run_max_waves(s->g.RB);
+        if (nw > per_env) nw = per_env;
+        const size_t lds = (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g);
+        const bool fits = per_env <= 65535 && lds <= 160 * 1024;
+        const bool wanted = s->fused_mode == 2 || (n_steps >= 2 && s->g.E >= envs_knob);
+        if (fits && wanted) { run_waves = nw; run_lds = lds; }
+    }
+    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+    if (run_waves) {
+        int rc0 = ensure_commit(s);            // k_run starts from commit[] and leaves the new states there
+        if (rc0) return rc0;
+        a.launch = 0; a.from_commit = 1; a.ring = s->ring;
+        void (*krun)(StepArgs, int) = s->g.RB == 1 ? k_run<1> : s->g.RB == 2 ? k_run<2> : s->g.RB == 4 ? k_run<4> : k_run<8>;
+        if (run_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)run_lds));
+        hipLaunchKernelGGL(krun, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps);
+        n_steps = 0;                           // nothing left for the per-step loop
+    }
     const dim3 cell_grid((unsigned)((s->g.W + 255) / 256), (unsigned)s->g.H, (unsigned)s->g.E);
     for (int i = 0; i < n_steps; ++i) {
         a.launch = s->seq;

@@ -1,0 +1,281 @@
+"""GPU parity tests of the launch structures the benchmark really times, at the benchmark's grids:
+
+* the environment-resident launch (``k_run``: one workgroup owns an environment for all n steps of an
+  ``sf_step(n)`` call) - chunked stepping, hand-over to / from the per-step kernels, QUIT inside a
+  chunk, lazy attenuation, every wave-tile geometry;
+* ``k_select`` + persistent ``k_step`` forced (``set_fused(0)``) on BASELINE-size batches (C3 1024^2,
+  C4 2048^2, C5 1024^2 with agents), including batches in which a persistent wave takes several
+  tiles per step, with the spread-graph pass over the tile list switched on.
+
+Everything is compared bit for bit with ``oracle/fire_dense.c`` fed the device-built R table
+(reference semantics: simfire/game/managers/fire.py:616-719).  Run with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+
+import _golden
+from oracle import fire_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(kw, R8, inits, M_f=None):
+    from simfire_amd.engine import FireEngine
+    eng = FireEngine(**kw)
+    o = fire_dense.DenseOracle(**kw)
+    for x in (eng, o):
+        x.set_rtable(R8)
+        x.reset(inits)
+    return eng, o
+
+
+def _same(eng, o, n_envs, burn_envs=None, tag=None):
+    st, el = eng.status()
+    so, eo = o.status()
+    assert (st == so).all() and (el == eo).all(), tag
+    maps = eng.fire_maps()
+    for e in range(n_envs):
+        assert (maps[e] == o.fire_map(e)).all(), (tag, e)
+    for e in (range(n_envs) if burn_envs is None else burn_envs):
+        assert (eng.burn(e) == o.burn(e)).all(), (tag, e)
+
+
+# ------------------------------------------------------------------ resident launch
+@pytest.mark.parametrize("name", _golden.traj_names())
+def test_resident_replays_golden_trajectories(name):
+    """sf_step(1) through k_run on every golden trajectory: fire_map / status / elapsed_time per step
+    and the final burn_amounts equal the reference's."""
+    from simfire_amd.engine import FireEngine
+    d = _golden.load_traj(name)
+    eng = FireEngine(M_f=float(d["M_f"]), **_golden.engine_kwargs(d))
+    eng.set_fused(2)
+    eng.set_rtable(d["rtable"])
+    eng.reset([d["init_pos"]])
+    _golden.replay(eng, d)
+    assert (eng.burn(0) == d["burn"]).all()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_resident_chunked_random_worlds(seed):
+    """Random worlds (exact R ties, 4/8 connectivity, attenuation, runtime cut-off, barren patches so that
+    some environments reach QUIT inside a chunk), stepped in chunks of random length through k_run with
+    control lines (also on burning cells), a wholesale fire_map replacement and environment resets
+    between chunks - equal to the oracle after every chunk."""
+    rng = np.random.default_rng(8100 + seed)
+    H, W = int(rng.integers(20, 200)), int(rng.integers(20, 300))
+    E = int(rng.integers(1, 7))
+    md = int(rng.integers(1, 6))
+    att, diag = bool(rng.integers(2)), bool(rng.integers(2))
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=md, pixel_scale=float(rng.choice([5.0, 20.0, 50.0])),
+              update_rate=float(rng.choice([1.0, 0.5, 1.5])),
+              max_time=(None if rng.random() < 0.6 else float(rng.integers(10, 60))),
+              attenuate_line_ros=att, diagonal_spread=diag)
+    R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.1] = 0.0
+    if rng.random() < 0.5:
+        R8[:, :, W // 2:] = 0.0                                  # fires die against the barren half
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.set_rows_per_band(int(rng.choice([1, 2, 2, 4, 8])))
+    done = 0
+    while done < 90:
+        n = int(rng.integers(1, 17))
+        if rng.random() < 0.5:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(int(rng.integers(1, 30)))]
+            e0 = int(rng.integers(E))
+            burning = np.argwhere(o.fire_map(e0) == 1)
+            if len(burning):
+                y, x = burning[rng.integers(len(burning))]
+                pts += [(e0, int(x), int(y), int(rng.integers(3, 6))), (e0, int(x), int(y), int(rng.integers(3, 6)))]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        if rng.random() < 0.1:
+            e0 = int(rng.integers(E))
+            new = o.fire_map(e0).copy()
+            new[rng.random((H, W)) < 0.05] = 0
+            eng.load_fire_map(e0, new)
+            o.load_fire_map(e0, new)
+        if rng.random() < 0.1:
+            e0, x, y = int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H))
+            eng.reset_env(e0, x, y)
+            o.reset_env(e0, x, y)
+        eng.step(n)
+        o.step(n)
+        done += n
+        _same(eng, o, E, tag=(seed, done))
+
+
+def test_resident_hands_over_to_per_step_kernels_and_back():
+    """k_run leaves the committed states and the tile activity map exactly as the per-step kernels
+    expect them (and takes them over from those): alternate between all four launch structures and
+    the generic kernel without reading anything back in between."""
+    rng = np.random.default_rng(41)
+    H, W, E = 150, 330, 5
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0,
+              attenuate_line_ros=True, max_time=70.0)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
+    R8[:, :, 250:] = 0.0
+    inits = [(5, 5), (160, 70), (90, 140), (320, 10), (200, 100)]      # (320, 10) sits in barren ground: QUIT early
+    eng, o = _pair(kw, R8, inits)
+    eng.set_async(True)
+    sched = [(2, 7), (0, 3), (2, 1), (1, 4), (2, 9), ("generic", 2), (2, 5), (0, 2), (2, 11), (1, 1), (2, 30)]
+    for i, (mode, n) in enumerate(sched):
+        if mode == "generic":
+            eng.set_generic(True)
+        else:
+            eng.set_generic(False)
+            eng.set_fused(mode)
+        pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(25)]
+        eng.apply_mitigation(pts)
+        o.apply_mitigation(pts)
+        eng.step(n)
+        o.step(n)
+        if i in (4, 8):
+            _same(eng, o, E, tag=i)
+    eng.sync()
+    _same(eng, o, E, tag="end")
+    assert not eng.status()[0][:, 0].all()
+
+
+def test_resident_dense_mode_and_status_histograms():
+    """Dense cross-check mode inside k_run (every tile of the environment on the LDS list every step),
+    and the per-tile status histograms behind the result block stay right when k_run is the only writer."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c3(256, 3)
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    eng.set_fused(2)
+    for dense, n in [(False, 20), (True, 15), (False, 40), (True, 5), (False, 60)]:
+        eng.set_dense(dense)
+        eng.step(n)
+        o.step(n)
+        st, _ = eng.status()
+        maps = eng.fire_maps()
+        for e in range(3):
+            assert (st[e, 2:8] == np.bincount(maps[e].ravel(), minlength=6)).all()
+        _same(eng, o, 3, tag=(dense, n))
+
+
+@pytest.mark.parametrize("waves", [1, 3, 16])
+def test_resident_any_workgroup_size(waves, monkeypatch):
+    """Fewer waves than live tiles: the waves of the workgroup take several tiles per step off the shared
+    cursor (their LDS scratch is reused); the result must not depend on the workgroup size."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r)
+        import numpy as np
+        from oracle import fire_dense
+        from simfire_amd import workloads
+        from simfire_amd.engine import FireEngine
+        w = workloads.c3(512, 4)
+        eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+        eng.set_layers(*w.layers())
+        o = fire_dense.DenseOracle(**w.engine_kwargs())
+        o.set_rtable(eng.get_rtable())
+        eng.reset(w.init_xy); o.reset(w.init_xy)
+        eng.set_fused(2)
+        for n in (70, 1, 130):
+            eng.step(n); o.step(n, 4)
+        assert (eng.status()[0] == o.status()[0]).all()
+        for e in range(4):
+            assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
+        print("OK")
+    """ % root)
+    env = dict(os.environ, SF_RUN_WAVES=str(waves))       # read once per process: run in a child
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+# ------------------------------------------------------------------ BASELINE-size batches, every launch structure
+def _workload_run(w, chunks, fused, agent_pts=None, threads=32, burn_envs=(0, 1), graph=False, dense=False, waves_per_cu=None):
+    from simfire_amd.engine import FireEngine
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.set_rtable(eng.get_rtable())                    # common table: step parity must then be bit-exact
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    eng.set_fused(fused)
+    eng.set_dense(dense)
+    if graph:
+        eng.enable_spread_graph(True)
+    done = 0
+    for n in chunks:
+        if agent_pts is None:
+            eng.step(n)
+            o.step(n, threads)
+        else:
+            eng.set_async(True)
+            for s in range(n):
+                eng.apply_mitigation(agent_pts[done + s])
+                eng.step(1)
+                o.apply_mitigation(agent_pts[done + s])
+                o.step(1, threads)
+            eng.sync()
+            eng.set_async(False)
+        done += n
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), done
+    maps = eng.fire_maps()
+    for e in range(w.n_envs):
+        assert (maps[e] == o.fire_map(e)).all(), e
+    for e in burn_envs:
+        assert (eng.burn(e) == o.burn(e)).all(), e
+    if graph:
+        for e in burn_envs:
+            assert (eng.spread_parents(e) == o.parents(e)).all(), e
+    return eng, o
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_c3_full_grid_32_envs(fused):
+    """C3 grid (1024^2), 32 environments = 16384 wave tiles: above the fused-launch limit, so fused = 0 is
+    k_select (3 x 3 tile flags over 16 x 32 tiles per environment) + persistent k_step; fused = 2 is k_run."""
+    from simfire_amd import workloads
+    _workload_run(workloads.c3(1024, 32), [100, 150], fused)
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_c3_benched_batch_256_envs(fused):
+    """The batch bench.py times: 1024^2 x 256 environments, 150 steps, every environment's final map."""
+    from simfire_amd import workloads
+    _workload_run(workloads.c3(1024, 256), [150], fused, burn_envs=(0, 100, 255))
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_c4_full_grid_8_envs(fused):
+    """C4 grid (2048^2, varying wind), 8 environments = 16384 wave tiles of 32 x 64 per environment."""
+    from simfire_amd import workloads
+    w = workloads.c4(2048, 8)
+    w.init_xy[0] = (1023, 700)          # at the 64-column chunk seams / tile corners
+    w.init_xy[1] = (1024, 1503)
+    w.init_xy[2] = (2047, 2047)
+    _workload_run(w, [60, 90], fused)
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_c5_full_grid_agents(fused):
+    """C5 at its grid: 1024^2 x 32 environments x 64 agents writing one control-line cell per step
+    (lazy attenuation, lines on burning cells), scatter + step pairs enqueued asynchronously.
+    (fused = 2: every step(1) is one k_run launch.)"""
+    from simfire_amd import workloads
+    w = workloads.c5(1024, 32, 64)
+    pts = workloads.agent_walk(32, 64, 1024, 1024, 120)
+    _workload_run(w, [50, 70], fused, agent_pts=pts)
+
+
+def test_persistent_waves_take_several_tiles_with_graph():
+    """set_dense + set_fused(0) on 1024^2 x 16 environments = 8192 list entries for 6144 persistent waves:
+    the grid-stride loop of k_step runs a second iteration (the wave's LDS is reused for the next tile)
+    and k_graph_pass_tiles walks a list longer than its grid."""
+    from simfire_amd import workloads
+    _workload_run(workloads.c3(1024, 16), [40, 40], 0, graph=True, dense=True)
+    # and sparse: many more live tiles than resident waves needs a big batch - covered by bench.py's own check
