@@ -11,9 +11,11 @@ from simfire_amd import workloads            # noqa: E402
 from simfire_amd.engine import FireEngine    # noqa: E402
 from simfire_amd import _lib                 # noqa: E402
 
-NAMES = ["outside step_tile (select, barriers, waiting for the slowest wave)", "rows arrive, quick reject, tile flags",
-         "staging + row loop", "prefix sum + list building", "walk (burn / R-table round trip)", "write-back",
-         "flags + statistics"]
+NAMES = ["0 outside step_tile (select, barriers, waiting for the slowest wave)", "1 sprite rows + seams arrive, quick reject",
+         "2 tile flags, ballots", "3 staging + interest bitmap + vector list", "4 vector item + LDS rows + neighbour masks",
+         "5 status SWAR, stores issued", "6 prefix sum + frontier list", "7 walk: item, neighbourhood, winner",
+         "8 walk: burn / table entry arrive, update", "9 walk: ignition stores, fence", "10 end of pass", "11 tdirty",
+         "12 tile flags, predicates, epilogue", "13", "14", "15"]
 
 
 def main():
@@ -38,7 +40,10 @@ def main():
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
     fn(0, log.ctypes.data_as(ctypes.c_void_p))
     tiles = int(out[3])
-    ph = [int(out[i]) for i in (0, 1, 2, 4, 5, 6, 7)]
+    ph16 = np.zeros(16, dtype=np.uint64)
+    eng._L.sf_debug_phases.argtypes = [ctypes.c_void_p]
+    eng._L.sf_debug_phases(ph16.ctypes.data_as(ctypes.c_void_p))
+    ph = [int(v) for v in ph16]
     res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "tiles_per_step": tiles / steps,
            "clocks_per_tile": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},
            "clocks_per_tile_total": round(sum(ph) / tiles, 1)}

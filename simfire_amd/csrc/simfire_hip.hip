@@ -157,8 +157,8 @@ static void choose_rows_per_band(Geo &g, int rows)
 {
     int rb = 1;
     while (rb * 2 <= rows && rb < 8) rb *= 2;    // the kernel is instantiated for 1, 2, 4, 8
-    // per wave: list + sprite-mask tile [LR * RB + 2][LC * 16 + 16] + 16 + status tile [LR * RB][LC * 16]
-    auto wave_bytes = [&](int r) { return kListCap * 2 + (g.LR * r + 2) * (g.LC * 16 + 16) + 16 + g.LR * r * g.LC * 16; };
+    // per wave: frontier list + vector list [64 * RB] u16 + sprite-mask tile [LR * RB + 2][LC * 16 + 16] + 16
+    auto wave_bytes = [&](int r) { return kListCap * 2 + 128 * r + (g.LR * r + 2) * (g.LC * 16 + 16) + 16; };
     while (rb > 1 && wave_bytes(rb) > 40 * 1024) rb /= 2;
     g.RB = rb;
     g.lds_wave_bytes = (wave_bytes(rb) + 15) / 16 * 16;
@@ -194,9 +194,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     // 64 x (16 * RB) cells = 64 x 64 at RB = 4 - square tiles minimise the number of tiles a fire
     // front crosses (measured on C3: 64 x 64 beats 128 x 32 by 8 % and 256 x 16 by 25 %)
     g.LC = 1; g.logLC = 0;
-    int lc_max = 4;
-    if (const char *v = getenv("SF_LC")) lc_max = atoi(v);   // developer knob
-    while (g.LC < g.PV && g.LC < lc_max) { g.LC <<= 1; g.logLC++; }
+    while (g.LC < g.PV && g.LC < 4) { g.LC <<= 1; g.logLC++; }      // narrower tiles only on grids of one chunk (no seams)
     g.LR = 64 / g.LC;
     g.chunks_x = (g.PV + g.LC - 1) / g.LC;
     g.dense = 0;
@@ -939,6 +937,15 @@ extern "C" int sf_debug_wave_log(int32_t arm, unsigned long long *out)
     int v = -1;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log_launch), &v, sizeof v);
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_log), sizeof(unsigned long long) * 16384 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef SF_PHASES
+extern "C" int sf_debug_phases(unsigned long long *out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long z[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif
 
