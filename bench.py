@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
     ap.add_argument("--generic", action="store_true", help="plain one-thread-per-cell kernel instead of the tiled kernels")
-    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2],
+    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="-1 automatic, 0 always k_select + k_step, 1 always one fused launch per step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the\n"

@@ -224,6 +224,9 @@ int sf_set_generic(sf_sim *sim, int32_t on);
  * (falls back to the per-step launches while the spread graph / history by-products are on or
  * max_fire_duration > 5). */
 int sf_set_fused(sf_sim *sim, int32_t mode);
+/* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
+ * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, -1 = none yet. */
+int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);
 

@@ -11,11 +11,11 @@ from simfire_amd import workloads            # noqa: E402
 from simfire_amd.engine import FireEngine    # noqa: E402
 from simfire_amd import _lib                 # noqa: E402
 
-NAMES = ["0 outside step_tile (select, barriers, waiting for the slowest wave)", "1 sprite rows + seams arrive, quick reject",
-         "2 tile flags, ballots", "3 staging + interest bitmap + vector list", "4 vector item + LDS rows + neighbour masks",
+NAMES = ["0 barrier at the end of the step (waiting for the slowest wave)", "1 interest bitmap + ranks",
+         "2 vector list written, barrier", "3", "4 vector item + rows + neighbour masks arrive",
          "5 status SWAR, stores issued", "6 prefix sum + frontier list", "7 walk: item, neighbourhood, winner",
-         "8 walk: burn / table entry arrive, update", "9 walk: ignition stores, fence", "10 end of pass", "11 tdirty",
-         "12 tile flags, predicates, epilogue", "13", "14", "15"]
+         "8 walk: burn / table entry arrive, update", "9 walk: ignition stores, fence", "10 end of batch", "11",
+         "12 epilogue", "13", "14", "15"]
 
 
 def main():
@@ -39,14 +39,14 @@ def main():
     ms = eng.step_timed(steps)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
     fn(0, log.ctypes.data_as(ctypes.c_void_p))
-    tiles = int(out[3])
+    tiles = max(int(out[5]) // 64, 1)      # batches of 64 vectors (approx.)
     ph16 = np.zeros(16, dtype=np.uint64)
     eng._L.sf_debug_phases.argtypes = [ctypes.c_void_p]
     eng._L.sf_debug_phases(ph16.ctypes.data_as(ctypes.c_void_p))
     ph = [int(v) for v in ph16]
-    res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "tiles_per_step": tiles / steps,
-           "clocks_per_tile": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},
-           "clocks_per_tile_total": round(sum(ph) / tiles, 1)}
+    res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "vector_batches_per_step": tiles / steps, "vectors_per_step": int(out[5]) / steps, "frontier_cells_per_step": int(out[2]) / steps, "walks_per_step": int(out[4]) / steps,
+           "clocks_per_batch": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},
+           "clocks_per_batch_total": round(sum(ph) / tiles, 1)}
     clk = log[:envs, 0].astype(np.float64)
     til = log[:envs, 1].astype(np.float64)
     stp = log[:envs, 2].astype(np.float64)
@@ -56,7 +56,7 @@ def main():
         "tiles_pct_0_50_90_99_100": [float(np.percentile(til, p)) for p in (0, 50, 90, 99, 100)],
         "sum_clocks_over_max": float(clk.sum() / max(clk.max(), 1.0)),
         "slowest_10": [{"env": int(e), "clocks": float(clk[e]), "tiles": float(til[e]), "steps_at_end": float(stp[e]),
-                        "clocks_per_tile": float(clk[e] / max(til[e], 1))} for e in order[:10]]}
+                        "clocks_per_batch": float(clk[e] / max(til[e], 1))} for e in order[:10]]}
     print(json.dumps(res, indent=1))
 
 

@@ -12,7 +12,7 @@ import csv, collections, glob
 for f in sorted(glob.glob("$O/pmc/*counter_collection.csv")):
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_run" in r["Kernel_Name"]:
+        if "k_run" in r["Kernel_Name"] and "rebuild" not in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in sorted(acc.items()):
         print(f.split("/")[-1], k, "launches", len(v), "top3", ["%.4g" % x for x in sorted(v)[-3:]])

@@ -49,6 +49,8 @@ struct Geo {
     long long rt_env;             // element stride between the R tables of two environments (0 = one shared table)
     int Hs;                       // bytes per seam column (row y at index y + kSeamPad; zero guards; covers partial tiles)
     long long seam_env;           // bytes of seam columns per environment = (chunks_x + 1) * 2 * Hs
+    int VW;                       // 64-bit words per row of the vector bitmap = ceil(PV / 64)
+    long long vb_env;             // words of vector bitmap per environment = H * VW
 };
 
 struct StepArgs {
@@ -70,6 +72,7 @@ struct StepArgs {
     uint8_t *seam;       // [E][chunks_x + 1][2][Hs] copies of the sprite-mask columns either side of every chunk boundary
     uint8_t *tdirty;     // [E][TY][TX] 1 = the tile's status bytes changed since its histogram was last taken (result block)
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
+    unsigned long long *vbits;   // [E][H][VW] vector bitmap: bit v of row y = the 16-cell vector holds a sprite bit (k_run)
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

@@ -1,0 +1,429 @@
+// Environment-resident stepping: sf_step(n) as ONE launch, k_run.
+// Part of the single translation unit simfire_hip.hip (see its header comment for the design).
+// Replaces n calls of RothermelFireManager.update, simfire/game/managers/fire.py:616-719, per environment.
+#pragma once
+
+#include "sf_common.h"
+#include "sf_step_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Environments never read each other's state (simulation.py:202-214), so a workgroup owns one
+// environment for all n steps and nothing is synchronised across workgroups: no per-step launch (and
+// with it no L2 write-back / invalidate between steps - an environment's cells stay in the L2 of the XCD
+// its workgroup sits on), no sweep over every tile of every environment, and a fast environment never
+// waits for a slow one.
+//
+// A resident workgroup does not work tile by tile.  What it keeps in LDS for the whole launch is the
+// environment's VECTOR BITMAP: one bit per 16-cell vector of the sprite-mask plane, set while the vector
+// holds any sprite bit (1024 x 1024 cells = 1024 rows x 64 bits = 8 KB).  Per step:
+//   interest  every thread dilates the bitmap rows it owns by one vector in x and one row in y (a handful
+//             of 64-bit shifts / ORs): the vectors in which anything can happen in this step.  A wave
+//             prefix sum + one LDS atomic per wave turn them into the step's vector list (y | v << 16).
+//   vectors   the waves take batches of 64 list entries off a shared cursor, one 16-cell vector per lane:
+//             3 sprite rows + the two edge cells per row + the status vector straight from the cell planes
+//             (the lines sit in this CU's L1 / the XCD's L2 from the step before), SWAR over the 16 cells
+//             (4 per VALU op): expiry -> BURNED (fire.py:116-161), slot recycling, eligible & next to a
+//             live sprite (fire.py:163-234) -> 16-bit frontier mask; changed vectors are stored at once;
+//             a vector that holds no sprite bit any more leaves the bitmap
+//   frontier  the same wave ranks the frontier cells of its batch with one DPP prefix sum into its LDS
+//             window and walks them one cell per lane: 3 x 3 sprite masks (three unaligned dword loads),
+//             winner source, one f64 table entry, burn += R dt - attenuation, burn > pixel_scale ->
+//             BURNING (fire.py:696-710, 550-589): two byte stores + the vector's bit in the bitmap
+//   fold      the predicates of fire.py:637-652 are two LDS bytes; every thread folds them into its copy of
+//             the environment state
+// Two workgroup barriers per step.  What one wave writes to the cell planes is read by the others in the
+// next step through the CU's own L1 / L2 (one workgroup = one CU: workgroup-scope ordering is enough);
+// inside a step the update is in place, like in the tiled kernels: concurrent writers only touch the two
+// mask slots (t and t - md - 2) that every reader masks out.
+// The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
+// them when it switches back), the vector bitmap is not maintained there (k_rebuild_vbits).
+// ------------------------------------------------------------------------------------------
+constexpr int kRunWin = 384;       // frontier cells per walk window of a wave (u32 items in LDS)
+constexpr int kRunCtl = 16;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps)
+constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row)
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap)
+{
+    size_t b = (size_t)g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * kRunWin * 4 + kRunCtl * 4;
+#ifdef SF_PHASES
+    b += 16 * 16 * 4;              // + phase clocks [waves][16]
+#endif
+    return b;
+}
+
+struct RunEnv {                    // per-environment bases (wave-uniform)
+    uint8_t *age, *status;
+    double *burn;
+    uint32_t *settled;
+    const double *rt;
+    unsigned long long *vb;        // LDS bitmap [H][VW]
+    uint8_t *tdirty;               // [TY][TX] of this environment: status histogram of the wave tile is stale
+};
+
+// The walk: one frontier cell per lane.  item = y | x << 16 | status after the prune << 28.
+__device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev, const Masks &mk, int complete,
+                                            uint32_t lo_mask, uint32_t hi_mask, const uint32_t *clist, uint32_t pend,
+                                            int lane, PhaseClock &pc)
+{
+    const Geo &g = a.g;
+    WalkAcc acc = {0u, 0u, 0u, 0u};
+    for (uint32_t j = lane; j < pend; j += 64) {
+        const uint32_t it = clist[j];
+        const int y = it & 0xFFFF, x = (it >> 16) & 0xFFF;
+        const uint32_t s_post = it >> 28;                  // 0, 3, 4, 5: eligible by construction (fire.py:192-205)
+        const uint32_t idx = (uint32_t)(y * g.P + x);
+        // 3 x 3 sprite masks: bytes 0..2 = cells x-1, x, x+1 of the rows y-1, y, y+1 (zero guard rows at -1 and H)
+        const int xo = x ? x - 1 : 0;
+        const uint8_t *q = ev.age + ((y - 1) * g.P + xo);
+        uint32_t up3 = *reinterpret_cast<const u32_unaligned *>(q);
+        uint32_t mid3 = *reinterpret_cast<const u32_unaligned *>(q + g.P);
+        uint32_t dn3 = *reinterpret_cast<const u32_unaligned *>(q + 2 * g.P);
+        if (!x) { up3 <<= 8; mid3 <<= 8; dn3 <<= 8; }                              // no column -1
+        if (x + 1 >= g.W) { up3 &= 0xFFFFu; mid3 &= 0xFFFFu; dn3 &= 0xFFFFu; }      // no column W
+        const uint32_t own = (mid3 >> 8) & 0xFFu;
+        const int bestk = pick_winner8(up3, mid3, dn3, mk, lo_mask, hi_mask);
+        const bool is_cand = bestk >= 0;
+        pc.mark(7);          // list item, neighbourhood, winner
+        {
+            const unsigned long long cb = __ballot(is_cand);
+            acc.n_active += (uint32_t)__popcll(cb);
+            acc.cand |= cb != 0ull;
+        }
+        bool ignited = false;
+        if (is_cand) {
+            // both operands are requested before either is used: one memory round trip, not two
+            const double *rt_p = ev.rt + ((long long)bestk * g.H * g.P + idx);
+            const bool line = s_post >= SF_FIRELINE;
+            double bn = ev.burn[idx];
+            double r_tab = *rt_p;
+            uint32_t owed = 0;
+            if (line && g.att) owed = (uint32_t)complete - ev.settled[idx];
+            asm volatile("" : "+v"(bn), "+v"(r_tab), "+v"(owed));     // keeps the loads from being sunk behind the first use of bn
+            double ros = r_tab * g.update_rate;                                  // fire.py:696,705
+            if (line) {                                                          // fire.py:271-282
+                if (g.att) {
+                    const double f = line_factor(s_post);
+                    bn = lazy_sub(bn, f, owed);          // the updates since this cell was last touched (fire.py:278, ros = 0)
+                    ros = ros - f;
+                    ev.settled[idx] = (uint32_t)complete + 1u;                   // this update runs to the end: it has a candidate
+                } else ros = 0.0;
+            }
+            bn = bn + ros;                                                       // fire.py:710
+            ev.burn[idx] = bn;
+            pc.mark(8);      // burn / table entry arrived
+            if (bn > g.pixel_scale) {                                            // fire.py:568
+                ignited = true;
+                const uint8_t nb = (uint8_t)((own & ~mk.b_clr) | mk.b_new);       // fire.py:571-579
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the vector pass's 16-byte stores to these lines have landed
+                ev.status[idx] = (uint8_t)SF_BURNING;                            // fire.py:587
+                ev.age[idx] = nb;
+                atomicOr(&ev.vb[y * g.VW + (x >> 10)], 1ull << ((x >> 4) & 63));
+                ev.tdirty[(y / (g.LR * g.RB)) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+            }
+        }
+        acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    pc.mark(9);              // ignition stores
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
+{
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
+    const int e = blockIdx.x;
+    unsigned long long *vb = reinterpret_cast<unsigned long long *>(s_dyn);        // [H][VW]
+    uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)g.H * g.VW);       // [vcap]
+    uint32_t *clist = vlist + vcap + wave * kRunWin;                               // [kRunWin] per wave
+    uint32_t *ctl = vlist + vcap + n_waves * kRunWin;
+
+    EnvState st = a.commit[e];
+    if (!st.running) return;                    // frozen: run() no longer calls update (uniform over the workgroup)
+    unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
+    const int n_words = g.H * g.VW;
+    for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];
+    if (tid < kRunCtl) ctl[tid] = 0;
+    PhaseClock pc;
+#ifdef SF_PHASES
+    uint32_t *ph_acc = ctl + kRunCtl + wave * 16;
+    if (lane < 16) ph_acc[lane] = 0;
+    pc.start(ph_acc);
+#else
+    pc.start();
+#endif
+    __syncthreads();
+
+    RunEnv ev;
+    ev.age = a.age + (long long)e * g.age_env;
+    ev.status = a.status + (long long)e * g.plane_env;
+    ev.burn = a.burn + (long long)e * g.plane_env;
+    ev.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
+    ev.rt = a.rt + (long long)e * g.rt_env;
+    ev.vb = vb;
+    ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+    const int rpt = (g.H + nthr - 1) / nthr;                  // rows per thread (contiguous, so the list runs by rows)
+    const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
+
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
+    for (int s = 0; s < n_steps && st.running; ++s) {
+        const int k = s % 3, kn = (s + 1) % 3;
+        if (tid < 3) ctl[3 * tid + kn] = 0;     // ring slots of the next step (last read before the barrier that ended step s - 1)
+        const int t = st.steps + 1;
+        const Masks mk = make_masks(t, g.md, g.N);
+        const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
+        const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
+        const int exp_sh = __ffs(mk.b_exp) - 1;
+        const uint32_t lo_mask = g.diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = g.diag ? L4 : (L4 & 0x00FF00FFu);
+
+        // ---- interest: D = the bitmap dilated by one vector / one row (kept in registers: the passes below change the bitmap)
+        unsigned long long D[kRunMaxD];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int d = 0; d < kRunMaxD; ++d) {
+            D[d] = 0;
+            const int i = d / g.VW, w = d - i * g.VW;           // row of this thread, word of the row
+            const int y = tid * rpt + i;
+            if (i < rpt && y < g.H) {
+                unsigned long long acc = 0;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int yy = y + dy;
+                    if (yy < 0 || yy >= g.H) continue;
+                    const unsigned long long *row = vb + yy * g.VW;
+                    const unsigned long long c = row[w];
+                    acc |= c | (c << 1) | (c >> 1);
+                    if (w > 0) acc |= row[w - 1] >> 63;
+                    if (w + 1 < g.VW) acc |= row[w + 1] << 63;
+                }
+                if (g.dense) acc = ~0ull;
+                if (w == g.VW - 1) acc &= last_word_mask;
+                D[d] = acc;
+                cnt += (uint32_t)__popcll(acc);
+            }
+        }
+        // list positions: prefix sum inside the wave, one LDS atomic per wave for its range
+        const uint32_t incl = wave_scan_incl(cnt, lane);
+        const uint32_t wave_total = wave_last(incl);
+        uint32_t wbase = 0;
+        if (lane == 0 && wave_total) wbase = atomicAdd(&ctl[k], wave_total);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        const uint32_t pos0 = wbase + incl - cnt;
+        pc.mark(1);          // interest bitmap + ranks
+
+        uint32_t n_all = 0;
+        for (uint32_t cb = 0;; cb += (uint32_t)vcap) {
+            // ---- this chunk of the vector list (one chunk unless the fire needs more than vcap vectors)
+            {
+                uint32_t p = pos0;
+#pragma unroll
+                for (int d = 0; d < kRunMaxD; ++d) {
+                    unsigned long long m = D[d];
+                    const int i = d / g.VW, w = d - i * g.VW;
+                    const uint32_t base_item = (uint32_t)(tid * rpt + i) | ((uint32_t)(w * 64) << 16);
+                    while (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const uint32_t slot = p - cb;         // wraps for p < cb: not in this chunk
+                        if (slot < (uint32_t)vcap) vlist[slot] = base_item + ((uint32_t)b << 16);
+                        p++;
+                    }
+                }
+            }
+            __syncthreads();
+            n_all = ctl[k];
+            const uint32_t n_chunk = n_all - cb < (uint32_t)vcap ? n_all - cb : (uint32_t)vcap;
+            pc.mark(2);      // vector list written, barrier
+
+            // ---- batches of 64 vectors off the shared cursor
+            for (;;) {
+                uint32_t j0 = 0;
+                if (lane == 0) j0 = atomicAdd(&ctl[6 + k], 64u);
+                j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);
+                if (j0 >= n_chunk) break;
+                const bool has = j0 + lane < n_chunk;
+                const uint32_t item = has ? vlist[j0 + lane] : 0u;
+                const int y = item & 0xFFFF, v = item >> 16;
+                const int x0 = v * 16;
+                const uint32_t voff = (uint32_t)(y * g.P + x0);
+                const uint8_t *ra = ev.age + voff;
+                uint4 up = make_uint4(0, 0, 0, 0), mid = up, dn = up, sr = up;
+                uint32_t lin = 0, rin = 0;
+                if (has) {
+                    mid = *reinterpret_cast<const uint4 *>(ra);
+                    up = *reinterpret_cast<const uint4 *>(ra - g.P);
+                    dn = *reinterpret_cast<const uint4 *>(ra + g.P);
+                    sr = *reinterpret_cast<const uint4 *>(ev.status + voff);
+                    // the cells just left / right of the vector
+                    if (v > 0) {
+                        lin = *reinterpret_cast<const uint32_t *>(ra - 4);
+                        if (g.diag) lin |= *reinterpret_cast<const uint32_t *>(ra - g.P - 4) | *reinterpret_cast<const uint32_t *>(ra + g.P - 4);
+                        lin >>= 24;
+                    }
+                    if (x0 + 16 < g.W) {
+                        rin = *reinterpret_cast<const uint32_t *>(ra + 16);
+                        if (g.diag) rin |= *reinterpret_cast<const uint32_t *>(ra - g.P + 16) | *reinterpret_cast<const uint32_t *>(ra + g.P + 16);
+                        rin &= 0xFFu;
+                    }
+                }
+                n_vec_done += (lane == 0) ? (n_chunk - j0 < 64u ? n_chunk - j0 : 64u) : 0u;
+                lin &= mk.m_live;
+                rin &= mk.m_live;
+                const uint4 midL = and4(mid, L4);
+                const uint4 vsrc = and4(or4(up, dn), L4);
+                const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+                if (__ballot(any4(midL) != 0) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;   // FLAG_LIVE
+                uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
+                nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
+                nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
+                nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
+                nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
+                pc.mark(4);      // vector item + rows + neighbour masks
+
+                const uint4 ex4 = and4(mid, EXP4);
+                const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = spread ? any4(nb) : 0u;
+                if (has && any_clr) {   // recycle the slot of sprites that were pruned one step ago
+                    const uint4 av = and4(mid, ~CLR4);
+                    *reinterpret_cast<uint4 *>(ev.age + voff) = av;
+                    if (!any4(av)) atomicAnd(&vb[y * g.VW + (v >> 6)], ~(1ull << (v & 63)));     // no sprite bit left in the vector
+                }
+                uint32_t m16 = 0;
+                uint4 snew = sr;
+                if (has && (any_exp | any_nb)) {
+                    const uint4 s7 = and4(sr, 0x07070707u);
+                    // S1 prune: cells whose sprite reached max_fire_duration become BURNED
+                    uint4 em;   // 0xFF per expiring byte (x * 255 == (x << 8) - x: no 32-bit multiply)
+                    em.x = spread01((ex4.x >> exp_sh) & 0x01010101u);
+                    em.y = spread01((ex4.y >> exp_sh) & 0x01010101u);
+                    em.z = spread01((ex4.z >> exp_sh) & 0x01010101u);
+                    em.w = spread01((ex4.w >> exp_sh) & 0x01010101u);
+                    snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
+                    snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
+                    snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
+                    snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
+                    if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) {
+                        *reinterpret_cast<uint4 *>(ev.status + voff) = snew;
+                        // attenuation mode: a control line drawn on a burning cell ends when that sprite expires (the prune
+                        // overwrites it with BURNED, fire.py:140): make up the attenuation the cell is still owed
+                        if (g.att) {
+                            uint32_t sp16 = pack4(ge3_01(s7.x) & em.x & 0x01010101u) | (pack4(ge3_01(s7.y) & em.y & 0x01010101u) << 4) |
+                                            (pack4(ge3_01(s7.z) & em.z & 0x01010101u) << 8) | (pack4(ge3_01(s7.w) & em.w & 0x01010101u) << 12);
+                            while (sp16) {
+                                const int b = __ffs(sp16) - 1;
+                                sp16 &= sp16 - 1;
+                                const uint32_t s_pre = (pick(s7, b >> 2) >> (8 * (b & 3))) & 7u;
+                                ev.burn[voff + b] = lazy_sub(ev.burn[voff + b], line_factor(s_pre), (uint32_t)st.complete - ev.settled[voff + b]);
+                            }
+                        }
+                    }
+                    if (any_nb) {
+                        // frontier cells (0 / 1 per byte): eligible (fire.py:192-205) & next to a live sprite
+                        uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+                        uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+                        uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+                        uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+                        // pitch padding (x >= W) never takes part
+                        if (x0 + 16 > g.W) {
+                            const int nv = g.W - x0;          // valid cells of this vector
+                            p0 &= first01(nv); p1 &= first01(nv - 4); p2 &= first01(nv - 8); p3 &= first01(nv - 12);
+                        }
+                        m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+                    }
+                }
+                // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
+                const bool st_ch = ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) != 0;
+                if (st_ch) ev.tdirty[(y / (g.LR * g.RB)) * g.TX + (v >> g.logLC)] = 1;
+                pc.mark(5);      // status arrived, SWAR, stores issued
+
+                // ---- frontier cells of this batch -> the wave's window list -> walk
+                const uint32_t mine = (uint32_t)__popc(m16);
+                if (__ballot(mine != 0) != 0ull) {
+                    const uint32_t incl_c = wave_scan_incl(mine, lane);
+                    const uint32_t total = wave_last(incl_c);
+                    const uint32_t excl = incl_c - mine;
+#pragma unroll 1
+                    for (uint32_t win = 0; win < total; win += (uint32_t)kRunWin) {
+                        uint32_t pos = excl, m = m16;
+                        while (m) {
+                            const int b = __ffs(m) - 1;
+                            m &= m - 1;
+                            const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
+                            if (slot < (uint32_t)kRunWin) {
+                                const uint32_t code = (pick(snew, b >> 2) >> (8 * (b & 3))) & 7u;
+                                clist[slot] = (uint32_t)y | ((uint32_t)(x0 + b) << 16) | (code << 28);
+                            }
+                            pos++;
+                        }
+                        const uint32_t tot = total - win < (uint32_t)kRunWin ? total - win : (uint32_t)kRunWin;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        pc.mark(6);  // prefix sum + frontier list
+                        const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, tot, lane, pc);
+                        n_active += wk.n_active;
+                        n_ignite += wk.n_ignite;
+                        if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
+                        n_items_acc += (lane == 0) ? tot : 0u;
+                        n_phase2++;
+                    }
+                }
+                pc.mark(10);
+            }
+            if (cb + (uint32_t)vcap >= n_all) break;       // (uniform) the usual case: one chunk
+            __syncthreads();                               // everybody is done with this chunk's list
+            if (tid == 0) ctl[6 + k] = 0;
+        }
+        __syncthreads();
+        pc.mark(0);          // waiting for the slowest wave of the step
+        // ---- fold (every thread the same arithmetic on the same values)
+        st = fold_state(st, ctl[3 + k], g);
+        st.running = __builtin_amdgcn_readfirstlane(st.running);
+        st.steps = __builtin_amdgcn_readfirstlane(st.steps);
+        st.complete = __builtin_amdgcn_readfirstlane(st.complete);
+        st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
+    }
+#ifdef SF_PHASES
+    pc.mark(12);
+    if (lane == 0 && g_wave_log_launch == -2)
+        for (int q = 0; q < 16; ++q) if (pc.acc[q]) atomicAdd(&g_phase[q], (unsigned long long)pc.acc[q]);
+    if (lane == 0 && g_wave_log_launch == -2 && e < 4096) {      // per environment: clocks of the workgroup, vectors, steps
+        if (wave == 0) { g_wave_log[e * 4 + 0] = __builtin_readcyclecounter() - pc.t0; g_wave_log[e * 4 + 2] = (unsigned long long)st.steps; }
+        atomicAdd(&g_wave_log[e * 4 + 1], (unsigned long long)n_vec_done);
+    }
+#endif
+    // ---- hand the environment back: state, vector bitmap
+    __syncthreads();
+    if (tid == 0) a.commit[e] = st;
+    for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
+    if (a.counters && lane == 0) {
+        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
+        if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+        if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+        if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
+        if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
+        if (n_vec_done) atomicAdd(&cs[5], (unsigned long long)n_vec_done);   // 16-cell vectors visited
+    }
+}
+
+// The vector bitmap of environments [env0, env0 + n) from their sprite-mask planes (after steps of the per-step
+// kernels, which do not maintain it).  One wave per (row, 64-vector word).
+__global__ __launch_bounds__(64) void k_rebuild_vbits(Geo g, const uint8_t *age, unsigned long long *vbits, int env0)
+{
+    const int w = blockIdx.x, y = blockIdx.y, e = env0 + blockIdx.z, lane = threadIdx.x;
+    const int v = w * 64 + lane;
+    uint32_t any = 0;
+    if (v < g.PV) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16);
+        any = any4(r);
+    }
+    const unsigned long long bal = __ballot(any != 0);
+    if (lane == 0) vbits[(long long)e * g.vb_env + (long long)y * g.VW + w] = bal;
+}
+
+}  // namespace

@@ -691,7 +691,8 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
 }
 
 // ------------------------------------------------------------------------------------------
-// Environment-resident stepping: sf_step(n) as ONE launch.  Environments never read each other's
+// Environment-resident stepping, tile flavour (the vector flavour, k_run, is in sf_run_kernels.h):
+// sf_step(n) as ONE launch.  Environments never read each other's
 // state (simulation.py:202-214), so a workgroup owns one environment for all n steps and nothing
 // has to be synchronised across workgroups: no per-step launch (and with it no L2 write-back /
 // invalidate between steps - an environment's tiles stay in the L2 of the XCD its workgroup sits on),
@@ -706,20 +707,20 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
 //   fold     the predicates of fire.py:637-652 are two LDS bytes; every thread folds them into its
 //            copy of the environment state
 // Two workgroup barriers per step.  LDS: waves x lds_wave_bytes + 2 flag maps + u16 list + 9 control words.
-constexpr int kRunCtl = 12;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] list cursor (rings of 3 steps)
+constexpr int kRunTCtl = 12;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] list cursor (rings of 3 steps)
 __host__ __device__ inline int run_shared_bytes(const Geo &g)
 {
     const int fplane = (g.TYp * g.TXp + 15) / 16 * 16, per_env = (g.TY * g.TX + 7) / 8 * 8;
 #ifdef SF_PHASES
-    return 2 * fplane + 2 * per_env + kRunCtl * 4 + 16 * 16 * 4;      // + phase clocks [waves][16]
+    return 2 * fplane + 2 * per_env + kRunTCtl * 4 + 16 * 16 * 4;      // + phase clocks [waves][16]
 #else
-    return 2 * fplane + 2 * per_env + kRunCtl * 4;
+    return 2 * fplane + 2 * per_env + kRunTCtl * 4;
 #endif
 }
 
 constexpr int run_max_waves(int rb) { return rb <= 4 ? 16 : 8; }      // 64 x 128 tiles need more than 128 VGPRs per lane
 template <int RB>
-__global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run(StepArgs a, int n_steps)
+__global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run_tiles(StepArgs a, int n_steps)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
@@ -738,12 +739,12 @@ __global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run(StepArgs a, int 
     if (!st.running) return;                    // frozen: run() no longer calls update (uniform over the workgroup)
     uint8_t *f_glob = a.tflags + ((long long)a.ring * g.E + e) * fplane;
     for (int i = tid; i < fplane; i += blockDim.x) { fcur[i] = f_glob[i]; fnext[i] = 0; }
-    if (tid < kRunCtl) ctl[tid] = 0;
+    if (tid < kRunTCtl) ctl[tid] = 0;
     __syncthreads();
 
     PhaseClock pc;
 #ifdef SF_PHASES
-    uint32_t *ph_acc = ctl + kRunCtl + wave * 16;
+    uint32_t *ph_acc = ctl + kRunTCtl + wave * 16;
     if (lane < 16) ph_acc[lane] = 0;
     pc.start(ph_acc);
 #else
@@ -990,7 +991,7 @@ __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t 
 }
 
 __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commit, uint8_t *tflags, int ring,
-                           const int32_t *xy, int env0, int n)
+                           unsigned long long *vbits, const int32_t *xy, int env0, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1000,6 +1001,7 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     age_store(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x, 1u);   // ignition step 0
     const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
     tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
+    vbits[(long long)e * g.vb_env + (long long)y * g.VW + (x >> 10)] = 1ull << ((x >> 4) & 63);        // (cleared by the caller)
     EnvState s;
     s.running = 1; s.steps = 0; s.complete = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);

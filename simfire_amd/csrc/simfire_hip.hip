@@ -81,6 +81,7 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 #include "sf_common.h"
 #include "sf_step_kernels.h"
 #include "sf_aux_kernels.h"
+#include "sf_run_kernels.h"
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -112,6 +113,10 @@ struct sf_sim {
     size_t n_tiles_max = 0;
     void *status_pinned = nullptr;     // pinned landing zone of the result block (int32 [E][8] + double [E])
     bool tdirty_all = true;            // every histogram is stale (reset, fire_map replaced, geometry changed, per-cell kernel ran)
+    unsigned long long *vbits = nullptr;   // vector bitmap of the resident launch (k_run)
+    bool vbits_valid = false;          // vbits matches the sprite-mask planes (k_run / reset keep it; the per-step kernels do not)
+    bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
+    int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -239,6 +244,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.seam_env = (long long)(g.chunks_x + 1) * 2 * g.Hs;
     TRY(dev_alloc(s, &s->seam, (size_t)g.E * g.seam_env));
     if (g.att) TRY(dev_alloc(s, &s->settled, cells));
+    g.VW = (g.PV + 63) / 64; g.vb_env = (long long)g.H * g.VW;
+    TRY(dev_alloc(s, &s->vbits, (size_t)g.E * g.vb_env));
     s->n_tiles_max = (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x;      // RB = 1 is the finest tiling
     TRY(dev_alloc(s, &s->tdirty, s->n_tiles_max));
     TRY(dev_alloc(s, &s->thist, s->n_tiles_max * 8));
@@ -250,6 +257,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
+    HIPCHK(hipMemsetAsync(s->vbits, 0, (size_t)g.E * g.vb_env * sizeof(unsigned long long), s->stream));
     if (s->settled) HIPCHK(hipMemsetAsync(s->settled, 0, cells * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
@@ -266,7 +274,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist,
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
@@ -323,13 +331,7 @@ extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // also clears the list counters of the tiled path
     choose_rows_per_band(s->g, rows);
     s->tdirty_all = true;
-    // the tile activity map is laid out per wave tile: rebuild it for the new geometry
-    HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
-    if (s->was_reset) {
-        int rc = rebuild_tflags(s, 0, s->g.E);
-        if (rc) return rc;
-    }
-    HIPCHK(hipStreamSynchronize(s->stream));
+    s->tiles_valid = false;            // the tile activity map is laid out per wave tile: rebuilt for the new geometry before the next tiled step
     return SF_OK;
 }
 
@@ -398,17 +400,8 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
     if (!s) return fail(SF_EINVAL, "sf_set_generic: null handle");
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the list counters of the tiled path restart clean
-    const bool was = s->generic;
     s->generic = on != 0;
     s->tdirty_all = true;
-    if (was && !s->generic && s->was_reset && s->g.ab == 1) {
-        HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
-        int rc = rebuild_tflags(s, 0, s->g.E);
-        if (rc) return rc;
-        rc = rebuild_seams(s, 0, s->g.E);
-        if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(s->stream));
-    }
     return SF_OK;
 }
 
@@ -416,7 +409,7 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
  * 2 = one environment-resident launch per sf_step call (k_run) whenever the handle's options allow it */
 extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 {
-    if (!s || mode < -1 || mode > 2) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0, 1 or 2");
+    if (!s || mode < -1 || mode > 3) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0, 1, 2 or 3");
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
@@ -681,8 +674,9 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     const size_t fplane = (size_t)g.TYp * g.TXp;
     for (int k = 0; k < 2; ++k)
         HIPCHK(hipMemsetAsync(s->tflags + ((size_t)k * g.E + env0) * fplane, 0, (size_t)n * fplane, s->stream));
+    HIPCHK(hipMemsetAsync(s->vbits + (size_t)env0 * g.vb_env, 0, (size_t)n * g.vb_env * sizeof(unsigned long long), s->stream));
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
-                       s->tflags, s->ring, (const int32_t *)s->stage, env0, n);
+                       s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n);
     HIPCHK(hipGetLastError());
     rc = rebuild_seams(s, env0, n);
     if (rc) return rc;
@@ -695,7 +689,7 @@ extern "C" int sf_reset(sf_sim *s, const int32_t *init_xy)
 {
     if (!s || !init_xy) return fail(SF_EINVAL, "sf_reset: null argument");
     int rc = reset_range(s, 0, s->g.E, init_xy);
-    if (rc == SF_OK) s->was_reset = true;
+    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->tiles_valid = true; }     // every environment freshly written
     return rc;
 }
 
@@ -800,6 +794,36 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     return SF_OK;
 }
 
+// The per-step tiled kernels keep the tile activity map and the seam planes, the resident launch keeps the vector
+// bitmap; whichever a launch needs is rebuilt from the sprite-mask planes if the other kind ran in between.
+static int ensure_tiles(sf_sim *s)
+{
+    if (s->tiles_valid) return SF_OK;
+    HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
+    int rc = rebuild_tflags(s, 0, s->g.E);
+    if (rc) return rc;
+    rc = rebuild_seams(s, 0, s->g.E);
+    if (rc) return rc;
+    s->tiles_valid = true;
+    return SF_OK;
+}
+static int ensure_vbits(sf_sim *s)
+{
+    if (s->vbits_valid) return SF_OK;
+    const Geo &g = s->g;
+    hipLaunchKernelGGL(k_rebuild_vbits, dim3(g.VW, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->age, s->vbits, 0);
+    HIPCHK(hipGetLastError());
+    s->vbits_valid = true;
+    return SF_OK;
+}
+
+extern "C" int sf_last_step_launch(sf_sim *s, int32_t *kind)
+{
+    if (!s || !kind) return fail(SF_EINVAL, "sf_last_step_launch: null argument");
+    *kind = s->last_kind;
+    return SF_OK;
+}
+
 static int step_impl(sf_sim *s, int n_steps, float *ms)
 {
     if (!s) return fail(SF_EINVAL, "sf_step: null handle");
@@ -828,30 +852,71 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
     const bool generic = s->g.ab > 1 || s->generic;
     // Environment-resident launch (k_run): all n steps of an environment in one workgroup.  Not with the
     // per-step by-products (spread graph, history) and not for the wide sprite planes.
-    int run_waves = 0;
+    int run_waves = 0, run_vcap = 0;
     size_t run_lds = 0;
-    if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1) {
+    int runt_waves = 0;                        // tile flavour of the resident launch (sf_set_fused(3))
+    size_t runt_lds = 0;
+    if (!generic && !a.parents && !s->history && s->fused_mode == 3) {
         static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
-        static const int envs_knob = getenv("SF_RUN_MIN_ENVS") ? atoi(getenv("SF_RUN_MIN_ENVS")) : 64;
         const int per_env = s->g.TY * s->g.TX;
         int nw = waves_knob < 1 ? 1 : waves_knob;
         if (nw > run_max_waves(s->g.RB)) nw = run_max_waves(s->g.RB);
         if (nw > per_env) nw = per_env;
+        while (nw > 1 && (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g) > 160 * 1024) --nw;
         const size_t lds = (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g);
-        const bool fits = per_env <= 65535 && lds <= 160 * 1024;
-        const bool wanted = s->fused_mode == 2 || (n_steps >= 2 && s->g.E >= envs_knob);
-        if (fits && wanted) { run_waves = nw; run_lds = lds; }
+        if (per_env <= 65535 && lds <= 160 * 1024) { runt_waves = nw; runt_lds = lds; }
     }
-    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+    if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
+        static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
+        static const int envs_knob = getenv("SF_RUN_MIN_ENVS") ? atoi(getenv("SF_RUN_MIN_ENVS")) : 64;
+        static const int vcap_knob = getenv("SF_RUN_VCAP") ? atoi(getenv("SF_RUN_VCAP")) : 4096;
+        const Geo &g = s->g;
+        int nw = waves_knob < 1 ? 1 : (waves_knob > 16 ? 16 : waves_knob);
+        const int need = (g.H + 63) / 64;                     // a thread per bitmap row is all the interest pass can use
+        if (nw > need) nw = need;
+        const int min_nw = (int)(((long long)g.H * g.VW + 64 * kRunMaxD - 1) / (64 * kRunMaxD));   // rows per thread x words per row <= kRunMaxD
+        if (nw < min_nw) nw = min_nw;
+        long long all_vec = (long long)g.H * g.PV;
+        int vcap = vcap_knob < 64 ? 64 : vcap_knob;
+        if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
+        const size_t lds = run_lds_bytes(g, nw, vcap);
+        const bool fits = nw <= 16 && g.W <= 4096 && g.H <= 65535 && g.VW <= kRunMaxD && lds <= 160 * 1024;
+        const bool wanted = s->fused_mode == 2 || (n_steps >= 2 && g.E >= envs_knob);
+        if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
+    }
     if (run_waves) {
         int rc0 = ensure_commit(s);            // k_run starts from commit[] and leaves the new states there
         if (rc0) return rc0;
+        rc0 = ensure_vbits(s);
+        if (rc0) return rc0;
+    } else if (!generic) {
+        int rc0 = ensure_tiles(s);
+        if (rc0) return rc0;
+        if (runt_waves) { rc0 = ensure_commit(s); if (rc0) return rc0; }
+    }
+    a.vbits = s->vbits;
+    if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+    if (runt_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        void (*krun)(StepArgs, int) = s->g.RB == 1 ? k_run<1> : s->g.RB == 2 ? k_run<2> : s->g.RB == 4 ? k_run<4> : k_run<8>;
+        void (*krun)(StepArgs, int) = s->g.RB == 1 ? k_run_tiles<1> : s->g.RB == 2 ? k_run_tiles<2> : s->g.RB == 4 ? k_run_tiles<4> : k_run_tiles<8>;
+        if (runt_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)runt_lds));
+        hipLaunchKernelGGL(krun, dim3((unsigned)s->g.E), dim3((unsigned)runt_waves * 64), runt_lds, s->stream, a, n_steps);
+        s->vbits_valid = false;
+        s->last_kind = 4;
+        n_steps = 0;
+    } else if (run_waves) {
+        a.launch = 0; a.from_commit = 1; a.ring = s->ring;
         if (run_lds > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)run_lds));
-        hipLaunchKernelGGL(krun, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)run_lds));
+        hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps, run_vcap);
+        s->tiles_valid = false;                // the tile activity map / seam planes are not kept by k_run
+        s->last_kind = 2;
         n_steps = 0;                           // nothing left for the per-step loop
+    } else if (n_steps > 0) {
+        s->vbits_valid = false;                // the per-step kernels do not keep the vector bitmap
+        if (generic) s->tiles_valid = false;   // nor does the per-cell kernel keep the tile maps
+        s->last_kind = generic ? 3 : (fused ? 1 : 0);
     }
     const dim3 cell_grid((unsigned)((s->g.W + 255) / 256), (unsigned)s->g.H, (unsigned)s->g.E);
     for (int i = 0; i < n_steps; ++i) {

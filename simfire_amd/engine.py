@@ -195,8 +195,15 @@ class FireEngine:
         _lib.check(self._L.sf_sync(self._h))
 
     def set_fused(self, mode=-1):
-        """-1 auto, 0 always k_select + k_step, 1 always one fused launch per step."""
+        """-1 auto, 0 always k_select + k_step, 1 always one fused launch per step, 2 one environment-resident
+        launch per ``step(n)`` call (k_run)."""
         _lib.check(self._L.sf_set_fused(self._h, int(mode)))
+
+    def last_launch_kind(self):
+        """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, -1 none yet."""
+        v = C.c_int32(-1)
+        _lib.check(self._L.sf_last_step_launch(self._h, C.byref(v)))
+        return int(v.value)
 
     # neighbour order of the parent masks = adj_locs of simfire/utils/graph.py:125-134
     GRAPH_DX = (+1, +1, 0, -1, -1, -1, 0, +1)
@@ -335,7 +342,7 @@ class FireEngine:
         out = np.zeros(8, dtype=np.int64)
         _lib.check(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
         return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
-                    active_waves=int(out[3]), frontier_walks=int(out[4]))
+                    active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]))
 
     def update_status_device(self):
         _lib.check(self._L.sf_update_status_device(self._h))

@@ -40,21 +40,22 @@ def _same(eng, o, n_envs, burn_envs=None, tag=None):
 
 
 # ------------------------------------------------------------------ resident launch
+@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("name", _golden.traj_names())
-def test_resident_replays_golden_trajectories(name):
-    """sf_step(1) through k_run on every golden trajectory: fire_map / status / elapsed_time per step
-    and the final burn_amounts equal the reference's."""
+def test_resident_replays_golden_trajectories(name, mode):
+    """sf_step(1) through the resident launches (2: k_run, vector bitmap; 3: k_run_tiles) on every golden
+    trajectory: fire_map / status / elapsed_time per step and the final burn_amounts equal the reference's."""
     from simfire_amd.engine import FireEngine
     d = _golden.load_traj(name)
     eng = FireEngine(M_f=float(d["M_f"]), **_golden.engine_kwargs(d))
-    eng.set_fused(2)
+    eng.set_fused(mode)
     eng.set_rtable(d["rtable"])
     eng.reset([d["init_pos"]])
     _golden.replay(eng, d)
     assert (eng.burn(0) == d["burn"]).all()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(12))
 def test_resident_chunked_random_worlds(seed):
     """Random worlds (exact R ties, 4/8 connectivity, attenuation, runtime cut-off, barren patches so that
     some environments reach QUIT inside a chunk), stepped in chunks of random length through k_run with
@@ -75,7 +76,7 @@ def test_resident_chunked_random_worlds(seed):
         R8[:, :, W // 2:] = 0.0                                  # fires die against the barren half
     inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
     eng, o = _pair(kw, R8, inits)
-    eng.set_fused(2)
+    eng.set_fused(2 + seed % 2)
     eng.set_rows_per_band(int(rng.choice([1, 2, 2, 4, 8])))
     done = 0
     while done < 90:
@@ -119,7 +120,7 @@ def test_resident_hands_over_to_per_step_kernels_and_back():
     inits = [(5, 5), (160, 70), (90, 140), (320, 10), (200, 100)]      # (320, 10) sits in barren ground: QUIT early
     eng, o = _pair(kw, R8, inits)
     eng.set_async(True)
-    sched = [(2, 7), (0, 3), (2, 1), (1, 4), (2, 9), ("generic", 2), (2, 5), (0, 2), (2, 11), (1, 1), (2, 30)]
+    sched = [(2, 7), (0, 3), (3, 4), (2, 1), (1, 4), (2, 9), ("generic", 2), (3, 5), (0, 2), (2, 11), (3, 1), (1, 1), (2, 30)]
     for i, (mode, n) in enumerate(sched):
         if mode == "generic":
             eng.set_generic(True)
@@ -131,14 +132,15 @@ def test_resident_hands_over_to_per_step_kernels_and_back():
         o.apply_mitigation(pts)
         eng.step(n)
         o.step(n)
-        if i in (4, 8):
+        if i in (5, 9):
             _same(eng, o, E, tag=i)
     eng.sync()
     _same(eng, o, E, tag="end")
     assert not eng.status()[0][:, 0].all()
 
 
-def test_resident_dense_mode_and_status_histograms():
+@pytest.mark.parametrize("mode", [2, 3])
+def test_resident_dense_mode_and_status_histograms(mode):
     """Dense cross-check mode inside k_run (every tile of the environment on the LDS list every step),
     and the per-tile status histograms behind the result block stay right when k_run is the only writer."""
     from simfire_amd import workloads
@@ -150,7 +152,7 @@ def test_resident_dense_mode_and_status_histograms():
     o.set_rtable(eng.get_rtable())
     eng.reset(w.init_xy)
     o.reset(w.init_xy)
-    eng.set_fused(2)
+    eng.set_fused(mode)
     for dense, n in [(False, 20), (True, 15), (False, 40), (True, 5), (False, 60)]:
         eng.set_dense(dense)
         eng.step(n)
@@ -162,8 +164,9 @@ def test_resident_dense_mode_and_status_histograms():
         _same(eng, o, 3, tag=(dense, n))
 
 
+@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("waves", [1, 3, 16])
-def test_resident_any_workgroup_size(waves, monkeypatch):
+def test_resident_any_workgroup_size(waves, mode):
     """Fewer waves than live tiles: the waves of the workgroup take several tiles per step off the shared
     cursor (their LDS scratch is reused); the result must not depend on the workgroup size."""
     import subprocess, sys, os, textwrap
@@ -180,15 +183,15 @@ def test_resident_any_workgroup_size(waves, monkeypatch):
         o = fire_dense.DenseOracle(**w.engine_kwargs())
         o.set_rtable(eng.get_rtable())
         eng.reset(w.init_xy); o.reset(w.init_xy)
-        eng.set_fused(2)
+        eng.set_fused(%d)
         for n in (70, 1, 130):
             eng.step(n); o.step(n, 4)
         assert (eng.status()[0] == o.status()[0]).all()
         for e in range(4):
             assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
         print("OK")
-    """ % root)
-    env = dict(os.environ, SF_RUN_WAVES=str(waves))       # read once per process: run in a child
+    """ % (root, mode))
+    env = dict(os.environ, SF_RUN_WAVES=str(waves), SF_RUN_VCAP="256")       # read once per process: run in a child
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
@@ -235,7 +238,7 @@ def _workload_run(w, chunks, fused, agent_pts=None, threads=32, burn_envs=(0, 1)
     return eng, o
 
 
-@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("fused", [0, 2, 3])
 def test_c3_full_grid_32_envs(fused):
     """C3 grid (1024^2), 32 environments = 16384 wave tiles: above the fused-launch limit, so fused = 0 is
     k_select (3 x 3 tile flags over 16 x 32 tiles per environment) + persistent k_step; fused = 2 is k_run."""
@@ -243,14 +246,14 @@ def test_c3_full_grid_32_envs(fused):
     _workload_run(workloads.c3(1024, 32), [100, 150], fused)
 
 
-@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("fused", [0, 2, 3])
 def test_c3_benched_batch_256_envs(fused):
     """The batch bench.py times: 1024^2 x 256 environments, 150 steps, every environment's final map."""
     from simfire_amd import workloads
     _workload_run(workloads.c3(1024, 256), [150], fused, burn_envs=(0, 100, 255))
 
 
-@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("fused", [0, 2, 3])
 def test_c4_full_grid_8_envs(fused):
     """C4 grid (2048^2, varying wind), 8 environments = 16384 wave tiles of 32 x 64 per environment."""
     from simfire_amd import workloads
@@ -261,7 +264,7 @@ def test_c4_full_grid_8_envs(fused):
     _workload_run(w, [60, 90], fused)
 
 
-@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("fused", [0, 2, 3])
 def test_c5_full_grid_agents(fused):
     """C5 at its grid: 1024^2 x 32 environments x 64 agents writing one control-line cell per step
     (lazy attenuation, lines on burning cells), scatter + step pairs enqueued asynchronously.
