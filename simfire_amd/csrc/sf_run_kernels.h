@@ -248,36 +248,48 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                 j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);
                 if (j0 >= n_chunk) break;
                 const bool has = j0 + lane < n_chunk;
-                const uint32_t item = has ? vlist[j0 + lane] : 0u;
-                const int y = item & 0xFFFF, v = item >> 16;
+                const uint32_t item = has ? vlist[j0 + lane] : 0xFFFFFFFFu;
+                const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
                 const int x0 = v * 16;
                 const uint32_t voff = (uint32_t)(y * g.P + x0);
                 const uint8_t *ra = ev.age + voff;
                 uint4 up = make_uint4(0, 0, 0, 0), mid = up, dn = up, sr = up;
-                uint32_t lin = 0, rin = 0;
                 if (has) {
                     mid = *reinterpret_cast<const uint4 *>(ra);
                     up = *reinterpret_cast<const uint4 *>(ra - g.P);
                     dn = *reinterpret_cast<const uint4 *>(ra + g.P);
                     sr = *reinterpret_cast<const uint4 *>(ev.status + voff);
-                    // the cells just left / right of the vector
-                    if (v > 0) {
-                        lin = *reinterpret_cast<const uint32_t *>(ra - 4);
-                        if (g.diag) lin |= *reinterpret_cast<const uint32_t *>(ra - g.P - 4) | *reinterpret_cast<const uint32_t *>(ra + g.P - 4);
-                        lin >>= 24;
-                    }
-                    if (x0 + 16 < g.W) {
-                        rin = *reinterpret_cast<const uint32_t *>(ra + 16);
-                        if (g.diag) rin |= *reinterpret_cast<const uint32_t *>(ra - g.P + 16) | *reinterpret_cast<const uint32_t *>(ra + g.P + 16);
-                        rin &= 0xFFu;
-                    }
+                }
+                // The cells just left / right of the vector.  The list runs by rows, so the vector to the left, if it is
+                // interesting at all, is the list entry before this one, i.e. the lane below - and if it is not
+                // interesting, it and the vectors above / below it hold no sprite bit: the edge cells are zero.  Only
+                // the first / last lane of a batch have to look the cells up in the plane.
+                const uint32_t item_l = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x138, 0xF, 0xF, false);   // wave_shr:1
+                const uint32_t item_r = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x130, 0xF, 0xF, false);   // wave_shl:1
+                const bool last_lane = j0 + lane + 1 == n_chunk || lane == 63;
+                uint32_t lin = 0, rin = 0;
+                if (has && lane == 0 && v > 0) {
+                    lin = *reinterpret_cast<const uint32_t *>(ra - 4);
+                    if (g.diag) lin |= *reinterpret_cast<const uint32_t *>(ra - g.P - 4) | *reinterpret_cast<const uint32_t *>(ra + g.P - 4);
+                    lin >>= 24;
+                }
+                if (has && last_lane && x0 + 16 < g.W) {
+                    rin = *reinterpret_cast<const uint32_t *>(ra + 16);
+                    if (g.diag) rin |= *reinterpret_cast<const uint32_t *>(ra - g.P + 16) | *reinterpret_cast<const uint32_t *>(ra + g.P + 16);
+                    rin &= 0xFFu;
                 }
                 n_vec_done += (lane == 0) ? (n_chunk - j0 < 64u ? n_chunk - j0 : 64u) : 0u;
-                lin &= mk.m_live;
-                rin &= mk.m_live;
                 const uint4 midL = and4(mid, L4);
                 const uint4 vsrc = and4(or4(up, dn), L4);
                 const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+                {
+                    const uint32_t e_l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hsrc.w, 0x138, 0xF, 0xF, false) >> 24;
+                    const uint32_t e_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hsrc.x, 0x130, 0xF, 0xF, false) & 0xFFu;
+                    if (lane != 0 && item_l + 0x10000u == item) lin = e_l;
+                    if (!last_lane && item_r == item + 0x10000u) rin = e_r;
+                }
+                lin &= mk.m_live;
+                rin &= mk.m_live;
                 if (__ballot(any4(midL) != 0) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;   // FLAG_LIVE
                 uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
                 nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
