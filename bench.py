@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: cell-updates/s of the Rothermel fire-spread step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--envs E] [--size S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--envs E] [--size S]
 
-One "step" = one launch of the step kernel over the whole batch of environments
-(= one ``RothermelFireManager.update`` per environment, simfire/game/managers/fire.py:616-719).
-Default workload = BASELINE config C3: 1024x1024 operational-style terrain, 256 batched
-environments with random ignitions, one GPU; with ``--gpus N`` every rank runs its own 256
-environments (weak scaling, different ignition seeds) and the per-environment result blocks are
-all-gathered once per rollout over RCCL.  Layers are synthetic, the R table
-and the reset are outside the timed region, inputs are resident in HBM when timing starts.
+One "step" = one ``RothermelFireManager.update`` per environment of the batch
+(simfire/game/managers/fire.py:616-719).  Default workload = BASELINE config C3: 1024x1024
+operational-style terrain, 256 batched environments with random ignitions, one GPU.  With
+``--gpus N`` every rank runs its own block of environments (weak scaling, different ignition seeds, no
+data-path collective) and the per-environment result blocks are all-gathered once per rollout over
+RCCL.  ``python bench.py --gpus N`` launches its N ranks itself; under ``torch.distributed.run`` it
+uses the ranks it is given.  Layers are synthetic, the R table and the reset are
+outside the timed region, inputs are resident in HBM when timing starts.
 
-Prints ONE JSON line (rank 0).  ``roofline.achieved`` uses the ALGORITHMIC bytes of section 8d,
-cells x (4 + 24 phi) per launch (phi = measured fraction of cells whose burn_amounts were
-touched), over the average step-kernel duration measured with HIP events on the library's
-stream; ``roofline.traffic`` is the HBM bytes per launch from the rocprofv3 PMC pass committed
-under profiles/ (null if no such pass exists for this workload).
+Prints ONE JSON line (rank 0).  ``roofline.achieved`` uses the ALGORITHMIC bytes of section 8d -
+cell-updates performed x 4 B + active cell-updates x 24 B - over the step kernels' duration measured
+with HIP events on the library's stream.  After the timed rollout, outside the timed region, the result
+block of every environment and the fire maps of a sample are compared with ``oracle/fire_dense.c`` run
+on the host cores over the same rollout (``"verified"``); that oracle run is also the timed
+``cpu_baseline`` (kind "port").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells", 4: "k_run_tiles"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -40,18 +45,48 @@ def parse():
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--rows-per-band", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-env measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle run (no cpu_baseline, no verification)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (`also`)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--dense", action="store_true", help="visit every tile every step (no tile skipping)")
+    ap.add_argument("--dense", action="store_true", help="visit every tile / vector every step (no skipping)")
     ap.add_argument("--generic", action="store_true", help="plain one-thread-per-cell kernel instead of the tiled kernels")
     ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
-                    help="-1 automatic, 0 always k_select + k_step, 1 always one fused launch per step")
+                    help="-1 automatic, 0 k_select + k_step per step, 1 one fused launch per step, "
+                         "2 one environment-resident launch per rollout (k_run), 3 its tile flavour (k_run_tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the\n"
+                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
                          "multi-rank code path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-sweep roofline measurement")
-    return ap.parse_args()
+    ap.add_argument("--dense-leg", action="store_true", help="also measure the same workload with skipping off")
+    ap.add_argument("--no-dense-leg", action="store_true", help="(accepted for older scripts; the dense leg is off by default)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch / rendezvous / all-gather plumbing without touching a GPU (CPU test of --gpus N)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------- launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` outside a launcher: start the N ranks ourselves (one process per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, as torch.distributed.run would
+    set them).  Rank 0's stdout (the JSON line) is passed through."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    sys.exit(rc)
 
 
 def make_workload(name, size, envs, env_offset):
@@ -65,8 +100,7 @@ def make_workload(name, size, envs, env_offset):
     return workloads.c5(size, envs or 64, env_offset=env_offset)
 
 
-def run_gpu(w, steps, warmup, device, rows_per_band=0, agent_pts=None):
-    """Returns (engine, kernel_ms over the timed steps, counters over the timed steps)."""
+def make_engine(w, device, rows_per_band=0):
     from simfire_amd.engine import FireEngine
     eng = FireEngine(M_f=w.M_f, device=device, **w.engine_kwargs())
     if rows_per_band:
@@ -76,7 +110,7 @@ def run_gpu(w, steps, warmup, device, rows_per_band=0, agent_pts=None):
     return eng
 
 
-def timed_steps(eng, w, steps, first_step, agent_pts):
+def timed_steps(eng, steps, first_step, agent_pts):
     """K steps, returns the GPU milliseconds of the step kernels (HIP events on the library's
     stream); with agents (C5) every step is preceded by the mitigation scatter."""
     if agent_pts is None:
@@ -88,7 +122,7 @@ def timed_steps(eng, w, steps, first_step, agent_pts):
     return ms
 
 
-def run_steps(eng, w, steps, first_step, agent_pts):
+def run_steps(eng, steps, first_step, agent_pts):
     """The rollout loop as a harness would run it: nothing is read back per step, so with agents
     the scatter + step pairs are only enqueued (async mode) and waited for once at the end."""
     if agent_pts is None:
@@ -102,17 +136,27 @@ def run_steps(eng, w, steps, first_step, agent_pts):
     eng.set_async(False)
 
 
-def cpu_baseline(w, steps, warmup, threads, agent_pts=None):
-    """The C oracle (oracle/fire_dense.c) on the host cores, on a bounded sample of the same
-    workload: the first ``n`` environments, same W + K steps, K timed."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_rollout(w, rtable, steps, warmup, threads, agent_pts, n_check):
+    """oracle/fire_dense.c (the CPU restatement pinned to the reference's golden vectors) over the same
+    rollout on the first ``n_check`` environments: the checker of the timed GPU rollout and, timed on the
+    K steps after the warm-up, the CPU baseline.  It steps with the device-built R table, so that the
+    comparison of fire maps / counts / steps is bit for bit."""
     from oracle import fire_dense
-    threads = threads or min(os.cpu_count() or 1, 32)
-    n = min(w.n_envs, 4 * threads)
     kw = w.engine_kwargs()
-    kw["n_envs"] = n
+    kw["n_envs"] = n_check
     o = fire_dense.DenseOracle(**kw)
-    o.build_rtable(w.w_0, w.delta, w.M_x, w.sigma, w.elevation, w.U, w.U_dir, w.M_f)
-    o.reset(w.init_xy[:n])
+    o.set_rtable(rtable)
+    o.reset(w.init_xy[:n_check])
 
     def go(k, first):
         if agent_pts is None:
@@ -120,29 +164,16 @@ def cpu_baseline(w, steps, warmup, threads, agent_pts=None):
         else:
             for s in range(k):
                 p = agent_pts[first + s]
-                o.apply_mitigation(p[p[:, 0] < n])
+                o.apply_mitigation(p[p[:, 0] < n_check])
                 o.step(1, threads)
 
     go(warmup, 0)
-    # bound the sample to roughly 10-30 s: time a short probe first
-    probe = min(steps, 20)
+    st0 = o.status()[0]
     t0 = time.perf_counter()
-    go(probe, warmup)
+    go(steps, warmup)
     dt = time.perf_counter() - t0
-    k = probe
-    remaining = steps - probe
-    if remaining > 0:
-        budget = max(0, int((20.0 - dt) / max(dt / probe, 1e-9)))
-        extra = min(remaining, budget)
-        if extra > 0:
-            t1 = time.perf_counter()
-            go(extra, warmup + probe)
-            dt += time.perf_counter() - t1
-            k += extra
-    H, W = w.shape
-    return {"value": H * W * n * k / dt, "unit": "cell-updates/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/fire_dense.c (OpenMP over envs), first {n} envs of the workload, "
-                      f"{k} timed steps after {warmup} warm-up steps, {dt:.1f} s"}
+    st1 = o.status()[0]
+    return o, st1, int((st1[:, 1] - st0[:, 1]).sum()), dt
 
 
 def measure(eng, w, a, agent_pts, dense):
@@ -151,61 +182,116 @@ def measure(eng, w, a, agent_pts, dense):
     eng.set_dense(dense)
     eng.reset(w.init_xy)
     if a.warmup:
-        timed_steps(eng, w, a.warmup, 0, agent_pts)
+        timed_steps(eng, a.warmup, 0, agent_pts)
     st0, _ = eng.status()
-    kernel_ms = timed_steps(eng, w, a.steps, a.warmup, agent_pts)
+    kernel_ms = timed_steps(eng, a.steps, a.warmup, agent_pts)
+    kind = eng.last_launch_kind()
     st1, _ = eng.status()
     env_steps = int((st1[:, 1] - st0[:, 1]).sum())
     eng.reset(w.init_xy)
     if a.warmup:
-        timed_steps(eng, w, a.warmup, 0, agent_pts)
+        timed_steps(eng, a.warmup, 0, agent_pts)
     eng.enable_counters(True)
     eng.counters(reset=True)
-    timed_steps(eng, w, a.steps, a.warmup, agent_pts)
+    timed_steps(eng, a.steps, a.warmup, agent_pts)
     cnt = eng.counters()
     eng.enable_counters(False)
-    return kernel_ms, env_steps, cnt
+    return kernel_ms, env_steps, cnt, kind
 
 
-def roofline_block(w, a, kernel_ms, cnt, tile_cells, traffic):
-    """bytes = cell_updates_performed x 4 + active_cell_updates x 24, per launch."""
-    performed = cnt["active_waves"] * tile_cells / a.steps            # cells scanned per step
-    active = cnt["active_cell_updates"] / a.steps
-    alg_bytes = performed * 4.0 + active * 24.0
-    launch_ms = kernel_ms / a.steps
-    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense):
+    """bytes = cell-updates performed x 4 + active cell-updates x 24.  The cell-updates performed
+    are the cells the kernel really sweeps: the cells of the wave tiles visited (tiled kernels) or of the
+    16-cell vectors visited (k_run).  With a resident launch one launch = the whole K-step rollout."""
+    H, W = w.shape
+    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16      # all K steps
+    active = cnt["active_cell_updates"]
+    if dense:
+        # the dense sweep reads 1 B (the sprite mask) of a quiescent cell and rejects it; charging the 4 B of
+        # the model to cells whose status byte is never touched would report more than the peak
+        alg_bytes, model = cells * 1.0 + active * 24.0, "cells scanned x 1 B (sprite-mask read, reject) + active x 24 B"
+    else:
+        alg_bytes, model = cells * 4.0 + active * 24.0, ("cells swept x 4 B (status + sprite mask, R + W) + active x 24 B "
+                                                         "(burn R + W, one table entry)")
+    sec = kernel_ms * 1e-3
+    achieved = alg_bytes / sec / 1e9
+    resident = kind in (2, 4)
+    launches = 1 if resident else a.steps * (2 if kind == 0 else 1)
+    traffic = None
+    if pmc and pmc.get("steps") == a.steps and pmc.get("warmup") == a.warmup and pmc.get("kernel") == LAUNCH_KINDS.get(kind):
+        traffic = pmc.get("hbm_bytes_per_launch")           # measured on this very window by profiles/collect_pmc.sh
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_select + k_step",
-            "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
-            "cells_scanned_per_launch": performed, "active_cell_updates_per_launch": active,
-            "tiles_visited_per_launch": cnt["active_waves"] / a.steps,
-            "frontier_walks_per_launch": cnt["frontier_walks"] / a.steps,
-            # bytes the PMC pass really saw on the fabric per launch / this launch time
-            "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None}
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": LAUNCH_KINDS.get(kind, "?"),
+            "bytes_model": model, "launches": launches, "steps_per_launch": a.steps if resident else 1,
+            "launch_ms": kernel_ms / (1 if resident else a.steps), "kernel_ms_per_step": kernel_ms / a.steps,
+            "algorithmic_bytes_per_launch": alg_bytes / (1 if resident else a.steps),
+            "cells_swept_per_step": cells / a.steps, "active_cell_updates_per_step": active / a.steps,
+            "tiles_visited_per_step": cnt["active_waves"] / a.steps, "vectors_visited_per_step": cnt["vectors"] / a.steps,
+            "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
+            # window-independent rates (the headline counts H x W per environment step, however small the fire)
+            "active_cell_updates_per_s": active / sec, "cells_swept_per_s": cells / sec,
+            "dense_cell_updates_per_s_kernel": H * W * env_steps / sec,
+            # what a dense sweep would have to move for the same update() calls, over this kernel time (not a
+            # roofline figure: the point of the sparse path is that these bytes are never moved)
+            "dense_equivalent_gbs": H * W * env_steps * 4.0 / sec / 1e9}
+
+
+def reference_python_timing():
+    p = os.path.join(ROOT, "tests", "golden", "reference_timing.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    envs_local = a.envs or {"c2": 1, "c3": 256, "c4": 128, "c5": 64}[a.workload]
+
+    if a.plumbing_only:
+        # the N > 1 plumbing without a GPU: rendezvous, one all-gather of a result block, one JSON line
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        block = torch.full((envs_local, 8), rank, dtype=torch.int32)
+        out = torch.zeros((world * envs_local, 8), dtype=torch.int32)
+        if world > 1:
+            dist.all_gather_into_tensor(out, block)
+            dist.barrier()
+        else:
+            out = block
+        if rank == 0:
+            ok = all(int(out[r * envs_local, 0]) == r for r in range(world))
+            print(json.dumps({"plumbing_only": True, "n_gpus": world, "gathered_rows": int(out.shape[0]), "ok": ok}))
+            sys.stdout.flush()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     n_dev = torch.cuda.device_count()
+    if world > n_dev and a.backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s): RCCL needs one GPU per rank "
+                         "(--backend gloo exercises the multi-rank path on fewer GPUs)")
     device = local_rank % n_dev                      # one process per GPU (gloo test runs may share one)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     coll_dev = f"cuda:{device}" if (dist is None or a.backend == "nccl") else "cpu"
 
-    envs_local = a.envs or {"c2": 1, "c3": 256, "c4": 128, "c5": 64}[a.workload]
     w = make_workload(a.workload, a.size, envs_local, env_offset=rank * envs_local)
     H, W = w.shape
     agent_pts = None
@@ -213,7 +299,7 @@ def main():
         from simfire_amd import workloads
         agent_pts = workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup,
                                          env_offset=rank * envs_local)
-    eng = run_gpu(w, a.steps, a.warmup, device, a.rows_per_band)
+    eng = make_engine(w, device, a.rows_per_band)
     eng.set_dense(a.dense)
     eng.set_generic(a.generic)
     eng.set_fused(a.fused)
@@ -221,7 +307,7 @@ def main():
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
     if a.warmup:
-        timed_steps(eng, w, a.warmup, 0, agent_pts)
+        timed_steps(eng, a.warmup, 0, agent_pts)
     eng.copy_status_to(result.data_ptr())
     steps_before = result[:, 1].sum().item()
     if dist is not None:
@@ -237,7 +323,7 @@ def main():
     # ------------------------------------------------------------------ timed region
     fence()
     t0 = time.perf_counter()
-    run_steps(eng, w, a.steps, a.warmup, agent_pts)
+    run_steps(eng, a.steps, a.warmup, agent_pts)
     eng.copy_status_to(result.data_ptr())            # per-env result block (episode returns)
     if dist is not None:
         dist.all_gather_into_tensor(gathered, result.to(coll_dev))  # RCCL over xGMI, once per rollout
@@ -245,6 +331,31 @@ def main():
     dt = time.perf_counter() - t0
     # ---------------------------------------------------------------------------------
     env_steps = result[:, 1].sum().item() - steps_before      # update() calls really made
+    local_block = result.cpu().numpy()
+
+    # ---- outside the timed region: check the rollout that was just timed against the oracle.  A one-GPU run
+    # checks every environment (and times the oracle: cpu_baseline); in a multi-rank run every rank checks the
+    # first environments of its own shard with its share of the host cores.
+    verified, cpu_base, n_check = None, None, 0
+    if not a.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        threads = a.cpu_threads or max(1, min(cores, 32) // world)
+        n_check = w.n_envs if world == 1 else min(w.n_envs, 8)
+        sample = sorted(set([0, n_check // 2, n_check - 1]))
+        maps = {e: eng.fire_map(e) for e in sample}
+        o, ost, o_steps, o_dt = oracle_rollout(w, eng.get_rtable(), a.steps, a.warmup, threads, agent_pts, n_check)
+        verified = bool((local_block[:n_check] == ost).all()) and all(bool((maps[e] == o.fire_map(e)).all()) for e in sample)
+        if world == 1:
+            cpu_base = {"value": H * W * o_steps / o_dt, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+                        "cpu_model": cpu_model(),
+                        "sample": f"oracle/fire_dense.c (OpenMP over envs), all {n_check} envs of the workload, the same "
+                                  f"{a.steps} steps after {a.warmup} warm-up steps, {o_dt:.1f} s; counts update() calls "
+                                  "really made, like `value`"}
+            ref = reference_python_timing()
+            if ref:
+                cpu_base["reference_python"] = ref
+        del o
+
     if dist is not None:
         red = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=coll_dev)
         tmax = red[:1].clone()
@@ -252,20 +363,21 @@ def main():
         tot = red[1:].clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt, env_steps = float(tmax.item()), float(tot.item())
+        if verified is not None:
+            v = torch.tensor([1 if verified else 0], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            verified = bool(v.item())
     res = gathered.cpu().numpy()
 
     if rank == 0:
         geo = eng.geometry()
-        geo_tile_cells = geo["tile_w"] * geo["tile_h"]
-        kms, env_steps_local, cnt = measure(eng, w, a, agent_pts, a.dense)
-        tile_cells = geo_tile_cells
-        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")
-        traffic = traffic_dense = None
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                j = json.load(f)
-                traffic = j.get("hbm_bytes_per_launch_dense" if a.dense else "hbm_bytes_per_launch")
-                traffic_dense = j.get("hbm_bytes_per_launch_dense")
+        tile_cells = geo["tile_w"] * geo["tile_h"]
+        kms, env_steps_local, cnt, kind = measure(eng, w, a, agent_pts, a.dense)
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
         out = {
             "metric": "cell-updates/sec (grid x envs x steps)",
             # every update() call really made (environments that reached QUIT stop counting,
@@ -276,36 +388,47 @@ def main():
             "ms_per_step": dt * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 status + u8 sprite masks + f64 burn_amounts", "data": "synthetic",
+            "verified": verified,
+            "verification": (None if verified is None else
+                             f"result block (running, steps, cells per BurnStatus) of {n_check} environments per rank + fire "
+                             "maps of 3 of them after the timed rollout == oracle/fire_dense.c on the same inputs, bit for bit"),
             "config": {"workload": w.name, "grid": [H, W], "envs_per_gpu": w.n_envs,
                        "envs_total": w.n_envs * world, "max_fire_duration": w.max_fire_duration,
                        "pixel_scale": w.pixel_scale, "ros_attenuation": w.attenuate_line_ros,
-                       "agents_per_env": w.agents_per_env, "tile_skipping": not a.dense,
+                       "agents_per_env": w.agents_per_env, "skipping": not a.dense,
                        "wave_tile": [geo["tile_h"], geo["tile_w"]],
+                       "wind_generator": w.extra.get("wind_generator", "constant"),
+                       "collective_backend": (None if world == 1 else a.backend),
                        "env_steps_executed": env_steps, "env_steps_requested": w.n_envs * world * a.steps,
                        "envs_running_at_end": int(res[:, 0].sum()),
                        "burned_cells_total": int(res[:, 4].sum())},
-            "roofline": roofline_block(w, a, kms, cnt, tile_cells, traffic),
+            "roofline": roofline_block(w, a, kms, cnt, tile_cells, kind, env_steps_local, pmc, a.dense),
         }
-        out["roofline"]["note"] = ("algorithmic bytes of the cell-updates actually performed (tiles visited x tile "
-                                   "cells x 4 B + active cells x 24 B); quiescent tiles are skipped via the tile "
-                                   "activity map" if not a.dense else "dense sweep: every tile visited every step")
-        if world == 1 and not a.dense and not a.no_dense_leg:
-            kd, _, cd = measure(eng, w, a, agent_pts, True)
-            out["roofline_dense"] = roofline_block(w, a, kd, cd, tile_cells, traffic_dense)
-            out["roofline_dense"]["note"] = ("same workload with tile skipping off: every cell scanned every step.  The "
-                                             "4 B per cell-update of the algorithmic model (status and sprite mask, "
-                                             "read + write) is more than this kernel moves for a quiescent cell (1 B: "
-                                             "the sprite-mask rows, then a wave-level reject), so 'achieved' is a "
-                                             "rate in model bytes; the bytes really moved are 'traffic' / 'traffic_gbs'")
-            out["roofline_dense"]["value_cell_updates_per_s"] = H * W * env_steps_local / (kd * 1e-3)
+        out["roofline"]["note"] = ("only the tiles / 16-cell vectors in which something can change are visited; `achieved` counts "
+                                   "the cells of those" if not a.dense else "dense sweep: everything visited every step")
+        if world == 1 and not a.dense and a.dense_leg:
+            kd, esl, cd, kindd = measure(eng, w, a, agent_pts, True)
+            out["roofline_dense"] = roofline_block(w, a, kd, cd, tile_cells, kindd, esl, None, True)
             eng.set_dense(False)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, a.steps, a.warmup, a.cpu_threads, agent_pts)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         if world == 1 and not a.no_extra and a.workload == "c3":
-            # secondary: BASELINE config C2 (1 env, 1024^2) - launch-latency bound
+            also = {}
+            # the throughput regime: same workload, 4 x the batch (256 environments do not fill the chip)
             eng.close()
+            big = make_workload("c3", a.size, 4 * w.n_envs, 0)
+            eb = make_engine(big, device, a.rows_per_band)
+            eb.set_fused(a.fused)
+            kb, esb, cb, kindb = measure(eb, big, a, None, False)
+            rb = roofline_block(big, a, kb, cb, tile_cells, kindb, esb, None, False)
+            also["c3_x%d_throughput_regime" % big.n_envs] = {
+                "value_kernel": H * W * esb / (kb * 1e-3), "unit": "cell-updates/s", "kernel_ms_per_step": kb / a.steps,
+                "roofline": {k: rb[k] for k in ("achieved", "frac", "kernel", "cells_swept_per_step", "cells_swept_per_s",
+                                                "active_cell_updates_per_s", "algorithmic_bytes_per_launch")}}
+            eb.close()
+            # BASELINE config C2 (1 env, 1024^2) - latency bound
             w2 = make_workload("c2", a.size, 1, 0)
-            e2 = run_gpu(w2, a.steps, a.warmup, device)
+            e2 = make_engine(w2, device)
             e2.step(a.warmup)
             s0, _ = e2.status()
             torch.cuda.synchronize()
@@ -314,11 +437,13 @@ def main():
             dt2 = time.perf_counter() - t0
             st2, _ = e2.status()
             done = int(st2[0, 1] - s0[0, 1])
-            out["also"] = {"c2_operational_1env": {
+            also["c2_operational_1env"] = {
                 "value": H * W * done / dt2, "unit": "cell-updates/s", "ms_per_step": dt2 * 1e3 / a.steps,
                 "kernel_ms_per_step": kms2 / a.steps, "steps_executed": done, "running_at_end": int(st2[0, 0]),
-                "burned_cells": int(st2[0, 4])}}
+                "burned_cells": int(st2[0, 4]), "kernel": LAUNCH_KINDS.get(e2.last_launch_kind(), "?")}
+            out["also"] = also
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -222,8 +222,13 @@ int sf_set_generic(sf_sim *sim, int32_t on);
  * otherwise one fused launch per step up to 12288 wave tiles, k_select + k_step above.
  * 0 = always two launches per step, 1 = always one fused launch per step, 2 = always the resident launch
  * (falls back to the per-step launches while the spread graph / history by-products are on or
- * max_fire_duration > 5). */
+ * max_fire_duration > 5), 3 = the tile flavour of the resident launch (k_run_tiles; development / cross-check). */
 int sf_set_fused(sf_sim *sim, int32_t mode);
+/* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
+ * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay
+ * QUIT in the result block, spread stays off); 0 (default) = a QUIT environment is frozen, as FireSimulation.run
+ * (simulation.py:533) never calls update again. */
+int sf_set_prune_after_quit(sf_sim *sim, int32_t on);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
  * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, -1 = none yet. */
 int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);

@@ -1,53 +1,60 @@
 #!/bin/bash
 # rocprofv3 passes behind the numbers in DESIGN.md / bench.py ("roofline.traffic").
-# Run on the GPU box from the repo root:  bash profiles/collect_pmc.sh
+# Run on the GPU box from the repo root:  bash profiles/collect_pmc.sh [round-tag]
 # Counters are collected in their own runs (separate --pmc passes, no trace domains besides
-# --kernel-trace), as MI355X_MICROARCH.md prescribes.
+# --kernel-trace), as MI355X_MICROARCH.md prescribes.  Window = bench.py's default (--steps 1000 --warmup 20).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01
+R=${1:-r02}
+O=gpurun_out/$R
 mkdir -p $O
-B="python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-extra --no-dense-leg"
+B="python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-extra"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/sf_mb profiles/streaming_microbench.hip
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o sparse -- $B > $O/bench_sparse.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o dense -- $B --dense > $O/bench_dense.json 2>/dev/null
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc -o sparse_fetch -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc -o sparse_write -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc -o dense_fetch -- $B --dense > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc -o dense_write -- $B --dense > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o default -- $B > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o perstep -- $B --fused 0 > $O/bench_under_rocprof_perstep.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc -o fetch -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc -o write -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc -o calib_fetch -- /tmp/sf_mb > $O/calib.txt 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $O/pmc -o sparse_sq -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $O/pmc -o sq -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES -d $O/pmc -o sq2 -- $B > /dev/null 2>&1
 rm -f $O/stats/*_kernel_trace.csv
-python - <<'PY'
+R=$R python - <<'PY'
 import csv, glob, collections, json, os
-O="gpurun_out/r01"
-def per_kernel(path):
+R=os.environ["R"]; O=f"gpurun_out/{R}"
+def launches(path, want):
+    """counter values of the launches of kernel `want`, in launch order"""
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         kn=r["Kernel_Name"]
-        kn="k_step" if "k_step" in kn else ("k_select" if "k_select" in kn else kn[:48])
-        acc[(kn, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if want in kn and "rebuild" not in kn and "k_run_tiles" not in kn:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
-out={}
-for tag in ("sparse","dense"):
-    tot={}
-    for cn in ("fetch","write"):
-        acc=per_kernel(f"{O}/pmc/{tag}_{cn}_counter_collection.csv")
-        s=0.0
-        for (k,c),v in acc.items():
-            if k in ("k_step","k_select"):
-                v=v[20:1020]         # the timed 1000 steps (after 20 warm-up launches)
-                s+=sum(v)/len(v)
-        tot[cn]=s
-    out[tag]=tot
-cal=per_kernel(f"{O}/pmc/calib_fetch_counter_collection.csv")
-out["calibration_fetch_kb"]={k[0]:sum(v)/len(v) for k,v in cal.items()}
-json.dump(out, open(f"{O}/pmc_summary_raw.json","w"), indent=1)
-acc=per_kernel(f"{O}/pmc/sparse_sq_counter_collection.csv")
-with open(f"{O}/sq_counters_sparse.csv","w") as f:
-    f.write("kernel,counter,mean_over_timed_steps\n")
-    for (k,c),v in sorted(acc.items()):
-        if k in ("k_step","k_select"):
-            v=v[20:1020]; f.write(f"{k},{c},{sum(v)/len(v):.1f}\n")
+bench=json.load(open(f"{O}/bench_under_rocprof.json"))
+kernel=bench["roofline"]["kernel"]
+# bench.py launches k_run: warm-up (20 steps), timed rollout (1000), then measure(): warm-up, timed, warm-up, counted.
+# The 1000-step launches are the large ones: take the largest value per counter (they are identical rollouts).
+out={"workload": bench["config"]["workload"], "kernel": kernel, "steps": bench["steps"], "warmup": bench["warmup"],
+     "command": "bash profiles/collect_pmc.sh (rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE | WRITE_SIZE in separate passes -- python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-extra)",
+     "per_launch": "one launch of k_run = the whole 1000-step rollout of all environments (the window bench.py times)"}
+raw={}
+for cn,f in (("fetch","fetch"),("write","write")):
+    acc=launches(f"{O}/pmc/{f}_counter_collection.csv", "k_run")
+    for k,v in acc.items(): raw[k]=max(v)
+out["raw_kb"]=raw
+cal=collections.defaultdict(list)
+for r in csv.DictReader(open(f"{O}/pmc/calib_fetch_counter_collection.csv")):
+    cal[r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
+out["calibration_fetch_kb"]={k:sum(v)/len(v) for k,v in cal.items()}
+out["correction"]="FETCH_SIZE x 2 (gfx950, 16 B/lane loads: MI355X_MICROARCH.md HBM section, re-checked by profiles/streaming_microbench.hip); WRITE_SIZE as is (uncalibrated); counters are in KB"
+out["hbm_bytes_per_launch"]=(raw.get("FETCH_SIZE",0)*2+raw.get("WRITE_SIZE",0))*1024
+out["hbm_bytes_per_step"]=out["hbm_bytes_per_launch"]/bench["steps"]
+out["algorithmic_bytes_per_launch"]=bench["roofline"]["algorithmic_bytes_per_launch"]
+out["note"]="FETCH_SIZE counts L2 fills from the fabric (HBM or the 256 MB memory-side cache)"
+json.dump(out, open(f"{O}/pmc_traffic.json","w"), indent=1)
+with open(f"{O}/sq_counters.csv","w") as f:
+    f.write("kernel,counter,value_of_the_1000_step_launch\n")
+    for p in ("sq","sq2"):
+        for k,v in sorted(launches(f"{O}/pmc/{p}_counter_collection.csv","k_run").items()):
+            f.write(f"{kernel},{k},{max(v):.0f}\n")
 print(json.dumps(out, indent=1))
 for f in glob.glob(f"{O}/pmc/*.csv"): os.remove(f)
 PY

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sf_set_generic": [_VP, _I32],
     "sf_set_fused": [_VP, _I32],
     "sf_last_step_launch": [_VP, C.POINTER(_I32)],
+    "sf_set_prune_after_quit": [_VP, _I32],
     "sf_set_async": [_VP, _I32],
     "sf_sync": [_VP],
     "sf_set_threshold": [_VP, C.c_double],

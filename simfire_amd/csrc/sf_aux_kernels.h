@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
         atomicSub(&out[e * 8 + 2], h[threadIdx.x]);                          // UNBURNED = H * W - the others
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        out[e * 8 + 0] = commit[e].running;
+        out[e * 8 + 0] = commit[e].running == 1;
         out[e * 8 + 1] = commit[e].steps;
         atomicAdd(&out[e * 8 + 2], g.H * g.W);
     }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *stat
         }
         if (others) atomicSub(&out[e * 8 + 2], others);                              // UNBURNED = H * W - the others
         if (blockIdx.x == 0 && wave == 0) {
-            out[e * 8 + 0] = commit[e].running;
+            out[e * 8 + 0] = commit[e].running == 1;
             out[e * 8 + 1] = commit[e].steps;
             atomicAdd(&out[e * 8 + 2], g.H * g.W);
         }

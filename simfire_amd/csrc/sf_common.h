@@ -26,7 +26,7 @@ constexpr uint32_t FLAG_CAND = 0x100u; // (own byte of the flag word, so the til
 // some sprite has a cell to spread into     (fire.py:651)
 
 struct EnvState {
-    int32_t running;    // GameStatus.RUNNING
+    int32_t running;    // 1 = GameStatus.RUNNING, 0 = QUIT (frozen), 2 = QUIT on the runtime check but still pruning (sf_set_prune_after_quit)
     int32_t steps;      // update() calls made so far; the next step has index t = steps + 1
     int32_t complete;   // updates so far that ran to the end (had a candidate: fire.py:651-652 not taken)
     int32_t time_quit;  // the next update() will hit the runtime check (fire.py:641-643)
@@ -49,6 +49,7 @@ struct Geo {
     long long rt_env;             // element stride between the R tables of two environments (0 = one shared table)
     int Hs;                       // bytes per seam column (row y at index y + kSeamPad; zero guards; covers partial tiles)
     long long seam_env;           // bytes of seam columns per environment = (chunks_x + 1) * 2 * Hs
+    int prune_after_quit;         // 1: environments that QUIT on the runtime check keep pruning (EnvState.running = 2)
     int VW;                       // 64-bit words per row of the vector bitmap = ceil(PV / 64)
     long long vb_env;             // words of vector bitmap per environment = H * VW
 };
@@ -134,7 +135,10 @@ __device__ inline EnvState fold_state(EnvState s, uint32_t f, const Geo &g)
     if (!s.running) return s;                       // frozen: run() no longer calls update
     s.steps += 1;
     if (!(f & FLAG_LIVE)) { s.running = 0; return s; }                    // fire.py:637-638
-    if (s.time_quit) { s.running = 0; return s; }                         // fire.py:641-643
+    // fire.py:641-643.  The reference's update() keeps pruning / ageing the sprites on every later call
+    // (fire.py:631-633 run before the check); callers that go on calling update() after QUIT get that with
+    // prune_after_quit (state 2: the step kernels still visit the environment, spread stays off).
+    if (s.time_quit) { s.running = g.prune_after_quit ? 2 : 0; return s; }
     if (f & FLAG_CAND) { s.elapsed += g.update_rate; s.complete += 1; }   // fire.py:717; else fire.py:651-652
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || s.elapsed > g.max_time);
     return s;

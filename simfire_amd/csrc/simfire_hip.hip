@@ -96,6 +96,7 @@ struct sf_sim {
     int8_t *history = nullptr;         // sf_enable_history: [E][history_cap][H][W] fire maps after each update
     int history_cap = 0;
     double *smag = nullptr, *sdir = nullptr;
+    double slope_scale = 0.0;          // pixel_scale of the constructor: np.gradient spacing (fire.py:446), whatever the threshold becomes
     EnvState *commit = nullptr, *tmp = nullptr;
     uint32_t *flags = nullptr;
     unsigned long long *counters = nullptr;
@@ -190,6 +191,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     const long long P = ((long long)p->width + 15) / 16 * 16;
     if ((long long)p->height * P > (1ll << 26))
         return fail(SF_ENOTSUP, "sf_create: grids above 2^26 cells per environment are not supported");
+    if (p->height > 65535 || p->n_envs > 65535)
+        return fail(SF_ENOTSUP, "sf_create: more than 65535 rows or environments are not supported (launch grid limits)");
     HIPCHK(hipSetDevice(p->device));
     sf_sim *s = new sf_sim();
     s->p = *p;
@@ -209,6 +212,8 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.rt_env = p->per_env_terrain ? (long long)8 * g.H * P : 0;   // 1-byte plane: SWAR kernels; wider: generic per-cell kernel
     g.diag = p->diagonal_spread != 0; g.att = p->attenuate_line_ros != 0; g.has_max_time = p->has_max_time != 0;
     g.pixel_scale = p->pixel_scale; g.update_rate = p->update_rate; g.max_time = p->max_time;
+    s->slope_scale = p->pixel_scale;
+    g.prune_after_quit = 0;
     g.age_env = (long long)(g.H + 2) * g.P; g.plane_env = (long long)g.H * g.P;
     // rows per lane band: 2, i.e. wave tiles of 64 x 32 cells.  Measured on C3 / C4 / C5 once a wave needed
     // only 5.5 KB of LDS: shorter per-tile latency chains beat the fewer, larger 64 x 64 tiles by 6 / 14 / 17 %
@@ -218,9 +223,10 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
 
     int rc;
 #define TRY(x) do { rc = (x); if (rc != SF_OK) { sf_destroy(s); return rc; } } while (0)
+#define TRYHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { sf_destroy(s); return fail(SF_EHIP, "%s failed: %s", #x, hipGetErrorString(_e)); } } while (0)
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(SF_EHIP, "hipStreamCreate failed"); }
-    hipEventCreate(&s->ev0); hipEventCreate(&s->ev1);
-    for (int i = 0; i < sf_sim::kPtsRing; ++i) hipEventCreate(&s->ev_pts[i]);
+    TRYHIP(hipEventCreate(&s->ev0)); TRYHIP(hipEventCreate(&s->ev1));
+    for (int i = 0; i < sf_sim::kPtsRing; ++i) TRYHIP(hipEventCreate(&s->ev_pts[i]));
     const size_t cells = (size_t)g.E * g.plane_env;
     TRY(dev_alloc(s, &s->status, cells));
     TRY(dev_alloc(s, &s->age_alloc, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab));
@@ -252,19 +258,20 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) s->n_cu = prop.multiProcessorCount; }
     TRY(dev_alloc(s, &s->status_block, (size_t)8 * g.E));
     TRY(dev_alloc(s, &s->elapsed_dev, (size_t)g.E));
+    TRYHIP(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
+    TRYHIP(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
+    TRYHIP(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
+    TRYHIP(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
+    TRYHIP(hipMemsetAsync(s->vbits, 0, (size_t)g.E * g.vb_env * sizeof(unsigned long long), s->stream));
+    if (s->settled) TRYHIP(hipMemsetAsync(s->settled, 0, cells * sizeof(uint32_t), s->stream));
+    TRYHIP(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
+    TRYHIP(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
+    TRYHIP(hipMemsetAsync(s->age_alloc, 0, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab, s->stream));
+    TRYHIP(hipMemsetAsync(s->status, 0, cells, s->stream));
+    TRYHIP(hipMemsetAsync(s->burn, 0, cells * sizeof(double), s->stream));
+    TRYHIP(hipStreamSynchronize(s->stream));
 #undef TRY
-    HIPCHK(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * 3 * g.E, s->stream));
-    HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
-    HIPCHK(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
-    HIPCHK(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
-    HIPCHK(hipMemsetAsync(s->vbits, 0, (size_t)g.E * g.vb_env * sizeof(unsigned long long), s->stream));
-    if (s->settled) HIPCHK(hipMemsetAsync(s->settled, 0, cells * sizeof(uint32_t), s->stream));
-    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
-    HIPCHK(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
-    HIPCHK(hipMemsetAsync(s->age_alloc, 0, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab, s->stream));
-    HIPCHK(hipMemsetAsync(s->status, 0, cells, s->stream));
-    HIPCHK(hipMemsetAsync(s->burn, 0, cells * sizeof(double), s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+#undef TRYHIP
     *out = s;
     return SF_OK;
 }
@@ -352,6 +359,16 @@ extern "C" int sf_set_async(sf_sim *s, int32_t on)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_async: null handle");
     s->async = on != 0;
+    return SF_OK;
+}
+/* 1 = environments that QUIT on the runtime check keep pruning / ageing their sprites when sf_step is called again,
+ * like RothermelFireManager.update does on every call after that QUIT (fire.py:631-643); 0 (default) = frozen. */
+extern "C" int sf_set_prune_after_quit(sf_sim *s, int32_t on)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_prune_after_quit: null handle");
+    HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }
+    s->g.prune_after_quit = on != 0;
     return SF_OK;
 }
 extern "C" int sf_sync(sf_sim *s)
@@ -455,7 +472,7 @@ static int set_layers_impl(sf_sim *s, int env, const double *const src[7])
     for (int i = 0; i < 7; ++i)
         if (src[i]) HIPCHK(hipMemcpyAsync(s->layer(lo, i), src[i], n * sizeof(double), hipMemcpyHostToDevice, s->stream));
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
-    hipLaunchKernelGGL(k_slopes, grd, blk, 0, s->stream, g.H, g.W, s->layer(lo, 4), g.pixel_scale, s->smag, s->sdir);
+    hipLaunchKernelGGL(k_slopes, grd, blk, 0, s->stream, g.H, g.W, s->layer(lo, 4), s->slope_scale, s->smag, s->sdir);
     Thetas th;
     for (int k = 0; k < 8; ++k)   // theta = arctan2(src_y - dst_y, dst_x - src_x), float32 (rothermel.py:102)
         th.v[k] = atan2f((float)SF_SRC_DY[k], (float)(-SF_SRC_DX[k]));
@@ -1190,6 +1207,7 @@ extern "C" int sf_fire_map_device(sf_sim *s, void **ptr, int64_t *row_pitch, int
 {
     if (!s || !ptr || !row_pitch || !env_stride) return fail(SF_EINVAL, "sf_fire_map_device: null argument");
     *ptr = s->status; *row_pitch = s->g.P; *env_stride = s->g.plane_env;
+    s->tdirty_all = true;      // the caller holds a writable alias of the status plane: recount everything at the next query
     return SF_OK;
 }
 

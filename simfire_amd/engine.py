@@ -199,6 +199,10 @@ class FireEngine:
         launch per ``step(n)`` call (k_run)."""
         _lib.check(self._L.sf_set_fused(self._h, int(mode)))
 
+    def set_prune_after_quit(self, on=True):
+        """Environments that QUIT on the runtime check keep pruning when stepped again (fire.py:631-643)."""
+        _lib.check(self._L.sf_set_prune_after_quit(self._h, int(bool(on))))
+
     def last_launch_kind(self):
         """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, -1 none yet."""
         v = C.c_int32(-1)

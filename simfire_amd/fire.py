@@ -81,6 +81,7 @@ class RothermelFireManager:
             particle=(fuel_particle.h, fuel_particle.S_T, fuel_particle.S_e, fuel_particle.p_p), device=device)
         self._engine.set_layers(*planes, elevation, self.U, self.U_dir)
         self.slope_mag, self.slope_dir = self._engine.get_slopes()          # fire.py:436-449
+        self._engine.set_prune_after_quit(True)      # update() after a runtime QUIT still prunes (fire.py:631-643)
         self._engine.reset([self.init_pos])
         # the reference's fire_map lives with the caller; the device copy starts with the sprite
         # cell BURNING (simulation.py:565-566) and is re-synchronised whenever the caller's differs
@@ -144,9 +145,8 @@ class RothermelFireManager:
         ``load_mitigation``) is taken over first - sprites persist."""
         if fire_map.shape != self.screen_size:
             raise AssertionError("The fire map does not match the shape of the terrain")    # fire.py:264-269
-        if self._status == GameStatus.QUIT:
-            # the reference would run its QUIT branches again; nothing changes any more
-            return fire_map, GameStatus.QUIT
+        # (called again after QUIT, the reference prunes and ages its sprites once more before it returns QUIT,
+        # fire.py:631-643: the device does the same for a runtime QUIT; after a no-sprites QUIT nothing can change)
         if self._last_map is None or not np.array_equal(fire_map, self._last_map):
             self._engine.load_fire_map(0, fire_map)
         self._engine.step(1)
@@ -180,3 +180,53 @@ class RothermelFireManager:
     def draw_spread_graph(self, game_screen=None):
         raise NotImplementedError("drawing the spread graph over the terrain image is display code, outside "
                                   "simfire_amd's scope; use get_spread_graph() / spread_graph_edges")
+
+
+class ConstantSpreadFireManager:
+    """``simfire.game.managers.fire.ConstantSpreadFireManager`` (fire.py:722-787): same constructor, same
+    ``update(fire_map) -> fire_map``, same observable behaviour - which is not what its docstring promises.
+
+    The reference appends the sprites it creates without giving them durations (fire.py:776-779), and both its
+    own loop (``zip(self.sprites, self.durations)``, fire.py:766) and ``_prune_sprites`` (fire.py:143) pair the
+    two lists with ``zip``: only sprites that have a duration are ever aged, spread or pruned, and the prune
+    truncates ``sprites`` to the paired ones (fire.py:155-156).  So the ignition sprite spreads once, in the
+    update in which its duration equals ``rate_of_spread``, its neighbours turn BURNING and stay BURNING for
+    ever, and the ignition cell turns BURNED after ``max_fire_duration`` updates.  That is at most nine cell
+    writes in the lifetime of a manager: it runs on the host (no kernel, nothing to batch); the behaviour is
+    pinned by ``tests/golden/constant_spread.npz`` (generated from the reference).  ``FireSimulation`` never
+    uses this class (simulation.py:236-249 builds a ``RothermelFireManager``)."""
+
+    _NEIGHBOURS = ((1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1))      # fire.py:212-221
+
+    def __init__(self, init_pos: Tuple[int, int], fire_size: int, max_fire_duration: int, rate_of_spread: int) -> None:
+        self.init_pos = tuple(int(v) for v in init_pos)
+        self.fire_size = fire_size
+        self.max_fire_duration = max_fire_duration
+        self.rate_of_spread = rate_of_spread
+        self.attenuate_line_ros, self.headless, self.diagonal_spread = True, False, True      # base-class defaults, fire.py:57-62
+        self.sprites = [FireSprite(self.init_pos, fire_size)]
+        self.durations = [0]
+
+    def update(self, fire_map: np.ndarray) -> np.ndarray:
+        H, W = fire_map.shape
+        # prune: only (sprite, duration) PAIRS exist for it; unpaired sprites fall off the list (fire.py:143-156)
+        paired = list(zip(self.sprites, self.durations))
+        for sprite, d in paired:
+            if d >= self.max_fire_duration:
+                fire_map[sprite.rect.y, sprite.rect.x] = int(BurnStatus.BURNED)
+        alive = [(s, d) for s, d in paired if d < self.max_fire_duration]
+        self.sprites = [s for s, _ in alive]
+        self.durations = [d for _, d in alive]
+        # spread: again only paired sprites; the new ones get no duration (fire.py:766-781)
+        eligible = (BurnStatus.UNBURNED, BurnStatus.FIRELINE, BurnStatus.SCRATCHLINE, BurnStatus.WETLINE)
+        for sprite, d in list(zip(self.sprites, self.durations)):
+            if d != self.rate_of_spread:
+                continue
+            x, y = sprite.rect.x, sprite.rect.y
+            for dx, dy in self._NEIGHBOURS:
+                nx, ny = x + dx, y + dy
+                if 0 <= nx < W and 0 <= ny < H and fire_map[ny, nx] in eligible:
+                    self.sprites.append(FireSprite((nx, ny), self.fire_size))
+                    fire_map[ny, nx] = int(BurnStatus.BURNING)
+        self.durations = [d + 1 for d in self.durations]
+        return fire_map

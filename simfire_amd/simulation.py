@@ -88,7 +88,21 @@ class FireSimulation:
     def reset(self) -> None:
         """simulation.py:202-214: fire_map, agents, terrain, fire manager state, mitigations."""
         cfg = self.config
-        self._engine, self.terrain = _engine_from_config(cfg, 1, self._device)
+        # The device handle (layers in HBM, R table) is rebuilt only if something it was built from changed:
+        # an RL harness that calls reset() per episode with a new ignition pays one sf_reset, not k_rtable again.
+        key_objs = (cfg.terrain.fuel_layer.data, cfg.terrain.topography_layer.data, cfg.wind.speed, cfg.wind.direction,
+                    getattr(cfg, "fuel_codes", None))
+        key_vals = tuple(getattr(getattr(cfg, a), b) for a, b in _SHARED_FIELDS)
+        prev = getattr(self, "_engine_key", None)
+        if (prev is None or len(prev[0]) != len(key_objs) or any(a is not b for a, b in zip(prev[0], key_objs))
+                or prev[1] != key_vals):
+            if getattr(self, "_engine", None) is not None:
+                self._engine.close()
+            self._engine, self.terrain = _engine_from_config(cfg, 1, self._device)
+            self._engine_key = (key_objs, key_vals)
+        else:
+            self._engine.enable_history(0)
+            self._engine.enable_spread_graph(False)
         self._history_cap = 0
         self.fuel_particle = FuelParticle()
         self.environment = Environment(cfg.environment.moisture, cfg.wind.speed, cfg.wind.direction)
@@ -215,8 +229,10 @@ class FireSimulation:
         if pts:
             H, W = self.config.area.screen_size
             for (_, x, y, _) in pts:
-                if not (0 <= x < W and 0 <= y < H):
+                if not (-W <= x < W and -H <= y < H):
                     raise IndexError(f"mitigation point ({x}, {y}) is out of bounds for a {H}x{W} fire_map")
+            # the reference writes fire_map[y, x] (mitigation.py:75-78): NumPy indexing, negative indices wrap
+            pts = [(e, x % W, y % H, t) for (e, x, y, t) in pts]
             self._engine.apply_mitigation(pts)
             for kind in (BurnStatus.FIRELINE, BurnStatus.SCRATCHLINE, BurnStatus.WETLINE):
                 for (_, x, y, t) in pts:
@@ -410,8 +426,16 @@ class BatchedFireSimulation:
         return (self._engine.fire_maps() if return_maps else None), st[:, 0].astype(bool)
 
     def update_mitigation(self, points) -> None:
-        """rows (env, column, row, type)"""
-        self._engine.apply_mitigation(points)
+        """rows (env, column, row, type); negative column / row count from the end like the NumPy indexing of the
+        reference (mitigation.py:75-78); anything further out raises IndexError"""
+        q = np.asarray(points, dtype=np.int64).reshape(-1, 4).copy()
+        if len(q):
+            H, W = self.config.area.screen_size
+            if ((q[:, 1] < -W) | (q[:, 1] >= W) | (q[:, 2] < -H) | (q[:, 2] >= H)).any():
+                raise IndexError(f"mitigation point out of bounds for a {H}x{W} fire_map")
+            q[:, 1] %= W
+            q[:, 2] %= H
+            self._engine.apply_mitigation(q)
 
     def results(self):
         """int32 [E, 8]: running, elapsed_steps, cell counts per BurnStatus; float64 [E] elapsed_time."""

@@ -3,6 +3,7 @@
 LANDFIRE rasters and the ``noise`` package are not available offline, so the fuel-code
 raster, the elevation field and the wind fields are synthesised exactly as section 8d
 prescribes; they are *inputs* (fed identically to the CPU baseline), not part of the path."""
+import functools
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -121,24 +122,66 @@ def c5(size=1024, n_envs=64, n_agents=64, env_offset=0):
     return w
 
 
-def octave_field(H, W, seed, scale, octaves, persistence, lacunarity, lo, hi):
-    """Smooth multi-octave field in [lo, hi] standing in for the reference's simplex-noise wind maps
-    (simfire/world/wind_mechanics/perlin_wind.py:83-98, ``noise.snoise2`` - a third-party wheel that
-    is not available offline; parity for that generator is unpinned in the reference itself).
-    Sum of randomly oriented sinusoids per octave, float32 like ``perlin_wind.py:69-75``."""
-    rng = np.random.default_rng(seed)
+# Ken Perlin's reference permutation (the table simplex / improved-noise implementations ship, including the
+# `noise` wheel the reference calls)
+_PERM = np.array([
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21,
+    10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149,
+    56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229,
+    122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76,
+    132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226,
+    250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223,
+    183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108,
+    110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162,
+    241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45,
+    127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180],
+    dtype=np.int64)
+_GRAD2 = np.array([[1, 1], [-1, 1], [1, -1], [-1, -1], [1, 0], [-1, 0], [1, 0], [-1, 0], [0, 1], [0, -1], [0, 1], [0, -1]],
+                  dtype=np.float64)
+
+
+def simplex2(x, y, base=0):
+    """2-D simplex noise (Perlin 2001 / Gustavson 2005) on arrays, in [-1, 1]; ``base`` offsets the permutation
+    lookups like the ``base`` argument of ``noise.snoise2``."""
+    F2, G2 = 0.5 * (np.sqrt(3.0) - 1.0), (3.0 - np.sqrt(3.0)) / 6.0
+    s = (x + y) * F2
+    i, j = np.floor(x + s), np.floor(y + s)
+    t = (i + j) * G2
+    x0, y0 = x - (i - t), y - (j - t)
+    i1 = (x0 > y0).astype(np.int64)
+    j1 = 1 - i1
+    x1, y1 = x0 - i1 + G2, y0 - j1 + G2
+    x2, y2 = x0 - 1.0 + 2.0 * G2, y0 - 1.0 + 2.0 * G2
+    ii, jj = (i.astype(np.int64) + base) & 255, (j.astype(np.int64) + base) & 255
+    perm = np.concatenate([_PERM, _PERM])
+
+    def corner(xc, yc, gi):
+        tt = 0.5 - xc * xc - yc * yc
+        g = _GRAD2[gi % 12]
+        return np.where(tt > 0, tt ** 4 * (g[..., 0] * xc + g[..., 1] * yc), 0.0)
+
+    n = (corner(x0, y0, perm[ii + perm[jj]]) + corner(x1, y1, perm[ii + i1 + perm[jj + j1]]) +
+         corner(x2, y2, perm[ii + 1 + perm[jj + 1]]))
+    return 70.0 * n
+
+
+@functools.lru_cache(maxsize=8)
+def simplex_field(H, W, seed, scale, octaves, persistence, lacunarity, lo, hi):
+    """``WindNoise.generate_map_array`` (simfire/world/wind_mechanics/perlin_wind.py:69-98): fractal simplex
+    noise of (x / scale, y / scale) - octaves summed with amplitude x persistence and frequency x lacunarity,
+    normalised by the amplitude sum like ``noise.snoise2`` - mapped from [-1, 1] to [lo, hi], float32.
+    The generator is this build's own (the ``noise`` wheel is not available offline; the reference pins no value
+    of it for wind): the field is an INPUT, fed identically to the CPU baseline."""
     y, x = np.mgrid[0:H, 0:W].astype(np.float64)
-    z = np.zeros((H, W))
-    amp, freq, norm = 1.0, 1.0 / scale, 0.0
+    x, y = x / scale, y / scale
+    total, amp, freq, norm = np.zeros((H, W)), 1.0, 1.0, 0.0
     for _ in range(octaves):
-        for _ in range(3):
-            th, ph = rng.uniform(0, 2 * np.pi, 2)
-            z += amp / 3 * np.sin(2 * np.pi * freq * (x * np.cos(th) + y * np.sin(th)) + ph)
+        total += simplex2(x * freq, y * freq, base=seed) * amp
         norm += amp
-        amp *= persistence
         freq *= lacunarity
-    z = (z / norm + 1) / 2
-    return (z * (hi - lo) + lo).astype(np.float32)
+        amp *= persistence
+    value = total / norm
+    return (((value + 1.0) * (hi - lo)) / 2.0 + lo).astype(np.float32)
 
 
 def c4(size=2048, n_envs=128, env_offset=0):
@@ -146,8 +189,10 @@ def c4(size=2048, n_envs=128, env_offset=0):
     configs/operational_config.yml:106-122 (speed 7-47 mph, direction 0-360 deg), 128 envs per GPU."""
     w = c2(size, n_envs, name="c4_operational_%d_x%d" % (size, n_envs), env_offset=env_offset)
     H, W = w.shape
-    w.U = octave_field(H, W, 2345, 400, 3, 0.7, 2.0, 7 * 88.0, 47 * 88.0).astype(np.float64)
-    w.U_dir = octave_field(H, W, 650, 1500, 2, 0.9, 1.0, 0.0, 360.0).astype(np.float64)
+    # mph -> ft/min after the float32 map, like config.py:936-944
+    w.U = (simplex_field(H, W, 2345, 400, 3, 0.7, 2.0, 7.0, 47.0).astype(np.float64) * 88.0)
+    w.U_dir = simplex_field(H, W, 650, 1500, 2, 0.9, 1.0, 0.0, 360.0).astype(np.float64)
+    w.extra["wind_generator"] = "2-D simplex noise, operational_config.yml:106-122 parameters (own implementation)"
     return w
 
 

@@ -282,3 +282,134 @@ def test_persistent_waves_take_several_tiles_with_graph():
     from simfire_amd import workloads
     _workload_run(workloads.c3(1024, 16), [40, 40], 0, graph=True, dense=True)
     # and sparse: many more live tiles than resident waves needs a big batch - covered by bench.py's own check
+
+
+# ------------------------------------------------------------------ seam behaviours
+@pytest.mark.parametrize("mode", ["fused0", "fused1", "run", "run_tiles", "generic"])
+def test_update_after_runtime_quit_keeps_pruning(mode):
+    """RothermelFireManager.update called again after the runtime QUIT still prunes and ages the sprites
+    (fire.py:631-633 run before the check at 641): with sf_set_prune_after_quit the device does the same -
+    compared with the literal sprite-list restatement driven past QUIT, step by step until nothing burns."""
+    from oracle import fire_sprites
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(61)
+    H, W = 40, 70
+    kw = dict(shape=(H, W), max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, max_time=6.0,
+              attenuate_line_ros=True, diagonal_spread=True)
+    R8 = rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W))
+    init = (30, 20)
+    eng = FireEngine(**kw)
+    eng.set_prune_after_quit(True)
+    if mode == "generic":
+        eng.set_generic(True)
+    else:
+        eng.set_fused({"fused0": 0, "fused1": 1, "run": 2, "run_tiles": 3}[mode])
+    eng.set_rtable(R8)
+    eng.reset([init])
+    s = fire_sprites.SpriteFire((H, W), init, 4, 20.0, 1.0, rtable=R8, max_time=6.0, attenuate_line_ros=True)
+    fm = np.zeros((H, W), dtype=np.int64)
+    fm[init[1], init[0]] = 1
+    quit_seen = 0
+    for t in range(20):
+        fm, stt = s.update(fm)
+        eng.step(1)
+        assert (eng.fire_map(0) == fm).all(), t
+        st, el = eng.status()
+        assert int(st[0, 0]) == int(stt == fire_sprites.RUNNING), t
+        assert el[0] == s.elapsed_time
+        quit_seen += stt != fire_sprites.RUNNING
+    assert quit_seen >= 8 and not (fm == 1).any()      # QUIT came from the runtime check; every sprite was pruned afterwards
+    assert (eng.burn(0) == s.burn).all()
+    # default (flag off): a QUIT environment is frozen, as FireSimulation.run never calls update again
+    eng2 = FireEngine(**kw)
+    eng2.set_rtable(R8)
+    eng2.reset([init])
+    eng2.step(9)
+    m = eng2.fire_map(0).copy()
+    eng2.step(5)
+    assert (eng2.fire_map(0) == m).all() and (m == 1).any()
+
+
+def test_threshold_does_not_move_the_slopes():
+    """manager.pixel_scale = v after construction (test_fire.py:334) changes the ignition threshold only; slopes
+    built later from new layers still use the constructor's pixel_scale (fire.py:377, 446)."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(5)
+    H, W = 20, 30
+    lay = lambda: (np.full((H, W), 0.1), np.full((H, W), 1.0), np.full((H, W), 0.2), np.full((H, W), 2000.0),
+                   rng.uniform(0, 300, (H, W)), np.full((H, W), 500.0), np.full((H, W), 90.0))
+    a = FireEngine((H, W), pixel_scale=50.0)
+    layers = lay()
+    a.set_layers(*layers)
+    mag0, dir0 = a.get_slopes()
+    a.set_threshold(0.0)
+    a.set_layers(*layers)
+    mag1, dir1 = a.get_slopes()
+    assert (mag0 == mag1).all() and (dir0 == dir1).all() and np.isfinite(mag1).all()
+    exp_mag, exp_dir = fire_dense.slopes(layers[4], 50.0)
+    assert np.allclose(mag1, exp_mag, rtol=1e-13) and np.allclose(dir1, exp_dir, rtol=1e-12, atol=1e-15)
+
+
+def test_result_block_counts_follow_every_kind_of_status_write():
+    """The result block is assembled from cached per-tile status histograms; every writer of the status plane has
+    to invalidate them: steps (every launch structure), mitigation only, reset_env, load_fire_map, a geometry
+    change, the generic kernel, an external write through the zero-copy torch view."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(77)
+    H, W, E = 90, 200, 3
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0)
+    eng = FireEngine(**kw)
+    eng.set_rtable(rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W)))
+    eng.reset([(10, 10), (100, 45), (190, 80)])
+
+    def check(tag):
+        st, _ = eng.status()
+        maps = eng.fire_maps()
+        for e in range(E):
+            assert (st[e, 2:8] == np.bincount(maps[e].ravel(), minlength=6)).all(), (tag, e)
+
+    check("reset")
+    for i, mode in enumerate([0, 1, 2, 3, 2, 0]):
+        eng.set_fused(mode)
+        eng.step(3 + i)
+        check(("step", mode))
+        pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(30)]
+        eng.apply_mitigation(pts)
+        check(("mitigation only", mode))
+    eng.reset_env(1, 50, 50)
+    check("reset_env")
+    new = eng.fire_map(2).copy()
+    new[20:30, 40:90] = 4
+    eng.load_fire_map(2, new)
+    check("load_fire_map")
+    eng.set_rows_per_band(4)
+    check("rows_per_band")
+    eng.step(2)
+    check("step after geometry change")
+    eng.set_generic(True)
+    eng.step(2)
+    check("generic")
+    eng.set_generic(False)
+    eng.step(2)
+    check("tiled after generic")
+    t = eng.fire_maps_torch()
+    t[0, 5:9, 5:9] = 5                           # a caller writing through the view (not recommended, but possible)
+    import torch
+    torch.cuda.synchronize()
+    check("external write")
+
+
+def test_bench_two_ranks_on_one_gpu_shard_the_hip_engine():
+    """python bench.py --gpus 2 launches its two ranks itself; with --backend gloo both run the HIP engine on this
+    one GPU (env axis sharded, one all-gather of the result blocks) and rank 0 prints one line with n_gpus = 2
+    whose rollout was checked against the oracle."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "256",
+                          "--envs", "8", "--steps", "60", "--warmup", "5", "--no-extra", "--cpu-threads", "4"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="4"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["envs_total"] == 16 and j["verified"] is True
+    assert j["config"]["env_steps_executed"] > 0 and j["roofline"]["kernel"] in ("k_run", "k_step_fused", "k_select + k_step")

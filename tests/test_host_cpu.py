@@ -197,3 +197,20 @@ def test_error_code_mapping():
     with pytest.raises(NotImplementedError):
         _lib.check(rc)
     assert b"max_fire_duration" in lib.sf_last_error()
+
+
+def test_bench_self_launch_plumbing():
+    """`python bench.py --gpus 2` outside a launcher starts its two ranks itself (RANK / WORLD_SIZE / MASTER_*), they
+    rendezvous (gloo here: no GPU in this container), all-gather a result block and rank 0 prints ONE JSON line
+    with n_gpus = 2; under an existing launcher environment it uses the ranks it is given."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-only", "--envs", "3"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["gathered_rows"] == 6 and j["ok"] is True
+    one = subprocess.run([sys.executable, bench, "--plumbing-only", "--envs", "3"], capture_output=True, text=True, timeout=300)
+    assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

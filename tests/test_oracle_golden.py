@@ -239,3 +239,24 @@ def test_save_data_history_fixture():
     # the observation planes are the float32 / uint32 casts of the uniform fuel
     assert (d["attr_w_0"] == np.float32(w0)).all() and (d["attr_sigma"] == np.uint32(sg)).all()
     assert (d["attr_delta"] == np.float32(de)).all() and (d["attr_M_x"] == np.float32(mx)).all()
+
+
+def test_constant_spread_manager_matches_reference():
+    """ConstantSpreadFireManager (fire.py:722-787) is host logic (at most nine cell writes per manager): it must
+    reproduce what the reference class really does, recorded in tests/golden/constant_spread.npz."""
+    from simfire_amd.fire import ConstantSpreadFireManager
+    d = _golden.load("constant_spread.npz")
+    for i in range(int(d["n_cases"])):
+        H, W, x, y, md, ros, n = (int(v) for v in d[f"c{i}_args"])
+        m = ConstantSpreadFireManager((x, y), 1, md, ros)
+        fm = np.zeros((H, W), dtype=np.int64)
+        fm[y, x] = 1
+        for (lx, ly, t) in d[f"c{i}_lines"]:
+            fm[ly, lx] = t
+        for s in range(n):
+            out = m.update(fm)
+            assert out is fm
+            assert (fm == d[f"c{i}_maps"][s]).all(), (i, s)
+            assert len(m.sprites) == int(d[f"c{i}_n_sprites"][s]), (i, s)
+            exp = [int(v) for v in d[f"c{i}_durations"][s] if v >= 0]
+            assert m.durations == exp, (i, s)
