@@ -216,7 +216,7 @@ int sf_get_spread_parents(sf_sim *sim, int32_t env, uint8_t *parents_out);
 /* 1 = step with the generic one-thread-per-cell kernel (the product path for max_fire_duration > 5,
  * and an independent on-device cross-check of the tiled kernels otherwise), 0 = default. */
 int sf_set_generic(sf_sim *sim, int32_t on);
-/* Step launch structure.  -1 = automatic (default): sf_step(n >= 2) on a batch of >= 64 environments is ONE
+/* Step launch structure.  -1 = automatic (default): sf_step(n >= 2) on a grid up to 1024 cells wide is ONE
  * environment-resident launch (k_run: a workgroup owns an environment for all n steps; environments are
  * independent FireSimulation objects, simulation.py:202-214, so nothing is synchronised between them);
  * otherwise one fused launch per step up to 12288 wave tiles, k_select + k_step above.

@@ -207,7 +207,11 @@ __device__ __forceinline__ uint32_t ge3_01(uint32_t s7) { return ((s7 + 0x050505
 // 0/1 per byte: status == 0
 __device__ __forceinline__ uint32_t eq0_01(uint32_t s7) { return ~(s7 | (s7 >> 1) | (s7 >> 2)) & 0x01010101u; }
 // gather the 0/1 bytes of a dword into 4 bits
-__device__ __forceinline__ uint32_t pack4(uint32_t b01) { return (b01 * 0x01020408u) >> 24; }
+__device__ __forceinline__ uint32_t pack4(uint32_t b01)
+{
+    const uint32_t t = b01 | (b01 >> 7);          // bits 0,1 <- bytes 0,1; bits 16,17 <- bytes 2,3 (no 32-bit multiply: quarter rate)
+    return (t | (t >> 14)) & 0xFu;
+}
 
 __constant__ int c_dx[8] = {+1, 0, -1, +1, -1, +1, 0, -1};
 __constant__ int c_dy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};

@@ -67,7 +67,7 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
 // The walk: one frontier cell per lane.  item = y | x << 16 | status after the prune << 28.
 __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev, const Masks &mk, int complete,
                                             uint32_t lo_mask, uint32_t hi_mask, const uint32_t *clist, uint32_t pend,
-                                            int lane, PhaseClock &pc)
+                                            int lane, int th_log, PhaseClock &pc)
 {
     const Geo &g = a.g;
     WalkAcc acc = {0u, 0u, 0u, 0u};
@@ -96,7 +96,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
         bool ignited = false;
         if (is_cand) {
             // both operands are requested before either is used: one memory round trip, not two
-            const double *rt_p = ev.rt + ((long long)bestk * g.H * g.P + idx);
+            const double *rt_p = ev.rt + ((uint32_t)bestk * (uint32_t)(g.H * g.P) + idx);          // 8 H P < 2^29
             const bool line = s_post >= SF_FIRELINE;
             double bn = ev.burn[idx];
             double r_tab = *rt_p;
@@ -122,7 +122,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
                 ev.status[idx] = (uint8_t)SF_BURNING;                            // fire.py:587
                 ev.age[idx] = nb;
                 atomicOr(&ev.vb[y * g.VW + (x >> 10)], 1ull << ((x >> 4) & 63));
-                ev.tdirty[(y / (g.LR * g.RB)) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
             }
         }
         acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
     ev.rt = a.rt + (long long)e * g.rt_env;
     ev.vb = vb;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+    const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));      // wave-tile height is a power of two
     const int rpt = (g.H + nthr - 1) / nthr;                  // rows per thread (contiguous, so the list runs by rows)
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
@@ -183,29 +184,43 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
         const int exp_sh = __ffs(mk.b_exp) - 1;
         const uint32_t lo_mask = g.diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = g.diag ? L4 : (L4 & 0x00FF00FFu);
 
-        // ---- interest: D = the bitmap dilated by one vector / one row (kept in registers: the passes below change the bitmap)
+        // ---- interest: D = the bitmap dilated by one vector / one row (kept in registers: the passes below change the
+        // bitmap).  Dilation distributes over OR: OR the three rows first, dilate once.
         unsigned long long D[kRunMaxD];
         uint32_t cnt = 0;
+        if (g.VW == 1) {                                      // grids up to 1024 cells wide: one word per row
 #pragma unroll
-        for (int d = 0; d < kRunMaxD; ++d) {
-            D[d] = 0;
-            const int i = d / g.VW, w = d - i * g.VW;           // row of this thread, word of the row
-            const int y = tid * rpt + i;
-            if (i < rpt && y < g.H) {
-                unsigned long long acc = 0;
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int yy = y + dy;
-                    if (yy < 0 || yy >= g.H) continue;
-                    const unsigned long long *row = vb + yy * g.VW;
-                    const unsigned long long c = row[w];
-                    acc |= c | (c << 1) | (c >> 1);
-                    if (w > 0) acc |= row[w - 1] >> 63;
-                    if (w + 1 < g.VW) acc |= row[w + 1] << 63;
+            for (int d = 0; d < kRunMaxD; ++d) {
+                D[d] = 0;
+                const int y = tid * rpt + d;
+                if (d < rpt && y < g.H) {
+                    unsigned long long m = vb[y];
+                    if (y > 0) m |= vb[y - 1];
+                    if (y + 1 < g.H) m |= vb[y + 1];
+                    m = (m | (m << 1) | (m >> 1)) & last_word_mask;
+                    if (g.dense) m = last_word_mask;
+                    D[d] = m;
+                    cnt += (uint32_t)__popcll(m);
                 }
-                if (g.dense) acc = ~0ull;
-                if (w == g.VW - 1) acc &= last_word_mask;
-                D[d] = acc;
-                cnt += (uint32_t)__popcll(acc);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < kRunMaxD; ++d) {
+                D[d] = 0;
+                const int i = d / g.VW, w = d - i * g.VW;           // row of this thread, word of the row
+                const int y = tid * rpt + i;
+                if (i < rpt && y < g.H) {
+                    const unsigned long long *row = vb + y * g.VW;
+                    const int up_o = y > 0 ? -g.VW : 0, dn_o = y + 1 < g.H ? g.VW : 0;
+                    unsigned long long m = row[w] | row[w + up_o] | row[w + dn_o];
+                    m |= (m << 1) | (m >> 1);
+                    if (w > 0) m |= (row[w - 1] | row[w - 1 + up_o] | row[w - 1 + dn_o]) >> 63;
+                    if (w + 1 < g.VW) m |= (row[w + 1] | row[w + 1 + up_o] | row[w + 1 + dn_o]) << 63;
+                    if (g.dense) m = ~0ull;
+                    if (w == g.VW - 1) m &= last_word_mask;
+                    D[d] = m;
+                    cnt += (uint32_t)__popcll(m);
+                }
             }
         }
         // list positions: prefix sum inside the wave, one LDS atomic per wave for its range
@@ -241,43 +256,59 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
             const uint32_t n_chunk = n_all - cb < (uint32_t)vcap ? n_all - cb : (uint32_t)vcap;
             pc.mark(2);      // vector list written, barrier
 
-            // ---- batches of 64 vectors off the shared cursor
-            for (;;) {
-                uint32_t j0 = 0;
-                if (lane == 0) j0 = atomicAdd(&ctl[6 + k], 64u);
-                j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);
-                if (j0 >= n_chunk) break;
+            // ---- batches of 64 vectors off the shared cursor.  A wave requests the rows of its NEXT batch before it
+            // works on the current one: the walk's memory round trips hide the next batch's.  (Reading a neighbour
+            // vector before or after the current batch rewrites it makes no difference: in-place update, see above.)
+            struct VecIn { uint32_t item; uint4 up, mid, dn, sr; uint32_t l0, l1, l2, r0, r1, r2; };
+            auto grab = [&]() {
+                uint32_t j = 0;
+                if (lane == 0) j = atomicAdd(&ctl[6 + k], 64u);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+            };
+            auto fetch = [&](uint32_t j0, VecIn &in) {
                 const bool has = j0 + lane < n_chunk;
-                const uint32_t item = has ? vlist[j0 + lane] : 0xFFFFFFFFu;
+                const uint32_t item = vlist[has ? j0 + lane : n_chunk - 1];      // (idle lanes repeat the last entry: valid addresses)
                 const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
                 const int x0 = v * 16;
-                const uint32_t voff = (uint32_t)(y * g.P + x0);
-                const uint8_t *ra = ev.age + voff;
-                uint4 up = make_uint4(0, 0, 0, 0), mid = up, dn = up, sr = up;
-                if (has) {
-                    mid = *reinterpret_cast<const uint4 *>(ra);
-                    up = *reinterpret_cast<const uint4 *>(ra - g.P);
-                    dn = *reinterpret_cast<const uint4 *>(ra + g.P);
-                    sr = *reinterpret_cast<const uint4 *>(ev.status + voff);
-                }
+                const uint8_t *ra = ev.age + (uint32_t)(y * g.P + x0);
+                in.item = has ? item : 0xFFFFFFFFu;
+                in.mid = *reinterpret_cast<const uint4 *>(ra);
+                in.up = *reinterpret_cast<const uint4 *>(ra - g.P);
+                in.dn = *reinterpret_cast<const uint4 *>(ra + g.P);
+                in.sr = *reinterpret_cast<const uint4 *>(ev.status + (uint32_t)(y * g.P + x0));
                 // The cells just left / right of the vector.  The list runs by rows, so the vector to the left, if it is
                 // interesting at all, is the list entry before this one, i.e. the lane below - and if it is not
                 // interesting, it and the vectors above / below it hold no sprite bit: the edge cells are zero.  Only
                 // the first / last lane of a batch have to look the cells up in the plane.
+                // (loads only inside the branches - nothing that has to wait for them here)
+                in.l0 = in.l1 = in.l2 = in.r0 = in.r1 = in.r2 = 0;
+                if (has && lane == 0 && v > 0) {
+                    in.l0 = *reinterpret_cast<const uint32_t *>(ra - 4);
+                    if (g.diag) { in.l1 = *reinterpret_cast<const uint32_t *>(ra - g.P - 4); in.l2 = *reinterpret_cast<const uint32_t *>(ra + g.P - 4); }
+                }
+                if (has && (j0 + lane + 1 == n_chunk || lane == 63) && x0 + 16 < g.W) {
+                    in.r0 = *reinterpret_cast<const uint32_t *>(ra + 16);
+                    if (g.diag) { in.r1 = *reinterpret_cast<const uint32_t *>(ra - g.P + 16); in.r2 = *reinterpret_cast<const uint32_t *>(ra + g.P + 16); }
+                }
+            };
+            uint32_t j_next = grab();
+            VecIn nxt;
+            if (j_next < n_chunk) fetch(j_next, nxt);
+            while (j_next < n_chunk) {
+                const uint32_t j0 = j_next;
+                const VecIn cur = nxt;
+                j_next = grab();
+                if (j_next < n_chunk) fetch(j_next, nxt);
+                const bool has = cur.item != 0xFFFFFFFFu;
+                const uint32_t item = cur.item;
+                const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
+                const int x0 = v * 16;
+                const uint32_t voff = (uint32_t)(y * g.P + x0);
+                const uint4 up = cur.up, mid = cur.mid, dn = cur.dn, sr = cur.sr;
                 const uint32_t item_l = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x138, 0xF, 0xF, false);   // wave_shr:1
                 const uint32_t item_r = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x130, 0xF, 0xF, false);   // wave_shl:1
                 const bool last_lane = j0 + lane + 1 == n_chunk || lane == 63;
-                uint32_t lin = 0, rin = 0;
-                if (has && lane == 0 && v > 0) {
-                    lin = *reinterpret_cast<const uint32_t *>(ra - 4);
-                    if (g.diag) lin |= *reinterpret_cast<const uint32_t *>(ra - g.P - 4) | *reinterpret_cast<const uint32_t *>(ra + g.P - 4);
-                    lin >>= 24;
-                }
-                if (has && last_lane && x0 + 16 < g.W) {
-                    rin = *reinterpret_cast<const uint32_t *>(ra + 16);
-                    if (g.diag) rin |= *reinterpret_cast<const uint32_t *>(ra - g.P + 16) | *reinterpret_cast<const uint32_t *>(ra + g.P + 16);
-                    rin &= 0xFFu;
-                }
+                uint32_t lin = (cur.l0 | cur.l1 | cur.l2) >> 24, rin = (cur.r0 | cur.r1 | cur.r2) & 0xFFu;
                 n_vec_done += (lane == 0) ? (n_chunk - j0 < 64u ? n_chunk - j0 : 64u) : 0u;
                 const uint4 midL = and4(mid, L4);
                 const uint4 vsrc = and4(or4(up, dn), L4);
@@ -290,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                 }
                 lin &= mk.m_live;
                 rin &= mk.m_live;
-                if (__ballot(any4(midL) != 0) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;   // FLAG_LIVE
+                if (__ballot(has && any4(midL) != 0) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;   // FLAG_LIVE
                 uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
                 nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
                 nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
@@ -341,7 +372,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                         uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
                         uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
                         // pitch padding (x >= W) never takes part
-                        if (x0 + 16 > g.W) {
+                        if (__builtin_expect(x0 + 16 > g.W, 0)) {
                             const int nv = g.W - x0;          // valid cells of this vector
                             p0 &= first01(nv); p1 &= first01(nv - 4); p2 &= first01(nv - 8); p3 &= first01(nv - 12);
                         }
@@ -350,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                 }
                 // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
                 const bool st_ch = ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) != 0;
-                if (st_ch) ev.tdirty[(y / (g.LR * g.RB)) * g.TX + (v >> g.logLC)] = 1;
+                if (st_ch) ev.tdirty[(y >> th_log) * g.TX + (v >> g.logLC)] = 1;
                 pc.mark(5);      // status arrived, SWAR, stores issued
 
                 // ---- frontier cells of this batch -> the wave's window list -> walk
@@ -377,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         pc.mark(6);  // prefix sum + frontier list
-                        const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, tot, lane, pc);
+                        const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, tot, lane, th_log, pc);
                         n_active += wk.n_active;
                         n_ignite += wk.n_ignite;
                         if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
