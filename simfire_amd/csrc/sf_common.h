@@ -73,7 +73,8 @@ struct StepArgs {
     uint8_t *seam;       // [E][chunks_x + 1][2][Hs] copies of the sprite-mask columns either side of every chunk boundary
     uint8_t *tdirty;     // [E][TY][TX] 1 = the tile's status bytes changed since its histogram was last taken (result block)
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
-    unsigned long long *vbits;   // [E][H][VW] vector bitmap: bit v of row y = the 16-cell vector holds a sprite bit (k_run)
+    unsigned long long *vbits;   // [3][E][H][VW] vector bitmaps (k_run): bit v of row y = the 16-cell vector holds a sprite bit /
+                                 // holds one in its first cell / in its last cell
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };
@@ -206,6 +207,9 @@ __device__ __forceinline__ uint32_t first01(int n)
 __device__ __forceinline__ uint32_t ge3_01(uint32_t s7) { return ((s7 + 0x05050505u) >> 3) & 0x01010101u; }
 // 0/1 per byte: status == 0
 __device__ __forceinline__ uint32_t eq0_01(uint32_t s7) { return ~(s7 | (s7 >> 1) | (s7 >> 2)) & 0x01010101u; }
+// 0/1 per byte for status bytes 0..5: eligible for ignition (fire.py:192-205) = UNBURNED or a control line = not 1, 2
+// = bit2 | ~(bit0 ^ bit1)
+__device__ __forceinline__ uint32_t elig01(uint32_t s7) { return ((s7 >> 2) | ~(s7 ^ (s7 >> 1))) & 0x01010101u; }
 // gather the 0/1 bytes of a dword into 4 bits
 __device__ __forceinline__ uint32_t pack4(uint32_t b01)
 {

@@ -48,7 +48,8 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
 __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap)
 {
-    size_t b = (size_t)g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * kRunWin * 4 + kRunCtl * 4;
+    const int maps = g.VW == 1 ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
+    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * kRunWin * 4 + kRunCtl * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;              // + phase clocks [waves][16]
 #endif
@@ -61,6 +62,7 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
     uint32_t *settled;
     const double *rt;
     unsigned long long *vb;        // LDS bitmap [H][VW]
+    unsigned long long *vf, *vl;   // one-word rows only: the vector's first / last cell holds a sprite bit (else null)
     uint8_t *tdirty;               // [TY][TX] of this environment: status histogram of the wave tile is stale
 };
 
@@ -122,6 +124,10 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
                 ev.status[idx] = (uint8_t)SF_BURNING;                            // fire.py:587
                 ev.age[idx] = nb;
                 atomicOr(&ev.vb[y * g.VW + (x >> 10)], 1ull << ((x >> 4) & 63));
+                if (ev.vf) {
+                    if ((x & 15) == 0) atomicOr(&ev.vf[y], 1ull << (x >> 4));
+                    if ((x & 15) == 15) atomicOr(&ev.vl[y], 1ull << (x >> 4));
+                }
                 ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
             }
         }
@@ -141,7 +147,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     const int e = blockIdx.x;
     unsigned long long *vb = reinterpret_cast<unsigned long long *>(s_dyn);        // [H][VW]
-    uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)g.H * g.VW);       // [vcap]
+    const bool fine = g.VW == 1;                                                   // refined interest rule (see below)
+    unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
+    uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
     uint32_t *clist = vlist + vcap + wave * kRunWin;                               // [kRunWin] per wave
     uint32_t *ctl = vlist + vcap + n_waves * kRunWin;
 
@@ -150,6 +158,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * g.VW;
     for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];
+    if (fine)
+        for (int i = tid; i < g.H; i += nthr) {
+            vf[i] = vb_glob[(long long)g.E * g.vb_env + i];           // planes 1 / 2 of the bitmap array
+            vl[i] = vb_glob[2ll * g.E * g.vb_env + i];
+            ve[i] = ~0ull;                                             // "has an eligible cell": found out as the vectors are visited
+        }
     if (tid < kRunCtl) ctl[tid] = 0;
     PhaseClock pc;
 #ifdef SF_PHASES
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
     ev.burn = a.burn + (long long)e * g.plane_env;
     ev.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
     ev.rt = a.rt + (long long)e * g.rt_env;
-    ev.vb = vb;
+    ev.vb = vb; ev.vf = vf; ev.vl = vl;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
     const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));      // wave-tile height is a power of two
     const int rpt = (g.H + nthr - 1) / nthr;                  // rows per thread (contiguous, so the list runs by rows)
@@ -188,16 +202,24 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
         // bitmap).  Dilation distributes over OR: OR the three rows first, dilate once.
         unsigned long long D[kRunMaxD];
         uint32_t cnt = 0;
-        if (g.VW == 1) {                                      // grids up to 1024 cells wide: one word per row
+        if (fine) {
+            // Grids up to 1024 cells wide (one word per row).  A vector has to be visited if it holds a sprite bit (b1); if it
+            // has an eligible cell (e) and a sprite sits right above / below it (b0 | b2) or in the edge cell of a horizontal
+            // neighbour, rows y - 1 .. y + 1 (last cell of v - 1: l << 1; first cell of v + 1: f >> 1); and - so that a listed
+            // vector always finds its horizontal neighbour in the list when that neighbour's column matters to it, see the
+            // edge cells below - if the vector above / below it has a sprite in an edge cell (l0 | l2 | f0 | f2).
 #pragma unroll
             for (int d = 0; d < kRunMaxD; ++d) {
                 D[d] = 0;
                 const int y = tid * rpt + d;
                 if (d < rpt && y < g.H) {
-                    unsigned long long m = vb[y];
-                    if (y > 0) m |= vb[y - 1];
-                    if (y + 1 < g.H) m |= vb[y + 1];
-                    m = (m | (m << 1) | (m >> 1)) & last_word_mask;
+                    const int up_o = y > 0 ? -1 : 0, dn_o = y + 1 < g.H ? 1 : 0;
+                    const unsigned long long b1 = vb[y], l1 = vl[y], f1 = vf[y], e1 = ve[y];
+                    unsigned long long b02 = 0, l02 = 0, f02 = 0;
+                    if (up_o) { b02 = vb[y - 1]; l02 = vl[y - 1]; f02 = vf[y - 1]; }
+                    if (dn_o) { b02 |= vb[y + 1]; l02 |= vl[y + 1]; f02 |= vf[y + 1]; }
+                    unsigned long long m = b1 | (e1 & (b02 | ((l02 | l1) << 1) | ((f02 | f1) >> 1))) | l02 | f02;
+                    m &= last_word_mask;
                     if (g.dense) m = last_word_mask;
                     D[d] = m;
                     cnt += (uint32_t)__popcll(m);
@@ -291,6 +313,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                     if (g.diag) { in.r1 = *reinterpret_cast<const uint32_t *>(ra - g.P + 16); in.r2 = *reinterpret_cast<const uint32_t *>(ra + g.P + 16); }
                 }
             };
+            uint32_t n_pend = 0;                          // frontier cells waiting in this wave's list (wave-uniform)
             uint32_t j_next = grab();
             VecIn nxt;
             if (j_next < n_chunk) fetch(j_next, nxt);
@@ -335,6 +358,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                     const uint4 av = and4(mid, ~CLR4);
                     *reinterpret_cast<uint4 *>(ev.age + voff) = av;
                     if (!any4(av)) atomicAnd(&vb[y * g.VW + (v >> 6)], ~(1ull << (v & 63)));     // no sprite bit left in the vector
+                    if (fine) {
+                        if (!(av.x & 0xFFu) && (mid.x & 0xFFu)) atomicAnd(&vf[y], ~(1ull << v));
+                        if (!(av.w >> 24) && (mid.w >> 24)) atomicAnd(&vl[y], ~(1ull << v));
+                    }
                 }
                 uint32_t m16 = 0;
                 uint4 snew = sr;
@@ -367,10 +394,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                     }
                     if (any_nb) {
                         // frontier cells (0 / 1 per byte): eligible (fire.py:192-205) & next to a live sprite
-                        uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
-                        uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
-                        uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
-                        uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+                        uint32_t p0 = elig01(snew.x) & nz01(nb.x);
+                        uint32_t p1 = elig01(snew.y) & nz01(nb.y);
+                        uint32_t p2 = elig01(snew.z) & nz01(nb.z);
+                        uint32_t p3 = elig01(snew.w) & nz01(nb.w);
                         // pitch padding (x >= W) never takes part
                         if (__builtin_expect(x0 + 16 > g.W, 0)) {
                             const int nv = g.W - x0;          // valid cells of this vector
@@ -379,44 +406,82 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                         m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
                     }
                 }
+                if (fine && has) {
+                    // no eligible cell left in the vector (fire.py:192-205: UNBURNED or a control line)?  Then sprites next
+                    // to it are no reason to visit it.  (snew still lacks this step's ignitions: found out at the next visit.)
+                    uint32_t el = elig01(snew.x) | elig01(snew.y) |
+                                  elig01(snew.z) | elig01(snew.w);
+                    if (__builtin_expect(x0 + 16 > g.W, 0)) {          // pitch padding is UNBURNED for ever: only real cells count
+                        const int nv = g.W - x0;
+                        el = (elig01(snew.x) & first01(nv)) | (elig01(snew.y) & first01(nv - 4)) |
+                             (elig01(snew.z) & first01(nv - 8)) | (elig01(snew.w) & first01(nv - 12));
+                    }
+                    if (!el) atomicAnd(&ve[y], ~(1ull << v));
+                }
                 // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
                 const bool st_ch = ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) != 0;
                 if (st_ch) ev.tdirty[(y >> th_log) * g.TX + (v >> g.logLC)] = 1;
                 pc.mark(5);      // status arrived, SWAR, stores issued
 
-                // ---- frontier cells of this batch -> the wave's window list -> walk
+                // ---- frontier cells of this batch -> the wave's window list.  The list is walked in full wavefronts:
+                // whole multiples of 64 cells now, the remainder stays for the next batch (or the end of the step).
                 const uint32_t mine = (uint32_t)__popc(m16);
                 if (__ballot(mine != 0) != 0ull) {
                     const uint32_t incl_c = wave_scan_incl(mine, lane);
                     const uint32_t total = wave_last(incl_c);
                     const uint32_t excl = incl_c - mine;
+                    uint32_t win = 0;
 #pragma unroll 1
-                    for (uint32_t win = 0; win < total; win += (uint32_t)kRunWin) {
+                    while (win < total) {
+                        const uint32_t room = (uint32_t)kRunWin - n_pend;
+                        const uint32_t take = total - win < room ? total - win : room;
                         uint32_t pos = excl, m = m16;
                         while (m) {
                             const int b = __ffs(m) - 1;
                             m &= m - 1;
                             const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
-                            if (slot < (uint32_t)kRunWin) {
+                            if (slot < take) {
                                 const uint32_t code = (pick(snew, b >> 2) >> (8 * (b & 3))) & 7u;
-                                clist[slot] = (uint32_t)y | ((uint32_t)(x0 + b) << 16) | (code << 28);
+                                clist[n_pend + slot] = (uint32_t)y | ((uint32_t)(x0 + b) << 16) | (code << 28);
                             }
                             pos++;
                         }
-                        const uint32_t tot = total - win < (uint32_t)kRunWin ? total - win : (uint32_t)kRunWin;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        pc.mark(6);  // prefix sum + frontier list
-                        const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, tot, lane, th_log, pc);
-                        n_active += wk.n_active;
-                        n_ignite += wk.n_ignite;
-                        if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
-                        n_items_acc += (lane == 0) ? tot : 0u;
-                        n_phase2++;
+                        n_pend += take;
+                        win += take;
+                        const uint32_t full = win < total ? n_pend : (n_pend & ~63u);     // window full: everything (a multiple of 64)
+                        if (full) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            pc.mark(6);  // prefix sum + frontier list
+                            const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, full, lane, th_log, pc);
+                            n_active += wk.n_active;
+                            n_ignite += wk.n_ignite;
+                            if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
+                            n_items_acc += (lane == 0) ? full : 0u;
+                            n_phase2++;
+                            const uint32_t rem = n_pend - full;                            // < 64: move it to the front
+                            uint32_t keep = 0;
+                            if ((uint32_t)lane < rem) keep = clist[full + lane];
+                            __builtin_amdgcn_wave_barrier();
+                            if ((uint32_t)lane < rem) clist[lane] = keep;
+                            n_pend = rem;
+                        }
                     }
                 }
                 pc.mark(10);
+            }
+            if (n_pend) {                                  // what is left of the wave's frontier list
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, n_pend, lane, th_log, pc);
+                n_active += wk.n_active;
+                n_ignite += wk.n_ignite;
+                if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                             // FLAG_CAND
+                n_items_acc += (lane == 0) ? n_pend : 0u;
+                n_phase2++;
+                n_pend = 0;
             }
             if (cb + (uint32_t)vcap >= n_all) break;       // (uniform) the usual case: one chunk
             __syncthreads();                               // everybody is done with this chunk's list
@@ -444,6 +509,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
     __syncthreads();
     if (tid == 0) a.commit[e] = st;
     for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
+    if (fine)
+        for (int i = tid; i < g.H; i += nthr) {
+            vb_glob[(long long)g.E * g.vb_env + i] = vf[i];
+            vb_glob[2ll * g.E * g.vb_env + i] = vl[i];
+        }
     if (a.counters && lane == 0) {
         unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
@@ -460,13 +530,13 @@ __global__ __launch_bounds__(64) void k_rebuild_vbits(Geo g, const uint8_t *age,
 {
     const int w = blockIdx.x, y = blockIdx.y, e = env0 + blockIdx.z, lane = threadIdx.x;
     const int v = w * 64 + lane;
-    uint32_t any = 0;
-    if (v < g.PV) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16);
-        any = any4(r);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (v < g.PV) r = *reinterpret_cast<const uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16);
+    const unsigned long long b = __ballot(any4(r) != 0), f = __ballot((r.x & 0xFFu) != 0), l = __ballot((r.w >> 24) != 0);
+    if (lane == 0) {
+        const long long o = (long long)e * g.vb_env + (long long)y * g.VW + w, plane = (long long)g.E * g.vb_env;
+        vbits[o] = b; vbits[plane + o] = f; vbits[2 * plane + o] = l;      // any sprite bit / in the first cell / in the last cell
     }
-    const unsigned long long bal = __ballot(any != 0);
-    if (lane == 0) vbits[(long long)e * g.vb_env + (long long)y * g.VW + w] = bal;
 }
 
 }  // namespace

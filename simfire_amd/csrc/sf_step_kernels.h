@@ -493,10 +493,10 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             }
             if (any_nb) {
                 // frontier cells (0 / 1 per byte): eligible (fire.py:192-205) & next to a live sprite
-                uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
-                uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
-                uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
-                uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+                uint32_t p0 = elig01(snew.x) & nz01(nb.x);
+                uint32_t p1 = elig01(snew.y) & nz01(nb.y);
+                uint32_t p2 = elig01(snew.z) & nz01(nb.z);
+                uint32_t p3 = elig01(snew.w) & nz01(nb.w);
                 // pitch padding (x >= W) never takes part
                 const int xs = xv * 16;
                 if (xs + 16 > g.W) {
@@ -1001,7 +1001,13 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commi
     age_store(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x, 1u);   // ignition step 0
     const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
     tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
-    vbits[(long long)e * g.vb_env + (long long)y * g.VW + (x >> 10)] = 1ull << ((x >> 4) & 63);        // (cleared by the caller)
+    {   // vector bitmaps of the resident launch (cleared by the caller): any sprite bit / first cell / last cell
+        const long long o = (long long)e * g.vb_env + (long long)y * g.VW + (x >> 10), plane = (long long)g.E * g.vb_env;
+        const unsigned long long bit = 1ull << ((x >> 4) & 63);
+        vbits[o] = bit;
+        if ((x & 15) == 0) vbits[plane + o] = bit;
+        if ((x & 15) == 15) vbits[2 * plane + o] = bit;
+    }
     EnvState s;
     s.running = 1; s.steps = 0; s.complete = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);

@@ -251,7 +251,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->seam, (size_t)g.E * g.seam_env));
     if (g.att) TRY(dev_alloc(s, &s->settled, cells));
     g.VW = (g.PV + 63) / 64; g.vb_env = (long long)g.H * g.VW;
-    TRY(dev_alloc(s, &s->vbits, (size_t)g.E * g.vb_env));
+    TRY(dev_alloc(s, &s->vbits, (size_t)3 * g.E * g.vb_env));
     s->n_tiles_max = (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x;      // RB = 1 is the finest tiling
     TRY(dev_alloc(s, &s->tdirty, s->n_tiles_max));
     TRY(dev_alloc(s, &s->thist, s->n_tiles_max * 8));
@@ -262,7 +262,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRYHIP(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
     TRYHIP(hipMemsetAsync(s->n_active, 0, 16 * sizeof(uint32_t), s->stream));
     TRYHIP(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
-    TRYHIP(hipMemsetAsync(s->vbits, 0, (size_t)g.E * g.vb_env * sizeof(unsigned long long), s->stream));
+    TRYHIP(hipMemsetAsync(s->vbits, 0, (size_t)3 * g.E * g.vb_env * sizeof(unsigned long long), s->stream));
     if (s->settled) TRYHIP(hipMemsetAsync(s->settled, 0, cells * sizeof(uint32_t), s->stream));
     TRYHIP(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
     TRYHIP(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
@@ -691,7 +691,8 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     const size_t fplane = (size_t)g.TYp * g.TXp;
     for (int k = 0; k < 2; ++k)
         HIPCHK(hipMemsetAsync(s->tflags + ((size_t)k * g.E + env0) * fplane, 0, (size_t)n * fplane, s->stream));
-    HIPCHK(hipMemsetAsync(s->vbits + (size_t)env0 * g.vb_env, 0, (size_t)n * g.vb_env * sizeof(unsigned long long), s->stream));
+    for (int k = 0; k < 3; ++k)
+        HIPCHK(hipMemsetAsync(s->vbits + ((size_t)k * g.E + env0) * g.vb_env, 0, (size_t)n * g.vb_env * sizeof(unsigned long long), s->stream));
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
                        s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n);
     HIPCHK(hipGetLastError());
