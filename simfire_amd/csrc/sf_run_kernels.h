@@ -40,7 +40,8 @@ namespace {
 // The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
 // them when it switches back), the vector bitmap is not maintained there (k_rebuild_vbits).
 // ------------------------------------------------------------------------------------------
-constexpr int kRunWin = 384;       // frontier cells per walk window of a wave (u32 items in LDS)
+constexpr int kRunWin = 384;       // frontier cells per walk window of a wave (u16 items in LDS)
+constexpr int kStripDw = 21;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
 constexpr int kRunCtl = 16;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps)
 constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row)
 
@@ -49,7 +50,7 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap)
 {
     const int maps = g.VW == 1 ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
-    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * kRunWin * 4 + kRunCtl * 4;
+    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (kRunWin * 2 + 64 * kStripDw * 4) + kRunCtl * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;              // + phase clocks [waves][16]
 #endif
@@ -66,26 +67,29 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
     uint8_t *tdirty;               // [TY][TX] of this environment: status histogram of the wave tile is stale
 };
 
-// The walk: one frontier cell per lane.  item = y | x << 16 | status after the prune << 28.
+// The walk: one frontier cell per lane.  item = lane of the vector in the batch | cell in the vector << 6 | status after the
+// prune << 10.  The 3 x 3 sprite masks come from the batch's strip buffer in LDS (the rows the vector pass has just loaded, with
+// the cell left / right of the vector): no memory round trip before the winner is known.
 __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev, const Masks &mk, int complete,
-                                            uint32_t lo_mask, uint32_t hi_mask, const uint32_t *clist, uint32_t pend,
-                                            int lane, int th_log, PhaseClock &pc)
+                                            uint32_t lo_mask, uint32_t hi_mask, const uint16_t *clist, const uint32_t *strips,
+                                            uint32_t pend, int lane, int th_log, PhaseClock &pc)
 {
     const Geo &g = a.g;
     WalkAcc acc = {0u, 0u, 0u, 0u};
     for (uint32_t j = lane; j < pend; j += 64) {
         const uint32_t it = clist[j];
-        const int y = it & 0xFFFF, x = (it >> 16) & 0xFFF;
-        const uint32_t s_post = it >> 28;                  // 0, 3, 4, 5: eligible by construction (fire.py:192-205)
+        const int jl = it & 63, b = (it >> 6) & 15;
+        const uint32_t s_post = it >> 10;                  // 0, 3, 4, 5: eligible by construction (fire.py:192-205)
+        const uint32_t *rec = strips + jl * kStripDw;
+        const uint32_t hdr = rec[0];
+        const int y = hdr & 0xFFFF, x = (int)(hdr >> 16) * 16 + b;
         const uint32_t idx = (uint32_t)(y * g.P + x);
-        // 3 x 3 sprite masks: bytes 0..2 = cells x-1, x, x+1 of the rows y-1, y, y+1 (zero guard rows at -1 and H)
-        const int xo = x ? x - 1 : 0;
-        const uint8_t *q = ev.age + ((y - 1) * g.P + xo);
-        uint32_t up3 = *reinterpret_cast<const u32_unaligned *>(q);
-        uint32_t mid3 = *reinterpret_cast<const u32_unaligned *>(q + g.P);
-        uint32_t dn3 = *reinterpret_cast<const u32_unaligned *>(q + 2 * g.P);
-        if (!x) { up3 <<= 8; mid3 <<= 8; dn3 <<= 8; }                              // no column -1
-        if (x + 1 >= g.W) { up3 &= 0xFFFFu; mid3 &= 0xFFFFu; dn3 &= 0xFFFFu; }      // no column W
+        // bytes 0..2 = cells x-1, x, x+1 of the rows y-1, y, y+1: cell b sits at byte 4 + b of a row strip
+        const int q = (3 + b) >> 2;
+        const uint32_t sh = (uint32_t)(3 + b) & 3u;
+        const uint32_t up3 = __builtin_amdgcn_alignbyte(rec[2 + q], rec[1 + q], sh);
+        const uint32_t mid3 = __builtin_amdgcn_alignbyte(rec[8 + q], rec[7 + q], sh);
+        const uint32_t dn3 = __builtin_amdgcn_alignbyte(rec[14 + q], rec[13 + q], sh);
         const uint32_t own = (mid3 >> 8) & 0xFFu;
         const int bestk = pick_winner8(up3, mid3, dn3, mk, lo_mask, hi_mask);
         const bool is_cand = bestk >= 0;
@@ -120,7 +124,12 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
             if (bn > g.pixel_scale) {                                            // fire.py:568
                 ignited = true;
                 const uint8_t nb = (uint8_t)((own & ~mk.b_clr) | mk.b_new);       // fire.py:571-579
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the vector pass's 16-byte stores to these lines have landed
+                // These byte stores follow, in program order, the 16-byte stores of the vector pass to the same lines: stores of one
+                // wave reach the L2 in issue order (same line = same channel queue; profiles/store_order_probe.hip: 0 of 5.2e9
+                // inverted).  -DSF_STORE_ORDER_WAIT restores an explicit wait for the earlier stores' acknowledgements.
+#ifdef SF_STORE_ORDER_WAIT
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 ev.status[idx] = (uint8_t)SF_BURNING;                            // fire.py:587
                 ev.age[idx] = nb;
                 atomicOr(&ev.vb[y * g.VW + (x >> 10)], 1ull << ((x >> 4) & 63));
@@ -140,7 +149,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
     return acc;
 }
 
-__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
+__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
@@ -150,8 +159,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
     const bool fine = g.VW == 1;                                                   // refined interest rule (see below)
     unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
-    uint32_t *clist = vlist + vcap + wave * kRunWin;                               // [kRunWin] per wave
-    uint32_t *ctl = vlist + vcap + n_waves * kRunWin;
+    uint32_t *strips = vlist + vcap + wave * (64 * kStripDw);                      // [64][kStripDw] per wave
+    uint16_t *clist = reinterpret_cast<uint16_t *>(vlist + vcap + n_waves * (64 * kStripDw)) + wave * kRunWin;   // [kRunWin] per wave
+    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw) + n_waves * kRunWin / 2;
 
     EnvState st = a.commit[e];
     if (!st.running) return;                    // frozen: run() no longer calls update (uniform over the workgroup)
@@ -261,14 +271,23 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                 uint32_t p = pos0;
 #pragma unroll
                 for (int d = 0; d < kRunMaxD; ++d) {
-                    unsigned long long m = D[d];
+                    const unsigned long long m = D[d];
                     const int i = d / g.VW, w = d - i * g.VW;
                     const uint32_t base_item = (uint32_t)(tid * rpt + i) | ((uint32_t)(w * 64) << 16);
-                    while (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        m &= m - 1;
+                    // (two 32-bit loops: a row along a front holds tens of vectors, and this loop is serial per thread)
+                    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+                    while (lo) {
+                        const uint32_t b = (uint32_t)__ffs(lo) - 1u;
+                        lo &= lo - 1;
                         const uint32_t slot = p - cb;         // wraps for p < cb: not in this chunk
-                        if (slot < (uint32_t)vcap) vlist[slot] = base_item + ((uint32_t)b << 16);
+                        if (slot < (uint32_t)vcap) vlist[slot] = base_item + (b << 16);
+                        p++;
+                    }
+                    while (hi) {
+                        const uint32_t b = (uint32_t)__ffs(hi) + 31u;
+                        hi &= hi - 1;
+                        const uint32_t slot = p - cb;
+                        if (slot < (uint32_t)vcap) vlist[slot] = base_item + (b << 16);
                         p++;
                     }
                 }
@@ -284,11 +303,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
             struct VecIn { uint32_t item; uint4 up, mid, dn, sr; uint32_t l0, l1, l2, r0, r1, r2; };
             auto grab = [&]() {
                 uint32_t j = 0;
-                if (lane == 0) j = atomicAdd(&ctl[6 + k], 64u);
+                if (lane == 0) j = atomicAdd(&ctl[6 + k], (uint32_t)bsz);
                 return (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
             };
             auto fetch = [&](uint32_t j0, VecIn &in) {
-                const bool has = j0 + lane < n_chunk;
+                const bool has = lane < bsz && j0 + lane < n_chunk;
                 const uint32_t item = vlist[has ? j0 + lane : n_chunk - 1];      // (idle lanes repeat the last entry: valid addresses)
                 const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
                 const int x0 = v * 16;
@@ -308,12 +327,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                     in.l0 = *reinterpret_cast<const uint32_t *>(ra - 4);
                     if (g.diag) { in.l1 = *reinterpret_cast<const uint32_t *>(ra - g.P - 4); in.l2 = *reinterpret_cast<const uint32_t *>(ra + g.P - 4); }
                 }
-                if (has && (j0 + lane + 1 == n_chunk || lane == 63) && x0 + 16 < g.W) {
+                if (has && (j0 + lane + 1 == n_chunk || lane == bsz - 1) && x0 + 16 < g.W) {
                     in.r0 = *reinterpret_cast<const uint32_t *>(ra + 16);
                     if (g.diag) { in.r1 = *reinterpret_cast<const uint32_t *>(ra - g.P + 16); in.r2 = *reinterpret_cast<const uint32_t *>(ra + g.P + 16); }
                 }
             };
-            uint32_t n_pend = 0;                          // frontier cells waiting in this wave's list (wave-uniform)
             uint32_t j_next = grab();
             VecIn nxt;
             if (j_next < n_chunk) fetch(j_next, nxt);
@@ -330,17 +348,32 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                 const uint4 up = cur.up, mid = cur.mid, dn = cur.dn, sr = cur.sr;
                 const uint32_t item_l = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x138, 0xF, 0xF, false);   // wave_shr:1
                 const uint32_t item_r = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x130, 0xF, 0xF, false);   // wave_shl:1
-                const bool last_lane = j0 + lane + 1 == n_chunk || lane == 63;
-                uint32_t lin = (cur.l0 | cur.l1 | cur.l2) >> 24, rin = (cur.r0 | cur.r1 | cur.r2) & 0xFFu;
-                n_vec_done += (lane == 0) ? (n_chunk - j0 < 64u ? n_chunk - j0 : 64u) : 0u;
+                const bool last_lane = j0 + lane + 1 == n_chunk || lane == bsz - 1;
+                n_vec_done += (lane == 0) ? (n_chunk - j0 < (uint32_t)bsz ? n_chunk - j0 : (uint32_t)bsz) : 0u;
                 const uint4 midL = and4(mid, L4);
                 const uint4 vsrc = and4(or4(up, dn), L4);
                 const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+                // per row: the cell left of the vector in byte 3 of l?, the cell right of it in byte 0 of r?
+                uint32_t l0 = cur.l0 & 0xFF000000u, l1 = cur.l1 & 0xFF000000u, l2 = cur.l2 & 0xFF000000u;
+                uint32_t r0 = cur.r0 & 0xFFu, r1 = cur.r1 & 0xFFu, r2 = cur.r2 & 0xFFu;
                 {
-                    const uint32_t e_l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hsrc.w, 0x138, 0xF, 0xF, false) >> 24;
-                    const uint32_t e_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hsrc.x, 0x130, 0xF, 0xF, false) & 0xFFu;
-                    if (lane != 0 && item_l + 0x10000u == item) lin = e_l;
-                    if (!last_lane && item_r == item + 0x10000u) rin = e_r;
+                    const uint32_t dl0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid.w, 0x138, 0xF, 0xF, false);
+                    const uint32_t dl1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)up.w, 0x138, 0xF, 0xF, false);
+                    const uint32_t dl2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dn.w, 0x138, 0xF, 0xF, false);
+                    const uint32_t dr0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid.x, 0x130, 0xF, 0xF, false);
+                    const uint32_t dr1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)up.x, 0x130, 0xF, 0xF, false);
+                    const uint32_t dr2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dn.x, 0x130, 0xF, 0xF, false);
+                    if (lane != 0 && item_l + 0x10000u == item) { l0 = dl0 & 0xFF000000u; l1 = dl1 & 0xFF000000u; l2 = dl2 & 0xFF000000u; }
+                    if (!last_lane && item_r == item + 0x10000u) { r0 = dr0 & 0xFFu; r1 = dr1 & 0xFFu; r2 = dr2 & 0xFFu; }
+                }
+                uint32_t lin = (g.diag ? (l0 | l1 | l2) : l0) >> 24, rin = g.diag ? (r0 | r1 | r2) : r0;
+                // park the rows for the walk (this wave's strip buffer; the walk of the previous batch is over)
+                if (has) {
+                    uint32_t *rec = strips + lane * kStripDw;
+                    rec[0] = item & 0x00FFFFFFu;                     // y | v << 16
+                    rec[1] = l1; rec[2] = up.x; rec[3] = up.y; rec[4] = up.z; rec[5] = up.w; rec[6] = r1;
+                    rec[7] = l0; rec[8] = mid.x; rec[9] = mid.y; rec[10] = mid.z; rec[11] = mid.w; rec[12] = r0;
+                    rec[13] = l2; rec[14] = dn.x; rec[15] = dn.y; rec[16] = dn.z; rec[17] = dn.w; rec[18] = r2;
                 }
                 lin &= mk.m_live;
                 rin &= mk.m_live;
@@ -423,65 +456,42 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap)
                 if (st_ch) ev.tdirty[(y >> th_log) * g.TX + (v >> g.logLC)] = 1;
                 pc.mark(5);      // status arrived, SWAR, stores issued
 
-                // ---- frontier cells of this batch -> the wave's window list.  The list is walked in full wavefronts:
-                // whole multiples of 64 cells now, the remainder stays for the next batch (or the end of the step).
+                // ---- frontier cells of this batch -> the wave's list -> walk (windows of kRunWin cells: a batch holds up to 1024)
                 const uint32_t mine = (uint32_t)__popc(m16);
                 if (__ballot(mine != 0) != 0ull) {
                     const uint32_t incl_c = wave_scan_incl(mine, lane);
                     const uint32_t total = wave_last(incl_c);
                     const uint32_t excl = incl_c - mine;
-                    uint32_t win = 0;
 #pragma unroll 1
-                    while (win < total) {
-                        const uint32_t room = (uint32_t)kRunWin - n_pend;
-                        const uint32_t take = total - win < room ? total - win : room;
+                    for (uint32_t win = 0; win < total; win += (uint32_t)kRunWin) {
                         uint32_t pos = excl, m = m16;
                         while (m) {
                             const int b = __ffs(m) - 1;
                             m &= m - 1;
                             const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
-                            if (slot < take) {
+                            if (slot < (uint32_t)kRunWin) {
                                 const uint32_t code = (pick(snew, b >> 2) >> (8 * (b & 3))) & 7u;
-                                clist[n_pend + slot] = (uint32_t)y | ((uint32_t)(x0 + b) << 16) | (code << 28);
+                                clist[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)b << 6) | (code << 10));
                             }
                             pos++;
                         }
-                        n_pend += take;
-                        win += take;
-                        const uint32_t full = win < total ? n_pend : (n_pend & ~63u);     // window full: everything (a multiple of 64)
-                        if (full) {
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            pc.mark(6);  // prefix sum + frontier list
-                            const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, full, lane, th_log, pc);
-                            n_active += wk.n_active;
-                            n_ignite += wk.n_ignite;
-                            if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
-                            n_items_acc += (lane == 0) ? full : 0u;
-                            n_phase2++;
-                            const uint32_t rem = n_pend - full;                            // < 64: move it to the front
-                            uint32_t keep = 0;
-                            if ((uint32_t)lane < rem) keep = clist[full + lane];
-                            __builtin_amdgcn_wave_barrier();
-                            if ((uint32_t)lane < rem) clist[lane] = keep;
-                            n_pend = rem;
-                        }
+                        const uint32_t tot = total - win < (uint32_t)kRunWin ? total - win : (uint32_t)kRunWin;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        pc.mark(6);  // prefix sum + frontier list
+                        const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, strips, tot, lane, th_log, pc);
+                        n_active += wk.n_active;
+                        n_ignite += wk.n_ignite;
+                        if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
+                        n_items_acc += (lane == 0) ? tot : 0u;
+                        n_phase2++;
                     }
+                } else {
+                    // (the strip buffer is rewritten by the next batch: order this batch's LDS traffic before it)
+                    __builtin_amdgcn_wave_barrier();
                 }
                 pc.mark(10);
-            }
-            if (n_pend) {                                  // what is left of the wave's frontier list
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, n_pend, lane, th_log, pc);
-                n_active += wk.n_active;
-                n_ignite += wk.n_ignite;
-                if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                             // FLAG_CAND
-                n_items_acc += (lane == 0) ? n_pend : 0u;
-                n_phase2++;
-                n_pend = 0;
             }
             if (cb + (uint32_t)vcap >= n_all) break;       // (uniform) the usual case: one chunk
             __syncthreads();                               // everybody is done with this chunk's list

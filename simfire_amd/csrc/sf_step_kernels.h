@@ -20,10 +20,10 @@ namespace {
 //   RB = rows per lane band (compile time: the RB + 2 age rows and RB status rows of a lane live
 //   in registers and are all requested before any of them is used).  A wave tile is LC x 16
 //   cells by LR x RB rows (64 x 32 by default).
-// Dynamic LDS of k_step, per wave: frontier list [kListCap] u16, vector list [64 * RB] u16, then the staged
-// sprite-mask tile [LR * RB + 2][LC * 16 + 16] bytes (tile row 0 = the row above the tile; byte 15 of a row's
-// pad holds its left seam cell, byte 0 of the NEXT row's pad its right seam cell) + 16.
-// 3.7 KB per wave at LC = 4, RB = 2; 6.4 KB at RB = 4.
+// Dynamic LDS of k_step, per wave: frontier list [kListCap] u16, then the staged sprite-mask tile
+// [LR * RB + 2][LC * 16 + 16] bytes (tile row 0 = the row above the tile; byte 15 of a row's pad holds its
+// left seam cell, byte 0 of the NEXT row's pad its right seam cell) + 16, then the status tile
+// [LR * RB][LC * 16].  5.5 KB per wave at LC = 4, RB = 2.
 // ------------------------------------------------------------------------------------------
 constexpr int kSelectThreads = 1024;     // few, large workgroups: one list-slot atomic each, and they all hit one address
 __global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
@@ -170,30 +170,29 @@ __device__ __forceinline__ int pick_winner8(uint32_t up3, uint32_t mid3, uint32_
 }
 
 // Phase 2: the whole wave walks the compacted frontier of its tile, one cell per lane.
-// item = row in tile | x in tile << 7 | status after the prune << 13.  The 3 x 3 neighbourhood of sprite
-// masks comes from the wave's LDS copy of the tile (which keeps the masks from before the step: what this
-// step adds or recycles is masked out by every reader anyway); an ignition goes straight to the cell
-// planes as two byte stores (plus the seam copy on a chunk edge) - they are issued after this lane has
-// waited for its burn / table loads, hence after the 16-byte stores of the vector pass have landed.
+// item = row in band | owner lane << 5 | cell in vector << 11.  Everything about the cell is read
+// from the LDS copies of the tile (3 x 3 neighbourhood of sprite masks, status byte); an ignition
+// is written back into those copies - the cell planes in HBM are updated once, from LDS, at the end.
 template <int RB>
-__device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, int complete,
-                                             uint32_t lo_mask, uint32_t hi_mask, const uint8_t *tile_lds,
-                                             const uint16_t *s_list, uint32_t pend, int lane, PhaseClock &pc)
+__device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, bool spread,
+                                             int complete, uint8_t *tile_lds, uint8_t *stat_lds, const uint16_t *s_list,
+                                             uint32_t pend, int lane)
 {
     const Geo &g = a.g;
-    const int LC = g.LC, row_pitch = LC * 16 + 16, TH = g.LR * RB, TW = LC * 16;
+    const int LC = g.LC, row_pitch = LC * 16 + 16;
     WalkAcc acc = {0u, 0u, 0u, 0u};
-    uint8_t *age_e = a.age + (long long)e * g.age_env;
-    uint8_t *st_e = a.status + (long long)e * g.plane_env;
+    const uint32_t L4w = rep4(mk.m_live);
+    const uint32_t lo_mask = g.diag ? L4w : (L4w & 0xFF00FF00u), hi_mask = g.diag ? L4w : (L4w & 0x00FF00FFu);
     for (uint32_t j = lane; j < pend; j += 64) {
         const uint32_t it = s_list[j];
-        const int ry = it & 127, x6 = (it >> 7) & 63;
-        const uint32_t s_post = it >> 13;                  // 0, 3, 4, 5: eligible by construction (fire.py:192-205)
-        const int x = chunk * TW + x6, y = yw + ry;
+        const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
+        const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
+        const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
         const uint32_t idx = (uint32_t)(y * g.P + x);
         const long long cell = (long long)e * g.plane_env + idx;
         // 3x3 neighbourhood from the staged tile: two aligned dwords per row, funnel shift
-        const uint8_t *q = tile_lds + ry * row_pitch + 15 + x6;        // cell (x - 1, y - 1)
+        uint8_t *own_age = tile_lds + (orr * RB + i + 1) * row_pitch + 16 + oc * 16 + b;
+        const uint8_t *q = own_age - row_pitch - 1;
         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u);
         const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - sh);
         const uint32_t *qb = reinterpret_cast<const uint32_t *>(q - sh + row_pitch);
@@ -201,10 +200,18 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         const uint32_t up3 = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh);
         const uint32_t mid3 = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh);
         const uint32_t dn3 = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh);
+        uint8_t *own_st = stat_lds + ((orr * RB + i) * LC + oc) * 16 + b;
         const uint32_t own = (mid3 >> 8) & 0xFFu;
+        // the status tile still holds the value from before this step's prune
+        const uint32_t s_pre = *own_st & 7u;
+        const bool expired = (own & mk.b_exp) != 0;
         const int bestk = pick_winner8(up3, mid3, dn3, mk, lo_mask, hi_mask);
-        const bool is_cand = bestk >= 0;
-        pc.mark(7);          // list item, neighbourhood, winner
+        const uint32_t s_post = expired ? (uint32_t)SF_BURNED : s_pre;
+        const bool eligible = (s_post == SF_UNBURNED) || (s_post >= SF_FIRELINE);   // fire.py:192-205
+        const bool is_cand = spread && eligible && bestk >= 0;
+        uint32_t st_new = s_post;                        // S1 prune
+        if (g.att && expired && s_pre >= SF_FIRELINE)     // a line on a burning cell, overwritten by the prune (fire.py:140)
+            a.burn[cell] = lazy_sub(a.burn[cell], line_factor(s_pre), (uint32_t)complete - a.settled[cell]);
         {
             const unsigned long long cb = __ballot(is_cand);
             acc.n_active += (uint32_t)__popcll(cb);
@@ -230,28 +237,21 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
                 } else ros = 0.0;
             }
             bn = bn + ros;                                                       // fire.py:710
-            a.burn[cell] = bn;
-            pc.mark(8);      // burn / table entry arrived
             if (bn > g.pixel_scale) {                                            // fire.py:568
                 ignited = true;
-                acc.edges |= 1u | (ry == 0 ? 4u : 0u) | (ry == TH - 1 ? 8u : 0u) | (x6 == 0 ? 16u : 0u) | (x6 == TW - 1 ? 32u : 0u);
-                const uint8_t nb = (uint8_t)((own & ~mk.b_clr) | mk.b_new);       // fire.py:571-579
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the vector pass's stores to these lines have landed
-                st_e[idx] = (uint8_t)SF_BURNING;                                 // fire.py:587
-                age_e[idx] = nb;
-                if (g.chunks_x > 1) {                     // keep the seam planes in step: first / last column of the chunk
-                    uint8_t *sp = a.seam + (long long)e * g.seam_env + kSeamPad + y;
-                    if (x6 == 0 && chunk > 0) sp[(long long)(chunk * 2 + 1) * g.Hs] = nb;
-                    if (x6 == TW - 1 && chunk + 1 < g.chunks_x) sp[(long long)((chunk + 1) * 2) * g.Hs] = nb;
-                }
+                acc.edges |= 1u | ((orr == 0 && i == 0) ? 4u : 0u) | ((orr == g.LR - 1 && i == RB - 1) ? 8u : 0u) |
+                             ((oc == 0 && b == 0) ? 16u : 0u) | ((oc == LC - 1 && b == 15) ? 32u : 0u);
+                st_new = SF_BURNING;                                             // fire.py:587
+                *own_age = (uint8_t)((own & ~mk.b_clr) | mk.b_new);              // fire.py:571-579
             }
+            a.burn[cell] = bn;
         }
         acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
+        *own_st = (uint8_t)st_new;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    pc.mark(9);              // ignition stores
     return acc;
 }
 
@@ -265,19 +265,6 @@ __device__ __forceinline__ unsigned long long load_rows(const uint8_t *p)
     return *reinterpret_cast<const unsigned long long *>(p);
 }
 
-// One wave, one tile of LC * 16 x LR * RB cells (64 x 16 RB), lane (r, c) = band r of RB rows, 16-cell vector c.
-//   load     every lane requests its RB sprite-mask rows (16 B each; the row above / below the tile by the
-//            first / last band) and the seam cells of its rows; quick reject by ballot; tile flags; the
-//            rows are parked in the wave's LDS tile (random access for the passes below)
-//   interest one ballot per row gives the bitmap "this 16-cell vector holds a sprite bit"; dilated by one
-//            vector in x and one row in y with a few SCALAR shifts it is the bitmap of the vectors in which
-//            anything can happen in this step.  mbcnt turns it into a list of (row, vector) items in LDS.
-//   vectors  the wave walks that list, one 16-cell vector per lane (a tile crossed by a fire front has
-//            30-60 of its 128-512 vectors on it): 3 rows + edge cells from the LDS tile, the status vector
-//            from the cell plane, SWAR over the 16 cells (4 per VALU op): expiry -> BURNED, slot recycling,
-//            eligible & next to a live sprite -> 16-bit frontier mask; changed vectors are stored at once
-//   frontier one DPP prefix sum ranks the frontier cells into the wave's LDS list, walk_body takes one
-//            cell per lane.
 template <int RB>
 __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int chunk, const EnvState &st, int lane,
                                           uint8_t *lds_wave, uint8_t *f_own, uint8_t *pred, uint32_t &n_active,
@@ -300,19 +287,20 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
     const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
     const int exp_sh = __ffs(mk.b_exp) - 1;
 
-    // LDS of this wave: frontier list (u16) | vector list (u16) | sprite-mask tile [LR * RB + 2][LC * 16 + 16] (+ 16)
+    // LDS of this wave: frontier list (u16) | sprite-mask tile [LR * RB + 2][LC * 16 + 16] (+ 16) | status tile [LR * RB][LC * 16]
     const int row_pitch = LC * 16 + 16;
     uint16_t *s_list = reinterpret_cast<uint16_t *>(lds_wave);
-    uint16_t *v_list = s_list + kListCap;
-    uint8_t *tile_lds = lds_wave + kListCap * 2 + 128 * RB;
+    uint8_t *tile_lds = lds_wave + kListCap * 2;
+    uint8_t *stat_lds = tile_lds + (LR * RB + 2) * row_pitch + 16;
     uint8_t *band_lds = tile_lds + r * RB * row_pitch;      // row k of the band = tile row r * RB + k (halo rows shared)
+    uint8_t *band_st = stat_lds + (r * RB) * (LC * 16);
     uint32_t tile_flags;
-    unsigned long long B[RB + 2];                       // per row of the lane bands: which lanes hold sprite bits (wave-uniform)
     {
-        // ---- request the RB + 2 age rows (zero guard rows at -1 and H) and the seam columns in one go
+        // ---- request the RB + 2 age rows (zero guard rows at -1 and H) and the seam columns in
+        // one go; after the quick reject the RB status rows; then park it all in LDS
         // a lane requests its own RB rows; the row above / below the tile only the first / last band
         // (the rows between two bands are the neighbour band's own rows, shared through LDS)
-        uint4 rows[RB + 2];
+        uint4 rows[RB + 2], sraw[RB];
         const uint8_t *win = age_e + ((y0 - 1) * g.P + cv * 16);
         const bool k_lo = r == 0, k_hi = r == LR - 1;
 #pragma unroll
@@ -343,13 +331,24 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
 #pragma unroll
             for (int k = 1; k <= RB; ++k) seam[k] = (uint32_t)(packed >> (8 * (k - 1))) & 0xFFu;
         }
+        // status rows: with the activity map nearly every visited tile is a live one, so they are
+        // requested together with the sprite rows (one memory round trip less); in the dense
+        // cross-check mode only after the quick reject (a quiescent tile costs its sprite rows only)
+        auto load_status = [&]() {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                sraw[i] = make_uint4(0, 0, 0, 0);
+                if (col_ok && y0 + i < g.H) sraw[i] = *reinterpret_cast<const uint4 *>(st_e + ((y0 + i) * g.P + cv * 16));
+            }
+        };
+        if (!g.dense) load_status();
 
         // ---- quick reject: nothing alive, expiring or recyclable in or next to this tile
         uint32_t hot = 0;
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) hot |= any4(rows[k]) | seam[k];
         if (__ballot(hot != 0) == 0ull) return;
-        pc.mark(1);          // sprite rows arrived
+        if (g.dense) load_status();
 
         // tile activity for the next step, part 1: sprite bits that survive this step's recycling,
         // overall and along the four tile edges (a neighbour tile only has to look if they are set)
@@ -368,102 +367,70 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         tile_flags = (__ballot(keep != 0) ? 1u : 0u) | (__ballot(e_top != 0) ? 4u : 0u) |
                      (__ballot(e_bot != 0) ? 8u : 0u) | (__ballot(e_lft != 0) ? 16u : 0u) |
                      (__ballot(e_rgt != 0) ? 32u : 0u);
-        // which vectors hold a sprite bit (the seam cell counts for the edge vector next to it)
-#pragma unroll
-        for (int k = 0; k < RB + 2; ++k) B[k] = __ballot((any4(rows[k]) | seam[k]) != 0);
 
-        pc.mark(2);          // tile flags, ballots
-        // ---- stage the sprite rows in LDS
+        pc.mark(1);          // sprite / status rows arrived, quick reject, tile flags
+        // ---- stage: everything below works out of LDS, so the registers above die here
 #pragma unroll
         for (int k = 0; k < RB + 2; ++k) {
             const bool mine = (k >= 1 && k <= RB) || (k == 0 && k_lo) || (k == RB + 1 && k_hi);
             if (!mine) continue;
             uint8_t *rp = band_lds + k * row_pitch;
             *reinterpret_cast<uint4 *>(rp + 16 + c * 16) = rows[k];
-            // (tiles narrower than 4 vectors only exist on grids of one chunk: no seams there)
             if (c == 0) rp[15] = (uint8_t)(seam_l ? seam[k] : 0u);
             if (c == LC - 1) rp[row_pitch] = (uint8_t)(seam_r ? seam[k] : 0u);    // pad byte 0 of the next row
         }
-    }
-
-    // ---- interest bitmap -> vector list.  Bit (r * LC + c) of I[k] = vector c of row k of band r has a sprite
-    // bit in its 3 x 3 vector neighbourhood.  All of it is scalar arithmetic on the ballots.
-    const unsigned long long col_first = LC == 4 ? 0x1111111111111111ull : (LC == 2 ? 0x5555555555555555ull : ~0ull);
-    const unsigned long long col_last = col_first << (LC - 1);
-    uint32_t n_vec = 0;
-    {
-        unsigned long long Hd[RB + 2];
 #pragma unroll
-        for (int k = 0; k < RB + 2; ++k) Hd[k] = B[k] | ((B[k] << 1) & ~col_first) | ((B[k] >> 1) & ~col_last);
-        const bool partial = yw + LR * RB > g.H || (chunk + 1) * LC > g.PV;      // tile reaches past the grid (wave-uniform)
-        const unsigned long long lane_bit = 1ull << lane;
-#pragma unroll
-        for (int k = 1; k <= RB; ++k) {
-            const unsigned long long above = (k == 1) ? ((Hd[RB] << LC) | Hd[0]) : Hd[k - 1];
-            const unsigned long long below = (k == RB) ? ((Hd[1] >> LC) | Hd[RB + 1]) : Hd[k + 1];
-            unsigned long long I = Hd[k] | above | below;
-            if (partial) I &= __ballot(col_ok && y0 + k - 1 < g.H);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0u));
-            if (I & lane_bit) v_list[n_vec + rank] = (uint16_t)(((k - 1) << 6) | lane);
-            n_vec += (uint32_t)__popcll(I);
-        }
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = sraw[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    pc.mark(3);              // staging + vector list
 
-    const uint32_t lo_mask = g.diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = g.diag ? L4 : (L4 & 0x00FF00FFu);
-    bool live_any = false, st_dirty = false;            // wave-wide (SGPR)
-    WalkAcc tot_acc = {0u, 0u, 0u, 0u};
+    // ---- phase 1: per row, SWAR over the lane's 16 cells: which cells are frontier cells
+    // (eligible and next to a live sprite; all control-line cells when attenuation is on), which
+    // sprites expire / which slots are recycled.  A real loop: one copy of the row code, few
+    // live registers, operands from LDS.  fm[i / 2] collects the 16-bit cell masks of the rows.
+    uint32_t fm[(RB + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < (RB + 1) / 2; ++k) fm[k] = 0;
+    bool live_any = false;              // wave-wide (SGPR): some cell of the tile holds a live sprite
+    uint32_t dirty = 0;   // dirty: bit i = status vector, bit 16 + i = age vector of row i
 #pragma unroll 1
-    for (uint32_t vb = 0; vb < n_vec; vb += 64) {
-        // ---- vector pass: lane <- one listed vector
-        const bool has = vb + lane < n_vec;
-        const uint32_t item = has ? v_list[vb + lane] : 0u;
-        const int ol = item & 63, kk = item >> 6;
-        const int oc = ol & (LC - 1), orr = ol >> g.logLC;
-        const int ry = orr * RB + kk, y = yw + ry, xv = chunk * LC + oc;
-        const uint32_t voff = (uint32_t)(y * g.P + xv * 16);
-        uint4 sr = make_uint4(0, 0, 0, 0);
-        if (has) sr = *reinterpret_cast<const uint4 *>(st_e + voff);
-        const uint8_t *vp = tile_lds + (ry + 1) * row_pitch + 16 + oc * 16;
-        const uint4 up = *reinterpret_cast<const uint4 *>(vp - row_pitch);
-        const uint4 mid = *reinterpret_cast<const uint4 *>(vp);
-        const uint4 dn = *reinterpret_cast<const uint4 *>(vp + row_pitch);
-        // the cells just left / right of the vector (neighbour vector, or the seam cell parked in the row padding)
-        uint32_t lin = reinterpret_cast<const uint32_t *>(vp - 4)[0] >> 24, rin = reinterpret_cast<const uint32_t *>(vp + 16)[0] & 0xFFu;
-        if (g.diag) {
-            lin |= (reinterpret_cast<const uint32_t *>(vp - row_pitch - 4)[0] | reinterpret_cast<const uint32_t *>(vp + row_pitch - 4)[0]) >> 24;
-            rin |= (reinterpret_cast<const uint32_t *>(vp - row_pitch + 16)[0] | reinterpret_cast<const uint32_t *>(vp + row_pitch + 16)[0]) & 0xFFu;
-        }
-        lin &= mk.m_live;
-        rin &= mk.m_live;
+    for (int i = 0; i < RB; ++i) {
+        const int y = y0 + i;
+        uint8_t *rp = band_lds + i * row_pitch + 16 + c * 16;
+        const uint4 up = *reinterpret_cast<const uint4 *>(rp);
+        const uint4 mid = *reinterpret_cast<const uint4 *>(rp + row_pitch);
+        const uint4 dn = *reinterpret_cast<const uint4 *>(rp + 2 * row_pitch);
         const uint4 midL = and4(mid, L4);
         const uint4 vsrc = and4(or4(up, dn), L4);
         const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
-        live_any |= __ballot(has && any4(midL) != 0) != 0ull;
+        live_any |= __ballot(any4(midL) != 0) != 0ull;
+        // horizontal neighbours: the bytes just left / right of the lane's 16 cells (the
+        // neighbour lane's data, or the seam column parked in the row padding)
+        uint32_t lin = rp[row_pitch - 1], rin = rp[row_pitch + 16];
+        if (g.diag) {
+            lin |= (uint32_t)rp[-1] | (uint32_t)rp[2 * row_pitch - 1];
+            rin |= (uint32_t)rp[16] | (uint32_t)rp[2 * row_pitch + 16];
+        }
+        lin &= mk.m_live;
+        rin &= mk.m_live;
         uint4 nb;   // per cell: OR of the live masks of its (4 or 8) neighbours
         nb.x = vsrc.x | ((hsrc.x << 8) | lin) | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 1);
         nb.y = vsrc.y | __builtin_amdgcn_alignbyte(hsrc.y, hsrc.x, 3) | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 1);
         nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
         nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
 
-        pc.mark(4);          // vector item + LDS rows + neighbour masks
         const uint4 ex4 = and4(mid, EXP4);
-        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = spread ? any4(nb) : 0u;
-        if (has && any_clr) {   // recycle the slot of sprites that were pruned one step ago
-            const uint4 av = and4(mid, ~CLR4);
-            *reinterpret_cast<uint4 *>(age_e + voff) = av;
-            if (g.chunks_x > 1) {       // keep the seam planes in step: first / last column of the chunk
-                uint8_t *sp = a.seam + (long long)e * g.seam_env + kSeamPad + y;
-                if (oc == 0 && chunk > 0) sp[(long long)(chunk * 2 + 1) * g.Hs] = (uint8_t)(av.x & 0xFFu);
-                if (oc == LC - 1 && chunk + 1 < g.chunks_x) sp[(long long)((chunk + 1) * 2) * g.Hs] = (uint8_t)(av.w >> 24);
-            }
+        const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = any4(nb);
+        const bool row_ok = col_ok && y < g.H;
+        if (row_ok && any_clr) {   // recycle the slot of sprites that were pruned one step ago
+            *reinterpret_cast<uint4 *>(rp + row_pitch) = and4(mid, ~CLR4);
+            dirty |= 0x10000u << i;
         }
         uint32_t m16 = 0;
-        uint4 snew = sr;
-        if (has && (any_exp | any_nb)) {
+        if (row_ok && (any_exp | any_nb)) {
+            const uint4 sr = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
             const uint4 s7 = and4(sr, 0x07070707u);
             // S1 prune: cells whose sprite reached max_fire_duration become BURNED
             uint4 em;   // 0xFF per expiring byte (x * 255 == (x << 8) - x: no 32-bit multiply)
@@ -471,85 +438,120 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
             em.y = spread01((ex4.y >> exp_sh) & 0x01010101u);
             em.z = spread01((ex4.z >> exp_sh) & 0x01010101u);
             em.w = spread01((ex4.w >> exp_sh) & 0x01010101u);
+            uint4 snew;
             snew.x = (s7.x & ~em.x) | (0x02020202u & em.x);
             snew.y = (s7.y & ~em.y) | (0x02020202u & em.y);
             snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
             snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
-            if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) {
-                *reinterpret_cast<uint4 *>(st_e + voff) = snew;
-                // attenuation mode: a control line drawn on a burning cell ends when that sprite expires (the prune
-                // overwrites it with BURNED, fire.py:140): make up the attenuation the cell is still owed
-                if (g.att) {
-                    uint32_t sp16 = pack4(ge3_01(s7.x) & em.x & 0x01010101u) | (pack4(ge3_01(s7.y) & em.y & 0x01010101u) << 4) |
-                                    (pack4(ge3_01(s7.z) & em.z & 0x01010101u) << 8) | (pack4(ge3_01(s7.w) & em.w & 0x01010101u) << 12);
-                    while (sp16) {
-                        const int b = __ffs(sp16) - 1;
-                        sp16 &= sp16 - 1;
-                        const uint32_t s_pre = (pick(s7, b >> 2) >> (8 * (b & 3))) & 7u;
-                        const long long cell = (long long)e * g.plane_env + voff + b;
-                        a.burn[cell] = lazy_sub(a.burn[cell], line_factor(s_pre), (uint32_t)st.complete - a.settled[cell]);
-                    }
-                }
+            if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) dirty |= 1u << i;
+            // frontier cells (0 / 1 per byte): eligible & next to a live sprite
+            uint32_t p0 = (eq0_01(snew.x) | ge3_01(snew.x)) & nz01(nb.x);
+            uint32_t p1 = (eq0_01(snew.y) | ge3_01(snew.y)) & nz01(nb.y);
+            uint32_t p2 = (eq0_01(snew.z) | ge3_01(snew.z)) & nz01(nb.z);
+            uint32_t p3 = (eq0_01(snew.w) | ge3_01(snew.w)) & nz01(nb.w);
+            // attenuation mode: a control line drawn on a burning cell ends when that sprite expires (the
+            // prune overwrites it with BURNED); the walk then makes up the attenuation it is still owed
+            if (g.att) {
+                p0 |= ge3_01(s7.x) & em.x & 0x01010101u; p1 |= ge3_01(s7.y) & em.y & 0x01010101u;
+                p2 |= ge3_01(s7.z) & em.z & 0x01010101u; p3 |= ge3_01(s7.w) & em.w & 0x01010101u;
             }
-            if (any_nb) {
-                // frontier cells (0 / 1 per byte): eligible (fire.py:192-205) & next to a live sprite
-                uint32_t p0 = elig01(snew.x) & nz01(nb.x);
-                uint32_t p1 = elig01(snew.y) & nz01(nb.y);
-                uint32_t p2 = elig01(snew.z) & nz01(nb.z);
-                uint32_t p3 = elig01(snew.w) & nz01(nb.w);
-                // pitch padding (x >= W) never takes part
-                const int xs = xv * 16;
-                if (xs + 16 > g.W) {
-                    const int nv = g.W - xs;          // valid cells of this vector (may be <= 0)
-                    p0 &= first01(nv); p1 &= first01(nv - 4); p2 &= first01(nv - 8); p3 &= first01(nv - 12);
-                }
-                m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            // pitch padding (x >= W) never takes part
+            const int xs = cv * 16;
+            if (xs + 16 > g.W) {
+                const int nv = g.W - xs;          // valid cells of this vector (may be <= 0)
+                p0 &= first01(nv); p1 &= first01(nv - 4); p2 &= first01(nv - 8); p3 &= first01(nv - 12);
             }
+            m16 = pack4(p0) | (pack4(p1) << 4) | (pack4(p2) << 8) | (pack4(p3) << 12);
+            // the frontier cells get their new status from the walk, which reads the OLD status from
+            // LDS: only the other bytes may be replaced now.  0xFF where the cell is a frontier cell
+            uint4 keepm;
+            keepm.x = spread01(p0); keepm.y = spread01(p1); keepm.z = spread01(p2); keepm.w = spread01(p3);
+            uint4 mix;
+            mix.x = (sr.x & keepm.x) | (snew.x & ~keepm.x);
+            mix.y = (sr.y & keepm.y) | (snew.y & ~keepm.y);
+            mix.z = (sr.z & keepm.z) | (snew.z & ~keepm.z);
+            mix.w = (sr.w & keepm.w) | (snew.w & ~keepm.w);
+            *reinterpret_cast<uint4 *>(band_st + i * (LC * 16) + c * 16) = mix;
+            if (m16) dirty |= (1u << i);       // the walk rewrites those bytes (ignition)
         }
-        st_dirty |= __ballot((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) != 0ull;
+        if (i & 1) fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16 << 16; else fm[(i >> 1) < (RB + 1) / 2 ? (i >> 1) : 0] |= m16;
+    }
 
-        pc.mark(5);          // status arrived, SWAR, stores issued
-        // ---- compact the frontier cells of these vectors into the wave's list and walk it.  One prefix sum over
-        // the lanes gives every lane the ranks of its cells.  More frontier cells than the list holds (dense
-        // control lines) are walked in windows of kListCap ranks.
-        const uint32_t mine = (uint32_t)__popc(m16);
-        if (__ballot(mine != 0) != 0ull) {
-            const uint32_t incl_all = wave_scan_incl(mine, lane);
-            const uint32_t total = wave_last(incl_all);
-            const uint32_t excl = incl_all - mine;          // rank of this lane's first frontier cell
+    pc.mark(2);              // staging + row loop
+    // ---- compact the frontier cells into the wave's list and walk it.  One prefix sum over the
+    // lanes gives every lane the ranks of its cells.  If a tile has more frontier cells than the list
+    // holds (only with dense control lines) it is walked in windows of kListCap ranks.
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < (RB + 1) / 2; ++k) mine += (uint32_t)__popc(fm[k]);
+    WalkAcc tot_acc = {0u, 0u, 0u, 0u};
+    if (__ballot(mine != 0) != 0ull) {
+        const uint32_t incl_all = wave_scan_incl(mine, lane);
+        const uint32_t total = wave_last(incl_all);
+        const uint32_t excl = incl_all - mine;          // rank of this lane's first frontier cell
+        // one window unless the tile has more frontier cells than the list holds (dense control lines)
 #pragma unroll 1
-            for (uint32_t win = 0; win < total; win += (uint32_t)kListCap) {
-                uint32_t pos = excl, m = m16;
-                while (m) {
-                    const int b = __ffs(m) - 1;
-                    m &= m - 1;
-                    const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
-                    if (slot < (uint32_t)kListCap) {
-                        const uint32_t code = (pick(snew, b >> 2) >> (8 * (b & 3))) & 7u;
-                        s_list[slot] = (uint16_t)((uint32_t)ry | ((uint32_t)(oc * 16 + b) << 7) | (code << 13));
+        for (uint32_t win = 0; win < total; win += (uint32_t)kListCap) {
+            uint32_t pos = excl;
+#pragma unroll
+            for (int k = 0; k < (RB + 1) / 2; ++k) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * k + h;
+                    if (i >= RB) continue;
+                    uint32_t m = h ? (fm[k] >> 16) : (fm[k] & 0xFFFFu);
+                    while (m) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
+                        if (slot < (uint32_t)kListCap)
+                            s_list[slot] = (uint16_t)((uint32_t)i | ((uint32_t)lane << 5) | ((uint32_t)b << 11));
+                        pos++;
                     }
-                    pos++;
                 }
-                const uint32_t tot = total - win < (uint32_t)kListCap ? total - win : (uint32_t)kListCap;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                pc.mark(6);  // prefix sum + frontier list
-                const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, st.complete, lo_mask, hi_mask, tile_lds, s_list, tot, lane, pc);
-                acc_merge(tot_acc, w);
-                n_items_acc += (lane == 0) ? tot : 0u;
-                n_phase2++;
             }
+            const uint32_t tot = total - win < (uint32_t)kListCap ? total - win : (uint32_t)kListCap;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            pc.mark(3);      // prefix sum + list building
+            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.complete, tile_lds, stat_lds, s_list, tot, lane);
+            pc.mark(4);      // walk
+            acc_merge(tot_acc, w);
+            n_items_acc += (lane == 0) ? tot : 0u;
+            n_phase2++;
         }
-        pc.mark(10);
     }
     n_active += tot_acc.n_active;
     n_ignite += tot_acc.n_ignite;
 
+    // ---- write the changed vectors of the tile back from LDS to the cell planes
+    if (dirty) {
+#pragma unroll 1
+        for (int i = 0; i < RB; ++i) {
+            const uint32_t voff = (uint32_t)((y0 + i) * g.P + cv * 16);
+            if (dirty & (1u << i)) {
+                uint4 v = *reinterpret_cast<const uint4 *>(band_st + i * (LC * 16) + c * 16);
+                *reinterpret_cast<uint4 *>(st_e + voff) = v;
+            }
+            if (dirty & ((0x10000u | 1u) << i)) {
+                // bit i alone: an ignition may have set a sprite bit in this row
+                const uint4 av = *reinterpret_cast<const uint4 *>(band_lds + (i + 1) * row_pitch + 16 + c * 16);
+                *reinterpret_cast<uint4 *>(age_e + voff) = av;
+                // keep the seam planes in step: first / last column of the chunk
+                if (g.chunks_x > 1) {
+                    uint8_t *sp = a.seam + (long long)e * g.seam_env + kSeamPad + (y0 + i);
+                    if (c == 0 && chunk > 0) sp[(long long)(chunk * 2 + 1) * g.Hs] = (uint8_t)(av.x & 0xFFu);
+                    if (c == LC - 1 && chunk + 1 < g.chunks_x) sp[(long long)((chunk + 1) * 2) * g.Hs] = (uint8_t)(av.w >> 24);
+                }
+            }
+        }
+    }
+
     // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
-    if ((st_dirty || tot_acc.n_ignite) && lane == 0)
+    if (__ballot((dirty & 0xFFFFu) != 0) != 0ull && lane == 0)
         a.tdirty[((long long)e * g.TY + tyw) * g.TX + chunk] = 1;
-    pc.mark(11);
+    pc.mark(5);              // write-back
     // tile activity for the next step: sprites left in the tile or ignited in it (with their edge bits)
     // (f_own: this tile's entry in the flag map of the next step - global for k_step, LDS for k_run)
     {

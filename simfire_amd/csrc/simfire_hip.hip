@@ -163,8 +163,8 @@ static void choose_rows_per_band(Geo &g, int rows)
 {
     int rb = 1;
     while (rb * 2 <= rows && rb < 8) rb *= 2;    // the kernel is instantiated for 1, 2, 4, 8
-    // per wave: frontier list + vector list [64 * RB] u16 + sprite-mask tile [LR * RB + 2][LC * 16 + 16] + 16
-    auto wave_bytes = [&](int r) { return kListCap * 2 + 128 * r + (g.LR * r + 2) * (g.LC * 16 + 16) + 16; };
+    // per wave: list + sprite-mask tile [LR * RB + 2][LC * 16 + 16] + 16 + status tile [LR * RB][LC * 16]
+    auto wave_bytes = [&](int r) { return kListCap * 2 + (g.LR * r + 2) * (g.LC * 16 + 16) + 16 + g.LR * r * g.LC * 16; };
     while (rb > 1 && wave_bytes(rb) > 40 * 1024) rb /= 2;
     g.RB = rb;
     g.lds_wave_bytes = (wave_bytes(rb) + 15) / 16 * 16;
@@ -930,7 +930,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
         if (run_lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)run_lds));
-        hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps, run_vcap);
+        static const int bsz_knob = getenv("SF_RUN_BATCH") ? atoi(getenv("SF_RUN_BATCH")) : 64;       // vectors per batch (<= 64)
+        const int bsz = bsz_knob < 8 ? 8 : (bsz_knob > 64 ? 64 : bsz_knob);
+        hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps, run_vcap, bsz);
         s->tiles_valid = false;                // the tile activity map / seam planes are not kept by k_run
         s->last_kind = 2;
         n_steps = 0;                           // nothing left for the per-step loop
