@@ -110,30 +110,32 @@ def make_engine(w, device, rows_per_band=0):
     return eng
 
 
+class AgentPoints:
+    """C5: the agents' control-line cells of every step, as rows (env, x, y, type) for the oracle and as the block
+    int32 [steps][envs][agents][3] in GPU memory that sf_step_mitigated takes (resident before the timed region)."""
+
+    def __init__(self, rows, n_envs, n_agents, device):
+        import torch
+        self.rows = rows
+        a = np.asarray(rows, dtype=np.int32).reshape(rows.shape[0], n_envs, n_agents, 4)[..., 1:]
+        self.block = torch.from_numpy(np.ascontiguousarray(a)).to(f"cuda:{device}")
+
+
 def timed_steps(eng, steps, first_step, agent_pts):
-    """K steps, returns the GPU milliseconds of the step kernels (HIP events on the library's
-    stream); with agents (C5) every step is preceded by the mitigation scatter."""
+    """K steps, returns the GPU milliseconds of the step kernels (HIP events on the library's stream); with agents
+    (C5) every update is preceded by that step's control lines: one sf_step_mitigated call."""
     if agent_pts is None:
         return eng.step_timed(steps)
-    ms = 0.0
-    for s in range(steps):
-        eng.apply_mitigation(agent_pts[first_step + s])
-        ms += eng.step_timed(1)
-    return ms
+    return eng.step_mitigated(agent_pts.block[first_step:first_step + steps], timed=True)
 
 
 def run_steps(eng, steps, first_step, agent_pts):
-    """The rollout loop as a harness would run it: nothing is read back per step, so with agents
-    the scatter + step pairs are only enqueued (async mode) and waited for once at the end."""
+    """The rollout as a harness would run it: nothing is read back per step."""
     if agent_pts is None:
         eng.step(steps)
         return
-    eng.set_async(True)
-    for s in range(steps):
-        eng.apply_mitigation(agent_pts[first_step + s])
-        eng.step(1)
+    eng.step_mitigated(agent_pts.block[first_step:first_step + steps])
     eng.sync()
-    eng.set_async(False)
 
 
 def cpu_model():
@@ -163,7 +165,7 @@ def oracle_rollout(w, rtable, steps, warmup, threads, agent_pts, n_check):
             o.step(k, threads)
         else:
             for s in range(k):
-                p = agent_pts[first + s]
+                p = agent_pts.rows[first + s]
                 o.apply_mitigation(p[p[:, 0] < n_check])
                 o.step(1, threads)
 
@@ -297,8 +299,8 @@ def main():
     agent_pts = None
     if a.workload == "c5":
         from simfire_amd import workloads
-        agent_pts = workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup,
-                                         env_offset=rank * envs_local)
+        agent_pts = AgentPoints(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup,
+                                                     env_offset=rank * envs_local), w.n_envs, w.agents_per_env, device)
     eng = make_engine(w, device, a.rows_per_band)
     eng.set_dense(a.dense)
     eng.set_generic(a.generic)

@@ -229,6 +229,14 @@ int sf_set_fused(sf_sim *sim, int32_t mode);
  * QUIT in the result block, spread stays off); 0 (default) = a QUIT environment is frozen, as FireSimulation.run
  * (simulation.py:533) never calls update again. */
 int sf_set_prune_after_quit(sf_sim *sim, int32_t on);
+/* A rollout in which control lines are drawn before every update - the loop of an RL harness whose agents' moves are known
+ * in advance,   for s in range(n_steps): sim.update_mitigation(points[s]); sim.run(1)   (simulation.py:449-478, 501-553;
+ * BASELINE config C5) - as ONE call.  pts: int32 [n_steps][n_envs][k][3] = (column, row, type) per environment and step, a
+ * host pointer (device_pointer = 0) or a device pointer (1); entries whose type is not a control line (3, 4, 5) or whose
+ * position is off the grid are skipped (use them as padding).  Where the environment-resident launch can run, an
+ * environment's points are applied inside the kernel right before that environment's update; otherwise the call enqueues
+ * n_steps scatter + step pairs.  ms_out (may be null): GPU milliseconds of the call. */
+int sf_step_mitigated(sf_sim *sim, int32_t n_steps, const int32_t *pts, int32_t k, int32_t device_pointer, float *ms_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
  * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, -1 = none yet. */
 int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);

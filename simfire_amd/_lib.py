@@ -51,6 +51,7 @@ SIGNATURES = {
     "sf_load_fire_map": [_VP, _I32, _VP],
     "sf_step": [_VP, _I32],
     "sf_step_timed": [_VP, _I32, C.POINTER(C.c_float)],
+    "sf_step_mitigated": [_VP, _I32, _VP, _I32, _I32, C.POINTER(C.c_float)],
     "sf_get_fire_map": [_VP, _I32, _VP],
     "sf_get_fire_maps": [_VP, _VP],
     "sf_get_burn": [_VP, _I32, _VP],

@@ -75,6 +75,8 @@ struct StepArgs {
     uint8_t *parents;    // [E][H][P] spread-graph parent masks (null unless sf_enable_spread_graph)
     unsigned long long *vbits;   // [3][E][H][VW] vector bitmaps (k_run): bit v of row y = the 16-cell vector holds a sprite bit /
                                  // holds one in its first cell / in its last cell
+    const int32_t *mit;  // k_run only: control-line points [n_steps][E][mit_k][3] = (column, row, type) applied before each step, or null
+    int mit_k;
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw) + n_waves * kRunWin / 2;
 
     EnvState st = a.commit[e];
-    if (!st.running) return;                    // frozen: run() no longer calls update (uniform over the workgroup)
+    if (!st.running && !a.mit) return;          // frozen: run() no longer calls update (uniform over the workgroup)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * g.VW;
     for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];
@@ -198,8 +198,44 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
-    for (int s = 0; s < n_steps && st.running; ++s) {
+    for (int s = 0; s < n_steps && (st.running || a.mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
+        if (a.mit) {
+            // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80): this
+            // environment's points of step s, the same two passes as k_mitigate_clear / k_mitigate_write - clear (and make
+            // up the attenuation a line cell is owed under its old type), then byte-wise atomic max of the line types
+            // (FIRELINE < SCRATCHLINE < WETLINE = the reference's write order for duplicates).  Also after QUIT: the
+            // harness keeps drawing lines on a fire that is out.
+            const int32_t *pts = a.mit + ((long long)s * g.E + e) * a.mit_k * 3;
+            for (int i = tid; i < a.mit_k; i += nthr) {
+                const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
+                if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
+                const uint32_t o = (uint32_t)(y * g.P + x);
+                uint32_t *word = reinterpret_cast<uint32_t *>(ev.status + (o & ~3u));
+                const int sh = (int)(o & 3u) * 8;
+                const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
+                if (g.att && old >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(old), (uint32_t)st.complete - ev.settled[o]);
+            }
+            __syncthreads();
+            for (int i = tid; i < a.mit_k; i += nthr) {
+                const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
+                if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
+                const uint32_t o = (uint32_t)(y * g.P + x);
+                uint32_t *word = reinterpret_cast<uint32_t *>(ev.status + (o & ~3u));
+                const int sh = (int)(o & 3u) * 8;
+                uint32_t old = *word, seen;
+                do {
+                    seen = old;
+                    if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
+                    old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
+                } while (old != seen);
+                if (g.att) ev.settled[o] = (uint32_t)st.complete;      // idempotent: every point of this step on this cell stores the same count
+                ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                if (fine) atomicOr(&ve[y], 1ull << (x >> 4));          // a control line is an eligible cell
+            }
+            __syncthreads();
+            if (!st.running) continue;          // (uniform) the fire is out: nothing to step
+        }
         if (tid < 3) ctl[3 * tid + kn] = 0;     // ring slots of the next step (last read before the barrier that ended step s - 1)
         const int t = st.steps + 1;
         const Masks mk = make_masks(t, g.md, g.N);

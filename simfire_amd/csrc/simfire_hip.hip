@@ -131,6 +131,8 @@ struct sf_sim {
     size_t pts_cap = 0;
     hipEvent_t ev_pts[kPtsRing] = {};
     int pts_slot = 0;
+    int32_t *mit_stage = nullptr;      // sf_step_mitigated: device copy of a host point block / expanded rows of one step
+    size_t mit_stage_bytes = 0;
     bool async = false;                // sf_set_async: calls that return no data do not synchronise
     bool have_rt = false, was_reset = false, counters_on = false;
     int seq = 0;                       // index (mod 6) of the next step launch
@@ -281,7 +283,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits,
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
@@ -842,7 +844,9 @@ extern "C" int sf_last_step_launch(sf_sim *s, int32_t *kind)
     return SF_OK;
 }
 
-static int step_impl(sf_sim *s, int n_steps, float *ms)
+constexpr int SF_INTERNAL_NO_RESIDENT = 1;       // step_impl: the resident launch was asked for (mitigated rollout) but cannot run
+
+static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev = nullptr, int mit_k = 0)
 {
     if (!s) return fail(SF_EINVAL, "sf_step: null handle");
     if (n_steps < 0) return fail(SF_EINVAL, "sf_step: n_steps must be >= 0");
@@ -902,9 +906,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms)
         // automatic: multi-step calls on grids up to 1024 cells wide (measured on 1024^2, 1 .. 1024 environments: 1.2 - 1.4 x
         // faster than the per-step launches at every batch size; on 2048^2 an environment's fire is too much work for the one
         // CU that owns it and the per-step launches, which spread tiles over the whole chip, win by 1.4 - 2 x)
-        const bool wanted = s->fused_mode == 2 || (n_steps >= 2 && g.VW == 1 && g.E >= envs_knob);
+        const bool wanted = s->fused_mode == 2 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
     }
+    if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
+    a.mit = mit_dev; a.mit_k = mit_k;
     if (run_waves) {
         int rc0 = ensure_commit(s);            // k_run starts from commit[] and leaves the new states there
         if (rc0) return rc0;
@@ -1042,6 +1048,71 @@ extern "C" int sf_step_timed(sf_sim *s, int32_t n_steps, float *ms_out)
 {
     if (!ms_out) return fail(SF_EINVAL, "sf_step_timed: null ms_out");
     return step_impl(s, n_steps, ms_out);
+}
+
+// rows (env, column, row, type) of one step out of a point block [n_steps][E][k][3]
+__global__ void k_expand_pts(int E, int k, const int32_t *blk, int32_t *rows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * k) return;
+    rows[4 * i] = i / k; rows[4 * i + 1] = blk[3 * i]; rows[4 * i + 2] = blk[3 * i + 1]; rows[4 * i + 3] = blk[3 * i + 2];
+}
+
+/* A rollout in which control lines are drawn before every update - the loop
+ *     for s in range(n_steps): sim.update_mitigation(points[s]); sim.run(1)
+ * of an RL harness whose agents' moves are known in advance (BASELINE config C5: 64 agents per environment writing one
+ * line cell per step) - as ONE call.  pts: int32 [n_steps][n_envs][k][3] = (column, row, type) per environment and step;
+ * entries whose type is not a control line (3, 4, 5) or whose position is off the grid are skipped (padding).
+ * Where the environment-resident launch can run it applies an environment's points inside the kernel, right before that
+ * environment's update; otherwise the call enqueues n_steps scatter + step pairs.  ms_out (may be null): GPU milliseconds. */
+extern "C" int sf_step_mitigated(sf_sim *s, int32_t n_steps, const int32_t *pts, int32_t k, int32_t device_pointer, float *ms_out)
+{
+    if (!s) return fail(SF_EINVAL, "sf_step_mitigated: null handle");
+    if (n_steps < 0 || k < 0 || (n_steps > 0 && k > 0 && !pts)) return fail(SF_EINVAL, "sf_step_mitigated: bad arguments");
+    if (ms_out) *ms_out = 0.f;
+    if (n_steps == 0) return SF_OK;
+    if (k == 0) return step_impl(s, n_steps, ms_out);
+    if (!s->have_rt) return fail(SF_ESTATE, "sf_step: call sf_set_layers or sf_set_rtable first");
+    if (!s->was_reset) return fail(SF_ESTATE, "sf_step: call sf_reset first");
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    const size_t per_step = (size_t)g.E * k * 3, rows_bytes = (size_t)g.E * k * 4 * sizeof(int32_t);
+    const size_t blk_bytes = device_pointer ? 0 : (size_t)n_steps * per_step * sizeof(int32_t);
+    if (blk_bytes + rows_bytes > s->mit_stage_bytes) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (s->mit_stage) HIPCHK(hipFree(s->mit_stage));
+        s->mit_stage = nullptr; s->mit_stage_bytes = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->mit_stage), blk_bytes + rows_bytes));
+        s->mit_stage_bytes = blk_bytes + rows_bytes;
+    }
+    int32_t *rows = s->mit_stage;                                     // [E * k][4], fallback path
+    const int32_t *blk = pts;
+    if (!device_pointer) {
+        int32_t *d = s->mit_stage + (size_t)g.E * k * 4;
+        HIPCHK(hipMemcpyAsync(d, pts, blk_bytes, hipMemcpyHostToDevice, s->stream));
+        blk = d;
+    }
+    int rc = step_impl(s, n_steps, ms_out, blk, k);
+    if (rc != SF_INTERNAL_NO_RESIDENT) return rc;
+    // per-step launches: scatter the step's points, then one update
+    const bool was_async = s->async;
+    s->async = true;
+    float total = 0.f;
+    for (int i = 0; i < n_steps && rc != SF_EHIP; ++i) {
+        hipLaunchKernelGGL(k_expand_pts, dim3((unsigned)((g.E * k + 255) / 256)), dim3(256), 0, s->stream, g.E, k,
+                           blk + (size_t)i * per_step, rows);
+        rc = scatter_points(s, rows, g.E * k, false);
+        if (rc) break;
+        float ms1 = 0.f;
+        rc = step_impl(s, 1, ms_out ? &ms1 : nullptr);
+        if (rc) break;
+        total += ms1;
+    }
+    s->async = was_async;
+    if (rc) return rc;
+    if (ms_out) *ms_out = total;
+    if (!s->async) HIPCHK(hipStreamSynchronize(s->stream));
+    return SF_OK;
 }
 
 static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)

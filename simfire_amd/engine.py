@@ -138,6 +138,26 @@ class FireEngine:
         _lib.check(self._L.sf_step_timed(self._h, int(n), C.byref(ms)))
         return float(ms.value)
 
+    def step_mitigated(self, pts, timed=False):
+        """``for s in range(n): update_mitigation(pts[s]); step(1)`` as one call.  ``pts``: int32 [n, n_envs, k, 3] =
+        (column, row, type) per environment and step - a NumPy array or a torch CUDA tensor on this GPU; entries with a
+        type outside 3..5 are padding.  Returns the GPU milliseconds if ``timed``."""
+        ms = C.c_float(0.0)
+        if isinstance(pts, np.ndarray) or not hasattr(pts, "data_ptr"):
+            q = np.ascontiguousarray(np.asarray(pts, dtype=np.int32))
+            if q.ndim != 4 or q.shape[1] != self.n_envs or q.shape[3] != 3:
+                raise ValueError(f"expected points of shape [n_steps, {self.n_envs}, k, 3], got {q.shape}")
+            _lib.check(self._L.sf_step_mitigated(self._h, q.shape[0], _ptr(q), q.shape[2], 0, C.byref(ms) if timed else None))
+        else:
+            import torch
+            if pts.dtype != torch.int32 or pts.dim() != 4 or pts.shape[1] != self.n_envs or pts.shape[3] != 3 or not pts.is_cuda:
+                raise ValueError(f"expected a CUDA int32 tensor of shape [n_steps, {self.n_envs}, k, 3]")
+            pts = pts.contiguous()
+            _lib.check(self._L.sf_step_mitigated(self._h, int(pts.shape[0]), C.c_void_p(pts.data_ptr()), int(pts.shape[2]), 1,
+                                                 C.byref(ms) if timed else None))
+            self._keep_alive = pts
+        return float(ms.value) if timed else None
+
     # ------------------------------------------------------------------------ outputs
     def fire_map(self, env=0):
         out = np.empty((self.H, self.W), dtype=np.uint8)

@@ -437,6 +437,15 @@ class BatchedFireSimulation:
             q[:, 2] %= H
             self._engine.apply_mitigation(q)
 
+    def rollout(self, points, return_maps: bool = False):
+        """``for s in range(n): update_mitigation(points[s]); run(1)`` for every environment as one device call
+        (``sf_step_mitigated``): ``points`` int32 [n, n_envs, k, 3] = (column, row, type) per step, environment and
+        agent - NumPy or a torch CUDA tensor; entries with a type outside FIRELINE / SCRATCHLINE / WETLINE are padding.
+        Returns (fire maps or None, active [n_envs]) like ``run``."""
+        self._engine.step_mitigated(points)
+        st, _ = self._engine.status()
+        return (self._engine.fire_maps() if return_maps else None), st[:, 0].astype(bool)
+
     def results(self):
         """int32 [E, 8]: running, elapsed_steps, cell counts per BurnStatus; float64 [E] elapsed_time."""
         return self._engine.status()

@@ -28,7 +28,7 @@ def world(seed):
               attenuate_line_ros=att, diagonal_spread=diag)
     xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
     eng, o = FireEngine(**kw), fire_dense.DenseOracle(**kw)
-    eng.set_fused(int(rng.integers(-1, 2)))
+    eng.set_fused(int(rng.integers(-1, 4)))            # automatic, two launches, fused, resident (k_run), resident tiles
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
@@ -66,12 +66,14 @@ def world(seed):
             eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
         elif r < 0.50:
             eng.set_generic(bool(rng.integers(2)))
-        elif r < 0.53:
+        elif r < 0.56:
+            eng.set_fused(int(rng.integers(-1, 4)))        # hand-over between the launch structures mid-run
+        elif r < 0.59:
             e = int(rng.integers(E))       # burn_amounts round trip: settles whatever is owed, must change nothing
             b = eng.burn(e)
             assert (b == o.burn(e)).all(), (seed, t, e, "burn before round trip")
             eng.set_burn(e, b)
-        n = int(rng.choice([1, 1, 1, 2, 5]))
+        n = int(rng.choice([1, 1, 1, 2, 5, 17]))
         eng.step(n)
         o.step(n)
         if rng.random() < 0.6 or t == steps - 1:      # otherwise the states stay in the device rings

@@ -413,3 +413,92 @@ def test_bench_two_ranks_on_one_gpu_shard_the_hip_engine():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["envs_total"] == 16 and j["verified"] is True
     assert j["config"]["env_steps_executed"] > 0 and j["roofline"]["kernel"] in ("k_run", "k_step_fused", "k_select + k_step")
+
+
+# ------------------------------------------------------------------ rollouts with control lines before every update
+def _blk(agent_pts, E, k):
+    """[n][E * k][4] rows (env, x, y, type), env-major -> [n][E][k][3]"""
+    a = np.asarray(agent_pts, dtype=np.int32)
+    return np.ascontiguousarray(a.reshape(a.shape[0], E, k, 4)[..., 1:])
+
+
+@pytest.mark.parametrize("mode", [-1, 0, 2, "torch"])
+@pytest.mark.parametrize("att", [False, True])
+def test_mitigated_rollout_equals_update_mitigation_run_pairs(mode, att):
+    """sf_step_mitigated == `for s: update_mitigation(points[s]); run(1)` (simulation.py:449-478, 501-553): inside k_run
+    (automatic / forced), as scatter + step pairs (forced per-step launches), from a device tensor; duplicates with
+    type precedence, lines on burning cells, padding / off-grid entries, an environment that reaches QUIT half-way
+    (its lines are still drawn), lazy attenuation."""
+    import torch
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(314 + int(att))
+    H, W, E, K, n = 90, 210, 5, 12, 60
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0,
+              attenuate_line_ros=att, max_time=45.0)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
+    R8[:, :, 150:] = 0.0
+    inits = [(5, 5), (100, 40), (60, 80), (200, 10), (140, 50)]          # (200, 10): barren ground, QUIT at once
+    eng = FireEngine(**kw)
+    o = fire_dense.DenseOracle(**kw)
+    for x in (eng, o):
+        x.set_rtable(R8)
+        x.reset(inits)
+    if mode != "torch":
+        eng.set_fused(mode)
+    done = 0
+    for chunk in (1, 7, 22, 30):
+        blk = np.zeros((chunk, E, K, 3), dtype=np.int32)
+        blk[..., 0] = rng.integers(0, W, (chunk, E, K))
+        blk[..., 1] = rng.integers(0, H, (chunk, E, K))
+        blk[..., 2] = rng.integers(2, 7, (chunk, E, K))                  # 2 and 6: not control lines, skipped
+        blk[:, :, 0, 0] = W + 3                                           # off the grid: skipped
+        blk[:, :, 1, :2] = blk[:, :, 2, :2]                              # duplicates, maybe of another type
+        for s in range(chunk):
+            cur = o.fire_map(0)
+            burning = np.argwhere(cur == 1)
+            if len(burning):                                              # a line on a burning cell of environment 0
+                y, x = burning[rng.integers(len(burning))]
+                blk[s, 0, 3] = (x, y, int(rng.integers(3, 6)))
+            rows = [(e, int(blk[s, e, i, 0]), int(blk[s, e, i, 1]), int(blk[s, e, i, 2])) for e in range(E) for i in range(K)
+                    if 3 <= blk[s, e, i, 2] <= 5 and 0 <= blk[s, e, i, 0] < W]
+            o.apply_mitigation(rows)
+            o.step(1)
+        # (the oracle went through the chunk step by step above, which is how the burning cells were found;
+        # the engine gets the finished block in one call)
+        eng.step_mitigated(torch.from_numpy(blk).cuda() if mode == "torch" else blk)
+        done += chunk
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), (mode, att, done)
+        maps = eng.fire_maps()
+        for e in range(E):
+            assert (maps[e] == o.fire_map(e)).all(), (mode, att, done, e)
+    for e in range(E):
+        assert (eng.burn(e) == o.burn(e)).all(), (mode, att, e)
+    assert not eng.status()[0][:, 0].all()
+    want = {-1: 2, 0: 0, 2: 2, "torch": 2}[mode]
+    assert eng.last_launch_kind() in (want, 1 if want == 0 else want)
+
+
+def test_c5_rollout_in_one_launch():
+    """BASELINE config C5 at its grid (1024^2, 64 agents per environment, attenuation on), 24 environments, 150 steps: the
+    whole rollout - control lines before every update - as one resident launch, against the oracle's scatter + step loop."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    E, K, n = 24, 64, 150
+    w = workloads.c5(1024, E, K)
+    pts = workloads.agent_walk(E, K, 1024, 1024, n)
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    blk = _blk(pts, E, K)
+    eng.step_mitigated(blk[:100])
+    eng.step_mitigated(blk[100:])
+    assert eng.last_launch_kind() == 2
+    for s in range(n):
+        o.apply_mitigation(pts[s])
+        o.step(1, 32)
+    _same(eng, o, E, burn_envs=(0, 11, 23), tag="c5 rollout")
