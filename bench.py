@@ -33,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells", 4: "k_run_tiles"}
+LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells", 4: "k_run_tiles", 5: "k_front",
+                6: "k_front + k_run (overflow)"}
 
 
 def parse(argv=None):
@@ -50,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dense", action="store_true", help="visit every tile / vector every step (no skipping)")
     ap.add_argument("--generic", action="store_true", help="plain one-thread-per-cell kernel instead of the tiled kernels")
-    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4],
                     help="-1 automatic, 0 k_select + k_step per step, 1 one fused launch per step, "
                          "2 one environment-resident launch per rollout (k_run), 3 its tile flavour (k_run_tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -206,7 +207,8 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
     are the cells the kernel really sweeps: the cells of the wave tiles visited (tiled kernels) or of the
     16-cell vectors visited (k_run).  With a resident launch one launch = the whole K-step rollout."""
     H, W = w.shape
-    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16      # all K steps
+    # all K steps; k_front: one cell per frontier record visited and per sprite expiry / recycling event
+    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16 + cnt["records"] + cnt["sprite_events"]
     active = cnt["active_cell_updates"]
     if dense:
         # the dense sweep reads 1 B (the sprite mask) of a quiescent cell and rejects it; charging the 4 B of
@@ -217,7 +219,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
                                                          "(burn R + W, one table entry)")
     sec = kernel_ms * 1e-3
     achieved = alg_bytes / sec / 1e9
-    resident = kind in (2, 4)
+    resident = kind in (2, 4, 5, 6)
     launches = 1 if resident else a.steps * (2 if kind == 0 else 1)
     traffic = None
     if pmc and pmc.get("steps") == a.steps and pmc.get("warmup") == a.warmup and pmc.get("kernel") == LAUNCH_KINDS.get(kind):
@@ -230,6 +232,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
             "cells_swept_per_step": cells / a.steps, "active_cell_updates_per_step": active / a.steps,
             "tiles_visited_per_step": cnt["active_waves"] / a.steps, "vectors_visited_per_step": cnt["vectors"] / a.steps,
             "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
+            "records_visited_per_step": cnt["records"] / a.steps, "sprite_events_per_step": cnt["sprite_events"] / a.steps,
             # window-independent rates (the headline counts H x W per environment step, however small the fire)
             "active_cell_updates_per_s": active / sec, "cells_swept_per_s": cells / sec,
             "dense_cell_updates_per_s_kernel": H * W * env_steps / sec,
@@ -406,7 +409,7 @@ def main():
                        "burned_cells_total": int(res[:, 4].sum())},
             "roofline": roofline_block(w, a, kms, cnt, tile_cells, kind, env_steps_local, pmc, a.dense),
         }
-        out["roofline"]["note"] = ("only the tiles / 16-cell vectors in which something can change are visited; `achieved` counts "
+        out["roofline"]["note"] = ("only the tiles / 16-cell vectors / frontier records in which something can change are visited; `achieved` counts "
                                    "the cells of those" if not a.dense else "dense sweep: everything visited every step")
         if world == 1 and not a.dense and a.dense_leg:
             kd, esl, cd, kindd = measure(eng, w, a, agent_pts, True)

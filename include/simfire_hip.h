@@ -222,7 +222,10 @@ int sf_set_generic(sf_sim *sim, int32_t on);
  * otherwise one fused launch per step up to 12288 wave tiles, k_select + k_step above.
  * 0 = always two launches per step, 1 = always one fused launch per step, 2 = always the resident launch
  * (falls back to the per-step launches while the spread graph / history by-products are on or
- * max_fire_duration > 5), 3 = the tile flavour of the resident launch (k_run_tiles; development / cross-check). */
+ * max_fire_duration > 5), 3 = the tile flavour of the resident launch (k_run_tiles; development / cross-check),
+ * 4 = one frontier-resident launch per call (k_front: per environment the burning sprites and their ignition candidates
+ * are kept as lists in LDS for all n steps; falls back to 2 in attenuation mode, in the visit-everything mode and when
+ * control lines are applied inside the launch). */
 int sf_set_fused(sf_sim *sim, int32_t mode);
 /* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
  * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay
@@ -238,7 +241,9 @@ int sf_set_prune_after_quit(sf_sim *sim, int32_t on);
  * n_steps scatter + step pairs.  ms_out (may be null): GPU milliseconds of the call. */
 int sf_step_mitigated(sf_sim *sim, int32_t n_steps, const int32_t *pts, int32_t k, int32_t device_pointer, float *ms_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
- * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, -1 = none yet. */
+ * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = k_run_tiles, 5 = one
+ * frontier-resident launch (k_front), 6 = k_front, and k_run for the steps of environments that outgrew k_front's
+ * record capacity, -1 = none yet. */
 int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);

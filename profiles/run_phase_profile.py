@@ -25,7 +25,8 @@ def main():
     eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
     eng.set_layers(*w.layers())
     eng.reset(w.init_xy)
-    eng.set_fused(2)
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    eng.set_fused(mode)
     eng.step(20)
     eng.enable_counters(True)
     out = np.zeros(8, dtype=np.int64)
@@ -44,6 +45,11 @@ def main():
     eng._L.sf_debug_phases.argtypes = [ctypes.c_void_p]
     eng._L.sf_debug_phases(ph16.ctypes.data_as(ctypes.c_void_p))
     ph = [int(v) for v in ph16]
+    if mode == 4:
+        NAMES[:] = ["0", "1 rebuild at launch start", "2 record + 3 x 3 sprite masks arrive", "3 update, stores, compaction", "4 barrier A",
+                    "5 barrier B", "6 expiry stores issued", "7 winner, table entry of a new winner direction", "8 recycle", "9 offers to neighbours -> new records",
+                    "10", "11", "12 epilogue", "13", "14", "15"]
+        tiles = max(int(out[6]) // 64, 1)       # batches of 64 records (approx.)
     res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "vector_batches_per_step": tiles / steps, "vectors_per_step": int(out[5]) / steps, "frontier_cells_per_step": int(out[2]) / steps, "walks_per_step": int(out[4]) / steps,
            "clocks_per_batch": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},
            "clocks_per_batch_total": round(sum(ph) / tiles, 1)}

@@ -77,6 +77,7 @@ struct StepArgs {
                                  // holds one in its first cell / in its last cell
     const int32_t *mit;  // k_run only: control-line points [n_steps][E][mit_k][3] = (column, row, type) applied before each step, or null
     int mit_k;
+    const int32_t *todo; // k_run only: steps to do per environment (what k_front left over), or null = n_steps for all
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

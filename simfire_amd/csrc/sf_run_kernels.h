@@ -165,6 +165,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
 
     EnvState st = a.commit[e];
     if (!st.running && !a.mit) return;          // frozen: run() no longer calls update (uniform over the workgroup)
+    if (a.todo) {                               // the steps k_front left over for this environment (usually none)
+        n_steps = a.todo[e];
+        if (n_steps <= 0) return;
+    }
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * g.VW;
     for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];

@@ -82,6 +82,9 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 #include "sf_step_kernels.h"
 #include "sf_aux_kernels.h"
 #include "sf_run_kernels.h"
+#include "sf_front_kernels.h"
+
+constexpr int kFrontWheelCap = 8192;      // k_front: ignitions per environment and step the sprite wheel holds (more: k_run takes over)
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -117,7 +120,11 @@ struct sf_sim {
     unsigned long long *vbits = nullptr;   // vector bitmap of the resident launch (k_run)
     bool vbits_valid = false;          // vbits matches the sprite-mask planes (k_run / reset keep it; the per-step kernels do not)
     bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
-    int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell
+    int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell, 4 k_run_tiles, 5 k_front
+    int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
+    uint32_t *wheel = nullptr;         // k_front: sprite wheel [E][md + 4][kFrontWheelCap] cell positions per ignition step
+    int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
+    int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -254,6 +261,12 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     if (g.att) TRY(dev_alloc(s, &s->settled, cells));
     g.VW = (g.PV + 63) / 64; g.vb_env = (long long)g.H * g.VW;
     TRY(dev_alloc(s, &s->vbits, (size_t)3 * g.E * g.vb_env));
+    TRY(dev_alloc(s, &s->todo, (size_t)g.E));
+    if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * (g.md + 4) * kFrontWheelCap));
+    TRYHIP(hipHostMalloc(reinterpret_cast<void **>(&s->ovf_pinned), sizeof(int32_t), hipHostMallocMapped));
+    TRYHIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->ovf_mapped), s->ovf_pinned, 0));
+    *s->ovf_pinned = 0;
+    TRYHIP(hipMemsetAsync(s->todo, 0, (size_t)g.E * sizeof(int32_t), s->stream));
     s->n_tiles_max = (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x;      // RB = 1 is the finest tiling
     TRY(dev_alloc(s, &s->tdirty, s->n_tiles_max));
     TRY(dev_alloc(s, &s->thist, s->n_tiles_max * 8));
@@ -283,9 +296,10 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->mit_stage,
+    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
+    if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
         if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
         if (s->ev_pts[i]) (void)hipEventDestroy(s->ev_pts[i]);
@@ -425,10 +439,11 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
 }
 
 /* -1 = choose by problem size (default), 0 = always k_select + k_step, 1 = always one fused launch per step,
- * 2 = one environment-resident launch per sf_step call (k_run) whenever the handle's options allow it */
+ * 2 = one environment-resident launch per sf_step call (k_run) whenever the handle's options allow it, 3 = k_run_tiles,
+ * 4 = one frontier-resident launch per sf_step call (k_front) whenever they allow it (else as 2) */
 extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 {
-    if (!s || mode < -1 || mode > 3) return fail(SF_EINVAL, "sf_set_fused: mode must be -1, 0, 1, 2 or 3");
+    if (!s || mode < -1 || mode > 4) return fail(SF_EINVAL, "sf_set_fused: mode must be -1 ... 4");
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
@@ -888,6 +903,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         const size_t lds = (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g);
         if (per_env <= 65535 && lds <= 160 * 1024) { runt_waves = nw; runt_lds = lds; }
     }
+    int fr_waves = 0, fr_rc = 0, fr_wc = 0, fr_ic = 0;     // frontier-resident launch (k_front)
+    size_t fr_lds = 0;
+    int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
+    size_t fit_lds = 0;
     if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
         static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
         static const int envs_knob = getenv("SF_RUN_MIN_ENVS") ? atoi(getenv("SF_RUN_MIN_ENVS")) : 1;
@@ -906,13 +925,34 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // automatic: multi-step calls on grids up to 1024 cells wide (measured on 1024^2, 1 .. 1024 environments: 1.2 - 1.4 x
         // faster than the per-step launches at every batch size; on 2048^2 an environment's fire is too much work for the one
         // CU that owns it and the per-step launches, which spread tiles over the whole chip, win by 1.4 - 2 x)
-        const bool wanted = s->fused_mode == 2 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
+        const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
+        if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
+        // k_front: the frontier records of an environment in LDS.  Needs k_run as its overflow fallback; not in attenuation
+        // mode, not with control lines inside the launch, not in the visit-everything cross-check mode.
+        static const int front_min_steps = getenv("SF_FRONT_MIN_STEPS") ? atoi(getenv("SF_FRONT_MIN_STEPS")) : 4;
+        static const int front_off = getenv("SF_FRONT_OFF") ? atoi(getenv("SF_FRONT_OFF")) : 1;      // (not the automatic choice yet)
+        const bool front_wanted = s->fused_mode == 4 || (s->fused_mode < 0 && n_steps >= front_min_steps && !front_off);
+        if (fits && front_wanted && !g.att && !mit_dev && !g.dense) {
+            static const int fw_knob = getenv("SF_FRONT_WAVES") ? atoi(getenv("SF_FRONT_WAVES")) : 0;
+            static const int frc_knob = getenv("SF_FRONT_RC") ? atoi(getenv("SF_FRONT_RC")) : 0;
+            static const int fwc_knob = getenv("SF_FRONT_WC") ? atoi(getenv("SF_FRONT_WC")) : 0;
+            static const int fic_knob = getenv("SF_FRONT_IC") ? atoi(getenv("SF_FRONT_IC")) : 0;
+            const bool many = g.E > s->n_cu;              // more environments than CUs: smaller workgroups, several per CU
+            fr_waves = fw_knob ? fw_knob : (many ? 8 : 16);
+            if (fr_waves > 16) fr_waves = 16;
+            fr_rc = frc_knob ? frc_knob : (many ? 192 : 320);
+            fr_wc = fwc_knob ? fwc_knob : kFrontWheelCap;
+            if (fr_wc > kFrontWheelCap) fr_wc = kFrontWheelCap;
+            fr_ic = fic_knob ? fic_knob : (many ? 1024 : 2048);
+            fr_lds = front_lds_bytes(fr_waves, fr_rc, fr_ic);
+            if (fr_lds > 160 * 1024) fr_waves = 0;
+        }
     }
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
-    a.mit = mit_dev; a.mit_k = mit_k;
-    if (run_waves) {
-        int rc0 = ensure_commit(s);            // k_run starts from commit[] and leaves the new states there
+    a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr;
+    if (run_waves || fr_waves) {
+        int rc0 = ensure_commit(s);            // k_run / k_front start from commit[] and leave the new states there
         if (rc0) return rc0;
         rc0 = ensure_vbits(s);
         if (rc0) return rc0;
@@ -931,6 +971,38 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         hipLaunchKernelGGL(krun, dim3((unsigned)s->g.E), dim3((unsigned)runt_waves * 64), runt_lds, s->stream, a, n_steps);
         s->vbits_valid = false;
         s->last_kind = 4;
+        n_steps = 0;
+    } else if (fr_waves) {
+        a.launch = 0; a.from_commit = 1; a.ring = s->ring;
+        if (fr_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_lds));
+        *s->ovf_pinned = 0;
+        hipLaunchKernelGGL(k_front, dim3((unsigned)s->g.E), dim3((unsigned)fr_waves * 64), fr_lds, s->stream, a, n_steps, fr_rc, fr_wc, fr_ic,
+                           s->wheel, s->todo, s->ovf_mapped);
+        s->tiles_valid = false; s->vbits_valid = false;     // neither bookkeeping is kept by k_front
+        s->last_kind = 5;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (*s->ovf_pinned) {
+            // some environment outgrew its record / wheel capacity: k_run finishes its steps from the planes
+            s->front_fallbacks++;
+            s->last_kind = 6;
+            static const int dbg = getenv("SF_FRONT_DEBUG") ? atoi(getenv("SF_FRONT_DEBUG")) : 0;
+            if (dbg) {
+                std::vector<int32_t> td((size_t)s->g.E);
+                HIPCHK(hipMemcpy(td.data(), s->todo, td.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                int n_left = 0; long long sum = 0;
+                for (int32_t v : td) { n_left += v > 0; sum += v; }
+                fprintf(stderr, "[k_front] overflow reasons 0x%x (1 records, 2 wheel, 4 ignition list): %d of %d environments, %lld of %d steps left on average\n",
+                        *s->ovf_pinned & 0xFF, n_left, s->g.E, n_left ? sum / n_left : 0, n_steps);
+            }
+            hipLaunchKernelGGL(k_rebuild_vbits_todo, dim3((unsigned)s->g.E), dim3(256), 0, s->stream, s->g, (const uint8_t *)s->age, s->vbits,
+                               (const int32_t *)s->todo);
+            a.todo = s->todo;
+            if (fit_lds > 64 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
+            hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)fit_waves * 64), fit_lds, s->stream, a, n_steps, fit_vcap, 64);
+        }
         n_steps = 0;
     } else if (run_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;

@@ -224,7 +224,8 @@ class FireEngine:
         _lib.check(self._L.sf_set_prune_after_quit(self._h, int(bool(on))))
 
     def last_launch_kind(self):
-        """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, -1 none yet."""
+        """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, 4 k_run_tiles,
+        5 frontier-resident launch (k_front), 6 k_front + k_run for left-over steps, -1 none yet."""
         v = C.c_int32(-1)
         _lib.check(self._L.sf_last_step_launch(self._h, C.byref(v)))
         return int(v.value)
@@ -366,7 +367,8 @@ class FireEngine:
         out = np.zeros(8, dtype=np.int64)
         _lib.check(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
         return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
-                    active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]))
+                    active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]),
+                    records=int(out[6]), sprite_events=int(out[7]))
 
     def update_status_device(self):
         _lib.check(self._L.sf_update_status_device(self._h))

@@ -28,7 +28,7 @@ def world(seed):
               attenuate_line_ros=att, diagonal_spread=diag)
     xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
     eng, o = FireEngine(**kw), fire_dense.DenseOracle(**kw)
-    eng.set_fused(int(rng.integers(-1, 4)))            # automatic, two launches, fused, resident (k_run), resident tiles
+    eng.set_fused(int(rng.integers(-1, 5)))            # automatic, two launches, fused, resident (k_run), resident tiles
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
@@ -67,7 +67,7 @@ def world(seed):
         elif r < 0.50:
             eng.set_generic(bool(rng.integers(2)))
         elif r < 0.56:
-            eng.set_fused(int(rng.integers(-1, 4)))        # hand-over between the launch structures mid-run
+            eng.set_fused(int(rng.integers(-1, 5)))        # hand-over between the launch structures mid-run
         elif r < 0.59:
             e = int(rng.integers(E))       # burn_amounts round trip: settles whatever is owed, must change nothing
             b = eng.burn(e)

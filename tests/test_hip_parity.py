@@ -501,7 +501,7 @@ def test_c4_wind_field_workload():
     _workload_pair(w, 120, 60)
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2, 3])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("name", ["g3_lines_a1", "g4_lines_on_burning", "g7_early_return", "g6_runtime"])
 def test_launch_structures(name, fused):
     """One fused launch per step (small problems), k_select + persistent k_step (large ones) and the two
@@ -516,7 +516,7 @@ def test_launch_structures(name, fused):
     assert (eng.burn(0) == d["burn"]).all()
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2, 3])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
 def test_c3_both_launch_structures(fused):
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
@@ -836,7 +836,7 @@ def test_history_ring_equals_per_update_maps(mode):
 
 
 @pytest.mark.parametrize("fill", [0.5, 1.0])
-@pytest.mark.parametrize("fused", [0, 1, 2, 3])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
 def test_frontier_larger_than_list_window(fill, fused):
     """With rate-of-spread attenuation every control-line cell is a frontier cell of every step.  A
     64 x 64 wave tile then holds up to 4096 of them, far more than one walk window of the per-wave
