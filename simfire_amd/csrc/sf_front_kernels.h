@@ -51,11 +51,12 @@ constexpr int FC_RR = 33;       // round-robin cursor: wave that gets the next n
 constexpr uint32_t FR_FRESH = 0x80u;   // record meta: offered in the step before, nothing fetched yet (direction bits = the offering sprite's)
 constexpr int FC_MULTI = 34;    // some cell holds (held) more than one sprite bit (control line drawn on a burning cell): recycle bits by read-modify-write
 
+constexpr int kFrGroup = 4;     // chunks of 64 records a wave works on between two rounds of stores
 constexpr int kFrRegs = 2;      // wheel entries per thread kept in registers (lists up to kFrRegs x threads entries; longer: direct loads)
 
-__host__ __device__ inline size_t front_lds_bytes(int n_waves, int rc, int ic)
+__host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int rc, int ic)
 {
-    size_t b = (size_t)n_waves * rc * 24 + (size_t)ic * 4 + kFrCtl * 4;
+    size_t b = (size_t)n_waves * rc * 24 + (size_t)ic * 4 + kFrCtl * 4 + (size_t)((g.TY * g.TX + 31) / 32) * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;
 #endif
@@ -68,6 +69,7 @@ struct FrontLds {
     uint32_t *wheel;             // [md + 4][WC] (global memory)
     uint32_t *ign;               // [IC]
     uint32_t *ctl;               // [kFrCtl]
+    uint32_t *tbits;             // [ceil(TY TX / 32)] wave tiles whose status bytes changed in this launch (-> tdirty at the end)
     int RC, WC, IC, n_waves;
 };
 
@@ -88,6 +90,13 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 {
     typedef uint32_t __attribute__((aligned(1))) u32u;
     return *reinterpret_cast<const u32u *>(p);
+}
+
+// the status histogram of a wave tile goes stale (result block, k_counts_tiles): noted in LDS, written out at the end of the launch
+__device__ __forceinline__ void front_tile_dirty(const FrontLds &L, int tile)
+{
+    const uint32_t bit = 1u << (tile & 31);
+    if (!(L.tbits[tile >> 5] & bit)) atomicOr(&L.tbits[tile >> 5], bit);
 }
 
 // rank of this lane among the lanes of the wave for which `p` holds, and their number
@@ -292,7 +301,10 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     L.wheel = wheel_all + (size_t)e * NW * WC;
     L.ign = L.meta + (size_t)n_waves * RC;
     L.ctl = L.ign + IC;
+    L.tbits = L.ctl + kFrCtl;
     uint32_t *ctl = L.ctl;
+    const int tb_words = (g.TY * g.TX + 31) / 32;
+    for (int i = tid; i < tb_words; i += nthr) L.tbits[i] = 0;
 
     EnvState st = a.commit[e];
     if (!st.running) {                           // frozen: run() no longer calls update (uniform over the workgroup)
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     if (tid < kFrCtl) ctl[tid] = 0;
     PhaseClock pc;
 #ifdef SF_PHASES
-    uint32_t *ph_acc = ctl + kFrCtl + wave * 16;
+    uint32_t *ph_acc = L.tbits + tb_words + wave * 16;
     if (lane < 16) ph_acc[lane] = 0;
     pc.start(ph_acc);
 #else
@@ -373,104 +385,131 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         const int li_exp = slot_of(t - g.md - 1, NW), li_clr = slot_of(t - g.md - 2, NW), li_new = slot_of(t, NW);
         const int par = t & 1;
 
-        // ---- sprites ignited at t - md - 1 expire: BURNED (fire.py:116-161), whatever the cell holds by now
         if (tid == 0) ctl[FC_WC + slot_of(t + 1, NW)] = 0;        // list of the next step (its sprites were recycled in step t - 1)
+
+        // ---- the records of this wave, compacted in place.  Loads and stores share one counter and a wait for a load is a
+        // wait for every store issued before it, so the stores go last: up to kFrGroup x 64 records are read, their masks
+        // (and whatever a fresh record needs) requested, the table entries of changed winners requested, everything decided
+        // and written to LDS - and only then the cell planes are written.
+        if (spread) {
+            const uint32_t n = min(ctl[FC_RC + wave], (uint32_t)RC);
+            const uint32_t base = (uint32_t)wave * (uint32_t)RC;
+            uint32_t wcur = 0;
+            for (uint32_t c0 = 0; c0 < n; c0 += 64u * kFrGroup) {
+                uint32_t pos[kFrGroup], meta[kFrGroup], up3[kFrGroup], mid3[kFrGroup], dn3[kFrGroup], idx[kFrGroup];
+                double bn[kFrGroup], ros[kFrGroup], rtv[kFrGroup];
+                bool has[kFrGroup], okf[kFrGroup], cand[kFrGroup], need[kFrGroup], ignite[kFrGroup], keep[kFrGroup];
+#pragma unroll
+                for (int q = 0; q < kFrGroup; ++q) {
+                    has[q] = false; okf[q] = true; cand[q] = need[q] = ignite[q] = keep[q] = false;
+                    if (c0 + 64u * q < n) {                                       // (uniform)
+                        const uint32_t i = c0 + 64u * q + lane;
+                        has[q] = i < n;
+                        const uint32_t o = base + (has[q] ? i : n - 1);
+                        pos[q] = L.pos[o]; meta[q] = L.meta[o]; bn[q] = L.burn[o]; ros[q] = L.ros[o];
+                        const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
+                        idx[q] = (uint32_t)(y * g.P + x);
+                        const uint8_t *pa = ev.age + idx[q];
+                        const int off = x > 0 ? 1 : 0;              // (nothing is read left of column 0)
+                        up3[q] = load_u32_unaligned(pa - g.P - off); mid3[q] = load_u32_unaligned(pa - off); dn3[q] = load_u32_unaligned(pa + g.P - off);
+                        if (meta[q] & FR_FRESH) {
+                            // a record offered in the step before: status, accumulator and the table entry of the offering
+                            // sprite's direction (= the winner of this step) come with the masks
+                            const uint32_t code = ev.status[idx[q]];
+                            bn[q] = ev.burn[idx[q]];
+                            ros[q] = ev.rt[(meta[q] & 7u) * HP + idx[q]] * g.update_rate;          // fire.py:696,705
+                            okf[q] = code == SF_UNBURNED || code >= SF_FIRELINE;             // fire.py:192-205
+                            meta[q] = (meta[q] & 15u) | (code << 4);
+                        }
+                    }
+                }
+                FR_WAIT();
+                pc.mark(2);          // records + neighbourhoods arrive
+                int bestk[kFrGroup];
+#pragma unroll
+                for (int q = 0; q < kFrGroup; ++q) {
+                    if (c0 + 64u * q < n) {
+                        const int x = pos[q] & 0xFFFF;
+                        if (x == 0) { up3[q] <<= 8; mid3[q] <<= 8; dn3[q] <<= 8; }
+                        if (x == g.W - 1) { up3[q] &= 0xFFFFu; mid3[q] &= 0xFFFFu; dn3[q] &= 0xFFFFu; }     // the next byte is not a cell of this row
+                        const uint32_t own = (mid3[q] >> 8) & 0xFFu;
+                        // own sprite expires in this update: the prune makes the cell BURNED (fire.py:140) - not eligible
+                        const bool elig = has[q] && okf[q] && !(own & mk.b_exp);
+                        bestk[q] = pick_winner8(up3[q], mid3[q], dn3[q], mk, lo_mask, hi_mask);
+                        cand[q] = elig && bestk[q] >= 0;
+                        need[q] = cand[q] && (meta[q] & 15u) != (8u | (uint32_t)bestk[q]);
+                        rtv[q] = 0.0;
+                        if (need[q]) rtv[q] = ev.rt[(uint32_t)bestk[q] * HP + idx[q]];
+                    }
+                }
+                FR_WAIT();
+                pc.mark(7);          // winners; table entries of new winner directions arrive
+#pragma unroll
+                for (int q = 0; q < kFrGroup; ++q) {
+                    if (c0 + 64u * q < n) {
+                        if (need[q]) { ros[q] = rtv[q] * g.update_rate; meta[q] = (meta[q] & ~15u) | 8u | (uint32_t)bestk[q]; }     // fire.py:696,705
+                        const unsigned long long cb = __ballot(cand[q]);
+                        n_active += (uint32_t)__popcll(cb);
+                        if (cb != 0ull && lane == 0) ctl[FC_CAND + par] = 1;
+                        if (cand[q]) {
+                            const bool line = (meta[q] >> 4) >= SF_FIRELINE;
+                            bn[q] = bn[q] + (line ? 0.0 : ros[q]);                               // fire.py:280-282, 710
+                            ignite[q] = bn[q] > g.pixel_scale;                                   // fire.py:568
+                        }
+                        keep[q] = cand[q] && !ignite[q];
+                        const unsigned long long kb = __ballot(keep[q]);
+                        if (keep[q]) {
+                            const uint32_t w = base + wcur + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u));
+                            L.pos[w] = pos[q]; L.meta[w] = meta[q]; L.burn[w] = bn[q]; L.ros[w] = ros[q];
+                        }
+                        wcur += (uint32_t)__popcll(kb);
+                    }
+                }
+                // ---- the cell planes: accumulators of the records that leave, ignitions
+#pragma unroll
+                for (int q = 0; q < kFrGroup; ++q) {
+                    if (c0 + 64u * q < n) {
+                        if (has[q] && !keep[q]) ev.burn[idx[q]] = bn[q];
+                        uint32_t n_ig;
+                        const uint32_t ig_rank = wave_rank(ignite[q], n_ig);
+                        if (n_ig) {
+                            // wheel + ignition list: one atomic per wave and list
+                            uint32_t wb = 0, ib = 0;
+                            if (lane == 0) { wb = atomicAdd(&ctl[FC_WC + li_new], n_ig); ib = atomicAdd(&ctl[FC_IGN + par], n_ig); }
+                            wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+                            ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)ib);
+                            if (ignite[q]) {
+                                const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
+                                const uint32_t own = (mid3[q] >> 8) & 0xFFu;
+                                if (own) ctl[FC_MULTI] = 1;                    // a second sprite on this cell (or one whose bit is still to be recycled)
+                                ev.status[idx[q]] = (uint8_t)SF_BURNING;                             // fire.py:587
+                                ev.age[idx[q]] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);            // fire.py:571-579
+                                front_tile_dirty(L, (y >> th_log) * g.TX + ((x >> 4) >> g.logLC));
+                                if (wb + ig_rank < (uint32_t)WC) L.wheel[li_new * WC + wb + ig_rank] = pos[q]; else atomicOr(&ctl[FC_OVF], 2u);
+                                if (ib + ig_rank < (uint32_t)IC) L.ign[ib + ig_rank] = pos[q]; else atomicOr(&ctl[FC_OVF], 4u);
+                            }
+                        }
+                        n_ignite += n_ig;
+                    }
+                }
+                pc.mark(3);          // update, compaction, stores issued
+            }
+            n_rec += (lane == 0) ? n : 0u;
+            if (lane == 0) ctl[FC_RC + wave] = wcur;
+        }
+        // ---- sprites ignited at t - md - 1 expire: BURNED (fire.py:116-161), whatever the cell holds by now.  (Independent of
+        // the records: a record whose own sprite expires now has seen that in its mask.)
         {
             const uint32_t n_exp = min(ctl[FC_WC + li_exp], (uint32_t)WC);
             for (uint32_t i = tid, k = 0; i < n_exp; i += nthr, ++k) {
                 const uint32_t pos = k < (uint32_t)kFrRegs ? (k == 0 ? cur_exp[0] : cur_exp[1]) : L.wheel[li_exp * WC + i];
                 const int y = pos >> 16, x = pos & 0xFFFF;
                 ev.status[(uint32_t)(y * g.P + x)] = (uint8_t)SF_BURNED;
-                ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                front_tile_dirty(L, (y >> th_log) * g.TX + ((x >> 4) >> g.logLC));
             }
             n_events += (tid == 0) ? n_exp : 0u;
         }
         pc.mark(6);              // expiry stores issued
-
-        // ---- the records of this wave, 64 at a time, compacted in place
-        if (spread) {
-            const uint32_t n = min(ctl[FC_RC + wave], (uint32_t)RC);
-            const uint32_t base = (uint32_t)wave * (uint32_t)RC;
-            uint32_t wcur = 0;
-            for (uint32_t c = 0; c < n; c += 64) {
-                const uint32_t i = c + lane;
-                const bool has = i < n;
-                const uint32_t o = base + (has ? i : n - 1);
-                const uint32_t pos = L.pos[o];
-                uint32_t meta = L.meta[o];
-                double bn = L.burn[o], ros = L.ros[o];
-                const int y = pos >> 16, x = pos & 0xFFFF;
-                const uint32_t idx = (uint32_t)(y * g.P + x);
-                const uint8_t *pa = ev.age + idx;
-                const int off = x > 0 ? 1 : 0;              // (nothing is read left of column 0)
-                uint32_t up3 = load_u32_unaligned(pa - g.P - off), mid3 = load_u32_unaligned(pa - off), dn3 = load_u32_unaligned(pa + g.P - off);
-                bool fresh_ok = true;
-                if (meta & FR_FRESH) {
-                    // a record offered in the step before: status, accumulator and the table entry of the offering sprite's
-                    // direction (= the winner of this step) come with the masks
-                    const uint32_t code = ev.status[idx];
-                    bn = ev.burn[idx];
-                    ros = ev.rt[(meta & 7u) * HP + idx] * g.update_rate;                     // fire.py:696,705
-                    fresh_ok = code == SF_UNBURNED || code >= SF_FIRELINE;                   // fire.py:192-205
-                    meta = (meta & 15u) | (code << 4);
-                }
-                if (!off) { up3 <<= 8; mid3 <<= 8; dn3 <<= 8; }
-                if (x == g.W - 1) { up3 &= 0xFFFFu; mid3 &= 0xFFFFu; dn3 &= 0xFFFFu; }     // the next byte is not a cell of this row
-                FR_WAIT();
-                pc.mark(2);          // record + neighbourhood arrive
-                const uint32_t own = (mid3 >> 8) & 0xFFu;
-                // the cell's own sprite expires in this update: the prune has just made it BURNED (fire.py:140) - not eligible
-                const bool elig = has && fresh_ok && !(own & mk.b_exp);
-                const int bestk = pick_winner8(up3, mid3, dn3, mk, lo_mask, hi_mask);
-                const bool cand = elig && bestk >= 0;
-                if (cand && (meta & 15u) != (8u | (uint32_t)bestk)) {
-                    ros = ev.rt[(uint32_t)bestk * HP + idx] * g.update_rate;                 // fire.py:696,705
-                    meta = (meta & ~15u) | 8u | (uint32_t)bestk;
-                }
-                FR_WAIT();
-                pc.mark(7);          // winner; table entry of a new winner direction arrives
-                {
-                    const unsigned long long cb = __ballot(cand);
-                    n_active += (uint32_t)__popcll(cb);
-                    if (cb != 0ull && lane == 0) ctl[FC_CAND + par] = 1;
-                }
-                bool ignite = false;
-                if (cand) {
-                    const bool line = (meta >> 4) >= SF_FIRELINE;
-                    bn = bn + (line ? 0.0 : ros);                                        // fire.py:280-282, 710
-                    ignite = bn > g.pixel_scale;                                         // fire.py:568
-                }
-                const bool keep = cand && !ignite;
-                if (has && !keep) ev.burn[idx] = bn;
-                uint32_t n_ig;
-                const uint32_t ig_rank = wave_rank(ignite, n_ig);
-                if (n_ig) {
-                    // wheel + ignition list: one atomic per wave and list
-                    uint32_t wb = 0, ib = 0;
-                    if (lane == 0) { wb = atomicAdd(&ctl[FC_WC + li_new], n_ig); ib = atomicAdd(&ctl[FC_IGN + par], n_ig); }
-                    wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
-                    ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)ib);
-                    if (ignite) {
-                        if (own) ctl[FC_MULTI] = 1;                    // a second sprite on this cell (or one whose bit is still to be recycled)
-                        ev.status[idx] = (uint8_t)SF_BURNING;                                // fire.py:587
-                        ev.age[idx] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);               // fire.py:571-579
-                        ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
-                        if (wb + ig_rank < (uint32_t)WC) L.wheel[li_new * WC + wb + ig_rank] = pos; else atomicOr(&ctl[FC_OVF], 2u);
-                        if (ib + ig_rank < (uint32_t)IC) L.ign[ib + ig_rank] = pos; else atomicOr(&ctl[FC_OVF], 4u);
-                    }
-                }
-                n_ignite += n_ig;
-                const unsigned long long kb = __ballot(keep);
-                if (keep) {
-                    const uint32_t q = base + wcur + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u));
-                    L.pos[q] = pos; L.meta[q] = meta; L.burn[q] = bn; L.ros[q] = ros;
-                }
-                wcur += (uint32_t)__popcll(kb);
-                pc.mark(3);          // winner, update, compaction
-            }
-            n_rec += (lane == 0) ? n : 0u;
-            if (lane == 0) ctl[FC_RC + wave] = wcur;
-        }
         __syncthreads();
         pc.mark(4);              // barrier A
         uint32_t f = ctl[FC_CAND + par] ? FLAG_CAND : 0u;
@@ -481,6 +520,22 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         }
         if (tid == 0) { ctl[FC_IGN + (par ^ 1)] = 0; ctl[FC_CAND + (par ^ 1)] = 0; }
 
+        // ---- after barrier A.  Loads first: the wheel entries that expire in the next step (ignited at t - md: that list is
+        // complete), then the offers of this step's ignitions; the recycling stores go last.
+        uint32_t nx_exp[kFrRegs];
+        {
+            const int li_nx = slot_of(t - g.md, NW);
+            const uint32_t n_nx = min(ctl[FC_WC + li_nx], (uint32_t)WC);
+#pragma unroll
+            for (int k = 0; k < kFrRegs; ++k) {
+                const uint32_t i = (uint32_t)(tid + k * nthr);
+                nx_exp[k] = i < n_nx ? L.wheel[li_nx * WC + i] : 0u;
+            }
+        }
+        // ---- every cell ignited in this step offers a record to its neighbours (candidates from step t + 1 on)
+        front_offers(g, L, ev, mk, lo_mask, hi_mask, min(ctl[FC_IGN + par], (uint32_t)IC), HP, tid, lane, nthr);
+        FR_WAIT();
+        pc.mark(9);              // new records
         // ---- sprites ignited at t - md - 2: their mask bit is recycled for step t + 1
         {
             const uint32_t n_clr = n_prev;
@@ -492,24 +547,16 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                 ev.age[idx] = multi ? (uint8_t)(ev.age[idx] & ~mk.b_clr) : (uint8_t)0;
             }
             n_events += (tid == 0) ? n_clr : 0u;
-            FR_WAIT();
-            pc.mark(8);          // recycle
-            // next step: recycle what expired in this one; request the entries that expire next (ignited at t - md: complete)
-            const int li_nx = slot_of(t - g.md, NW);
-            const uint32_t n_nx = min(ctl[FC_WC + li_nx], (uint32_t)WC);
             n_prev = min(ctl[FC_WC + li_exp], (uint32_t)WC);
 #pragma unroll
-            for (int k = 0; k < kFrRegs; ++k) {
-                const uint32_t i = (uint32_t)(tid + k * nthr);
-                prev_exp[k] = cur_exp[k];
-                cur_exp[k] = i < n_nx ? L.wheel[li_nx * WC + i] : 0u;
-            }
+            for (int k = 0; k < kFrRegs; ++k) { prev_exp[k] = cur_exp[k]; cur_exp[k] = nx_exp[k]; }
         }
-        // ---- every cell ignited in this step offers a record to its neighbours (candidates from step t + 1 on)
-        front_offers(g, L, ev, mk, lo_mask, hi_mask, min(ctl[FC_IGN + par], (uint32_t)IC), HP, tid, lane, nthr);
-        FR_WAIT();
-        pc.mark(9);              // new records
-        __syncthreads();
+        pc.mark(8);              // recycle stores issued
+        // Barrier B orders LDS only (records, counters).  The stores of this phase are read two steps from now at the earliest
+        // (a recycled bit is outside the live window of step t + 1), i.e. after the full barrier A of the next step.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         pc.mark(5);              // barrier B
         st = fold_state(st, f, g);
         st.running = __builtin_amdgcn_readfirstlane(st.running);
@@ -538,6 +585,8 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         atomicAdd(&g_wave_log[e * 4 + 1], (unsigned long long)n_rec);
     }
 #endif
+    for (int i = tid; i < g.TY * g.TX; i += nthr)
+        if (L.tbits[i >> 5] & (1u << (i & 31))) ev.tdirty[i] = 1;
     if (tid == 0) {
         a.commit[e] = st;
         const int left = st.running ? n_steps - done : 0;

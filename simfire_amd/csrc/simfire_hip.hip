@@ -945,7 +945,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             fr_wc = fwc_knob ? fwc_knob : kFrontWheelCap;
             if (fr_wc > kFrontWheelCap) fr_wc = kFrontWheelCap;
             fr_ic = fic_knob ? fic_knob : (many ? 1024 : 2048);
-            fr_lds = front_lds_bytes(fr_waves, fr_rc, fr_ic);
+            fr_lds = front_lds_bytes(g, fr_waves, fr_rc, fr_ic);
             if (fr_lds > 160 * 1024) fr_waves = 0;
         }
     }
