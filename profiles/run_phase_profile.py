@@ -46,9 +46,9 @@ def main():
     eng._L.sf_debug_phases(ph16.ctypes.data_as(ctypes.c_void_p))
     ph = [int(v) for v in ph16]
     if mode == 4:
-        NAMES[:] = ["0", "1 rebuild at launch start", "2 record + 3 x 3 sprite masks arrive", "3 update, stores, compaction", "4 barrier A",
-                    "5 barrier B", "6 expiry stores issued", "7 winner, table entry of a new winner direction", "8 recycle", "9 offers to neighbours -> new records",
-                    "10", "11", "12 epilogue", "13", "14", "15"]
+        NAMES[:] = ["0", "1 rebuild at launch start", "2 records, 8 table look-ups each, winners, plane loads arrive", "3 update, compaction, stores issued", "4 barrier A",
+                    "5 barrier B", "6", "7", "8", "9 offers to neighbours -> new records",
+                    "10 rehash of the cell table", "11", "12 epilogue (planes written back)", "13", "14", "15"]
         tiles = max(int(out[6]) // 64, 1)       # batches of 64 records (approx.)
     res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "vector_batches_per_step": tiles / steps, "vectors_per_step": int(out[5]) / steps, "frontier_cells_per_step": int(out[2]) / steps, "walks_per_step": int(out[4]) / steps,
            "clocks_per_batch": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},

@@ -9,54 +9,60 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// The reference steps a LIST of burning sprites (fire.py:616-719); the cells anything happens to in an update are
-// the sprites themselves (ageing, expiry) and the cells next to them (ignition candidates).  k_front keeps exactly
-// those two sets, per environment, in the LDS of the workgroup that owns the environment for all n steps:
+// The reference steps a LIST of burning sprites (fire.py:616-719); the cells anything happens to in an update are the
+// sprites themselves (ageing, expiry) and the cells next to them (ignition candidates).  An environment that is owned by
+// one workgroup for all n steps is served by ONE CU, and what bounds it is not bytes but LINE TRANSACTIONS: a CU gets
+// through 0.1 - 0.25 scattered cache lines per clock when the whole chip does the same (profiles/scatter_probe.hip), and
+// every byte store / 8-byte load of a cell plane is one.  So k_front keeps everything that is read or written more than
+// once per cell in LDS and touches the planes once per event:
 //
-//   sprite wheel      one list of cell positions per ignition step s (ring of md + 4 lists): the sprites ignited at
-//                     step s expire at step s + md + 1 (-> BURNED, fire.py:116-161) and their mask bit is recycled
-//                     at step s + md + 2 - nothing is scanned to find them.  "Some sprite survives the prune"
-//                     (fire.py:637) = the lists of the live window are not all empty.  The lists are append-only
-//                     streams in global memory (an entry is written once, at the ignition, and read once, md steps
-//                     later, into a register one step ahead of its use); only their lengths live in LDS.
-//   frontier records  one record per ignition candidate (fire.py:163-234: eligible cell next to a live sprite):
-//                     position, burn_amounts[cell] (the f64 accumulator LIVES here while the cell is on the front,
-//                     fire.py:710), R dt of the cached winner direction (fire.py:696-705).  A record is created when
-//                     a neighbour ignites, and dropped (accumulator written back) when the cell ignites, loses its
-//                     last live neighbour or stops being eligible.
+//   cell table        an open-addressing hash table cell -> state in LDS: the step a burning / burned cell was ignited at
+//                     (its sprite is live for the md steps after it, fire.py:116-161, 633-647), FRONT (the cell has a
+//                     frontier record), GONE (it had one and lost its last live neighbour), INELIGIBLE.  The 3 x 3 sprite
+//                     neighbourhood of a candidate is eight table look-ups - the sprite-mask plane is not read at all
+//                     after the launch has started, and not written before it ends.
+//   frontier records  one per ignition candidate (fire.py:163-234: eligible cell next to a live sprite): position,
+//                     burn_amounts[cell] (the f64 accumulator LIVES here while the cell is on the front, fire.py:710),
+//                     R dt of the cached winner direction (fire.py:696-705).  A cell ignited in step t offers a record to
+//                     its neighbours: one compare-and-swap on the table per neighbour decides who is new.  A new record
+//                     fetches status, accumulator and table entry in ONE round trip at its first update.
 //
-// Per step and record: three 4-byte loads of the sprite-mask plane (3 x 3 neighbourhood; L1 / L2 hits), winner source
-// (pick_winner8), one f64 add, one compare.  The table entry is fetched only when the winner direction changes.  An
-// ignition writes the status byte and the sprite bit to the cell planes (they stay the complete state: everything here
-// is derived and is rebuilt from the planes at the start of a launch), appends the cell to the wheel and offers a
-// record to each of its neighbours.  The offer needs no lock and no lookup: the neighbour has a record already iff
-// it was a candidate in this step (eligible, live sprite next to it - read off its own 3 x 3 masks), and of several
-// cells that ignite next to it in the same step exactly one - the one that will be its winner source in the next
-// step - makes the record (and so fetches the right table entry with it).
-// Two workgroup barriers per step.  A step touches O(front) cells - no tiles, no vectors, no bitmaps.
+// Plane traffic per cell and lifetime: status + burn_amounts + R-table entry read once when the cell joins the front, the
+// table entry again when its winner direction changes, burn_amounts written once when it leaves, status written once when
+// it ignites - as BURNED straight away: nothing inside the launch tells BURNING from BURNED (neither is eligible,
+// fire.py:192-205), and the cells whose sprite has not expired by the end of the launch are set to BURNING then, when
+// the sprite-mask plane, the tile-dirty map and the accumulators of the records still alive are written too.
+// Two workgroup barriers per step; the second orders LDS only.
 //
-// Capacity: records / wheel / ignition lists have fixed LDS capacities.  Whatever overflows is DERIVED state only: the
-// workgroup finishes the step it is in (the planes are complete), writes the accumulators back and reports the steps it
-// did not do in todo[e]; the host runs those through k_run.
-// Not handled here (the host chooses k_run): attenuation mode, control lines inside the launch, dense mode.
+// Falls back to k_run per environment (todo[e] = steps not done): a cell that holds two sprites or a control line / an
+// UNBURNED status on a burning cell at launch start (E3 / E4 of SURVEY 8a - the lazy status needs one sprite per cell),
+// and any LDS capacity exceeded in flight (the workgroup finishes its step, writes everything back and stops).
+// Not handled here at all (the host chooses k_run): attenuation mode, control lines inside the launch, dense mode,
+// grids above 4096 x 4096.
 // ------------------------------------------------------------------------------------------
 constexpr int kFrCtl = 48;
 // control words
 constexpr int FC_RC = 0;        // [16] records per wave
-constexpr int FC_WC = 16;       // [12] wheel list lengths (ring of md + 4 <= 9 lists)
+constexpr int FC_WC = 16;       // [12] ignitions per step (ring of md + 4 steps): "some sprite survives the prune" (fire.py:637)
 constexpr int FC_IGN = 28;      // [2]  ignition list length (ring of 2 steps)
 constexpr int FC_CAND = 30;     // [2]  "some sprite has a cell to spread into" (fire.py:651), ring of 2 steps
-constexpr int FC_OVF = 32;      // a capacity was exceeded: 1 records, 2 wheel, 4 ignition list (OR)
+constexpr int FC_OVF = 32;      // a capacity was exceeded: 1 records, 4 ignition list, 8 cell table, 16 list of the launch-start sprites (OR)
 constexpr int FC_RR = 33;       // round-robin cursor: wave that gets the next new record
-constexpr uint32_t FR_FRESH = 0x80u;   // record meta: offered in the step before, nothing fetched yet (direction bits = the offering sprite's)
-constexpr int FC_MULTI = 34;    // some cell holds (held) more than one sprite bit (control line drawn on a burning cell): recycle bits by read-modify-write
+constexpr int FC_MULTI = 34;    // the environment holds a cell k_front does not handle (see above)
+constexpr int FC_KEYS = 35;     // keys in the cell table
+constexpr int FC_NREB = 36;     // sprite cells found in the planes at launch start
+constexpr uint32_t FR_FRESH = 0x80u;     // record meta: nothing fetched yet
+constexpr uint32_t FT_EMPTY = 0xFFFFFFFFu;
+constexpr int FT_MOD = 240;              // ignition steps are stored modulo this (old entries are purged at least every kFrPurge steps)
+constexpr uint32_t FT_FRONT = 250u, FT_GONE = 251u, FT_INELIG = 252u;
+constexpr int kFrPurge = 128;
+constexpr int kFrGroup = 2;     // chunks of 64 records a wave works on between two rounds of stores
+constexpr int kFrRecRegs = 4;   // records per lane of a wave kept in registers during a rehash (records per wave <= 64 x kFrRecRegs)
+constexpr int kFrScan = 24;     // table slots per thread kept in registers during a rehash (table size <= kFrScan x threads)
 
-constexpr int kFrGroup = 4;     // chunks of 64 records a wave works on between two rounds of stores
-constexpr int kFrRegs = 2;      // wheel entries per thread kept in registers (lists up to kFrRegs x threads entries; longer: direct loads)
-
-__host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int rc, int ic)
+__host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int rc, int ic, int tab)
 {
-    size_t b = (size_t)n_waves * rc * 24 + (size_t)ic * 4 + kFrCtl * 4 + (size_t)((g.TY * g.TX + 31) / 32) * 4;
+    size_t b = (size_t)n_waves * rc * 20 + (size_t)ic * 4 + (size_t)tab * 4 + kFrCtl * 4 + (size_t)((g.TY * g.TX + 31) / 32) * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;
 #endif
@@ -65,12 +71,12 @@ __host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int
 
 struct FrontLds {
     double *burn, *ros;          // [n_waves][RC]
-    uint32_t *pos, *meta;        // [n_waves][RC]   pos = y << 16 | x;  meta = winner direction | 8 (valid) | status << 4
-    uint32_t *wheel;             // [md + 4][WC] (global memory)
-    uint32_t *ign;               // [IC]
+    uint32_t *meta;              // [n_waves][RC]   winner direction | 8 (valid) | status << 4 | FR_FRESH | table slot << 8 (the slot holds the cell)
+    uint32_t *ign;               // [IC] cells ignited in this step
+    uint32_t *tab;               // [TAB] cell table: (y << 12 | x) << 8 | state
     uint32_t *ctl;               // [kFrCtl]
     uint32_t *tbits;             // [ceil(TY TX / 32)] wave tiles whose status bytes changed in this launch (-> tdirty at the end)
-    int RC, WC, IC, n_waves;
+    int RC, IC, TAB, n_waves;
 };
 
 struct FrontEnv {
@@ -78,6 +84,8 @@ struct FrontEnv {
     double *burn;
     const double *rt;
     uint8_t *tdirty;
+    uint32_t *reb;               // [reb_cap] (global) sprite cells of the launch start
+    int reb_cap;
 };
 
 #ifdef SF_PHASES
@@ -86,10 +94,80 @@ struct FrontEnv {
 #define FR_WAIT()
 #endif
 
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+__device__ __forceinline__ void lds_barrier()
 {
-    typedef uint32_t __attribute__((aligned(1))) u32u;
-    return *reinterpret_cast<const u32u *>(p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ uint32_t ft_home(const FrontLds &L, uint32_t cell) { return (uint32_t)(((unsigned long long)(cell * 0x9E3779B1u) * (uint32_t)L.TAB) >> 32); }
+__device__ __forceinline__ uint32_t ft_next(const FrontLds &L, uint32_t i) { return i + 1 == (uint32_t)L.TAB ? 0u : i + 1; }
+
+// state of a cell given the entry v found at its home slot i: FT_EMPTY if it has no entry
+__device__ __forceinline__ uint32_t ft_resolve(const FrontLds &L, uint32_t cell, uint32_t i, uint32_t v)
+{
+    for (int guard = 0; guard < L.TAB; ++guard) {
+        if (v == FT_EMPTY) return FT_EMPTY;
+        if ((v >> 8) == cell) return v & 0xFFu;
+        i = ft_next(L, i);
+        v = L.tab[i];
+    }
+    return FT_EMPTY;
+}
+
+// Claim a cell for a new record: true (and its slot) if the cell had no entry or was GONE; false if it has a record, is
+// burning / burned or known to be ineligible.  One compare-and-swap decides between concurrent claims.
+__device__ __forceinline__ bool ft_claim(const FrontLds &L, uint32_t cell, uint32_t &slot)
+{
+    uint32_t i = ft_home(L, cell);
+    const uint32_t want = (cell << 8) | FT_FRONT;
+    for (int guard = 0; guard < L.TAB; ++guard) {
+        uint32_t v = L.tab[i];
+        if (v == FT_EMPTY) {
+            v = atomicCAS(&L.tab[i], FT_EMPTY, want);
+            if (v == FT_EMPTY) { atomicAdd(&L.ctl[FC_KEYS], 1u); slot = i; return true; }
+        }
+        if ((v >> 8) == cell) {
+            if ((v & 0xFFu) != FT_GONE) return false;
+            slot = i;
+            return atomicCAS(&L.tab[i], v, want) == v;
+        }
+        i = ft_next(L, i);
+    }
+    atomicOr(&L.ctl[FC_OVF], 8u);
+    return false;
+}
+
+// Insert a cell that is known to have no entry (launch start, rehash); returns its slot
+__device__ __forceinline__ uint32_t ft_insert(const FrontLds &L, uint32_t entry)
+{
+    uint32_t i = ft_home(L, entry >> 8);
+    for (int guard = 0; guard < L.TAB; ++guard) {
+        if (L.tab[i] == FT_EMPTY && atomicCAS(&L.tab[i], FT_EMPTY, entry) == FT_EMPTY) return i;
+        i = ft_next(L, i);
+    }
+    atomicOr(&L.ctl[FC_OVF], 8u);
+    return 0;
+}
+
+// steps since the ignition recorded in a table state (modulo FT_MOD), as seen from step t
+__device__ __forceinline__ uint32_t ft_age(uint32_t state, int t_mod)
+{
+    int age = t_mod - (int)state;
+    if (age < 0) age += FT_MOD;
+    return (uint32_t)age;
+}
+
+// sprite mask of a cell at step t (the byte the sprite-mask plane would hold, sf_common.h make_masks) from its table state
+__device__ __forceinline__ uint32_t ft_mask(uint32_t state, int t_mod, int s0, const Geo &g)
+{
+    if (state >= (uint32_t)FT_MOD) return 0u;                          // no sprite (or no entry)
+    const uint32_t age = ft_age(state, t_mod);
+    if (age > (uint32_t)g.md + 1u) return 0u;                         // gone
+    int bit = s0 - (int)age;
+    if (bit < 0) bit += g.N;
+    return 1u << bit;
 }
 
 // the status histogram of a wave tile goes stale (result block, k_counts_tiles): noted in LDS, written out at the end of the launch
@@ -107,38 +185,38 @@ __device__ __forceinline__ uint32_t wave_rank(bool p, uint32_t &total)
     return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// New records of a wave (lanes with `want`): they are dealt round-robin to the waves' arrays, one LDS atomic on the shared
-// cursor per wave (false: no room, overflow flagged).  Must be called by all lanes of the wave.
-__device__ __forceinline__ bool front_add_wave(const FrontLds &L, bool want, uint32_t pos, uint32_t meta, double bn, double ros, int lane)
+// New (fresh) records of a wave (lanes with `want`): dealt round-robin to the waves' arrays, one LDS atomic on the shared
+// cursor per wave.  Must be called by all lanes of the wave.
+__device__ __forceinline__ void front_add_wave(const FrontLds &L, bool want, uint32_t meta, int lane)
 {
     uint32_t total;
     const uint32_t rank = wave_rank(want, total);
-    if (!total) return false;
+    if (!total) return;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&L.ctl[FC_RR], total);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (!want) return false;
-    const uint32_t w = (base + rank) % (uint32_t)L.n_waves;
+    if (!want) return;
+    // (the shorter of two arrays: keeps the waves' arrays level although records leave at random)
+    uint32_t w = (base + rank) % (uint32_t)L.n_waves;
+    const uint32_t w2 = (w + 7u) % (uint32_t)L.n_waves;
+    if (L.ctl[FC_RC + w2] < L.ctl[FC_RC + w]) w = w2;
     const uint32_t slot = atomicAdd(&L.ctl[FC_RC + w], 1u);
-    if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); return false; }
-    const uint32_t o = w * (uint32_t)L.RC + slot;
-    L.pos[o] = pos; L.meta[o] = meta; L.burn[o] = bn; L.ros[o] = ros;
-    return true;
+    if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); return; }
+    L.meta[w * (uint32_t)L.RC + slot] = meta;
 }
 
 // (divergent callers: the rebuild at launch start)
-__device__ __forceinline__ bool front_add(const FrontLds &L, uint32_t pos, uint32_t meta, double bn, double ros)
+__device__ __forceinline__ void front_add(const FrontLds &L, uint32_t meta, double bn)
 {
     const uint32_t w = atomicAdd(&L.ctl[FC_RR], 1u) % (uint32_t)L.n_waves;
     const uint32_t slot = atomicAdd(&L.ctl[FC_RC + w], 1u);
-    if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); return false; }
+    if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); return; }
     const uint32_t o = w * (uint32_t)L.RC + slot;
-    L.pos[o] = pos; L.meta[o] = meta; L.burn[o] = bn; L.ros[o] = ros;
-    return true;
+    L.meta[o] = meta; L.burn[o] = bn; L.ros[o] = 0.0;
 }
 
-// Launch start: one 16-cell vector of the sprite plane that holds a sprite bit or lies next to one that does ->
-// wheel entries for its sprite bits, records for its frontier cells.  Nothing is changed in the planes.
+// Launch start: one 16-cell vector of the sprite plane that holds a sprite bit or lies next to one that does -> table
+// entries for its sprite cells, records (+ FRONT entries) for its frontier cells.  Nothing is changed in the planes.
 __device__ __forceinline__ void front_rebuild_vector(const Geo &g, const FrontLds &L, const FrontEnv &ev, const Masks &mk, int t,
                                                      int y, int v)
 {
@@ -159,22 +237,24 @@ __device__ __forceinline__ void front_rebuild_vector(const Geo &g, const FrontLd
         if (g.diag) { r1 = *reinterpret_cast<const uint32_t *>(ra - g.P + 16); r2 = *reinterpret_cast<const uint32_t *>(ra + g.P + 16); }
     }
     const uint32_t L4 = rep4(mk.m_live);
-    // ---- wheel: every sprite bit of the vector, under the step it was ignited at (bit p <-> the one step s = p mod N
-    // of [t - md - 2, t - 1])
+    const uint4 s7 = and4(sr, 0x07070707u);
+    // ---- sprite cells: the step the sprite was ignited at (bit p <-> the one step s = p mod N of [t - md - 2, t - 1])
     if (any4(mid)) {
 #pragma unroll 1
         for (int b = 0; b < 16; ++b) {
-            uint32_t by = (pick(mid, b >> 2) >> (8 * (b & 3))) & 0xFFu;
-            if (by & (by - 1)) L.ctl[FC_MULTI] = 1;
-            while (by) {
-                const int p = __ffs(by) - 1;
-                by &= by - 1;
-                const int s = (t - 1) - slot_of(t - 1 - p, g.N);
-                const int li = slot_of(s, g.md + 4);
-                const uint32_t wi = atomicAdd(&L.ctl[FC_WC + li], 1u);
-                if (wi < (uint32_t)L.WC) L.wheel[li * L.WC + wi] = ((uint32_t)y << 16) | (uint32_t)(x0 + b);
-                else atomicOr(&L.ctl[FC_OVF], 2u);
-            }
+            const uint32_t by = (pick(mid, b >> 2) >> (8 * (b & 3))) & 0xFFu;
+            if (!by) continue;
+            const uint32_t code = (pick(s7, b >> 2) >> (8 * (b & 3))) & 7u;
+            // two sprites on one cell, or an eligible status on a burning cell (it will ignite again): not for k_front
+            if ((by & (by - 1)) || code == SF_UNBURNED || code >= SF_FIRELINE) { L.ctl[FC_MULTI] = 1; continue; }
+            const int p = __ffs(by) - 1;
+            const int s = (t - 1) - slot_of(t - 1 - p, g.N);
+            const uint32_t cell = ((uint32_t)y << 12) | (uint32_t)(x0 + b);
+            ft_insert(L, (cell << 8) | (uint32_t)slot_of(s, FT_MOD));
+            atomicAdd(&L.ctl[FC_KEYS], 1u);
+            atomicAdd(&L.ctl[FC_WC + slot_of(s, g.md + 4)], 1u);
+            const uint32_t ri = atomicAdd(&L.ctl[FC_NREB], 1u);
+            if (ri < (uint32_t)ev.reb_cap) ev.reb[ri] = ((uint32_t)y << 16) | (uint32_t)(x0 + b); else atomicOr(&L.ctl[FC_OVF], 16u);
         }
     }
     // ---- frontier cells: eligible (fire.py:192-205) & next to a live sprite (same byte algebra as the vector pass of k_run)
@@ -189,7 +269,6 @@ __device__ __forceinline__ void front_rebuild_vector(const Geo &g, const FrontLd
     nb.z = vsrc.z | __builtin_amdgcn_alignbyte(hsrc.z, hsrc.y, 3) | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 1);
     nb.w = vsrc.w | __builtin_amdgcn_alignbyte(hsrc.w, hsrc.z, 3) | ((hsrc.w >> 8) | (rin << 24));
     if (!any4(nb)) return;
-    const uint4 s7 = and4(sr, 0x07070707u);
     uint32_t p0 = elig01(s7.x) & nz01(nb.x), p1 = elig01(s7.y) & nz01(nb.y), p2 = elig01(s7.z) & nz01(nb.z), p3 = elig01(s7.w) & nz01(nb.w);
     if (x0 + 16 > g.W) {
         const int nv = g.W - x0;
@@ -200,117 +279,89 @@ __device__ __forceinline__ void front_rebuild_vector(const Geo &g, const FrontLd
         const int b = __ffs(m16) - 1;
         m16 &= m16 - 1;
         const int x = x0 + b;
+        if ((pick(mid, b >> 2) >> (8 * (b & 3))) & 0xFFu) continue;           // (holds a sprite: flagged above)
         const uint32_t code = (pick(s7, b >> 2) >> (8 * (b & 3))) & 7u;
         const double bn = ev.burn[voff + b];
-        front_add(L, ((uint32_t)y << 16) | (uint32_t)x, code << 4, bn, 0.0);
+        const uint32_t slot = ft_insert(L, ((((uint32_t)y << 12) | (uint32_t)x) << 8) | FT_FRONT);
+        atomicAdd(&L.ctl[FC_KEYS], 1u);
+        front_add(L, (code << 4) | (slot << 8), bn);
     }
 }
 
-__device__ __forceinline__ unsigned long long load_u64_unaligned(const uint8_t *p)
+// Rehash: the table keeps what still matters - sprites ignited at most md + 1 steps before step t (live or about to
+// expire) and the cells that have a record - and forgets the rest (burned-out cells,
+// GONE / INELIGIBLE marks: a cell that is offered a record again simply finds out again).  The records re-enter
+// themselves (they remember their slot); everything else travels through registers.  All threads; LDS barriers inside.
+__device__ __forceinline__ void front_rehash(const Geo &g, const FrontLds &L, int t, int tid, int wave, int lane, int nthr)
 {
-    typedef unsigned long long __attribute__((aligned(1))) u64u;
-    return *reinterpret_cast<const u64u *>(p);
-}
-
-// The cells ignited in this step offer a record to their neighbours, one ignited cell c per lane.  The neighbour n in
-// direction k takes it iff it had no live sprite next to it in this step (else it has its record, or has just ignited),
-// c is the first in priority order of the cells ignited next to n in this step - which makes c the winner source of n in
-// step t + 1, so the table entry fetched here is the one that step needs - and n is eligible (fire.py:192-205, status
-// after this step's prune and ignitions).  The first two conditions are read off the 5 x 5 sprite masks around c (five
-// 8-byte loads) and decide who gets a record; status, burn_amounts and the table entry are fetched by the record itself
-// together with its masks in the next step (an ineligible cell drops out there).
-__device__ __forceinline__ void front_offers(const Geo &g, const FrontLds &L, const FrontEnv &ev, const Masks &mk, uint32_t lo_mask,
-                                             uint32_t hi_mask, uint32_t n_ign, uint32_t HP, int tid, int lane, int nthr)
-{
-    constexpr int kDx[8] = {+1, 0, -1, +1, -1, +1, 0, -1}, kDy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};      // = c_dx / c_dy
-    const uint32_t N4 = rep4(mk.b_new);
-    const uint32_t lo_new = g.diag ? N4 : (N4 & 0xFF00FF00u), hi_new = g.diag ? N4 : (N4 & 0x00FF00FFu);
-    for (uint32_t i0 = 0; i0 < n_ign; i0 += (uint32_t)nthr) {          // (uniform trip count: the adds are wave-wide)
-        const uint32_t i = i0 + (uint32_t)tid;
-        const bool has = i < n_ign;
-        const uint32_t pos = has ? L.ign[i] : 0u;
-        const int cx = (int)(pos & 0xFFFF), cy = (int)(pos >> 16);
-        uint32_t wm = 0;                 // directions whose neighbour passes the sprite-mask conditions
-        if (has) {
-            // rows cy - 2 .. cy + 2, byte j = column cx - 2 + j; columns outside the grid read as 0, rows outside the guard rows too
-            const int sh = cx < 2 ? 2 - cx : 0;
-            const int jmax = g.W - cx + 2;
-            const unsigned long long colmask = jmax >= 8 ? ~0ull : ((1ull << (8 * jmax)) - 1ull);
-            unsigned long long R[5];
+    uint32_t keep[kFrScan];
+    const int t_mod = slot_of(t, FT_MOD);
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int y = cy - 2 + r;
-                R[r] = 0;
-                if (y >= -1 && y <= g.H) R[r] = (load_u64_unaligned(ev.age + (long long)y * g.P + (cx - 2 + sh)) << (8 * sh)) & colmask;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int dx = kDx[k], dy = kDy[k];
-                const bool diagonal_k = dx != 0 && dy != 0;
-                const int nx = cx - dx, ny = cy - dy;
-                const uint32_t up3 = (uint32_t)(R[1 - dy] >> (8 * (1 - dx))), mid3 = (uint32_t)(R[2 - dy] >> (8 * (1 - dx))),
-                               dn3 = (uint32_t)(R[3 - dy] >> (8 * (1 - dx)));
-                // the 8 neighbour masks of n in priority order (as pick_winner8)
-                const uint32_t lo = __builtin_amdgcn_perm(mid3, dn3, 0x06000102u), hi = __builtin_amdgcn_perm(mid3, up3, 0x00010204u);
-                const bool had_live = ((lo & lo_mask) | (hi & hi_mask)) != 0u;
-                const uint32_t cl = lo & lo_new, ch = hi & hi_new;
-                const int first_new = cl ? (__ffs(cl) - 1) >> 3 : (ch ? 4 + ((__ffs(ch) - 1) >> 3) : -1);
-                const bool ok = (g.diag || !diagonal_k) && nx >= 0 && nx < g.W && ny >= 0 && ny < g.H && !had_live && first_new == k;
-                wm |= ok ? (1u << k) : 0u;
-            }
-        }
-        // the neighbours that passed get a record (position + direction; everything else is fetched with their masks in
-        // the next step): ranks by one wave prefix sum, dealt round-robin to the waves' arrays
-        const uint32_t mine = (uint32_t)__popc(wm);
-        const uint32_t incl = wave_scan_incl(mine, lane);
-        const uint32_t total = wave_last(incl);
-        if (total) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&L.ctl[FC_RR], total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            uint32_t rank = base + incl - mine;
-            while (wm) {
-                const int k = __ffs(wm) - 1;
-                wm &= wm - 1;
-                const uint32_t w = rank % (uint32_t)L.n_waves;
-                ++rank;
-                const uint32_t slot = atomicAdd(&L.ctl[FC_RC + w], 1u);
-                if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); continue; }
-                const uint32_t o = w * (uint32_t)L.RC + slot;
-                L.pos[o] = ((uint32_t)(cy - c_dy[k]) << 16) | (uint32_t)(cx - c_dx[k]);
-                L.meta[o] = FR_FRESH | 8u | (uint32_t)k;
-            }
+    for (int j = 0; j < kFrScan; ++j) {
+        const int i = tid + j * nthr;
+        keep[j] = FT_EMPTY;
+        if (i < L.TAB) {
+            const uint32_t v = L.tab[i];
+            const uint32_t state = v & 0xFFu;
+            if (v != FT_EMPTY && state < (uint32_t)FT_MOD && ft_age(state, t_mod) <= (uint32_t)g.md + 1u) keep[j] = v;
         }
     }
+    const uint32_t n = min(L.ctl[FC_RC + wave], (uint32_t)L.RC);
+    const uint32_t base = (uint32_t)wave * (uint32_t)L.RC;
+    uint32_t rcell[kFrRecRegs];              // the cells of this wave's records (their table slots are about to go)
+#pragma unroll
+    for (int j = 0; j < kFrRecRegs; ++j) {
+        const uint32_t i = (uint32_t)lane + 64u * j;
+        rcell[j] = i < n ? L.tab[L.meta[base + i] >> 8] >> 8 : 0u;
+    }
+    lds_barrier();
+    for (int i = tid; i < L.TAB; i += nthr) L.tab[i] = FT_EMPTY;
+    if (tid == 0) L.ctl[FC_KEYS] = 0;
+    lds_barrier();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kFrScan; ++j)
+        if (keep[j] != FT_EMPTY) { ft_insert(L, keep[j]); ++mine; }
+#pragma unroll
+    for (int j = 0; j < kFrRecRegs; ++j) {
+        const uint32_t i = (uint32_t)lane + 64u * j;
+        if (i < n) {
+            const uint32_t slot = ft_insert(L, (rcell[j] << 8) | FT_FRONT);
+            L.meta[base + i] = (L.meta[base + i] & 0xFFu) | (slot << 8);
+            ++mine;
+        }
+    }
+    if (mine) atomicAdd(&L.ctl[FC_KEYS], mine);
+    lds_barrier();
 }
 
-__global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC, int WC, int IC, uint32_t *wheel_all,
-                                                int32_t *todo, int32_t *ovf_host)
+__global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC, int IC, int TAB, uint32_t *reb_all, int reb_cap, int32_t *todo,
+                                                int32_t *ovf_host, int32_t *dbg)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     const int e = blockIdx.x;
-    const int NW = g.md + 4;                     // wheel lists
+    const int NW = g.md + 4;                     // ring of per-step ignition counts
     FrontLds L;
-    L.RC = RC; L.WC = WC; L.IC = IC; L.n_waves = n_waves;
+    L.RC = RC; L.IC = IC; L.TAB = TAB; L.n_waves = n_waves;
     L.burn = reinterpret_cast<double *>(s_dyn);
     L.ros = L.burn + (size_t)n_waves * RC;
-    L.pos = reinterpret_cast<uint32_t *>(L.ros + (size_t)n_waves * RC);
-    L.meta = L.pos + (size_t)n_waves * RC;
-    L.wheel = wheel_all + (size_t)e * NW * WC;
+    L.meta = reinterpret_cast<uint32_t *>(L.ros + (size_t)n_waves * RC);
     L.ign = L.meta + (size_t)n_waves * RC;
-    L.ctl = L.ign + IC;
+    L.tab = L.ign + IC;
+    L.ctl = L.tab + TAB;
     L.tbits = L.ctl + kFrCtl;
     uint32_t *ctl = L.ctl;
     const int tb_words = (g.TY * g.TX + 31) / 32;
-    for (int i = tid; i < tb_words; i += nthr) L.tbits[i] = 0;
 
     EnvState st = a.commit[e];
     if (!st.running) {                           // frozen: run() no longer calls update (uniform over the workgroup)
         if (tid == 0) todo[e] = 0;
         return;
     }
+    for (int i = tid; i < tb_words; i += nthr) L.tbits[i] = 0;
+    for (int i = tid; i < TAB; i += nthr) L.tab[i] = FT_EMPTY;
     if (tid < kFrCtl) ctl[tid] = 0;
     PhaseClock pc;
 #ifdef SF_PHASES
@@ -328,13 +379,16 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     ev.burn = a.burn + (long long)e * g.plane_env;
     ev.rt = a.rt + (long long)e * g.rt_env;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+    ev.reb = reb_all + (size_t)e * reb_cap;
+    ev.reb_cap = reb_cap;
     const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));
     const uint32_t HP = (uint32_t)(g.H * g.P);
+    const int t_first = st.steps + 1;
 
-    // ---- rebuild the derived state from the planes: a thread per row of the vector bitmap (plane 0: the vector holds a
-    // sprite bit), dilated by one vector / one row
+    // ---- the derived state from the planes: a thread per row of the vector bitmap (plane 0: the vector holds a sprite bit),
+    // dilated by one vector / one row
     {
-        const Masks mk0 = make_masks(st.steps + 1, g.md, g.N);
+        const Masks mk0 = make_masks(t_first, g.md, g.N);
         const unsigned long long *B = a.vbits + (long long)e * g.vb_env;
         const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
         for (int y = tid; y < g.H; y += nthr) {
@@ -349,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                 while (m) {
                     const int b = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    front_rebuild_vector(g, L, ev, mk0, st.steps + 1, y, w * 64 + b);
+                    front_rebuild_vector(g, L, ev, mk0, t_first, y, w * 64 + b);
                 }
             }
         }
@@ -357,110 +411,134 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     __syncthreads();
     pc.mark(1);              // rebuild
 
-    uint32_t n_active = 0, n_ignite = 0, n_rec = 0, n_events = 0;
-    int done = 0;
-    bool ovf = ctl[FC_OVF] != 0;
-    // wheel entries in flight: cur = the sprites that expire in the next step to run, prev = those that expired in the step
-    // before it (their bit is recycled in the next step to run)
-    uint32_t cur_exp[kFrRegs], prev_exp[kFrRegs];
-    uint32_t n_prev;
-    {
-        const int t = st.steps + 1;
-        const int li_e = slot_of(t - g.md - 1, NW), li_c = slot_of(t - g.md - 2, NW);
-        const uint32_t n_e = min(ctl[FC_WC + li_e], (uint32_t)WC);
-        n_prev = min(ctl[FC_WC + li_c], (uint32_t)WC);
-#pragma unroll
-        for (int k = 0; k < kFrRegs; ++k) {
-            const uint32_t i = (uint32_t)(tid + k * nthr);
-            cur_exp[k] = i < n_e ? L.wheel[li_e * WC + i] : 0u;
-            prev_exp[k] = i < n_prev ? L.wheel[li_c * WC + i] : 0u;
-        }
-    }
+    uint32_t n_active = 0, n_ignite = 0, n_rec = 0;
+    int done = 0, since_purge = 0;
+    // what k_front does not handle, or a table that is too full to start with: nothing has been changed, k_run does all steps
+    const bool refuse = ctl[FC_MULTI] != 0 || ctl[FC_OVF] != 0 || ctl[FC_KEYS] * 20u > (uint32_t)TAB * 11u;
+    bool ovf = refuse;
     while (!ovf && done < n_steps && st.running) {
         const int t = st.steps + 1;
         const Masks mk = make_masks(t, g.md, g.N);
         const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
         const uint32_t L4 = rep4(mk.m_live);
         const uint32_t lo_mask = g.diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = g.diag ? L4 : (L4 & 0x00FF00FFu);
-        const int li_exp = slot_of(t - g.md - 1, NW), li_clr = slot_of(t - g.md - 2, NW), li_new = slot_of(t, NW);
+        const int s0 = slot_of(t, g.N);
+        const int t_mod = slot_of(t, FT_MOD);
+        const int li_new = slot_of(t, NW);
         const int par = t & 1;
 
-        if (tid == 0) ctl[FC_WC + slot_of(t + 1, NW)] = 0;        // list of the next step (its sprites were recycled in step t - 1)
+        // the table is kept at most 65 % full, and entries older than the step counter's modulus must not survive: forget
+        // what no longer matters (uniform decision)
+        if (ctl[FC_KEYS] * 20u > (uint32_t)TAB * 13u || since_purge >= kFrPurge) {
+            front_rehash(g, L, t, tid, wave, lane, nthr);
+            since_purge = 0;
+            if (ctl[FC_KEYS] * 20u > (uint32_t)TAB * 11u) atomicOr(&ctl[FC_OVF], 8u);      // (still above 55 %: the fire has outgrown it)
+            pc.mark(10);         // rehash
+        }
+        ++since_purge;
+        if (tid == 0) ctl[FC_WC + slot_of(t + 1, NW)] = 0;
 
         // ---- the records of this wave, compacted in place.  Loads and stores share one counter and a wait for a load is a
-        // wait for every store issued before it, so the stores go last: up to kFrGroup x 64 records are read, their masks
-        // (and whatever a fresh record needs) requested, the table entries of changed winners requested, everything decided
-        // and written to LDS - and only then the cell planes are written.
+        // wait for every store issued before it, so the stores go last.
         if (spread) {
             const uint32_t n = min(ctl[FC_RC + wave], (uint32_t)RC);
             const uint32_t base = (uint32_t)wave * (uint32_t)RC;
             uint32_t wcur = 0;
             for (uint32_t c0 = 0; c0 < n; c0 += 64u * kFrGroup) {
-                uint32_t pos[kFrGroup], meta[kFrGroup], up3[kFrGroup], mid3[kFrGroup], dn3[kFrGroup], idx[kFrGroup];
+                uint32_t pos[kFrGroup], meta[kFrGroup], idx[kFrGroup], code[kFrGroup];
+                int bestk[kFrGroup];
                 double bn[kFrGroup], ros[kFrGroup], rtv[kFrGroup];
-                bool has[kFrGroup], okf[kFrGroup], cand[kFrGroup], need[kFrGroup], ignite[kFrGroup], keep[kFrGroup];
+                bool has[kFrGroup], cand[kFrGroup], need[kFrGroup], ignite[kFrGroup], keep[kFrGroup], fresh[kFrGroup];
 #pragma unroll
                 for (int q = 0; q < kFrGroup; ++q) {
-                    has[q] = false; okf[q] = true; cand[q] = need[q] = ignite[q] = keep[q] = false;
+                    has[q] = cand[q] = need[q] = ignite[q] = keep[q] = fresh[q] = false;
+                    bestk[q] = -1; code[q] = 0; rtv[q] = 0.0; pos[q] = meta[q] = idx[q] = 0; bn[q] = ros[q] = 0.0;
                     if (c0 + 64u * q < n) {                                       // (uniform)
                         const uint32_t i = c0 + 64u * q + lane;
                         has[q] = i < n;
                         const uint32_t o = base + (has[q] ? i : n - 1);
-                        pos[q] = L.pos[o]; meta[q] = L.meta[o]; bn[q] = L.burn[o]; ros[q] = L.ros[o];
-                        const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
+                        meta[q] = L.meta[o]; bn[q] = L.burn[o]; ros[q] = L.ros[o];
+                        pos[q] = L.tab[meta[q] >> 8] >> 8;                      // the cell, y << 12 | x
+                        const int y = pos[q] >> 12, x = pos[q] & 0xFFF;
                         idx[q] = (uint32_t)(y * g.P + x);
-                        const uint8_t *pa = ev.age + idx[q];
-                        const int off = x > 0 ? 1 : 0;              // (nothing is read left of column 0)
-                        up3[q] = load_u32_unaligned(pa - g.P - off); mid3[q] = load_u32_unaligned(pa - off); dn3[q] = load_u32_unaligned(pa + g.P - off);
-                        if (meta[q] & FR_FRESH) {
-                            // a record offered in the step before: status, accumulator and the table entry of the offering
-                            // sprite's direction (= the winner of this step) come with the masks
-                            const uint32_t code = ev.status[idx[q]];
+                        fresh[q] = (meta[q] & FR_FRESH) != 0;
+                        // the 8 neighbour masks in priority order k = 0..7 (sf_common.h c_dx / c_dy): the home slots of all
+                        // eight are read first, then the (few) collisions are followed
+                        constexpr int kDx[8] = {+1, 0, -1, +1, -1, +1, 0, -1}, kDy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
+                        uint32_t nc[8], nh[8], nv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int nx = x + kDx[k], ny = y + kDy[k];
+                            const bool in = nx >= 0 && nx < g.W && ny >= 0 && ny < g.H;
+                            nc[k] = in ? (((uint32_t)ny << 12) | (uint32_t)nx) : 0xFFFFFFu;       // (0xFFFFFF: no cell has it)
+                            nh[k] = ft_home(L, nc[k]);
+                            nv[k] = in ? L.tab[nh[k]] : FT_EMPTY;
+                        }
+                        FR_WAIT();
+                        pc.mark(6);      // record + home slots of the 8 neighbours read
+                        uint32_t lo = 0, hi = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const uint32_t m = ft_mask(ft_resolve(L, nc[k], nh[k], nv[k]), t_mod, s0, g);
+                            if (k < 4) lo |= m << (8 * k); else hi |= m << (8 * (k - 4));
+                        }
+                        lo &= lo_mask; hi &= hi_mask;
+                        uint32_t ob = lo | hi;
+                        ob |= ob >> 16;
+                        ob = (ob | (ob >> 8)) & 0xFFu;
+                        if (ob) {                   // newest live sprite among the neighbours, ties: first in priority order (as pick_winner8)
+                            const uint32_t rr = ((ob << mk.rot) | (ob >> (mk.N - mk.rot))) & ((1u << mk.N) - 1u);
+                            int slot = (31 - __clz(rr)) - mk.rot;
+                            if (slot < 0) slot += mk.N;
+                            const uint32_t T = __builtin_amdgcn_perm(0u, 1u << slot, 0u);
+                            const uint32_t cl = lo & T, ch = hi & T;
+                            bestk[q] = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
+                        }
+                        FR_WAIT();
+                        pc.mark(7);      // collisions followed, winner
+                        cand[q] = has[q] && bestk[q] >= 0;
+                        code[q] = (meta[q] >> 4) & 7u;
+                        if (cand[q] && fresh[q]) {
+                            // first update of a record: status, accumulator and table entry in one round trip
+                            code[q] = ev.status[idx[q]];
                             bn[q] = ev.burn[idx[q]];
-                            ros[q] = ev.rt[(meta[q] & 7u) * HP + idx[q]] * g.update_rate;          // fire.py:696,705
-                            okf[q] = code == SF_UNBURNED || code >= SF_FIRELINE;             // fire.py:192-205
-                            meta[q] = (meta[q] & 15u) | (code << 4);
+                            rtv[q] = ev.rt[(uint32_t)bestk[q] * HP + idx[q]];
+                            need[q] = true;
+                        } else if (cand[q] && (meta[q] & 15u) != (8u | (uint32_t)bestk[q])) {
+                            rtv[q] = ev.rt[(uint32_t)bestk[q] * HP + idx[q]];
+                            need[q] = true;
                         }
                     }
                 }
                 FR_WAIT();
-                pc.mark(2);          // records + neighbourhoods arrive
-                int bestk[kFrGroup];
+                pc.mark(2);          // records, neighbourhoods, winners; plane loads arrive
 #pragma unroll
                 for (int q = 0; q < kFrGroup; ++q) {
                     if (c0 + 64u * q < n) {
-                        const int x = pos[q] & 0xFFFF;
-                        if (x == 0) { up3[q] <<= 8; mid3[q] <<= 8; dn3[q] <<= 8; }
-                        if (x == g.W - 1) { up3[q] &= 0xFFFFu; mid3[q] &= 0xFFFFu; dn3[q] &= 0xFFFFu; }     // the next byte is not a cell of this row
-                        const uint32_t own = (mid3[q] >> 8) & 0xFFu;
-                        // own sprite expires in this update: the prune makes the cell BURNED (fire.py:140) - not eligible
-                        const bool elig = has[q] && okf[q] && !(own & mk.b_exp);
-                        bestk[q] = pick_winner8(up3[q], mid3[q], dn3[q], mk, lo_mask, hi_mask);
-                        cand[q] = elig && bestk[q] >= 0;
-                        need[q] = cand[q] && (meta[q] & 15u) != (8u | (uint32_t)bestk[q]);
-                        rtv[q] = 0.0;
-                        if (need[q]) rtv[q] = ev.rt[(uint32_t)bestk[q] * HP + idx[q]];
-                    }
-                }
-                FR_WAIT();
-                pc.mark(7);          // winners; table entries of new winner directions arrive
-#pragma unroll
-                for (int q = 0; q < kFrGroup; ++q) {
-                    if (c0 + 64u * q < n) {
-                        if (need[q]) { ros[q] = rtv[q] * g.update_rate; meta[q] = (meta[q] & ~15u) | 8u | (uint32_t)bestk[q]; }     // fire.py:696,705
+                        if (need[q]) { ros[q] = rtv[q] * g.update_rate; meta[q] = (meta[q] & ~0x7Fu) | 8u | (uint32_t)bestk[q] | ((code[q] & 7u) << 4); }     // fire.py:696,705
+                        meta[q] &= ~FR_FRESH;
+                        bool inelig = false;
+                        if (fresh[q] && cand[q]) {
+                            inelig = !(code[q] == SF_UNBURNED || code[q] >= SF_FIRELINE);            // fire.py:192-205
+                            if (inelig) cand[q] = false;
+                        }
                         const unsigned long long cb = __ballot(cand[q]);
                         n_active += (uint32_t)__popcll(cb);
                         if (cb != 0ull && lane == 0) ctl[FC_CAND + par] = 1;
                         if (cand[q]) {
-                            const bool line = (meta[q] >> 4) >= SF_FIRELINE;
+                            const bool line = code[q] >= SF_FIRELINE;
                             bn[q] = bn[q] + (line ? 0.0 : ros[q]);                               // fire.py:280-282, 710
                             ignite[q] = bn[q] > g.pixel_scale;                                   // fire.py:568
                         }
                         keep[q] = cand[q] && !ignite[q];
+                        if (has[q] && !keep[q]) {
+                            // the cell leaves the front: burning from now on, ineligible, or without a live neighbour
+                            L.tab[meta[q] >> 8] = (pos[q] << 8) | (ignite[q] ? (uint32_t)t_mod : (inelig ? FT_INELIG : FT_GONE));
+                        }
                         const unsigned long long kb = __ballot(keep[q]);
                         if (keep[q]) {
                             const uint32_t w = base + wcur + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u));
-                            L.pos[w] = pos[q]; L.meta[w] = meta[q]; L.burn[w] = bn[q]; L.ros[w] = ros[q];
+                            L.meta[w] = meta[q]; L.burn[w] = bn[q]; L.ros[w] = ros[q];
                         }
                         wcur += (uint32_t)__popcll(kb);
                     }
@@ -469,23 +547,20 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
 #pragma unroll
                 for (int q = 0; q < kFrGroup; ++q) {
                     if (c0 + 64u * q < n) {
-                        if (has[q] && !keep[q]) ev.burn[idx[q]] = bn[q];
+                        // (a record that has never fetched its accumulator has none to write back)
+                        if (has[q] && !keep[q] && !(fresh[q] && !need[q])) ev.burn[idx[q]] = bn[q];
                         uint32_t n_ig;
                         const uint32_t ig_rank = wave_rank(ignite[q], n_ig);
                         if (n_ig) {
-                            // wheel + ignition list: one atomic per wave and list
-                            uint32_t wb = 0, ib = 0;
-                            if (lane == 0) { wb = atomicAdd(&ctl[FC_WC + li_new], n_ig); ib = atomicAdd(&ctl[FC_IGN + par], n_ig); }
-                            wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+                            uint32_t ib = 0;
+                            if (lane == 0) { atomicAdd(&ctl[FC_WC + li_new], n_ig); ib = atomicAdd(&ctl[FC_IGN + par], n_ig); }
                             ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)ib);
                             if (ignite[q]) {
-                                const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
-                                const uint32_t own = (mid3[q] >> 8) & 0xFFu;
-                                if (own) ctl[FC_MULTI] = 1;                    // a second sprite on this cell (or one whose bit is still to be recycled)
-                                ev.status[idx[q]] = (uint8_t)SF_BURNING;                             // fire.py:587
-                                ev.age[idx[q]] = (uint8_t)((own & ~mk.b_clr) | mk.b_new);            // fire.py:571-579
+                                const int y = pos[q] >> 12, x = pos[q] & 0xFFF;
+                                // fire.py:587 would write BURNING and the prune BURNED md + 1 updates later (fire.py:140): inside the
+                                // launch nothing tells the two apart, the cells still burning at its end are set right there
+                                ev.status[idx[q]] = (uint8_t)SF_BURNED;
                                 front_tile_dirty(L, (y >> th_log) * g.TX + ((x >> 4) >> g.logLC));
-                                if (wb + ig_rank < (uint32_t)WC) L.wheel[li_new * WC + wb + ig_rank] = pos[q]; else atomicOr(&ctl[FC_OVF], 2u);
                                 if (ib + ig_rank < (uint32_t)IC) L.ign[ib + ig_rank] = pos[q]; else atomicOr(&ctl[FC_OVF], 4u);
                             }
                         }
@@ -497,19 +572,6 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
             n_rec += (lane == 0) ? n : 0u;
             if (lane == 0) ctl[FC_RC + wave] = wcur;
         }
-        // ---- sprites ignited at t - md - 1 expire: BURNED (fire.py:116-161), whatever the cell holds by now.  (Independent of
-        // the records: a record whose own sprite expires now has seen that in its mask.)
-        {
-            const uint32_t n_exp = min(ctl[FC_WC + li_exp], (uint32_t)WC);
-            for (uint32_t i = tid, k = 0; i < n_exp; i += nthr, ++k) {
-                const uint32_t pos = k < (uint32_t)kFrRegs ? (k == 0 ? cur_exp[0] : cur_exp[1]) : L.wheel[li_exp * WC + i];
-                const int y = pos >> 16, x = pos & 0xFFFF;
-                ev.status[(uint32_t)(y * g.P + x)] = (uint8_t)SF_BURNED;
-                front_tile_dirty(L, (y >> th_log) * g.TX + ((x >> 4) >> g.logLC));
-            }
-            n_events += (tid == 0) ? n_exp : 0u;
-        }
-        pc.mark(6);              // expiry stores issued
         __syncthreads();
         pc.mark(4);              // barrier A
         uint32_t f = ctl[FC_CAND + par] ? FLAG_CAND : 0u;
@@ -520,43 +582,32 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         }
         if (tid == 0) { ctl[FC_IGN + (par ^ 1)] = 0; ctl[FC_CAND + (par ^ 1)] = 0; }
 
-        // ---- after barrier A.  Loads first: the wheel entries that expire in the next step (ignited at t - md: that list is
-        // complete), then the offers of this step's ignitions; the recycling stores go last.
-        uint32_t nx_exp[kFrRegs];
+        // ---- every cell ignited in this step offers a record to its neighbours (candidates from step t + 1 on): one claim on
+        // the cell table per (cell, direction)
         {
-            const int li_nx = slot_of(t - g.md, NW);
-            const uint32_t n_nx = min(ctl[FC_WC + li_nx], (uint32_t)WC);
-#pragma unroll
-            for (int k = 0; k < kFrRegs; ++k) {
-                const uint32_t i = (uint32_t)(tid + k * nthr);
-                nx_exp[k] = i < n_nx ? L.wheel[li_nx * WC + i] : 0u;
+            const uint32_t items = min(ctl[FC_IGN + par], (uint32_t)IC) * 8u;
+            for (uint32_t j0 = 0; j0 < items; j0 += (uint32_t)nthr) {          // (uniform trip count: the adds are wave-wide)
+                const uint32_t j = j0 + (uint32_t)tid;
+                bool want = j < items;
+                uint32_t slot = 0;
+                pc.mark(8);
+                if (want) {
+                    const uint32_t pos = L.ign[j >> 3];
+                    const int k = (int)(j & 7u);
+                    const int nx = (int)(pos & 0xFFF) - c_dx[k], ny = (int)(pos >> 12) - c_dy[k];
+                    const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
+                    want = (g.diag || !diagonal_k) && nx >= 0 && nx < g.W && ny >= 0 && ny < g.H;
+                    if (want) want = ft_claim(L, ((uint32_t)ny << 12) | (uint32_t)nx, slot);
+                }
+                FR_WAIT();
+                pc.mark(11);     // claims
+                front_add_wave(L, want, FR_FRESH | (slot << 8), lane);
             }
         }
-        // ---- every cell ignited in this step offers a record to its neighbours (candidates from step t + 1 on)
-        front_offers(g, L, ev, mk, lo_mask, hi_mask, min(ctl[FC_IGN + par], (uint32_t)IC), HP, tid, lane, nthr);
-        FR_WAIT();
         pc.mark(9);              // new records
-        // ---- sprites ignited at t - md - 2: their mask bit is recycled for step t + 1
-        {
-            const uint32_t n_clr = n_prev;
-            const bool multi = ctl[FC_MULTI] != 0;
-            for (uint32_t i = tid, k = 0; i < n_clr; i += nthr, ++k) {
-                const uint32_t pos = k < (uint32_t)kFrRegs ? (k == 0 ? prev_exp[0] : prev_exp[1]) : L.wheel[li_clr * WC + i];
-                const uint32_t idx = (uint32_t)((pos >> 16) * g.P + (pos & 0xFFFF));
-                // (a cell holds one sprite bit unless a control line was drawn on a burning cell: nothing to read then)
-                ev.age[idx] = multi ? (uint8_t)(ev.age[idx] & ~mk.b_clr) : (uint8_t)0;
-            }
-            n_events += (tid == 0) ? n_clr : 0u;
-            n_prev = min(ctl[FC_WC + li_exp], (uint32_t)WC);
-#pragma unroll
-            for (int k = 0; k < kFrRegs; ++k) { prev_exp[k] = cur_exp[k]; cur_exp[k] = nx_exp[k]; }
-        }
-        pc.mark(8);              // recycle stores issued
-        // Barrier B orders LDS only (records, counters).  The stores of this phase are read two steps from now at the earliest
-        // (a recycled bit is outside the live window of step t + 1), i.e. after the full barrier A of the next step.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        // Barrier B orders LDS only (records, table, counters): no plane access of the next step depends on one of this step
+        // other than through barrier A.
+        lds_barrier();
         pc.mark(5);              // barrier B
         st = fold_state(st, f, g);
         st.running = __builtin_amdgcn_readfirstlane(st.running);
@@ -565,16 +616,64 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
         ++done;
         ovf = ctl[FC_OVF] != 0;
+        if (dbg && tid == 0) {       // development aid (SF_FRONT_DEBUG): high-water marks per environment
+            uint32_t nr = 0;
+            for (int w = 0; w < n_waves; ++w) nr += ctl[FC_RC + w];
+            int32_t *d = dbg + 4 * e;
+            if ((int32_t)nr > d[0]) d[0] = (int32_t)nr;
+            if ((int32_t)ctl[FC_KEYS] > d[1]) d[1] = (int32_t)ctl[FC_KEYS];
+            if ((int32_t)ctl[FC_IGN + par] > d[2]) d[2] = (int32_t)ctl[FC_IGN + par];
+            if (ovf && !d[3]) d[3] = (int32_t)(ctl[FC_OVF] | (done << 8));
+        }
     }
-    // ---- hand the environment back: accumulators into the plane, "has a record" bits cleared, state, steps left over
-    {
+    // ---- hand the environment back (nothing to do if no step was made): the accumulators of the records still alive; then
+    // the planes' view of the sprites as the next update will find them
+    if (done > 0) {
+        const int t_next = st.steps + 1;
+        const int tn_mod = slot_of(t_next, FT_MOD);
+        const int s0n = slot_of(t_next, g.N);
         const uint32_t n = min(ctl[FC_RC + wave], (uint32_t)RC);
         const uint32_t base = (uint32_t)wave * (uint32_t)RC;
         for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t pos = L.pos[base + i];
-            const int y = pos >> 16, x = pos & 0xFFFF;
-            if (!(L.meta[base + i] & FR_FRESH)) ev.burn[(uint32_t)(y * g.P + x)] = L.burn[base + i];     // (a fresh record holds no accumulator yet)
+            const uint32_t m = L.meta[base + i];
+            const uint32_t cell = L.tab[m >> 8] >> 8;
+            if (!(m & FR_FRESH)) ev.burn[(uint32_t)((cell >> 12) * g.P + (cell & 0xFFFu))] = L.burn[base + i];     // (a fresh record holds no accumulator yet)
         }
+        // the sprites of the launch start: mask byte cleared (rewritten below if the bit is still due); BURNED if the sprite
+        // expired inside the launch (fire.py:116-161; nothing else can have happened to such a cell)
+        const uint32_t n_reb = min(ctl[FC_NREB], (uint32_t)ev.reb_cap);
+        for (uint32_t i = tid; i < n_reb; i += nthr) {
+            const uint32_t pos = ev.reb[i];
+            const int y = pos >> 16, x = pos & 0xFFFF;
+            const uint32_t idx = (uint32_t)(y * g.P + x);
+            const uint32_t cell = ((uint32_t)y << 12) | (uint32_t)x;
+            const uint32_t h = ft_home(L, cell);
+            const uint32_t state = ft_resolve(L, cell, h, L.tab[h]);
+            ev.age[idx] = 0;
+            // (the mask bit of an expired sprite waits one more update for its recycling, fire.py has no such thing: leaving it
+            // out changes nothing any kernel does)
+            if (state >= (uint32_t)FT_MOD || ft_age(state, tn_mod) >= (uint32_t)g.md + 2u) {
+                ev.status[idx] = (uint8_t)SF_BURNED;
+                front_tile_dirty(L, (y >> th_log) * g.TX + ((x >> 4) >> g.logLC));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < TAB; i += nthr) {
+            const uint32_t v = L.tab[i];
+            const uint32_t state = v & 0xFFu;
+            if (v == FT_EMPTY || state >= (uint32_t)FT_MOD) continue;
+            const uint32_t age = ft_age(state, tn_mod);
+            if (age < 1u || age > (uint32_t)g.md + 1u) continue;              // live or expiring at t_next: ignited at t_next - md - 1 .. t_next - 1
+            const uint32_t cell = v >> 8;
+            const uint32_t idx = (uint32_t)((cell >> 12) * g.P + (cell & 0xFFFu));
+            int bit = s0n - (int)age;
+            if (bit < 0) bit += g.N;
+            ev.age[idx] = (uint8_t)(1u << bit);
+            // ignited in this launch (the status written then was BURNED) and not expired before t_next: BURNING (fire.py:587)
+            if (age <= (uint32_t)done) ev.status[idx] = (uint8_t)SF_BURNING;
+        }
+        for (int i = tid; i < g.TY * g.TX; i += nthr)
+            if (L.tbits[i >> 5] & (1u << (i & 31))) ev.tdirty[i] = 1;
     }
 #ifdef SF_PHASES
     pc.mark(12);
@@ -585,20 +684,18 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         atomicAdd(&g_wave_log[e * 4 + 1], (unsigned long long)n_rec);
     }
 #endif
-    for (int i = tid; i < g.TY * g.TX; i += nthr)
-        if (L.tbits[i >> 5] & (1u << (i & 31))) ev.tdirty[i] = 1;
     if (tid == 0) {
         a.commit[e] = st;
         const int left = st.running ? n_steps - done : 0;
         todo[e] = left;
-        if (left > 0) atomicOr(reinterpret_cast<uint32_t *>(ovf_host), 0x100u | ctl[FC_OVF]);       // (host memory: system-scope atomic)
+        if (left > 0) atomicOr(reinterpret_cast<uint32_t *>(ovf_host), 0x100u | ctl[FC_OVF] | (ctl[FC_MULTI] ? 0x20u : 0u));       // (host memory: system-scope atomic)
     }
     if (a.counters && lane == 0) {
         unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
         if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
         if (n_rec) atomicAdd(&cs[6], (unsigned long long)n_rec);         // frontier records visited
-        if (n_events) atomicAdd(&cs[7], (unsigned long long)n_events);   // sprite expiry / recycling events
+        if (n_ignite) atomicAdd(&cs[7], (unsigned long long)n_ignite);   // cells whose status byte was written
     }
 }
 

@@ -84,7 +84,7 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 #include "sf_run_kernels.h"
 #include "sf_front_kernels.h"
 
-constexpr int kFrontWheelCap = 8192;      // k_front: ignitions per environment and step the sprite wheel holds (more: k_run takes over)
+constexpr int kFrontStartCap = 32768;      // k_front: sprite cells per environment at launch start it remembers (more: k_run takes over)
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -122,7 +122,7 @@ struct sf_sim {
     bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
     int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell, 4 k_run_tiles, 5 k_front
     int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
-    uint32_t *wheel = nullptr;         // k_front: sprite wheel [E][md + 4][kFrontWheelCap] cell positions per ignition step
+    uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
@@ -262,7 +262,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.VW = (g.PV + 63) / 64; g.vb_env = (long long)g.H * g.VW;
     TRY(dev_alloc(s, &s->vbits, (size_t)3 * g.E * g.vb_env));
     TRY(dev_alloc(s, &s->todo, (size_t)g.E));
-    if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * (g.md + 4) * kFrontWheelCap));
+    if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * kFrontStartCap));
     TRYHIP(hipHostMalloc(reinterpret_cast<void **>(&s->ovf_pinned), sizeof(int32_t), hipHostMallocMapped));
     TRYHIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->ovf_mapped), s->ovf_pinned, 0));
     *s->ovf_pinned = 0;
@@ -903,7 +903,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         const size_t lds = (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g);
         if (per_env <= 65535 && lds <= 160 * 1024) { runt_waves = nw; runt_lds = lds; }
     }
-    int fr_waves = 0, fr_rc = 0, fr_wc = 0, fr_ic = 0;     // frontier-resident launch (k_front)
+    int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
     size_t fr_lds = 0;
     int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
     size_t fit_lds = 0;
@@ -933,19 +933,20 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         static const int front_min_steps = getenv("SF_FRONT_MIN_STEPS") ? atoi(getenv("SF_FRONT_MIN_STEPS")) : 4;
         static const int front_off = getenv("SF_FRONT_OFF") ? atoi(getenv("SF_FRONT_OFF")) : 1;      // (not the automatic choice yet)
         const bool front_wanted = s->fused_mode == 4 || (s->fused_mode < 0 && n_steps >= front_min_steps && !front_off);
-        if (fits && front_wanted && !g.att && !mit_dev && !g.dense) {
+        if (fits && front_wanted && !g.att && !mit_dev && !g.dense && g.H <= 4096 && g.W <= 4096) {
             static const int fw_knob = getenv("SF_FRONT_WAVES") ? atoi(getenv("SF_FRONT_WAVES")) : 0;
             static const int frc_knob = getenv("SF_FRONT_RC") ? atoi(getenv("SF_FRONT_RC")) : 0;
-            static const int fwc_knob = getenv("SF_FRONT_WC") ? atoi(getenv("SF_FRONT_WC")) : 0;
             static const int fic_knob = getenv("SF_FRONT_IC") ? atoi(getenv("SF_FRONT_IC")) : 0;
-            const bool many = g.E > s->n_cu;              // more environments than CUs: smaller workgroups, several per CU
+            static const int ftab_knob = getenv("SF_FRONT_TAB") ? atoi(getenv("SF_FRONT_TAB")) : 0;
+            const bool many = g.E > s->n_cu;              // more environments than CUs: smaller workgroups, two per CU
             fr_waves = fw_knob ? fw_knob : (many ? 8 : 16);
             if (fr_waves > 16) fr_waves = 16;
-            fr_rc = frc_knob ? frc_knob : (many ? 192 : 320);
-            fr_wc = fwc_knob ? fwc_knob : kFrontWheelCap;
-            if (fr_wc > kFrontWheelCap) fr_wc = kFrontWheelCap;
+            fr_rc = frc_knob ? frc_knob : 160;
+            if (fr_rc > 64 * kFrRecRegs) fr_rc = 64 * kFrRecRegs;
             fr_ic = fic_knob ? fic_knob : (many ? 1024 : 2048);
-            fr_lds = front_lds_bytes(g, fr_waves, fr_rc, fr_ic);
+            fr_tab = ftab_knob ? ftab_knob : (many ? 12288 : 24576);
+            if (fr_tab > kFrScan * fr_waves * 64) fr_tab = kFrScan * fr_waves * 64;
+            fr_lds = front_lds_bytes(g, fr_waves, fr_rc, fr_ic, fr_tab);
             if (fr_lds > 160 * 1024) fr_waves = 0;
         }
     }
@@ -977,12 +978,27 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         if (fr_lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_lds));
         *s->ovf_pinned = 0;
-        hipLaunchKernelGGL(k_front, dim3((unsigned)s->g.E), dim3((unsigned)fr_waves * 64), fr_lds, s->stream, a, n_steps, fr_rc, fr_wc, fr_ic,
-                           s->wheel, s->todo, s->ovf_mapped);
+        static const int fdbg = getenv("SF_FRONT_DEBUG") ? atoi(getenv("SF_FRONT_DEBUG")) : 0;
+        int32_t *dbg_dev = nullptr;
+        if (fdbg) { HIPCHK(hipMalloc(reinterpret_cast<void **>(&dbg_dev), (size_t)s->g.E * 16)); HIPCHK(hipMemsetAsync(dbg_dev, 0, (size_t)s->g.E * 16, s->stream)); }
+        hipLaunchKernelGGL(k_front, dim3((unsigned)s->g.E), dim3((unsigned)fr_waves * 64), fr_lds, s->stream, a, n_steps, fr_rc, fr_ic, fr_tab,
+                           s->wheel, kFrontStartCap, s->todo, s->ovf_mapped, dbg_dev);
         s->tiles_valid = false; s->vbits_valid = false;     // neither bookkeeping is kept by k_front
         s->last_kind = 5;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s->stream));
+        if (dbg_dev) {
+            std::vector<int32_t> d((size_t)s->g.E * 4);
+            HIPCHK(hipMemcpy(d.data(), dbg_dev, d.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipFree(dbg_dev));
+            int mr = 0, mk = 0, mi = 0;
+            for (int e = 0; e < s->g.E; ++e) { mr = std::max(mr, d[4 * e]); mk = std::max(mk, d[4 * e + 1]); mi = std::max(mi, d[4 * e + 2]); }
+            fprintf(stderr, "[k_front] %d steps: max records %d (cap %d), max table keys %d (table %d), max ignitions per step %d (cap %d)\n", n_steps, mr,
+                    fr_rc * fr_waves, mk, fr_tab, mi, fr_ic);
+            if (fdbg > 1)
+                for (int e = 0; e < s->g.E; ++e)
+                    if (d[4 * e + 3]) fprintf(stderr, "   env %d: overflow 0x%x after %d steps; records %d keys %d ign %d\n", e, d[4 * e + 3] & 0xFF, d[4 * e + 3] >> 8, d[4 * e], d[4 * e + 1], d[4 * e + 2]);
+        }
         if (*s->ovf_pinned) {
             // some environment outgrew its record / wheel capacity: k_run finishes its steps from the planes
             s->front_fallbacks++;
@@ -993,7 +1009,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                 HIPCHK(hipMemcpy(td.data(), s->todo, td.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
                 int n_left = 0; long long sum = 0;
                 for (int32_t v : td) { n_left += v > 0; sum += v; }
-                fprintf(stderr, "[k_front] overflow reasons 0x%x (1 records, 2 wheel, 4 ignition list): %d of %d environments, %lld of %d steps left on average\n",
+                fprintf(stderr, "[k_front] overflow reasons 0x%x (1 records, 4 ignition list, 8 cell table, 16 start list, 0x20 cell with two sprites / eligible burning cell): %d of %d environments, %lld of %d steps left on average\n",
                         *s->ovf_pinned & 0xFF, n_left, s->g.E, n_left ? sum / n_left : 0, n_steps);
             }
             hipLaunchKernelGGL(k_rebuild_vbits_todo, dim3((unsigned)s->g.E), dim3(256), 0, s->stream, s->g, (const uint8_t *)s->age, s->vbits,

@@ -196,10 +196,10 @@ def test_resident_any_workgroup_size(waves, mode):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("caps", [(4, 8, 4), (64, 12, 512), (64, 512, 6), (16, 64, 64)])
+@pytest.mark.parametrize("caps", [(4, 2048, 24576), (128, 6, 24576), (128, 2048, 300), (16, 64, 1024)])
 def test_front_overflow_is_finished_by_k_run(caps):
-    """k_front with tiny record / wheel / ignition-list capacities: whatever overflows is derived state, the environment
-    stops at a step boundary and k_run does the steps left over - same result, and the hand-over really happened."""
+    """k_front with tiny record / ignition-list / cell-table capacities: whatever overflows is derived state, the
+    environment stops at a step boundary and k_run does the steps left over - same result, and the hand-over really happened."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -226,7 +226,7 @@ def test_front_overflow_is_finished_by_k_run(caps):
         assert 6 in kinds, kinds
         print("OK")
     """ % root)
-    env = dict(os.environ, SF_FRONT_RC=str(caps[0]), SF_FRONT_WC=str(caps[1]), SF_FRONT_IC=str(caps[2]))
+    env = dict(os.environ, SF_FRONT_RC=str(caps[0]), SF_FRONT_IC=str(caps[1]), SF_FRONT_TAB=str(caps[2]))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
