@@ -16,15 +16,17 @@ namespace {
 // every byte store / 8-byte load of a cell plane is one.  So k_front keeps everything that is read or written more than
 // once per cell in LDS and touches the planes once per event:
 //
-//   cell table        an open-addressing hash table cell -> state in LDS: the step a burning / burned cell was ignited at
-//                     (its sprite is live for the md steps after it, fire.py:116-161, 633-647), FRONT (the cell has a
-//                     frontier record), GONE (it had one and lost its last live neighbour), INELIGIBLE.  The 3 x 3 sprite
-//                     neighbourhood of a candidate is eight table look-ups - the sprite-mask plane is not read at all
-//                     after the launch has started, and not written before it ends.
+//   cell table        cell -> state byte in LDS: the step a burning / burned cell was ignited at (its sprite is live for the
+//                     md steps after it, fire.py:116-161, 633-647), FRONT (the cell has a frontier record), GONE (it had
+//                     one and lost its last live neighbour), INELIGIBLE.  Stored as 8 x 8 (16 x 16 on grids above 1024) cell
+//                     tiles handed out of a pool on first touch, found through a directory with one entry per tile of the
+//                     grid: a look-up is two dependent LDS reads, no probing, no loops.  Tiles in which nothing is live
+//                     any more go back to the pool.  The 3 x 3 sprite neighbourhood of a candidate is eight look-ups - the
+//                     sprite-mask plane is not read at all after the launch has started, and not written before it ends.
 //   frontier records  one per ignition candidate (fire.py:163-234: eligible cell next to a live sprite): position,
 //                     burn_amounts[cell] (the f64 accumulator LIVES here while the cell is on the front, fire.py:710),
 //                     R dt of the cached winner direction (fire.py:696-705).  A cell ignited in step t offers a record to
-//                     its neighbours: one compare-and-swap on the table per neighbour decides who is new.  A new record
+//                     its neighbours: one compare-and-swap on the neighbour's state byte decides who is new.  A new record
 //                     fetches status, accumulator and table entry in ONE round trip at its first update.
 //
 // Plane traffic per cell and lifetime: status + burn_amounts + R-table entry read once when the cell joins the front, the
@@ -38,7 +40,7 @@ namespace {
 // UNBURNED status on a burning cell at launch start (E3 / E4 of SURVEY 8a - the lazy status needs one sprite per cell),
 // and any LDS capacity exceeded in flight (the workgroup finishes its step, writes everything back and stops).
 // Not handled here at all (the host chooses k_run): attenuation mode, control lines inside the launch, dense mode,
-// grids above 4096 x 4096.
+// grids above 2048 x 2048.
 // ------------------------------------------------------------------------------------------
 constexpr int kFrCtl = 48;
 // control words
@@ -46,23 +48,30 @@ constexpr int FC_RC = 0;        // [16] records per wave
 constexpr int FC_WC = 16;       // [12] ignitions per step (ring of md + 4 steps): "some sprite survives the prune" (fire.py:637)
 constexpr int FC_IGN = 28;      // [2]  ignition list length (ring of 2 steps)
 constexpr int FC_CAND = 30;     // [2]  "some sprite has a cell to spread into" (fire.py:651), ring of 2 steps
-constexpr int FC_OVF = 32;      // a capacity was exceeded: 1 records, 4 ignition list, 8 cell table, 16 list of the launch-start sprites (OR)
+constexpr int FC_OVF = 32;      // a capacity was exceeded: 1 records, 4 ignition list, 8 tile pool, 16 list of the launch-start sprites (OR)
 constexpr int FC_RR = 33;       // round-robin cursor: wave that gets the next new record
 constexpr int FC_MULTI = 34;    // the environment holds a cell k_front does not handle (see above)
-constexpr int FC_KEYS = 35;     // keys in the cell table
+constexpr int FC_POOL = 35;     // tiles ever taken from the pool (high-water mark)
 constexpr int FC_NREB = 36;     // sprite cells found in the planes at launch start
+constexpr int FC_FREE = 37;     // tiles on the free list
 constexpr uint32_t FR_FRESH = 0x80u;     // record meta: nothing fetched yet
-constexpr uint32_t FT_EMPTY = 0xFFFFFFFFu;
-constexpr int FT_MOD = 240;              // ignition steps are stored modulo this (old entries are purged at least every kFrPurge steps)
+// state byte of a cell: 0 = nothing known, 1 .. FT_MOD = ignited at step s, stored as (s mod FT_MOD) + 1, or
+constexpr int FT_MOD = 240;              // (old step bytes are purged at least every kFrPurge steps)
 constexpr uint32_t FT_FRONT = 250u, FT_GONE = 251u, FT_INELIG = 252u;
 constexpr int kFrPurge = 128;
 constexpr int kFrGroup = 2;     // chunks of 64 records a wave works on between two rounds of stores
-constexpr int kFrRecRegs = 4;   // records per lane of a wave kept in registers during a rehash (records per wave <= 64 x kFrRecRegs)
-constexpr int kFrScan = 24;     // table slots per thread kept in registers during a rehash (table size <= kFrScan x threads)
 
-__host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int rc, int ic, int tab)
+__host__ __device__ inline int front_tile_log(const Geo &g) { return (g.H <= 1024 && g.W <= 1024) ? 3 : 4; }
+__host__ __device__ inline int front_dir_entries(const Geo &g)
 {
-    size_t b = (size_t)n_waves * rc * 20 + (size_t)ic * 4 + (size_t)tab * 4 + kFrCtl * 4 + (size_t)((g.TY * g.TX + 31) / 32) * 4;
+    const int tl = front_tile_log(g);
+    return (((g.H + (1 << tl) - 1) >> tl) * ((g.W + (1 << tl) - 1) >> tl) + 1) & ~1;
+}
+__host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int rc, int ic, int nt)
+{
+    const int tl = front_tile_log(g);
+    size_t b = (size_t)n_waves * rc * 24 + (size_t)ic * 4 + (size_t)front_dir_entries(g) * 2 + ((size_t)nt << (2 * tl)) + (size_t)nt * 4 + kFrCtl * 4 +
+               (size_t)((g.TY * g.TX + 31) / 32) * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;
 #endif
@@ -71,12 +80,14 @@ __host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int
 
 struct FrontLds {
     double *burn, *ros;          // [n_waves][RC]
-    uint32_t *meta;              // [n_waves][RC]   winner direction | 8 (valid) | status << 4 | FR_FRESH | table slot << 8 (the slot holds the cell)
-    uint32_t *ign;               // [IC] cells ignited in this step
-    uint32_t *tab;               // [TAB] cell table: (y << 12 | x) << 8 | state
+    uint32_t *pos, *meta;        // [n_waves][RC]   pos = y << 16 | x; meta = winner direction | 8 (valid) | status << 4 | FR_FRESH | tile << 8
+    uint32_t *ign;               // [IC] cells ignited in this step (y << 16 | x)
+    uint16_t *dir;               // [TYD][TXD] tile of the cell table that covers this 2^tl x 2^tl block of the grid, + 1 (0: none)
+    uint8_t *pool;               // [NT][2^tl][2^tl] state bytes
+    uint16_t *town, *freel;      // [NT] directory entry that owns the tile (0xFFFF: free, 0xFFFE: taken but unused); free list
     uint32_t *ctl;               // [kFrCtl]
     uint32_t *tbits;             // [ceil(TY TX / 32)] wave tiles whose status bytes changed in this launch (-> tdirty at the end)
-    int RC, IC, TAB, n_waves;
+    int RC, IC, NT, n_waves, tl, TXD, TYD;
 };
 
 struct FrontEnv {
@@ -101,60 +112,87 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__device__ __forceinline__ uint32_t ft_home(const FrontLds &L, uint32_t cell) { return (uint32_t)(((unsigned long long)(cell * 0x9E3779B1u) * (uint32_t)L.TAB) >> 32); }
-__device__ __forceinline__ uint32_t ft_next(const FrontLds &L, uint32_t i) { return i + 1 == (uint32_t)L.TAB ? 0u : i + 1; }
-
-// state of a cell given the entry v found at its home slot i: FT_EMPTY if it has no entry
-__device__ __forceinline__ uint32_t ft_resolve(const FrontLds &L, uint32_t cell, uint32_t i, uint32_t v)
+__device__ __forceinline__ uint32_t tl_dir_index(const FrontLds &L, int y, int x) { return (uint32_t)((y >> L.tl) * L.TXD + (x >> L.tl)); }
+__device__ __forceinline__ uint32_t tl_addr(const FrontLds &L, uint32_t tile, int y, int x)
 {
-    for (int guard = 0; guard < L.TAB; ++guard) {
-        if (v == FT_EMPTY) return FT_EMPTY;
-        if ((v >> 8) == cell) return v & 0xFFu;
-        i = ft_next(L, i);
-        v = L.tab[i];
-    }
-    return FT_EMPTY;
+    const int m = (1 << L.tl) - 1;
+    return (tile << (2 * L.tl)) + (uint32_t)(((y & m) << L.tl) | (x & m));
+}
+// state byte of a cell (0: nothing known, also where no tile exists)
+__device__ __forceinline__ uint32_t tl_lookup(const FrontLds &L, int y, int x)
+{
+    const uint32_t d = L.dir[tl_dir_index(L, y, x)];
+    return d ? L.pool[tl_addr(L, d - 1, y, x)] : 0u;
 }
 
-// Claim a cell for a new record: true (and its slot) if the cell had no entry or was GONE; false if it has a record, is
-// burning / burned or known to be ineligible.  One compare-and-swap decides between concurrent claims.
-__device__ __forceinline__ bool ft_claim(const FrontLds &L, uint32_t cell, uint32_t &slot)
+// The tile that covers (y, x), + 1; taken from the free list / the pool and entered in the directory if there is none yet
+// (tiles are all zero when they are handed out).  The directory holds 16-bit entries, the atomics work on the 32-bit word
+// around one.  Whoever turns an empty entry into 0xFFFF allocates the tile and publishes it in the same loop iteration;
+// the others see 0xFFFF and try again (no tile is taken in vain, and nobody pushes the free list while it is popped).
+// 0: the pool is exhausted (overflow flagged).
+__device__ __forceinline__ uint32_t tl_tile(const FrontLds &L, int y, int x)
 {
-    uint32_t i = ft_home(L, cell);
-    const uint32_t want = (cell << 8) | FT_FRONT;
-    for (int guard = 0; guard < L.TAB; ++guard) {
-        uint32_t v = L.tab[i];
-        if (v == FT_EMPTY) {
-            v = atomicCAS(&L.tab[i], FT_EMPTY, want);
-            if (v == FT_EMPTY) { atomicAdd(&L.ctl[FC_KEYS], 1u); slot = i; return true; }
+    const uint32_t di = tl_dir_index(L, y, x);
+    uint32_t *word = reinterpret_cast<uint32_t *>(L.dir) + (di >> 1);
+    const int sh = (int)(di & 1u) * 16;
+    for (;;) {
+        const uint32_t old = *reinterpret_cast<volatile uint32_t *>(word);
+        const uint32_t d = (old >> sh) & 0xFFFFu;
+        if (d != 0u && d != 0xFFFFu) return d;
+        if (d == 0xFFFFu) continue;
+        if (atomicCAS(word, old, old | (0xFFFFu << sh)) != old) continue;
+        uint32_t idx = 0xFFFFFFFFu;
+        for (;;) {                                   // pop the free list, else the next untouched tile of the pool
+            const uint32_t f = *reinterpret_cast<volatile uint32_t *>(&L.ctl[FC_FREE]);
+            if (f == 0) break;
+            if (atomicCAS(&L.ctl[FC_FREE], f, f - 1) == f) { idx = L.freel[f - 1]; break; }
         }
-        if ((v >> 8) == cell) {
-            if ((v & 0xFFu) != FT_GONE) return false;
-            slot = i;
-            return atomicCAS(&L.tab[i], v, want) == v;
+        if (idx == 0xFFFFFFFFu) {
+            idx = atomicAdd(&L.ctl[FC_POOL], 1u);
+            if (idx >= (uint32_t)L.NT) {
+                atomicOr(&L.ctl[FC_OVF], 8u);
+                atomicAnd(word, ~(0xFFFFu << sh));
+                return 0;
+            }
         }
-        i = ft_next(L, i);
+        L.town[idx] = (uint16_t)di;
+        atomicAnd(word, ~((0xFFFFu ^ (idx + 1u)) << sh));          // 0xFFFF -> idx + 1
+        return idx + 1;
     }
-    atomicOr(&L.ctl[FC_OVF], 8u);
-    return false;
 }
 
-// Insert a cell that is known to have no entry (launch start, rehash); returns its slot
-__device__ __forceinline__ uint32_t ft_insert(const FrontLds &L, uint32_t entry)
+// Claim a cell for a new record: true (and its tile) if nothing was known about the cell or it was GONE; false if it has a
+// record, is burning / burned or known to be ineligible.  One compare-and-swap (on the word around the state byte)
+// decides between concurrent claims.
+__device__ __forceinline__ bool tl_claim(const FrontLds &L, int y, int x, uint32_t &tile)
 {
-    uint32_t i = ft_home(L, entry >> 8);
-    for (int guard = 0; guard < L.TAB; ++guard) {
-        if (L.tab[i] == FT_EMPTY && atomicCAS(&L.tab[i], FT_EMPTY, entry) == FT_EMPTY) return i;
-        i = ft_next(L, i);
+    const uint32_t d = tl_tile(L, y, x);
+    if (!d) return false;
+    tile = d - 1;
+    const uint32_t addr = tl_addr(L, tile, y, x);
+    uint32_t *word = reinterpret_cast<uint32_t *>(L.pool) + (addr >> 2);
+    const int sh = (int)(addr & 3u) * 8;
+    for (;;) {
+        const uint32_t old = *word;
+        const uint32_t b = (old >> sh) & 0xFFu;
+        if (b != 0u && b != FT_GONE) return false;
+        if (atomicCAS(word, old, (old & ~(0xFFu << sh)) | (FT_FRONT << sh)) == old) return true;
     }
-    atomicOr(&L.ctl[FC_OVF], 8u);
-    return 0;
 }
 
-// steps since the ignition recorded in a table state (modulo FT_MOD), as seen from step t
+// Set the state of a cell nothing is known about yet (launch start); returns its tile (0xFFFFFFFF: pool exhausted)
+__device__ __forceinline__ uint32_t tl_set(const FrontLds &L, int y, int x, uint32_t state)
+{
+    const uint32_t d = tl_tile(L, y, x);
+    if (!d) return 0xFFFFFFFFu;
+    L.pool[tl_addr(L, d - 1, y, x)] = (uint8_t)state;
+    return d - 1;
+}
+
+// steps since the ignition recorded in a state byte 1 .. FT_MOD (modulo FT_MOD), as seen from step t
 __device__ __forceinline__ uint32_t ft_age(uint32_t state, int t_mod)
 {
-    int age = t_mod - (int)state;
+    int age = t_mod - (int)state + 1;
     if (age < 0) age += FT_MOD;
     return (uint32_t)age;
 }
@@ -162,7 +200,7 @@ __device__ __forceinline__ uint32_t ft_age(uint32_t state, int t_mod)
 // sprite mask of a cell at step t (the byte the sprite-mask plane would hold, sf_common.h make_masks) from its table state
 __device__ __forceinline__ uint32_t ft_mask(uint32_t state, int t_mod, int s0, const Geo &g)
 {
-    if (state >= (uint32_t)FT_MOD) return 0u;                          // no sprite (or no entry)
+    if (state == 0u || state > (uint32_t)FT_MOD) return 0u;            // no sprite
     const uint32_t age = ft_age(state, t_mod);
     if (age > (uint32_t)g.md + 1u) return 0u;                         // gone
     int bit = s0 - (int)age;
@@ -187,7 +225,7 @@ __device__ __forceinline__ uint32_t wave_rank(bool p, uint32_t &total)
 
 // New (fresh) records of a wave (lanes with `want`): dealt round-robin to the waves' arrays, one LDS atomic on the shared
 // cursor per wave.  Must be called by all lanes of the wave.
-__device__ __forceinline__ void front_add_wave(const FrontLds &L, bool want, uint32_t meta, int lane)
+__device__ __forceinline__ void front_add_wave(const FrontLds &L, bool want, uint32_t pos, uint32_t meta, int lane)
 {
     uint32_t total;
     const uint32_t rank = wave_rank(want, total);
@@ -202,17 +240,18 @@ __device__ __forceinline__ void front_add_wave(const FrontLds &L, bool want, uin
     if (L.ctl[FC_RC + w2] < L.ctl[FC_RC + w]) w = w2;
     const uint32_t slot = atomicAdd(&L.ctl[FC_RC + w], 1u);
     if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); return; }
+    L.pos[w * (uint32_t)L.RC + slot] = pos;
     L.meta[w * (uint32_t)L.RC + slot] = meta;
 }
 
 // (divergent callers: the rebuild at launch start)
-__device__ __forceinline__ void front_add(const FrontLds &L, uint32_t meta, double bn)
+__device__ __forceinline__ void front_add(const FrontLds &L, uint32_t pos, uint32_t meta, double bn)
 {
     const uint32_t w = atomicAdd(&L.ctl[FC_RR], 1u) % (uint32_t)L.n_waves;
     const uint32_t slot = atomicAdd(&L.ctl[FC_RC + w], 1u);
     if (slot >= (uint32_t)L.RC) { atomicOr(&L.ctl[FC_OVF], 1u); return; }
     const uint32_t o = w * (uint32_t)L.RC + slot;
-    L.meta[o] = meta; L.burn[o] = bn; L.ros[o] = 0.0;
+    L.pos[o] = pos; L.meta[o] = meta; L.burn[o] = bn; L.ros[o] = 0.0;
 }
 
 // Launch start: one 16-cell vector of the sprite plane that holds a sprite bit or lies next to one that does -> table
@@ -249,9 +288,7 @@ __device__ __forceinline__ void front_rebuild_vector(const Geo &g, const FrontLd
             if ((by & (by - 1)) || code == SF_UNBURNED || code >= SF_FIRELINE) { L.ctl[FC_MULTI] = 1; continue; }
             const int p = __ffs(by) - 1;
             const int s = (t - 1) - slot_of(t - 1 - p, g.N);
-            const uint32_t cell = ((uint32_t)y << 12) | (uint32_t)(x0 + b);
-            ft_insert(L, (cell << 8) | (uint32_t)slot_of(s, FT_MOD));
-            atomicAdd(&L.ctl[FC_KEYS], 1u);
+            tl_set(L, y, x0 + b, (uint32_t)slot_of(s, FT_MOD) + 1u);
             atomicAdd(&L.ctl[FC_WC + slot_of(s, g.md + 4)], 1u);
             const uint32_t ri = atomicAdd(&L.ctl[FC_NREB], 1u);
             if (ri < (uint32_t)ev.reb_cap) ev.reb[ri] = ((uint32_t)y << 16) | (uint32_t)(x0 + b); else atomicOr(&L.ctl[FC_OVF], 16u);
@@ -282,60 +319,52 @@ __device__ __forceinline__ void front_rebuild_vector(const Geo &g, const FrontLd
         if ((pick(mid, b >> 2) >> (8 * (b & 3))) & 0xFFu) continue;           // (holds a sprite: flagged above)
         const uint32_t code = (pick(s7, b >> 2) >> (8 * (b & 3))) & 7u;
         const double bn = ev.burn[voff + b];
-        const uint32_t slot = ft_insert(L, ((((uint32_t)y << 12) | (uint32_t)x) << 8) | FT_FRONT);
-        atomicAdd(&L.ctl[FC_KEYS], 1u);
-        front_add(L, (code << 4) | (slot << 8), bn);
+        const uint32_t tile = tl_set(L, y, x, FT_FRONT);
+        if (tile != 0xFFFFFFFFu) front_add(L, ((uint32_t)y << 16) | (uint32_t)x, (code << 4) | (tile << 8), bn);
     }
 }
 
-// Rehash: the table keeps what still matters - sprites ignited at most md + 1 steps before step t (live or about to
-// expire) and the cells that have a record - and forgets the rest (burned-out cells,
-// GONE / INELIGIBLE marks: a cell that is offered a record again simply finds out again).  The records re-enter
-// themselves (they remember their slot); everything else travels through registers.  All threads; LDS barriers inside.
-__device__ __forceinline__ void front_rehash(const Geo &g, const FrontLds &L, int t, int tid, int wave, int lane, int nthr)
+// Clean-up of the cell table (all threads, between two steps; LDS barriers inside): step bytes of sprites that expired
+// before step t and the GONE / INELIGIBLE marks are forgotten (a cell that is offered a record again simply finds out
+// again); a tile in which nothing is left goes back to the free list.
+__device__ __forceinline__ void front_gc(const Geo &g, const FrontLds &L, int t, int tid, int nthr)
 {
-    uint32_t keep[kFrScan];
     const int t_mod = slot_of(t, FT_MOD);
+    const uint32_t n_tiles = min(L.ctl[FC_POOL], (uint32_t)L.NT);
+    const int words = 1 << (2 * L.tl - 2);
+    lds_barrier();
+    for (uint32_t idx = tid; idx < n_tiles; idx += nthr) {
+        if (L.town[idx] == 0xFFFFu) continue;
+        if (L.town[idx] == 0xFFFEu) {                // taken from the pool by the loser of a race for a directory entry, never used
+            L.town[idx] = 0xFFFFu;
+            L.freel[atomicAdd(&L.ctl[FC_FREE], 1u)] = (uint16_t)idx;
+            continue;
+        }
+        uint32_t *tw = reinterpret_cast<uint32_t *>(L.pool) + (size_t)idx * words;
+        uint32_t any = 0;
+        for (int w = 0; w < words; ++w) {
+            const uint32_t v = tw[w];
+            if (!v) continue;
+            uint32_t nv = 0;
 #pragma unroll
-    for (int j = 0; j < kFrScan; ++j) {
-        const int i = tid + j * nthr;
-        keep[j] = FT_EMPTY;
-        if (i < L.TAB) {
-            const uint32_t v = L.tab[i];
-            const uint32_t state = v & 0xFFu;
-            if (v != FT_EMPTY && state < (uint32_t)FT_MOD && ft_age(state, t_mod) <= (uint32_t)g.md + 1u) keep[j] = v;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = (v >> (8 * j)) & 0xFFu;
+                const bool keep = b == FT_FRONT || (b >= 1u && b <= (uint32_t)FT_MOD && ft_age(b, t_mod) <= (uint32_t)g.md + 1u);
+                if (keep) nv |= b << (8 * j);
+            }
+            if (nv != v) tw[w] = nv;
+            any |= nv;
+        }
+        if (!any) {
+            L.dir[L.town[idx]] = 0;
+            L.town[idx] = 0xFFFFu;
+            L.freel[atomicAdd(&L.ctl[FC_FREE], 1u)] = (uint16_t)idx;
         }
     }
-    const uint32_t n = min(L.ctl[FC_RC + wave], (uint32_t)L.RC);
-    const uint32_t base = (uint32_t)wave * (uint32_t)L.RC;
-    uint32_t rcell[kFrRecRegs];              // the cells of this wave's records (their table slots are about to go)
-#pragma unroll
-    for (int j = 0; j < kFrRecRegs; ++j) {
-        const uint32_t i = (uint32_t)lane + 64u * j;
-        rcell[j] = i < n ? L.tab[L.meta[base + i] >> 8] >> 8 : 0u;
-    }
-    lds_barrier();
-    for (int i = tid; i < L.TAB; i += nthr) L.tab[i] = FT_EMPTY;
-    if (tid == 0) L.ctl[FC_KEYS] = 0;
-    lds_barrier();
-    uint32_t mine = 0;
-#pragma unroll
-    for (int j = 0; j < kFrScan; ++j)
-        if (keep[j] != FT_EMPTY) { ft_insert(L, keep[j]); ++mine; }
-#pragma unroll
-    for (int j = 0; j < kFrRecRegs; ++j) {
-        const uint32_t i = (uint32_t)lane + 64u * j;
-        if (i < n) {
-            const uint32_t slot = ft_insert(L, (rcell[j] << 8) | FT_FRONT);
-            L.meta[base + i] = (L.meta[base + i] & 0xFFu) | (slot << 8);
-            ++mine;
-        }
-    }
-    if (mine) atomicAdd(&L.ctl[FC_KEYS], mine);
     lds_barrier();
 }
 
-__global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC, int IC, int TAB, uint32_t *reb_all, int reb_cap, int32_t *todo,
+__global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC, int IC, int NT, uint32_t *reb_all, int reb_cap, int32_t *todo,
                                                 int32_t *ovf_host, int32_t *dbg)
 {
     extern __shared__ uint4 s_dyn[];
@@ -344,14 +373,21 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     const int e = blockIdx.x;
     const int NW = g.md + 4;                     // ring of per-step ignition counts
     FrontLds L;
-    L.RC = RC; L.IC = IC; L.TAB = TAB; L.n_waves = n_waves;
+    L.RC = RC; L.IC = IC; L.NT = NT; L.n_waves = n_waves;
+    L.tl = front_tile_log(g);
+    L.TXD = (g.W + (1 << L.tl) - 1) >> L.tl; L.TYD = (g.H + (1 << L.tl) - 1) >> L.tl;
+    const int n_dir = front_dir_entries(g);
     L.burn = reinterpret_cast<double *>(s_dyn);
     L.ros = L.burn + (size_t)n_waves * RC;
-    L.meta = reinterpret_cast<uint32_t *>(L.ros + (size_t)n_waves * RC);
+    L.pos = reinterpret_cast<uint32_t *>(L.ros + (size_t)n_waves * RC);
+    L.meta = L.pos + (size_t)n_waves * RC;
     L.ign = L.meta + (size_t)n_waves * RC;
-    L.tab = L.ign + IC;
-    L.ctl = L.tab + TAB;
+    L.ctl = L.ign + IC;
     L.tbits = L.ctl + kFrCtl;
+    L.pool = reinterpret_cast<uint8_t *>(L.tbits + (g.TY * g.TX + 31) / 32);
+    L.dir = reinterpret_cast<uint16_t *>(L.pool + ((size_t)NT << (2 * L.tl)));
+    L.town = L.dir + n_dir;
+    L.freel = L.town + NT;
     uint32_t *ctl = L.ctl;
     const int tb_words = (g.TY * g.TX + 31) / 32;
 
@@ -361,11 +397,13 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         return;
     }
     for (int i = tid; i < tb_words; i += nthr) L.tbits[i] = 0;
-    for (int i = tid; i < TAB; i += nthr) L.tab[i] = FT_EMPTY;
+    for (int i = tid; i < (NT << (2 * L.tl - 2)); i += nthr) reinterpret_cast<uint32_t *>(L.pool)[i] = 0;
+    for (int i = tid; i < n_dir / 2; i += nthr) reinterpret_cast<uint32_t *>(L.dir)[i] = 0;
+    for (int i = tid; i < NT; i += nthr) L.town[i] = 0xFFFFu;
     if (tid < kFrCtl) ctl[tid] = 0;
     PhaseClock pc;
 #ifdef SF_PHASES
-    uint32_t *ph_acc = L.tbits + tb_words + wave * 16;
+    uint32_t *ph_acc = reinterpret_cast<uint32_t *>(L.freel + NT) + wave * 16;
     if (lane < 16) ph_acc[lane] = 0;
     pc.start(ph_acc);
 #else
@@ -414,7 +452,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     uint32_t n_active = 0, n_ignite = 0, n_rec = 0;
     int done = 0, since_purge = 0;
     // what k_front does not handle, or a table that is too full to start with: nothing has been changed, k_run does all steps
-    const bool refuse = ctl[FC_MULTI] != 0 || ctl[FC_OVF] != 0 || ctl[FC_KEYS] * 20u > (uint32_t)TAB * 11u;
+    const bool refuse = ctl[FC_MULTI] != 0 || ctl[FC_OVF] != 0;
     bool ovf = refuse;
     while (!ovf && done < n_steps && st.running) {
         const int t = st.steps + 1;
@@ -427,13 +465,13 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         const int li_new = slot_of(t, NW);
         const int par = t & 1;
 
-        // the table is kept at most 65 % full, and entries older than the step counter's modulus must not survive: forget
+        // the tile pool is kept below 7 / 8, and step bytes older than the step counter's modulus must not survive: forget
         // what no longer matters (uniform decision)
-        if (ctl[FC_KEYS] * 20u > (uint32_t)TAB * 13u || since_purge >= kFrPurge) {
-            front_rehash(g, L, t, tid, wave, lane, nthr);
+        if ((ctl[FC_POOL] - ctl[FC_FREE]) * 8u > (uint32_t)NT * 7u || since_purge >= kFrPurge) {
+            front_gc(g, L, t, tid, nthr);
             since_purge = 0;
-            if (ctl[FC_KEYS] * 20u > (uint32_t)TAB * 11u) atomicOr(&ctl[FC_OVF], 8u);      // (still above 55 %: the fire has outgrown it)
-            pc.mark(10);         // rehash
+            if ((ctl[FC_POOL] - ctl[FC_FREE]) * 8u > (uint32_t)NT * 7u) atomicOr(&ctl[FC_OVF], 8u);      // (the fire has outgrown the pool)
+            pc.mark(10);         // clean-up of the cell table
         }
         ++since_purge;
         if (tid == 0) ctl[FC_WC + slot_of(t + 1, NW)] = 0;
@@ -457,29 +495,27 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                         const uint32_t i = c0 + 64u * q + lane;
                         has[q] = i < n;
                         const uint32_t o = base + (has[q] ? i : n - 1);
-                        meta[q] = L.meta[o]; bn[q] = L.burn[o]; ros[q] = L.ros[o];
-                        pos[q] = L.tab[meta[q] >> 8] >> 8;                      // the cell, y << 12 | x
-                        const int y = pos[q] >> 12, x = pos[q] & 0xFFF;
+                        pos[q] = L.pos[o]; meta[q] = L.meta[o]; bn[q] = L.burn[o]; ros[q] = L.ros[o];
+                        const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
                         idx[q] = (uint32_t)(y * g.P + x);
                         fresh[q] = (meta[q] & FR_FRESH) != 0;
-                        // the 8 neighbour masks in priority order k = 0..7 (sf_common.h c_dx / c_dy): the home slots of all
-                        // eight are read first, then the (few) collisions are followed
+                        // the 8 neighbour masks in priority order k = 0..7 (sf_common.h c_dx / c_dy): eight directory reads, then
+                        // eight state bytes
                         constexpr int kDx[8] = {+1, 0, -1, +1, -1, +1, 0, -1}, kDy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
-                        uint32_t nc[8], nh[8], nv[8];
+                        uint32_t nd[8], nb8[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const int nx = x + kDx[k], ny = y + kDy[k];
-                            const bool in = nx >= 0 && nx < g.W && ny >= 0 && ny < g.H;
-                            nc[k] = in ? (((uint32_t)ny << 12) | (uint32_t)nx) : 0xFFFFFFu;       // (0xFFFFFF: no cell has it)
-                            nh[k] = ft_home(L, nc[k]);
-                            nv[k] = in ? L.tab[nh[k]] : FT_EMPTY;
+                            nd[k] = (nx >= 0 && nx < g.W && ny >= 0 && ny < g.H) ? L.dir[tl_dir_index(L, ny, nx)] : 0u;
                         }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) nb8[k] = nd[k] ? L.pool[tl_addr(L, nd[k] - 1, y + kDy[k], x + kDx[k])] : 0u;
                         FR_WAIT();
-                        pc.mark(6);      // record + home slots of the 8 neighbours read
+                        pc.mark(6);      // record, directory, state bytes of the 8 neighbours read
                         uint32_t lo = 0, hi = 0;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            const uint32_t m = ft_mask(ft_resolve(L, nc[k], nh[k], nv[k]), t_mod, s0, g);
+                            const uint32_t m = ft_mask(nb8[k], t_mod, s0, g);
                             if (k < 4) lo |= m << (8 * k); else hi |= m << (8 * (k - 4));
                         }
                         lo &= lo_mask; hi &= hi_mask;
@@ -495,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                             bestk[q] = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
                         }
                         FR_WAIT();
-                        pc.mark(7);      // collisions followed, winner
+                        pc.mark(7);      // winner
                         cand[q] = has[q] && bestk[q] >= 0;
                         code[q] = (meta[q] >> 4) & 7u;
                         if (cand[q] && fresh[q]) {
@@ -533,12 +569,13 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                         keep[q] = cand[q] && !ignite[q];
                         if (has[q] && !keep[q]) {
                             // the cell leaves the front: burning from now on, ineligible, or without a live neighbour
-                            L.tab[meta[q] >> 8] = (pos[q] << 8) | (ignite[q] ? (uint32_t)t_mod : (inelig ? FT_INELIG : FT_GONE));
+                            L.pool[tl_addr(L, meta[q] >> 8, (int)(pos[q] >> 16), (int)(pos[q] & 0xFFFF))] =
+                                (uint8_t)(ignite[q] ? (uint32_t)t_mod + 1u : (inelig ? FT_INELIG : FT_GONE));
                         }
                         const unsigned long long kb = __ballot(keep[q]);
                         if (keep[q]) {
                             const uint32_t w = base + wcur + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u));
-                            L.meta[w] = meta[q]; L.burn[w] = bn[q]; L.ros[w] = ros[q];
+                            L.pos[w] = pos[q]; L.meta[w] = meta[q]; L.burn[w] = bn[q]; L.ros[w] = ros[q];
                         }
                         wcur += (uint32_t)__popcll(kb);
                     }
@@ -556,7 +593,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                             if (lane == 0) { atomicAdd(&ctl[FC_WC + li_new], n_ig); ib = atomicAdd(&ctl[FC_IGN + par], n_ig); }
                             ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)ib);
                             if (ignite[q]) {
-                                const int y = pos[q] >> 12, x = pos[q] & 0xFFF;
+                                const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
                                 // fire.py:587 would write BURNING and the prune BURNED md + 1 updates later (fire.py:140): inside the
                                 // launch nothing tells the two apart, the cells still burning at its end are set right there
                                 ev.status[idx[q]] = (uint8_t)SF_BURNED;
@@ -589,19 +626,20 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
             for (uint32_t j0 = 0; j0 < items; j0 += (uint32_t)nthr) {          // (uniform trip count: the adds are wave-wide)
                 const uint32_t j = j0 + (uint32_t)tid;
                 bool want = j < items;
-                uint32_t slot = 0;
+                uint32_t tile = 0, npos = 0;
                 pc.mark(8);
                 if (want) {
                     const uint32_t pos = L.ign[j >> 3];
                     const int k = (int)(j & 7u);
-                    const int nx = (int)(pos & 0xFFF) - c_dx[k], ny = (int)(pos >> 12) - c_dy[k];
+                    const int nx = (int)(pos & 0xFFFF) - c_dx[k], ny = (int)(pos >> 16) - c_dy[k];
                     const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
                     want = (g.diag || !diagonal_k) && nx >= 0 && nx < g.W && ny >= 0 && ny < g.H;
-                    if (want) want = ft_claim(L, ((uint32_t)ny << 12) | (uint32_t)nx, slot);
+                    if (want) want = tl_claim(L, ny, nx, tile);
+                    npos = ((uint32_t)ny << 16) | (uint32_t)nx;
                 }
                 FR_WAIT();
                 pc.mark(11);     // claims
-                front_add_wave(L, want, FR_FRESH | (slot << 8), lane);
+                front_add_wave(L, want, npos, FR_FRESH | (tile << 8), lane);
             }
         }
         pc.mark(9);              // new records
@@ -621,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
             for (int w = 0; w < n_waves; ++w) nr += ctl[FC_RC + w];
             int32_t *d = dbg + 4 * e;
             if ((int32_t)nr > d[0]) d[0] = (int32_t)nr;
-            if ((int32_t)ctl[FC_KEYS] > d[1]) d[1] = (int32_t)ctl[FC_KEYS];
+            if ((int32_t)(ctl[FC_POOL] - ctl[FC_FREE]) > d[1]) d[1] = (int32_t)(ctl[FC_POOL] - ctl[FC_FREE]);
             if ((int32_t)ctl[FC_IGN + par] > d[2]) d[2] = (int32_t)ctl[FC_IGN + par];
             if (ovf && !d[3]) d[3] = (int32_t)(ctl[FC_OVF] | (done << 8));
         }
@@ -635,9 +673,8 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         const uint32_t n = min(ctl[FC_RC + wave], (uint32_t)RC);
         const uint32_t base = (uint32_t)wave * (uint32_t)RC;
         for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t m = L.meta[base + i];
-            const uint32_t cell = L.tab[m >> 8] >> 8;
-            if (!(m & FR_FRESH)) ev.burn[(uint32_t)((cell >> 12) * g.P + (cell & 0xFFFu))] = L.burn[base + i];     // (a fresh record holds no accumulator yet)
+            const uint32_t pos = L.pos[base + i];
+            if (!(L.meta[base + i] & FR_FRESH)) ev.burn[(uint32_t)((pos >> 16) * g.P + (pos & 0xFFFF))] = L.burn[base + i];     // (a fresh record holds no accumulator yet)
         }
         // the sprites of the launch start: mask byte cleared (rewritten below if the bit is still due); BURNED if the sprite
         // expired inside the launch (fire.py:116-161; nothing else can have happened to such a cell)
@@ -646,31 +683,35 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
             const uint32_t pos = ev.reb[i];
             const int y = pos >> 16, x = pos & 0xFFFF;
             const uint32_t idx = (uint32_t)(y * g.P + x);
-            const uint32_t cell = ((uint32_t)y << 12) | (uint32_t)x;
-            const uint32_t h = ft_home(L, cell);
-            const uint32_t state = ft_resolve(L, cell, h, L.tab[h]);
+            const uint32_t state = tl_lookup(L, y, x);
             ev.age[idx] = 0;
             // (the mask bit of an expired sprite waits one more update for its recycling, fire.py has no such thing: leaving it
             // out changes nothing any kernel does)
-            if (state >= (uint32_t)FT_MOD || ft_age(state, tn_mod) >= (uint32_t)g.md + 2u) {
+            if (state == 0u || state > (uint32_t)FT_MOD || ft_age(state, tn_mod) >= (uint32_t)g.md + 2u) {
                 ev.status[idx] = (uint8_t)SF_BURNED;
                 front_tile_dirty(L, (y >> th_log) * g.TX + ((x >> 4) >> g.logLC));
             }
         }
         __syncthreads();
-        for (int i = tid; i < TAB; i += nthr) {
-            const uint32_t v = L.tab[i];
-            const uint32_t state = v & 0xFFu;
-            if (v == FT_EMPTY || state >= (uint32_t)FT_MOD) continue;
-            const uint32_t age = ft_age(state, tn_mod);
-            if (age < 1u || age > (uint32_t)g.md + 1u) continue;              // live or expiring at t_next: ignited at t_next - md - 1 .. t_next - 1
-            const uint32_t cell = v >> 8;
-            const uint32_t idx = (uint32_t)((cell >> 12) * g.P + (cell & 0xFFFu));
-            int bit = s0n - (int)age;
-            if (bit < 0) bit += g.N;
-            ev.age[idx] = (uint8_t)(1u << bit);
-            // ignited in this launch (the status written then was BURNED) and not expired before t_next: BURNING (fire.py:587)
-            if (age <= (uint32_t)done) ev.status[idx] = (uint8_t)SF_BURNING;
+        {
+            const uint32_t n_tiles = min(ctl[FC_POOL], (uint32_t)NT);
+            const int cells = 1 << (2 * L.tl);
+            for (uint32_t i = tid; i < n_tiles * (uint32_t)cells; i += nthr) {
+                const uint32_t idx_t = i >> (2 * L.tl), off = i & (uint32_t)(cells - 1);
+                const uint32_t di = L.town[idx_t];
+                if (di >= 0xFFFEu) continue;
+                const uint32_t state = L.pool[i];
+                if (state == 0u || state > (uint32_t)FT_MOD) continue;
+                const uint32_t age = ft_age(state, tn_mod);
+                if (age < 1u || age > (uint32_t)g.md + 1u) continue;              // live or expiring at t_next: ignited at t_next - md - 1 .. t_next - 1
+                const int y = (int)((di / (uint32_t)L.TXD) << L.tl) + (int)(off >> L.tl), x = (int)((di % (uint32_t)L.TXD) << L.tl) + (int)(off & (uint32_t)((1 << L.tl) - 1));
+                const uint32_t idx = (uint32_t)(y * g.P + x);
+                int bit = s0n - (int)age;
+                if (bit < 0) bit += g.N;
+                ev.age[idx] = (uint8_t)(1u << bit);
+                // ignited in this launch (the status written then was BURNED) and not expired before t_next: BURNING (fire.py:587)
+                if (age <= (uint32_t)done) ev.status[idx] = (uint8_t)SF_BURNING;
+            }
         }
         for (int i = tid; i < g.TY * g.TX; i += nthr)
             if (L.tbits[i >> 5] & (1u << (i & 31))) ev.tdirty[i] = 1;

@@ -933,7 +933,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         static const int front_min_steps = getenv("SF_FRONT_MIN_STEPS") ? atoi(getenv("SF_FRONT_MIN_STEPS")) : 4;
         static const int front_off = getenv("SF_FRONT_OFF") ? atoi(getenv("SF_FRONT_OFF")) : 1;      // (not the automatic choice yet)
         const bool front_wanted = s->fused_mode == 4 || (s->fused_mode < 0 && n_steps >= front_min_steps && !front_off);
-        if (fits && front_wanted && !g.att && !mit_dev && !g.dense && g.H <= 4096 && g.W <= 4096) {
+        if (fits && front_wanted && !g.att && !mit_dev && !g.dense && g.H <= 2048 && g.W <= 2048) {
             static const int fw_knob = getenv("SF_FRONT_WAVES") ? atoi(getenv("SF_FRONT_WAVES")) : 0;
             static const int frc_knob = getenv("SF_FRONT_RC") ? atoi(getenv("SF_FRONT_RC")) : 0;
             static const int fic_knob = getenv("SF_FRONT_IC") ? atoi(getenv("SF_FRONT_IC")) : 0;
@@ -941,13 +941,18 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             const bool many = g.E > s->n_cu;              // more environments than CUs: smaller workgroups, two per CU
             fr_waves = fw_knob ? fw_knob : (many ? 8 : 16);
             if (fr_waves > 16) fr_waves = 16;
-            fr_rc = frc_knob ? frc_knob : 160;
-            if (fr_rc > 64 * kFrRecRegs) fr_rc = 64 * kFrRecRegs;
+            fr_rc = frc_knob ? frc_knob : (many ? 80 : 144);
             fr_ic = fic_knob ? fic_knob : (many ? 1024 : 2048);
-            fr_tab = ftab_knob ? ftab_knob : (many ? 12288 : 24576);
-            if (fr_tab > kFrScan * fr_waves * 64) fr_tab = kFrScan * fr_waves * 64;
+            // tiles of the cell table: whatever LDS is left (one workgroup per CU, or two when there are more environments than CUs)
+            const size_t budget = many ? 80 * 1024 - 512 : 160 * 1024 - 512;
+            const size_t fixed = front_lds_bytes(g, fr_waves, fr_rc, fr_ic, 0);
+            const size_t per_tile = ((size_t)1 << (2 * front_tile_log(g))) + 4;
+            fr_tab = ftab_knob ? ftab_knob : (fixed < budget ? (int)((budget - fixed) / per_tile) : 0);
+            if (fr_tab > 65000) fr_tab = 65000;
+            if (fr_tab > front_dir_entries(g)) fr_tab = front_dir_entries(g);
+            fr_tab &= ~1;
             fr_lds = front_lds_bytes(g, fr_waves, fr_rc, fr_ic, fr_tab);
-            if (fr_lds > 160 * 1024) fr_waves = 0;
+            if (fr_tab < 8 || fr_lds > 160 * 1024) fr_waves = 0;
         }
     }
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
@@ -993,7 +998,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             HIPCHK(hipFree(dbg_dev));
             int mr = 0, mk = 0, mi = 0;
             for (int e = 0; e < s->g.E; ++e) { mr = std::max(mr, d[4 * e]); mk = std::max(mk, d[4 * e + 1]); mi = std::max(mi, d[4 * e + 2]); }
-            fprintf(stderr, "[k_front] %d steps: max records %d (cap %d), max table keys %d (table %d), max ignitions per step %d (cap %d)\n", n_steps, mr,
+            fprintf(stderr, "[k_front] %d steps: max records %d (cap %d), max tiles of the cell table %d (pool %d), max ignitions per step %d (cap %d)\n", n_steps, mr,
                     fr_rc * fr_waves, mk, fr_tab, mi, fr_ic);
             if (fdbg > 1)
                 for (int e = 0; e < s->g.E; ++e)

@@ -196,9 +196,9 @@ def test_resident_any_workgroup_size(waves, mode):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("caps", [(4, 2048, 24576), (128, 6, 24576), (128, 2048, 300), (16, 64, 1024)])
+@pytest.mark.parametrize("caps", [(4, 2048, 0), (144, 6, 0), (144, 2048, 12), (16, 64, 40)])
 def test_front_overflow_is_finished_by_k_run(caps):
-    """k_front with tiny record / ignition-list / cell-table capacities: whatever overflows is derived state, the
+    """k_front with tiny record / ignition-list / cell-table (tile pool) capacities: whatever overflows is derived state, the
     environment stops at a step boundary and k_run does the steps left over - same result, and the hand-over really happened."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
