@@ -71,7 +71,7 @@ __host__ __device__ inline size_t front_lds_bytes(const Geo &g, int n_waves, int
 {
     const int tl = front_tile_log(g);
     size_t b = (size_t)n_waves * rc * 24 + (size_t)ic * 4 + (size_t)front_dir_entries(g) * 2 + ((size_t)nt << (2 * tl)) + (size_t)nt * 4 + kFrCtl * 4 +
-               (size_t)((g.TY * g.TX + 31) / 32) * 4;
+               (size_t)((((g.TY * g.TX + 31) / 32) + 1) & ~1) * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;
 #endif
@@ -206,6 +206,46 @@ __device__ __forceinline__ uint32_t ft_mask(uint32_t state, int t_mod, int s0, c
     int bit = s0 - (int)age;
     if (bit < 0) bit += g.N;
     return 1u << bit;
+}
+
+// The state bytes of the 3 x 3 cells around (y, x): r3[r] holds the cells x - 1, x, x + 1 of row y - 1 + r in its bytes 0 .. 2
+// (0 outside the grid and where no tile exists).  Four directory reads (the cells lie in at most four tiles) and one or
+// two aligned 8-byte reads per row instead of a directory read and a byte read per cell.
+__device__ __forceinline__ void tl_fetch3x3(const FrontLds &L, const Geo &g, int y, int x, uint32_t r3[3])
+{
+    const int m = (1 << L.tl) - 1;
+    const int xl = x > 0 ? x - 1 : 0, xr = x + 1 < g.W ? x + 1 : g.W - 1;
+    const int yt = y > 0 ? y - 1 : 0, yb = y + 1 < g.H ? y + 1 : g.H - 1;
+    const uint32_t dTL = L.dir[tl_dir_index(L, yt, xl)], dTR = L.dir[tl_dir_index(L, yt, xr)];
+    const uint32_t dBL = L.dir[tl_dir_index(L, yb, xl)], dBR = L.dir[tl_dir_index(L, yb, xr)];
+    const bool mid_top = (y >> L.tl) == (yt >> L.tl);
+    const int segl = xl & ~7, segr = xr & ~7;              // first column of the 8-byte segments that hold x - 1 / x + 1
+    const int sh = (x - 1 - segl) * 8;                     // (-8 at x = 0)
+    // all six reads are issued before any is used (no branches: where there is no tile, or no row, a read of the 8 zero bytes
+    // kept behind the control words takes its place)
+    const uint32_t zero_off = (uint32_t)(reinterpret_cast<const uint8_t *>(L.ctl + 40) - L.pool);
+    unsigned long long A[3], B[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y - 1 + r;
+        const bool in = yy >= 0 && yy < g.H;
+        const uint32_t dl = r == 0 ? dTL : (r == 2 ? dBL : (mid_top ? dTL : dBL));
+        const uint32_t dr = r == 0 ? dTR : (r == 2 ? dBR : (mid_top ? dTR : dBR));
+        const uint32_t rowoff = (uint32_t)((yy & m) << L.tl);
+        const uint32_t oa = (in && dl) ? ((dl - 1) << (2 * L.tl)) + rowoff + (uint32_t)(segl & m) : zero_off;
+        const uint32_t ob = (in && dr && segr != segl) ? ((dr - 1) << (2 * L.tl)) + rowoff + (uint32_t)(segr & m) : zero_off;
+        A[r] = *reinterpret_cast<const unsigned long long *>(L.pool + oa);
+        B[r] = *reinterpret_cast<const unsigned long long *>(L.pool + ob);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        unsigned long long v;
+        if (sh < 0) v = A[r] << 8;
+        else { v = A[r] >> sh; if (sh > 40) v |= B[r] << (64 - sh); }
+        uint32_t w = (uint32_t)v & 0xFFFFFFu;
+        if (x + 1 >= g.W) w &= 0xFFFFu;
+        r3[r] = w;
+    }
 }
 
 // the status histogram of a wave tile goes stale (result block, k_counts_tiles): noted in LDS, written out at the end of the launch
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
     L.ign = L.meta + (size_t)n_waves * RC;
     L.ctl = L.ign + IC;
     L.tbits = L.ctl + kFrCtl;
-    L.pool = reinterpret_cast<uint8_t *>(L.tbits + (g.TY * g.TX + 31) / 32);
+    L.pool = reinterpret_cast<uint8_t *>(L.tbits + ((((g.TY * g.TX + 31) / 32) + 1) & ~1));      // (8-byte aligned)
     L.dir = reinterpret_cast<uint16_t *>(L.pool + ((size_t)NT << (2 * L.tl)));
     L.town = L.dir + n_dir;
     L.freel = L.town + NT;
@@ -499,24 +539,19 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
                         const int y = pos[q] >> 16, x = pos[q] & 0xFFFF;
                         idx[q] = (uint32_t)(y * g.P + x);
                         fresh[q] = (meta[q] & FR_FRESH) != 0;
-                        // the 8 neighbour masks in priority order k = 0..7 (sf_common.h c_dx / c_dy): eight directory reads, then
-                        // eight state bytes
-                        constexpr int kDx[8] = {+1, 0, -1, +1, -1, +1, 0, -1}, kDy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
-                        uint32_t nd[8], nb8[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int nx = x + kDx[k], ny = y + kDy[k];
-                            nd[k] = (nx >= 0 && nx < g.W && ny >= 0 && ny < g.H) ? L.dir[tl_dir_index(L, ny, nx)] : 0u;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) nb8[k] = nd[k] ? L.pool[tl_addr(L, nd[k] - 1, y + kDy[k], x + kDx[k])] : 0u;
+                        // the 8 neighbour masks in priority order k = 0..7 (sf_common.h c_dx / c_dy) out of the 3 x 3 state bytes
+                        uint32_t r3[3];
+                        tl_fetch3x3(L, g, y, x, r3);
                         FR_WAIT();
-                        pc.mark(6);      // record, directory, state bytes of the 8 neighbours read
+                        pc.mark(6);      // record, directory, state rows of the neighbourhood read
                         uint32_t lo = 0, hi = 0;
+                        {
+                            constexpr int kDx[8] = {+1, 0, -1, +1, -1, +1, 0, -1}, kDy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const uint32_t m = ft_mask(nb8[k], t_mod, s0, g);
-                            if (k < 4) lo |= m << (8 * k); else hi |= m << (8 * (k - 4));
+                            for (int k = 0; k < 8; ++k) {
+                                const uint32_t m = ft_mask((r3[1 + kDy[k]] >> (8 * (1 + kDx[k]))) & 0xFFu, t_mod, s0, g);
+                                if (k < 4) lo |= m << (8 * k); else hi |= m << (8 * (k - 4));
+                            }
                         }
                         lo &= lo_mask; hi &= hi_mask;
                         uint32_t ob = lo | hi;
@@ -619,27 +654,46 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         }
         if (tid == 0) { ctl[FC_IGN + (par ^ 1)] = 0; ctl[FC_CAND + (par ^ 1)] = 0; }
 
-        // ---- every cell ignited in this step offers a record to its neighbours (candidates from step t + 1 on): one claim on
-        // the cell table per (cell, direction)
+        // ---- every cell ignited in this step offers a record to its neighbours (candidates from step t + 1 on), one ignited
+        // cell per lane: the 3 x 3 state bytes around it tell which neighbours can take one (nothing known about them, or GONE);
+        // one compare-and-swap on the neighbour's state byte decides who is new
         {
-            const uint32_t items = min(ctl[FC_IGN + par], (uint32_t)IC) * 8u;
-            for (uint32_t j0 = 0; j0 < items; j0 += (uint32_t)nthr) {          // (uniform trip count: the adds are wave-wide)
-                const uint32_t j = j0 + (uint32_t)tid;
-                bool want = j < items;
-                uint32_t tile = 0, npos = 0;
+            const uint32_t n_ign = min(ctl[FC_IGN + par], (uint32_t)IC);
+            constexpr int kDx[8] = {+1, 0, -1, +1, -1, +1, 0, -1}, kDy[8] = {+1, +1, +1, 0, 0, -1, -1, -1};
+            for (uint32_t i0 = 0; i0 < n_ign; i0 += (uint32_t)nthr) {          // (uniform trip count: the adds are wave-wide)
+                const uint32_t i = i0 + (uint32_t)tid;
+                const bool has = i < n_ign;
                 pc.mark(8);
-                if (want) {
-                    const uint32_t pos = L.ign[j >> 3];
-                    const int k = (int)(j & 7u);
-                    const int nx = (int)(pos & 0xFFFF) - c_dx[k], ny = (int)(pos >> 16) - c_dy[k];
-                    const bool diagonal_k = (k == 0 || k == 2 || k == 5 || k == 7);
-                    want = (g.diag || !diagonal_k) && nx >= 0 && nx < g.W && ny >= 0 && ny < g.H;
-                    if (want) want = tl_claim(L, ny, nx, tile);
-                    npos = ((uint32_t)ny << 16) | (uint32_t)nx;
+                const uint32_t pos = has ? L.ign[i] : 0u;
+                const int cx = (int)(pos & 0xFFFF), cy = (int)(pos >> 16);
+                uint32_t wm = 0;
+                if (has) {
+                    uint32_t r3[3];
+                    tl_fetch3x3(L, g, cy, cx, r3);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        // the cell whose source in direction k is this sprite sits at (cx - dx, cy - dy)
+                        const int nx = cx - kDx[k], ny = cy - kDy[k];
+                        const uint32_t b = (r3[1 - kDy[k]] >> (8 * (1 - kDx[k]))) & 0xFFu;
+                        const bool diagonal_k = kDx[k] != 0 && kDy[k] != 0;
+                        const bool ok = (g.diag || !diagonal_k) && nx >= 0 && nx < g.W && ny >= 0 && ny < g.H && (b == 0u || b == FT_GONE);
+                        wm |= ok ? (1u << k) : 0u;
+                    }
                 }
                 FR_WAIT();
-                pc.mark(11);     // claims
-                front_add_wave(L, want, npos, FR_FRESH | (tile << 8), lane);
+                pc.mark(11);     // neighbourhoods of the ignited cells
+                while (__ballot(wm != 0u) != 0ull) {
+                    bool want = wm != 0u;
+                    uint32_t tile = 0, npos = 0;
+                    if (want) {
+                        const int k = __ffs(wm) - 1;
+                        wm &= wm - 1;
+                        const int nx = cx - c_dx[k], ny = cy - c_dy[k];
+                        want = tl_claim(L, ny, nx, tile);
+                        npos = ((uint32_t)ny << 16) | (uint32_t)nx;
+                    }
+                    front_add_wave(L, want, npos, FR_FRESH | (tile << 8), lane);
+                }
             }
         }
         pc.mark(9);              // new records
