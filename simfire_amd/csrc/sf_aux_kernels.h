@@ -275,19 +275,33 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
 // (marked by the step kernels and the mitigation scatter) are recounted, the others come from the
 // cache.  A status query then costs a few MB of traffic instead of a sweep over every fire map.
 // thist: u16 [E * TY * TX][8], entries 1..5 = cells of that BurnStatus in the tile.
-constexpr int kCountTilesPerWave = 16;
+// One workgroup per environment.  A wave reads the dirty flags and the cached histograms of 64 tiles at once (one tile per
+// lane - the clean tiles cost one round trip for all of them); the tiles found dirty are then recounted by the whole
+// wave, one after the other.  The result block row of the environment (and its elapsed_time) is written without atomics.
 __global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *status, uint8_t *tdirty, uint16_t *thist,
-                                                      const EnvState *commit, int32_t *out)
+                                                      const EnvState *commit, int32_t *out, double *elapsed)
 {
-    const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int32_t s_tot[4][6];
+    const int e = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_env = g.TY * g.TX;
     const int c = lane & (g.LC - 1), r = lane >> g.logLC;
     int32_t tot[6] = {0, 0, 0, 0, 0, 0};
-    const int t0 = (blockIdx.x * 4 + wave) * kCountTilesPerWave;
-    for (int t = t0; t < t0 + kCountTilesPerWave && t < per_env; ++t) {
-        const long long idx = (long long)e * per_env + t;
-        if (tdirty[idx]) {
-            const int tyw = t / g.TX, chunk = t - tyw * g.TX;
+    for (int base = wave * 64; base < per_env; base += 256) {
+        const int t = base + lane;
+        const bool valid = t < per_env;
+        const long long idx = (long long)e * per_env + (valid ? t : per_env - 1);
+        const bool dirty = valid && tdirty[idx] != 0;
+        const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
+        if (valid && !dirty) {
+            tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
+            tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+        }
+        unsigned long long dm = __ballot(dirty);
+        while (dm) {
+            const int tt = base + __ffsll((long long)dm) - 1;
+            dm &= dm - 1;
+            const long long tidx = (long long)e * per_env + tt;
+            const int tyw = tt / g.TX, chunk = tt - tyw * g.TX;
             const int cv = chunk * g.LC + c, y0 = (tyw * g.LR + r) * g.RB;
             int32_t loc[6] = {0, 0, 0, 0, 0, 0};
             if (cv < g.PV)
@@ -307,29 +321,31 @@ __global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *stat
                 int32_t v = loc[k];
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
                 loc[k] = v;
-                tot[k] += v;
+                if (lane == 0) tot[k] += v;
             }
-            if (lane >= 1 && lane < 6) thist[idx * 8 + lane] = (uint16_t)(lane == 1 ? loc[1] : lane == 2 ? loc[2] : lane == 3 ? loc[3] : lane == 4 ? loc[4] : loc[5]);
-            if (lane == 0) tdirty[idx] = 0;
-        } else {
-            const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
-            tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
-            tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+            if (lane >= 1 && lane < 6) thist[tidx * 8 + lane] = (uint16_t)(lane == 1 ? loc[1] : lane == 2 ? loc[2] : lane == 3 ? loc[3] : lane == 4 ? loc[4] : loc[5]);
+            if (lane == 0) tdirty[tidx] = 0;
         }
     }
-    if (lane == 0) {
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+        int32_t v = tot[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) s_tot[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int32_t others = 0;
 #pragma unroll
         for (int k = 1; k < 6; ++k) {
-            if (tot[k]) atomicAdd(&out[e * 8 + 2 + k], tot[k]);
-            others += tot[k];
+            const int32_t v = s_tot[0][k] + s_tot[1][k] + s_tot[2][k] + s_tot[3][k];
+            out[e * 8 + 2 + k] = v;
+            others += v;
         }
-        if (others) atomicSub(&out[e * 8 + 2], others);                              // UNBURNED = H * W - the others
-        if (blockIdx.x == 0 && wave == 0) {
-            out[e * 8 + 0] = commit[e].running == 1;
-            out[e * 8 + 1] = commit[e].steps;
-            atomicAdd(&out[e * 8 + 2], g.H * g.W);
-        }
+        out[e * 8 + 2] = g.H * g.W - others;                                          // UNBURNED = H * W - the others
+        out[e * 8 + 0] = commit[e].running == 1;
+        out[e * 8 + 1] = commit[e].steps;
+        elapsed[e] = commit[e].elapsed;
     }
 }
 

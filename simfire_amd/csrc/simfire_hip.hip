@@ -1289,23 +1289,21 @@ static int update_status_async(sf_sim *s)
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
-    HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
     if (g.ab == 1 && !s->generic) {
-        // per-tile histograms: only the tiles touched since the last query are recounted
+        // per-tile histograms: only the tiles touched since the last query are recounted; one launch writes the whole block
         if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
         s->tdirty_all = false;
-        const int per_env = g.TY * g.TX;
-        hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)((per_env + 4 * kCountTilesPerWave - 1) / (4 * kCountTilesPerWave)), g.E),
-                           dim3(256), 0, s->stream, g, (const uint8_t *)s->status, s->tdirty, s->thist,
-                           (const EnvState *)s->commit, s->status_block);
+        hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(256), 0, s->stream, g, (const uint8_t *)s->status, s->tdirty, s->thist,
+                           (const EnvState *)s->commit, s->status_block, s->elapsed_dev);
     } else {
+        HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
         int bx = g.H < 64 ? g.H : 64;
         hipLaunchKernelGGL(k_counts, dim3(bx, g.E), dim3(256), 0, s->stream, g, (const uint8_t *)s->status,
                            (const EnvState *)s->commit, s->status_block);
         s->tdirty_all = true;
+        hipLaunchKernelGGL(k_elapsed, dim3((g.E + 255) / 256), dim3(256), 0, s->stream, g.E, (const EnvState *)s->commit,
+                           s->elapsed_dev);
     }
-    hipLaunchKernelGGL(k_elapsed, dim3((g.E + 255) / 256), dim3(256), 0, s->stream, g.E, (const EnvState *)s->commit,
-                       s->elapsed_dev);
     HIPCHK(hipGetLastError());
     return SF_OK;
 }
