@@ -131,12 +131,16 @@ def timed_steps(eng, steps, first_step, agent_pts):
 
 
 def run_steps(eng, steps, first_step, agent_pts):
-    """The rollout as a harness would run it: nothing is read back per step."""
-    if agent_pts is None:
-        eng.step(steps)
-        return
-    eng.step_mitigated(agent_pts.block[first_step:first_step + steps])
-    eng.sync()
+    """The rollout as a harness would run it: nothing is read back per step, and the host does not wait for the
+    step launches (sf_set_async) - the one wait of the rollout is the one for its result block."""
+    eng.set_async(True)
+    try:
+        if agent_pts is None:
+            eng.step(steps)
+        else:
+            eng.step_mitigated(agent_pts.block[first_step:first_step + steps])
+    finally:
+        eng.set_async(False)
 
 
 def cpu_model():

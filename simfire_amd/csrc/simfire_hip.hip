@@ -1357,10 +1357,10 @@ extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
 extern "C" int sf_copy_status_to(sf_sim *s, void *device_dst)
 {
     if (!s || !device_dst) return fail(SF_EINVAL, "sf_copy_status_to: null argument");
-    int rc = sf_update_status_device(s);
+    int rc = update_status_async(s);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(device_dst, s->status_block, sizeof(int32_t) * 8 * s->g.E, hipMemcpyDeviceToDevice, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));       // (one wait for steps still in flight, the count and the copy)
     return SF_OK;
 }
 
