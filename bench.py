@@ -230,6 +230,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
         traffic = pmc.get("hbm_bytes_per_launch")           # measured on this very window by profiles/collect_pmc.sh
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": LAUNCH_KINDS.get(kind, "?"),
+            "random_access": random_access_block(traffic, kernel_ms / (1 if resident else a.steps)),
             "bytes_model": model, "launches": launches, "steps_per_launch": a.steps if resident else 1,
             "launch_ms": kernel_ms / (1 if resident else a.steps), "kernel_ms_per_step": kernel_ms / a.steps,
             "algorithmic_bytes_per_launch": alg_bytes / (1 if resident else a.steps),
@@ -243,6 +244,31 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
             # what a dense sweep would have to move for the same update() calls, over this kernel time (not a
             # roofline figure: the point of the sparse path is that these bytes are never moved)
             "dense_equivalent_gbs": H * W * env_steps * 4.0 / sec / 1e9}
+
+
+def random_access_block(traffic, kernel_ms, n_cu=256, clock_ghz=2.4):
+    """The roofline a scatter of 1 - 16-byte accesses runs against: 64-byte sectors the fabric moved per
+    clock and CU in the timed launch (PMC traffic of profiles/collect_pmc.sh) next to what profiles/scatter_probe.hip
+    measured for every CU touching one line per lane at once (profiles/r02_scatter_probe.txt)."""
+    probe = {}
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_scatter_probe.txt")):
+            if "span   1024 MB" in line and "blocks  256 x 1024" in line:
+                rate = float(line.split("clocks per wave-")[1].split(",")[1].split("lines/clock/CU")[0])
+                if line.startswith("plain 8 B, 8 in flight "):
+                    probe["loads_8_in_flight"] = rate
+                elif line.startswith("store 1 B x 4 then a load"):
+                    probe["four_stores_then_a_load"] = rate
+    except (OSError, ValueError, IndexError):
+        pass
+    if not traffic or not probe:
+        return None
+    sectors = traffic / 64.0
+    per_clock_cu = sectors / (kernel_ms * 1e-3 * clock_ghz * 1e9) / n_cu
+    return {"sectors_64B_per_launch": sectors, "achieved_sectors_per_clock_per_cu": per_clock_cu,
+            "probe_sectors_per_clock_per_cu": probe, "clock_ghz_assumed": clock_ghz, "n_cu": n_cu,
+            "frac_of_probe_loads": per_clock_cu / probe["loads_8_in_flight"] if "loads_8_in_flight" in probe else None,
+            "source": "profiles/r02_scatter_probe.txt (profiles/scatter_probe.hip), profiles/pmc_traffic_*.json"}
 
 
 def reference_python_timing():

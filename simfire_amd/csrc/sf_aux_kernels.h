@@ -275,31 +275,39 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
 // (marked by the step kernels and the mitigation scatter) are recounted, the others come from the
 // cache.  A status query then costs a few MB of traffic instead of a sweep over every fire map.
 // thist: u16 [E * TY * TX][8], entries 1..5 = cells of that BurnStatus in the tile.
-// One workgroup per environment.  A wave reads the dirty flags and the cached histograms of 64 tiles at once (one tile per
-// lane - the clean tiles cost one round trip for all of them); the tiles found dirty are then recounted by the whole
-// wave, one after the other.  The result block row of the environment (and its elapsed_time) is written without atomics.
-__global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *status, uint8_t *tdirty, uint16_t *thist,
-                                                      const EnvState *commit, int32_t *out, double *elapsed)
+// One workgroup of 16 waves per environment.  Every lane reads the dirty flag and the cached histogram of one tile (the
+// clean tiles cost one round trip for all of them); the dirty tiles are collected in an LDS list and recounted by the
+// waves in turn, one wave per tile.  The result block row of the environment (and its elapsed_time) is written without
+// atomics, so nothing has to be zeroed first.
+constexpr int kCountsDirtyCap = 4096;
+__global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, uint8_t *tdirty, uint16_t *thist,
+                                                       const EnvState *commit, int32_t *out, double *elapsed)
 {
-    __shared__ int32_t s_tot[4][6];
-    const int e = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int32_t s_tot[16][6];
+    __shared__ uint16_t s_dirty[kCountsDirtyCap];
+    __shared__ uint32_t s_n;
+    const int e = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int per_env = g.TY * g.TX;
     const int c = lane & (g.LC - 1), r = lane >> g.logLC;
     int32_t tot[6] = {0, 0, 0, 0, 0, 0};
-    for (int base = wave * 64; base < per_env; base += 256) {
-        const int t = base + lane;
-        const bool valid = t < per_env;
-        const long long idx = (long long)e * per_env + (valid ? t : per_env - 1);
-        const bool dirty = valid && tdirty[idx] != 0;
-        const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
-        if (valid && !dirty) {
-            tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
-            tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+    // (more tiles than the list holds: in rounds)
+    for (int round0 = 0; round0 < per_env; round0 += kCountsDirtyCap) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const int round1 = round0 + kCountsDirtyCap < per_env ? round0 + kCountsDirtyCap : per_env;
+        for (int t = round0 + (int)threadIdx.x; t < round1; t += (int)blockDim.x) {
+            const long long idx = (long long)e * per_env + t;
+            if (tdirty[idx]) s_dirty[atomicAdd(&s_n, 1u)] = (uint16_t)(t - round0);
+            else {
+                const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
+                tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
+                tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+            }
         }
-        unsigned long long dm = __ballot(dirty);
-        while (dm) {
-            const int tt = base + __ffsll((long long)dm) - 1;
-            dm &= dm - 1;
+        __syncthreads();
+        const uint32_t n_dirty = s_n;
+        for (uint32_t q = wave; q < n_dirty; q += n_waves) {
+            const int tt = round0 + s_dirty[q];
             const long long tidx = (long long)e * per_env + tt;
             const int tyw = tt / g.TX, chunk = tt - tyw * g.TX;
             const int cv = chunk * g.LC + c, y0 = (tyw * g.LR + r) * g.RB;
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *stat
             if (lane >= 1 && lane < 6) thist[tidx * 8 + lane] = (uint16_t)(lane == 1 ? loc[1] : lane == 2 ? loc[2] : lane == 3 ? loc[3] : lane == 4 ? loc[4] : loc[5]);
             if (lane == 0) tdirty[tidx] = 0;
         }
+        __syncthreads();
     }
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
@@ -338,7 +347,8 @@ __global__ __launch_bounds__(256) void k_counts_tiles(Geo g, const uint8_t *stat
         int32_t others = 0;
 #pragma unroll
         for (int k = 1; k < 6; ++k) {
-            const int32_t v = s_tot[0][k] + s_tot[1][k] + s_tot[2][k] + s_tot[3][k];
+            int32_t v = 0;
+            for (int w = 0; w < n_waves; ++w) v += s_tot[w][k];
             out[e * 8 + 2 + k] = v;
             others += v;
         }

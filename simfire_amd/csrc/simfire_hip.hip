@@ -1293,7 +1293,7 @@ static int update_status_async(sf_sim *s)
         // per-tile histograms: only the tiles touched since the last query are recounted; one launch writes the whole block
         if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
         s->tdirty_all = false;
-        hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(256), 0, s->stream, g, (const uint8_t *)s->status, s->tdirty, s->thist,
+        hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(1024), 0, s->stream, g, (const uint8_t *)s->status, s->tdirty, s->thist,
                            (const EnvState *)s->commit, s->status_block, s->elapsed_dev);
     } else {
         HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
