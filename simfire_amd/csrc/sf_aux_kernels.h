@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
 // atomics, so nothing has to be zeroed first.
 constexpr int kCountsDirtyCap = 4096;
 __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, uint8_t *tdirty, uint16_t *thist,
-                                                       const EnvState *commit, int32_t *out, double *elapsed)
+                                                       const EnvState *commit, int32_t *out, double *elapsed, int32_t *out2)
 {
     __shared__ int32_t s_tot[16][6];
     __shared__ uint16_t s_dirty[kCountsDirtyCap];
@@ -356,6 +356,8 @@ __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *sta
         out[e * 8 + 0] = commit[e].running == 1;
         out[e * 8 + 1] = commit[e].steps;
         elapsed[e] = commit[e].elapsed;
+        if (out2)                                    // sf_copy_status_to: the caller's device buffer gets its copy right here
+            for (int k = 0; k < 8; ++k) out2[e * 8 + k] = out[e * 8 + k];
     }
 }
 

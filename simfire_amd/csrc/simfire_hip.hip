@@ -125,6 +125,7 @@ struct sf_sim {
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
+    size_t attr_run = 0, attr_front = 0;       // dynamic LDS sizes k_run / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -980,8 +981,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         n_steps = 0;
     } else if (fr_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        if (fr_lds > 64 * 1024)
+        if (fr_lds > 64 * 1024 && fr_lds > s->attr_front) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_lds));
+            s->attr_front = fr_lds;
+        }
         *s->ovf_pinned = 0;
         static const int fdbg = getenv("SF_FRONT_DEBUG") ? atoi(getenv("SF_FRONT_DEBUG")) : 0;
         int32_t *dbg_dev = nullptr;
@@ -1020,15 +1023,19 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             hipLaunchKernelGGL(k_rebuild_vbits_todo, dim3((unsigned)s->g.E), dim3(256), 0, s->stream, s->g, (const uint8_t *)s->age, s->vbits,
                                (const int32_t *)s->todo);
             a.todo = s->todo;
-            if (fit_lds > 64 * 1024)
+            if (fit_lds > 64 * 1024 && fit_lds > s->attr_run) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
+                s->attr_run = fit_lds;
+            }
             hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)fit_waves * 64), fit_lds, s->stream, a, n_steps, fit_vcap, 64);
         }
         n_steps = 0;
     } else if (run_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        if (run_lds > 64 * 1024)
+        if (run_lds > 64 * 1024 && run_lds > s->attr_run) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)run_lds));
+            s->attr_run = run_lds;
+        }
         static const int bsz_knob = getenv("SF_RUN_BATCH") ? atoi(getenv("SF_RUN_BATCH")) : 64;       // vectors per batch (<= 64)
         const int bsz = bsz_knob < 8 ? 8 : (bsz_knob > 64 ? 64 : bsz_knob);
         hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps, run_vcap, bsz);
@@ -1284,7 +1291,7 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
     return SF_OK;
 }
 
-static int update_status_async(sf_sim *s)
+static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
 {
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device));
@@ -1294,7 +1301,7 @@ static int update_status_async(sf_sim *s)
         if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
         s->tdirty_all = false;
         hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(1024), 0, s->stream, g, (const uint8_t *)s->status, s->tdirty, s->thist,
-                           (const EnvState *)s->commit, s->status_block, s->elapsed_dev);
+                           (const EnvState *)s->commit, s->status_block, s->elapsed_dev, copy_to);
     } else {
         HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
         int bx = g.H < 64 ? g.H : 64;
@@ -1303,6 +1310,7 @@ static int update_status_async(sf_sim *s)
         s->tdirty_all = true;
         hipLaunchKernelGGL(k_elapsed, dim3((g.E + 255) / 256), dim3(256), 0, s->stream, g.E, (const EnvState *)s->commit,
                            s->elapsed_dev);
+        if (copy_to) HIPCHK(hipMemcpyAsync(copy_to, s->status_block, sizeof(int32_t) * 8 * g.E, hipMemcpyDeviceToDevice, s->stream));
     }
     HIPCHK(hipGetLastError());
     return SF_OK;
@@ -1357,10 +1365,9 @@ extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
 extern "C" int sf_copy_status_to(sf_sim *s, void *device_dst)
 {
     if (!s || !device_dst) return fail(SF_EINVAL, "sf_copy_status_to: null argument");
-    int rc = update_status_async(s);
+    int rc = update_status_async(s, static_cast<int32_t *>(device_dst));       // (the counting kernel writes the copy too)
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(device_dst, s->status_block, sizeof(int32_t) * 8 * s->g.E, hipMemcpyDeviceToDevice, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));       // (one wait for steps still in flight, the count and the copy)
+    HIPCHK(hipStreamSynchronize(s->stream));       // (one wait for steps still in flight and the count)
     return SF_OK;
 }
 
