@@ -27,7 +27,7 @@ def main():
     eng.reset(w.init_xy)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     eng.set_fused(mode)
-    eng.step(20)
+    eng.step(int(sys.argv[4]) if len(sys.argv) > 4 else 20)
     eng.enable_counters(True)
     out = np.zeros(8, dtype=np.int64)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))

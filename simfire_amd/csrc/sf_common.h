@@ -52,12 +52,31 @@ struct Geo {
     int prune_after_quit;         // 1: environments that QUIT on the runtime check keep pruning (EnvState.running = 2)
     int VW;                       // 64-bit words per row of the vector bitmap = ceil(PV / 64)
     long long vb_env;             // words of vector bitmap per environment = H * VW
+    long long cells_env;          // bytes of the blocked cell plane per environment (resident launch) = (ceil(H / 4) + 2) * PV * 128
 };
+
+// ------------------------------------------------------------------------------------------
+// Blocked cell plane of the resident launch (k_run).  A 16-cell vector visit needs the sprite masks of rows y - 1, y, y + 1
+// and the status bytes of row y: four 64-byte sectors in four different lines of the row-major planes.  Here a SECTOR holds,
+// for one 16-cell vector and one PAIR of rows (2p, 2p + 1):  [mask row 2p | mask row 2p + 1 | status row 2p | status row 2p + 1],
+// and the two pairs of a row quad share a 128-byte line (the lines of a quad row run along x).  A visit then touches exactly
+// two sectors - the pair of y, and the pair above (y even) or below (y odd) - in one line (y mod 4 = 1, 2) or two.
+// One guard quad above and below every environment (row -1 and row H are zero for ever).
+__host__ __device__ inline int bl_vec(const Geo &g, int y, int v)      // byte offset of the sector of (row pair of y, vector v)
+{
+    return ((y >> 2) * g.PV + v) * 128 + ((y >> 1) & 1) * 64;
+}
+__host__ __device__ inline int bl_cell(const Geo &g, int y, int x)     // sprite mask of cell (y, x); its status byte is 32 further
+{
+    return bl_vec(g, y, x >> 4) + (y & 1) * 16 + (x & 15);
+}
+constexpr int kBlStatus = 32;      // status row = mask row + 32 inside a sector
 
 struct StepArgs {
     Geo g;
     uint8_t *status;
     uint8_t *age;        // points at row 0 of env 0 (guard row is at -P)
+    uint8_t *cells;      // k_run only: blocked cell plane (bl_vec), quad 0 of env 0; the row-major planes are stale while it is current
     double *burn;
     const double *rt;
     EnvState *commit;    // [E]   state between API calls

@@ -58,7 +58,7 @@ __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int v
 }
 
 struct RunEnv {                    // per-environment bases (wave-uniform)
-    uint8_t *age, *status;
+    uint8_t *cells;                // blocked cell plane (sf_common.h, bl_vec): sprite masks + status
     double *burn;
     uint32_t *settled;
     const double *rt;
@@ -130,8 +130,9 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 #ifdef SF_STORE_ORDER_WAIT
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-                ev.status[idx] = (uint8_t)SF_BURNING;                            // fire.py:587
-                ev.age[idx] = nb;
+                uint8_t *cell = ev.cells + bl_cell(g, y, x);
+                cell[kBlStatus] = (uint8_t)SF_BURNING;                           // fire.py:587
+                cell[0] = nb;
                 atomicOr(&ev.vb[y * g.VW + (x >> 10)], 1ull << ((x >> 4) & 63));
                 if (ev.vf) {
                     if ((x & 15) == 0) atomicOr(&ev.vf[y], 1ull << (x >> 4));
@@ -190,8 +191,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     __syncthreads();
 
     RunEnv ev;
-    ev.age = a.age + (long long)e * g.age_env;
-    ev.status = a.status + (long long)e * g.plane_env;
+    ev.cells = a.cells + (long long)e * g.cells_env;
     ev.burn = a.burn + (long long)e * g.plane_env;
     ev.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
     ev.rt = a.rt + (long long)e * g.rt_env;
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
                 if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
                 const uint32_t o = (uint32_t)(y * g.P + x);
-                uint32_t *word = reinterpret_cast<uint32_t *>(ev.status + (o & ~3u));
-                const int sh = (int)(o & 3u) * 8;
+                uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
+                const int sh = (x & 3) * 8;
                 const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
                 if (g.att && old >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(old), (uint32_t)st.complete - ev.settled[o]);
             }
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
                 if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
                 const uint32_t o = (uint32_t)(y * g.P + x);
-                uint32_t *word = reinterpret_cast<uint32_t *>(ev.status + (o & ~3u));
-                const int sh = (int)(o & 3u) * 8;
+                uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
+                const int sh = (x & 3) * 8;
                 uint32_t old = *word, seen;
                 do {
                     seen = old;
@@ -351,25 +351,35 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const uint32_t item = vlist[has ? j0 + lane : n_chunk - 1];      // (idle lanes repeat the last entry: valid addresses)
                 const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
                 const int x0 = v * 16;
-                const uint8_t *ra = ev.age + (uint32_t)(y * g.P + x0);
+                // two sectors: the row pair of y (its two mask rows + the status row), and one mask row of the pair above (y even)
+                // or below (y odd)
+                const int odd = y & 1;
+                const uint8_t *sec = ev.cells + bl_vec(g, y, v);
+                const uint8_t *p_mid = sec + odd * 16, *p_pair = sec + (odd ^ 1) * 16;
+                const uint8_t *p_far = ev.cells + bl_vec(g, odd ? y + 1 : y - 1, v) + (odd ^ 1) * 16;
+                const uint8_t *p_up = odd ? p_pair : p_far, *p_dn = odd ? p_far : p_pair;
                 in.item = has ? item : 0xFFFFFFFFu;
-                in.mid = *reinterpret_cast<const uint4 *>(ra);
-                in.up = *reinterpret_cast<const uint4 *>(ra - g.P);
-                in.dn = *reinterpret_cast<const uint4 *>(ra + g.P);
-                in.sr = *reinterpret_cast<const uint4 *>(ev.status + (uint32_t)(y * g.P + x0));
+                in.mid = *reinterpret_cast<const uint4 *>(p_mid);
+                in.sr = *reinterpret_cast<const uint4 *>(p_mid + kBlStatus);
+                {
+                    const uint4 r_pair = *reinterpret_cast<const uint4 *>(p_pair), r_far = *reinterpret_cast<const uint4 *>(p_far);
+                    in.up = odd ? r_pair : r_far;
+                    in.dn = odd ? r_far : r_pair;
+                }
                 // The cells just left / right of the vector.  The list runs by rows, so the vector to the left, if it is
                 // interesting at all, is the list entry before this one, i.e. the lane below - and if it is not
                 // interesting, it and the vectors above / below it hold no sprite bit: the edge cells are zero.  Only
                 // the first / last lane of a batch have to look the cells up in the plane.
                 // (loads only inside the branches - nothing that has to wait for them here)
                 in.l0 = in.l1 = in.l2 = in.r0 = in.r1 = in.r2 = 0;
+                // (the same rows of the vector to the left / right: one line = 128 bytes further along x)
                 if (has && lane == 0 && v > 0) {
-                    in.l0 = *reinterpret_cast<const uint32_t *>(ra - 4);
-                    if (g.diag) { in.l1 = *reinterpret_cast<const uint32_t *>(ra - g.P - 4); in.l2 = *reinterpret_cast<const uint32_t *>(ra + g.P - 4); }
+                    in.l0 = *reinterpret_cast<const uint32_t *>(p_mid - 128 + 12);
+                    if (g.diag) { in.l1 = *reinterpret_cast<const uint32_t *>(p_up - 128 + 12); in.l2 = *reinterpret_cast<const uint32_t *>(p_dn - 128 + 12); }
                 }
                 if (has && (j0 + lane + 1 == n_chunk || lane == bsz - 1) && x0 + 16 < g.W) {
-                    in.r0 = *reinterpret_cast<const uint32_t *>(ra + 16);
-                    if (g.diag) { in.r1 = *reinterpret_cast<const uint32_t *>(ra - g.P + 16); in.r2 = *reinterpret_cast<const uint32_t *>(ra + g.P + 16); }
+                    in.r0 = *reinterpret_cast<const uint32_t *>(p_mid + 128);
+                    if (g.diag) { in.r1 = *reinterpret_cast<const uint32_t *>(p_up + 128); in.r2 = *reinterpret_cast<const uint32_t *>(p_dn + 128); }
                 }
             };
             uint32_t j_next = grab();
@@ -384,7 +394,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const uint32_t item = cur.item;
                 const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
                 const int x0 = v * 16;
-                const uint32_t voff = (uint32_t)(y * g.P + x0);
+                const uint32_t voff = (uint32_t)(y * g.P + x0);             // burn_amounts / settled: row-major
+                uint8_t *vmask = ev.cells + bl_vec(g, y, v) + (y & 1) * 16;  // this vector's mask row; its status row is kBlStatus further
                 const uint4 up = cur.up, mid = cur.mid, dn = cur.dn, sr = cur.sr;
                 const uint32_t item_l = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x138, 0xF, 0xF, false);   // wave_shr:1
                 const uint32_t item_r = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)item, 0x130, 0xF, 0xF, false);   // wave_shl:1
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const uint32_t any_exp = any4(ex4), any_clr = any4(and4(mid, CLR4)), any_nb = spread ? any4(nb) : 0u;
                 if (has && any_clr) {   // recycle the slot of sprites that were pruned one step ago
                     const uint4 av = and4(mid, ~CLR4);
-                    *reinterpret_cast<uint4 *>(ev.age + voff) = av;
+                    *reinterpret_cast<uint4 *>(vmask) = av;
                     if (!any4(av)) atomicAnd(&vb[y * g.VW + (v >> 6)], ~(1ull << (v & 63)));     // no sprite bit left in the vector
                     if (fine) {
                         if (!(av.x & 0xFFu) && (mid.x & 0xFFu)) atomicAnd(&vf[y], ~(1ull << v));
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     snew.z = (s7.z & ~em.z) | (0x02020202u & em.z);
                     snew.w = (s7.w & ~em.w) | (0x02020202u & em.w);
                     if ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) {
-                        *reinterpret_cast<uint4 *>(ev.status + voff) = snew;
+                        *reinterpret_cast<uint4 *>(vmask + kBlStatus) = snew;
                         // attenuation mode: a control line drawn on a burning cell ends when that sprite expires (the prune
                         // overwrites it with BURNED, fire.py:140): make up the attenuation the cell is still owed
                         if (g.att) {
@@ -587,6 +598,27 @@ __global__ __launch_bounds__(64) void k_rebuild_vbits(Geo g, const uint8_t *age,
         const long long o = (long long)e * g.vb_env + (long long)y * g.VW + w, plane = (long long)g.E * g.vb_env;
         vbits[o] = b; vbits[plane + o] = f; vbits[2 * plane + o] = l;      // any sprite bit / in the first cell / in the last cell
     }
+}
+
+// Row-major planes <-> blocked cell plane, one thread per 16-cell vector (the host switches when the resident launch and the
+// per-step kernels / getters alternate: ensure_bl / ensure_rm).
+__global__ __launch_bounds__(64) void k_rm_to_bl(Geo g, const uint8_t *status, const uint8_t *age, uint8_t *cells)
+{
+    const int v = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
+    if (v >= g.PV) return;
+    const uint4 m = *reinterpret_cast<const uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16);
+    const uint4 st = *reinterpret_cast<const uint4 *>(status + (long long)e * g.plane_env + (long long)y * g.P + v * 16);
+    uint8_t *row = cells + (long long)e * g.cells_env + bl_vec(g, y, v) + (y & 1) * 16;
+    *reinterpret_cast<uint4 *>(row) = m;
+    *reinterpret_cast<uint4 *>(row + kBlStatus) = st;
+}
+__global__ __launch_bounds__(64) void k_bl_to_rm(Geo g, const uint8_t *cells, uint8_t *status, uint8_t *age)
+{
+    const int v = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
+    if (v >= g.PV) return;
+    const uint8_t *row = cells + (long long)e * g.cells_env + bl_vec(g, y, v) + (y & 1) * 16;
+    *reinterpret_cast<uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row);
+    *reinterpret_cast<uint4 *>(status + (long long)e * g.plane_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row + kBlStatus);
 }
 
 }  // namespace

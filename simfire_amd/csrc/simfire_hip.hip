@@ -93,6 +93,8 @@ struct sf_sim {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *status = nullptr, *age_alloc = nullptr, *age = nullptr;
+    uint8_t *cells_alloc = nullptr, *cells = nullptr;      // blocked cell plane of the resident launch (allocated at its first use)
+    bool bl_cur = false;               // the blocked plane holds the sprite masks / status bytes; the row-major planes are stale
     double *burn = nullptr, *rt = nullptr;
     double *lay_all = nullptr;         // [tables][7][H*W] dense: w0 delta Mx sigma elev U Udir (kept for the observation planes)
     double *layer(int table, int i) const { return lay_all + ((size_t)table * 7 + i) * (size_t)g.H * g.W; }
@@ -150,6 +152,7 @@ struct sf_sim {
 };
 
 static int ensure_commit(sf_sim *s);
+static int ensure_rm(sf_sim *s);
 
 static int ensure_stage(sf_sim *s, size_t bytes)
 {
@@ -261,6 +264,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->seam, (size_t)g.E * g.seam_env));
     if (g.att) TRY(dev_alloc(s, &s->settled, cells));
     g.VW = (g.PV + 63) / 64; g.vb_env = (long long)g.H * g.VW;
+    g.cells_env = (long long)((g.H + 3) / 4 + 2) * g.PV * 128;
     TRY(dev_alloc(s, &s->vbits, (size_t)3 * g.E * g.vb_env));
     TRY(dev_alloc(s, &s->todo, (size_t)g.E));
     if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * kFrontStartCap));
@@ -297,7 +301,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->wheel, s->mit_stage,
+    void *ptrs[] = {s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
@@ -698,6 +702,8 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
                         xy[2 * i + 1], env0 + i, g.H, g.W);
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
+    if (n == g.E) s->bl_cur = false;        // everything is rewritten: nothing to convert
+    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
     HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
@@ -743,6 +749,7 @@ extern "C" int sf_reset_env(sf_sim *s, int32_t env, int32_t x, int32_t y)
 static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n, bool sync)
 {
     const Geo &g = s->g;
+    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint32_t *)s->settled, s->burn,
                        (const EnvState *)s->commit, (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq,
@@ -816,6 +823,8 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
     rc = ensure_commit(s);
     if (rc) return rc;
+    rc = ensure_rm(s);
+    if (rc) return rc;
     if (g.att)
         hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, s->settled, s->burn,
                            (const EnvState *)s->commit, env, 1);
@@ -830,11 +839,40 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     return SF_OK;
 }
 
+// The resident launch works on the blocked cell plane (sf_common.h, bl_vec), everything else on the row-major planes; the
+// one that is current is converted when the other kind of work comes next (one sweep over the cell planes).
+static int ensure_rm(sf_sim *s)
+{
+    if (!s->bl_cur) return SF_OK;
+    const Geo &g = s->g;
+    hipLaunchKernelGGL(k_bl_to_rm, dim3((g.PV + 63) / 64, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->cells, s->status, s->age);
+    HIPCHK(hipGetLastError());
+    s->bl_cur = false;
+    return SF_OK;
+}
+static int ensure_bl(sf_sim *s)
+{
+    if (s->bl_cur) return SF_OK;
+    const Geo &g = s->g;
+    if (!s->cells_alloc) {
+        const size_t bytes = (size_t)g.E * g.cells_env;
+        int rc = dev_alloc(s, &s->cells_alloc, bytes);
+        if (rc) return rc;
+        s->cells = s->cells_alloc + (size_t)g.PV * 128;        // quad 0 of environment 0 (a guard quad above and below every environment)
+        HIPCHK(hipMemsetAsync(s->cells_alloc, 0, bytes, s->stream));
+    }
+    hipLaunchKernelGGL(k_rm_to_bl, dim3((g.PV + 63) / 64, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)s->age, s->cells);
+    HIPCHK(hipGetLastError());
+    s->bl_cur = true;
+    return SF_OK;
+}
+
 // The per-step tiled kernels keep the tile activity map and the seam planes, the resident launch keeps the vector
 // bitmap; whichever a launch needs is rebuilt from the sprite-mask planes if the other kind ran in between.
 static int ensure_tiles(sf_sim *s)
 {
     if (s->tiles_valid) return SF_OK;
+    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     HIPCHK(hipMemsetAsync(s->tflags, 0, s->tflags_bytes, s->stream));
     int rc = rebuild_tflags(s, 0, s->g.E);
     if (rc) return rc;
@@ -846,6 +884,7 @@ static int ensure_tiles(sf_sim *s)
 static int ensure_vbits(sf_sim *s)
 {
     if (s->vbits_valid) return SF_OK;
+    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     const Geo &g = s->g;
     hipLaunchKernelGGL(k_rebuild_vbits, dim3(g.VW, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->age, s->vbits, 0);
     HIPCHK(hipGetLastError());
@@ -872,7 +911,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     if (n_steps == 0) return SF_OK;
     HIPCHK(hipSetDevice(s->p.device));
     StepArgs a;
-    a.g = s->g; a.status = s->status; a.age = s->age; a.burn = s->burn; a.rt = s->rt;
+    a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     a.parents = s->graph_on ? s->parents : nullptr;
     const dim3 block(kWaves * 64);
@@ -963,12 +1002,16 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         if (rc0) return rc0;
         rc0 = ensure_vbits(s);
         if (rc0) return rc0;
+        rc0 = (run_waves && !fr_waves && !runt_waves) ? ensure_bl(s) : ensure_rm(s);
+        if (rc0) return rc0;
     } else if (!generic) {
         int rc0 = ensure_tiles(s);
         if (rc0) return rc0;
         if (runt_waves) { rc0 = ensure_commit(s); if (rc0) return rc0; }
     }
+    if (!(run_waves && !fr_waves && !runt_waves)) { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     a.vbits = s->vbits;
+    a.cells = s->cells;
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
     if (runt_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
@@ -1023,6 +1066,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             hipLaunchKernelGGL(k_rebuild_vbits_todo, dim3((unsigned)s->g.E), dim3(256), 0, s->stream, s->g, (const uint8_t *)s->age, s->vbits,
                                (const int32_t *)s->todo);
             a.todo = s->todo;
+            { int rc0 = ensure_bl(s); if (rc0) return rc0; }       // (what k_front left in the row-major planes, for every environment)
+            a.cells = s->cells;
             if (fit_lds > 64 * 1024 && fit_lds > s->attr_run) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
                 s->attr_run = fit_lds;
@@ -1222,6 +1267,8 @@ static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
     const size_t bytes = (size_t)n * g.H * g.W;
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
+    rc = ensure_rm(s);
+    if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H, n);
     hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, env0, (uint8_t *)s->stage);
     HIPCHK(hipGetLastError());
@@ -1261,6 +1308,8 @@ extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
     rc = ensure_commit(s);
     if (rc) return rc;
+    rc = ensure_rm(s);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_unpack_burn, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint32_t *)s->settled,
                        (const double *)s->burn, (const EnvState *)s->commit, env, (double *)s->stage);
     HIPCHK(hipGetLastError());
@@ -1281,6 +1330,8 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
     rc = ensure_commit(s);
     if (rc) return rc;
+    rc = ensure_rm(s);
+    if (rc) return rc;
     if (g.att)   // the caller's values are the truth now: nothing is owed any more
         hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, s->settled, s->burn,
                            (const EnvState *)s->commit, env, 0);
@@ -1296,6 +1347,7 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
+    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     if (g.ab == 1 && !s->generic) {
         // per-tile histograms: only the tiles touched since the last query are recounted; one launch writes the whole block
         if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
@@ -1381,6 +1433,9 @@ extern "C" int sf_status_device(sf_sim *s, void **ptr)
 extern "C" int sf_fire_map_device(sf_sim *s, void **ptr, int64_t *row_pitch, int64_t *env_stride)
 {
     if (!s || !ptr || !row_pitch || !env_stride) return fail(SF_EINVAL, "sf_fire_map_device: null argument");
+    HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
+    HIPCHK(hipStreamSynchronize(s->stream));
     *ptr = s->status; *row_pitch = s->g.P; *env_stride = s->g.plane_env;
     s->tdirty_all = true;      // the caller holds a writable alias of the status plane: recount everything at the next query
     return SF_OK;
