@@ -167,7 +167,10 @@ int sf_get_status(sf_sim *sim, int32_t *status /* [n_envs][8] */, double *elapse
 
 /* Device-side views for zero-copy consumers (RL observation tensors): pointer to the uint8
  * status plane of environment 0, row pitch and environment stride in bytes; the bytes are the
- * BurnStatus values 0..5. */
+ * BurnStatus values 0..5.  Call it again after stepping: while the resident launch (sf_step with
+ * n >= 2 on grids up to 1024 cells wide) keeps the cells in its blocked plane, the row-major plane
+ * returned here is refreshed by this call (one device-side sweep, no host copy) and is a read-only
+ * snapshot until the next one; the address does not change. */
 int sf_fire_map_device(sf_sim *sim, void **ptr, int64_t *row_pitch, int64_t *env_stride);
 /* Device buffer int32 [n_envs][8] filled by sf_update_status_device (same content as
  * sf_get_status) - the block that is all-gathered over RCCL by the multi-GPU host code. */

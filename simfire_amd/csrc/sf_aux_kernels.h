@@ -118,11 +118,14 @@ __global__ void k_unpack_f64(int H, int W, int P, const double *pitched, double 
     if (x >= W) return;
     dense[((long long)k * H + y) * W + x] = pitched[((long long)k * H + y) * P + x];
 }
-__global__ void k_unpack_status(Geo g, const uint8_t *status, int env0, uint8_t *dense)
+// (cells: the blocked cell plane when it is the current one - sf_common.h, bl_vec - else null)
+__global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cells, int env0, uint8_t *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, i = blockIdx.z;
     if (x >= g.W) return;
-    dense[((long long)i * g.H + y) * g.W + x] = status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x] & 7u;
+    const uint8_t st = cells ? cells[(long long)(env0 + i) * g.cells_env + bl_cell(g, y, x) + kBlStatus]
+                             : status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x];
+    dense[((long long)i * g.H + y) * g.W + x] = st & 7u;
 }
 
 // burn_amounts as the reference would hold them now: the attenuation a control-line cell is still owed
@@ -182,7 +185,7 @@ __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 //                     order for duplicates (simulation.py:476-478); each write is unconditional
 //                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.  The
 //                     new line cell owes attenuation from the next update on.
-__global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint32_t *settled, double *burn, const EnvState *commit,
+__global__ void k_mitigate_clear(Geo g, uint8_t *status, uint8_t *cells, const uint32_t *settled, double *burn, const EnvState *commit,
                                  const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
                                  const int32_t *pts, int n)
 {
@@ -192,8 +195,8 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint32_t *settled
     if (ty < SF_FIRELINE || ty > SF_WETLINE) return;                 // simulation.py:469-473
     if (e < 0 || e >= g.E || x < 0 || x >= g.W || y < 0 || y >= g.H) return;   // device-side lists are not pre-checked
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
-    uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
-    const int sh = (int)(o & 3) * 8;
+    uint32_t *word = reinterpret_cast<uint32_t *>(cells ? cells + (long long)e * g.cells_env + bl_cell(g, y, x & ~3) + kBlStatus : status + (o & ~3ll));
+    const int sh = (x & 3) * 8;
     const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
     if (g.att && old >= SF_FIRELINE) {
         const uint32_t now = (uint32_t)entering_state(commit, tmp, flags, launch, from_commit, e, g).complete;
@@ -201,7 +204,7 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, const uint32_t *settled
     }
 }
 
-__global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, uint8_t *tdirty, const EnvState *commit,
+__global__ void k_mitigate_write(Geo g, uint8_t *status, uint8_t *cells, uint32_t *settled, uint8_t *tdirty, const EnvState *commit,
                                  const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
                                  const int32_t *pts, int n)
 {
@@ -211,8 +214,8 @@ __global__ void k_mitigate_write(Geo g, uint8_t *status, uint32_t *settled, uint
     if (ty < SF_FIRELINE || ty > SF_WETLINE) return;
     if (e < 0 || e >= g.E || x < 0 || x >= g.W || y < 0 || y >= g.H) return;
     const long long o = (long long)e * g.plane_env + (long long)y * g.P + x;
-    uint32_t *word = reinterpret_cast<uint32_t *>(status + (o & ~3ll));
-    const int sh = (int)(o & 3) * 8;
+    uint32_t *word = reinterpret_cast<uint32_t *>(cells ? cells + (long long)e * g.cells_env + bl_cell(g, y, x & ~3) + kBlStatus : status + (o & ~3ll));
+    const int sh = (x & 3) * 8;
     uint32_t old = *word, seen;
     do {
         seen = old;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
 // waves in turn, one wave per tile.  The result block row of the environment (and its elapsed_time) is written without
 // atomics, so nothing has to be zeroed first.
 constexpr int kCountsDirtyCap = 4096;
-__global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, uint8_t *tdirty, uint16_t *thist,
+__global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
                                                        const EnvState *commit, int32_t *out, double *elapsed, int32_t *out2)
 {
     __shared__ int32_t s_tot[16][6];
@@ -315,7 +318,9 @@ __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *sta
             if (cv < g.PV)
                 for (int i = 0; i < g.RB; ++i) {
                     if (y0 + i >= g.H) break;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(status + (long long)e * g.plane_env + (long long)(y0 + i) * g.P + cv * 16);
+                    const int y = y0 + i;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(cells ? cells + (long long)e * g.cells_env + bl_vec(g, y, cv) + (y & 1) * 16 + kBlStatus
+                                                                           : status + (long long)e * g.plane_env + (long long)y * g.P + cv * 16);
                     if ((v.x | v.y | v.z | v.w) == 0u) continue;
                     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll

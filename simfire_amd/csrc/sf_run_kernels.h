@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64) void k_bl_to_rm(Geo g, const uint8_t *cells, ui
     const int v = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
     if (v >= g.PV) return;
     const uint8_t *row = cells + (long long)e * g.cells_env + bl_vec(g, y, v) + (y & 1) * 16;
-    *reinterpret_cast<uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row);
+    if (age) *reinterpret_cast<uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row);      // (null: a snapshot of the fire maps only)
     *reinterpret_cast<uint4 *>(status + (long long)e * g.plane_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row + kBlStatus);
 }
 

@@ -992,15 +992,21 @@ __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t 
     flags[e] = 0; flags[g.E + e] = 0; flags[2 * g.E + e] = 0;
 }
 
-__global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, EnvState *commit, uint8_t *tflags, int ring,
+__global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, uint8_t *cells, EnvState *commit, uint8_t *tflags, int ring,
                            unsigned long long *vbits, const int32_t *xy, int env0, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int e = env0 + i;
     const int x = xy[2 * i], y = xy[2 * i + 1];
-    status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
-    age_store(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x, 1u);   // ignition step 0
+    if (cells) {                        // the blocked cell plane is the current one (1-byte sprite masks)
+        uint8_t *cell = cells + (long long)e * g.cells_env + bl_cell(g, y, x);
+        cell[kBlStatus] = SF_BURNING;
+        cell[0] = 1u;
+    } else {
+        status[(long long)e * g.plane_env + (long long)y * g.P + x] = SF_BURNING;   // simulation.py:565-566
+        age_store(g, age + (long long)e * g.age_env * g.ab, (long long)y * g.P + x, 1u);   // ignition step 0
+    }
     const int tyw = y / (g.LR * g.RB), tx = (x / 16) / g.LC;
     tflags[(((long long)ring * g.E + e) * g.TYp + tyw + 1) * g.TXp + tx + 1] = 1 | 4 | 8 | 16 | 32;   // all edge bits: conservative
     {   // vector bitmaps of the resident launch (cleared by the caller): any sprite bit / first cell / last cell

@@ -153,6 +153,8 @@ struct sf_sim {
 
 static int ensure_commit(sf_sim *s);
 static int ensure_rm(sf_sim *s);
+static int alloc_bl(sf_sim *s);
+static bool prefers_bl(const sf_sim *s);
 
 static int ensure_stage(sf_sim *s, size_t bytes)
 {
@@ -702,10 +704,19 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
                         xy[2 * i + 1], env0 + i, g.H, g.W);
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
-    if (n == g.E) s->bl_cur = false;        // everything is rewritten: nothing to convert
-    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
-    HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
-    HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
+    if (n == g.E) {
+        // everything is rewritten, nothing to convert: into the blocked plane if the resident launch is what steps this handle
+        // (it did last, or nothing has stepped yet and it is the automatic choice), else into the row-major planes
+        const bool bl = prefers_bl(s) && (s->bl_cur || s->last_kind == 2 || s->last_kind == -1);
+        if (bl) { int rc0 = alloc_bl(s); if (rc0) return rc0; }
+        s->bl_cur = bl;
+    }
+    if (s->bl_cur)
+        HIPCHK(hipMemsetAsync(s->cells_alloc + (size_t)env0 * g.cells_env, 0, (size_t)n * g.cells_env, s->stream));
+    else {
+        HIPCHK(hipMemsetAsync(s->status + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
+        HIPCHK(hipMemsetAsync(s->age + ((long long)env0 * g.age_env - g.P) * g.ab, 0, (size_t)n * g.age_env * g.ab, s->stream));
+    }
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
     if (s->parents) HIPCHK(hipMemsetAsync(s->parents + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
     if (s->settled) HIPCHK(hipMemsetAsync(s->settled + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(uint32_t), s->stream));
@@ -717,11 +728,13 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
         HIPCHK(hipMemsetAsync(s->tflags + ((size_t)k * g.E + env0) * fplane, 0, (size_t)n * fplane, s->stream));
     for (int k = 0; k < 3; ++k)
         HIPCHK(hipMemsetAsync(s->vbits + ((size_t)k * g.E + env0) * g.vb_env, 0, (size_t)n * g.vb_env * sizeof(unsigned long long), s->stream));
-    hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->commit,
+    hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->bl_cur ? s->cells : nullptr, s->commit,
                        s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n);
     HIPCHK(hipGetLastError());
-    rc = rebuild_seams(s, env0, n);
-    if (rc) return rc;
+    if (!s->bl_cur) {                   // (the tile bookkeeping is not kept while the blocked plane is current: tiles_valid is false)
+        rc = rebuild_seams(s, env0, n);
+        if (rc) return rc;
+    }
     s->tdirty_all = true;
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
@@ -731,7 +744,7 @@ extern "C" int sf_reset(sf_sim *s, const int32_t *init_xy)
 {
     if (!s || !init_xy) return fail(SF_EINVAL, "sf_reset: null argument");
     int rc = reset_range(s, 0, s->g.E, init_xy);
-    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->tiles_valid = true; }     // every environment freshly written
+    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->tiles_valid = !s->bl_cur; }     // every environment freshly written
     return rc;
 }
 
@@ -749,12 +762,12 @@ extern "C" int sf_reset_env(sf_sim *s, int32_t env, int32_t x, int32_t y)
 static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n, bool sync)
 {
     const Geo &g = s->g;
-    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
+    uint8_t *cells = s->bl_cur ? s->cells : nullptr;
     const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, (const uint32_t *)s->settled, s->burn,
+    hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, cells, (const uint32_t *)s->settled, s->burn,
                        (const EnvState *)s->commit, (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq,
                        s->committed ? 1 : 0, pts_dev, n);
-    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, s->settled, s->tdirty,
+    hipLaunchKernelGGL(k_mitigate_write, grd, blk, 0, s->stream, g, s->status, cells, s->settled, s->tdirty,
                        (const EnvState *)s->commit, (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq,
                        s->committed ? 1 : 0, pts_dev, n);
     HIPCHK(hipGetLastError());
@@ -850,17 +863,29 @@ static int ensure_rm(sf_sim *s)
     s->bl_cur = false;
     return SF_OK;
 }
+static int alloc_bl(sf_sim *s)
+{
+    if (s->cells_alloc) return SF_OK;
+    const Geo &g = s->g;
+    const size_t bytes = (size_t)g.E * g.cells_env;
+    int rc = dev_alloc(s, &s->cells_alloc, bytes);
+    if (rc) return rc;
+    s->cells = s->cells_alloc + (size_t)g.PV * 128;        // quad 0 of environment 0 (a guard quad above and below every environment)
+    HIPCHK(hipMemsetAsync(s->cells_alloc, 0, bytes, s->stream));
+    return SF_OK;
+}
+// Will sf_step(n >= 2) of this handle pick the resident launch (the automatic rule of step_impl)?  Then a reset writes the
+// blocked plane straight away.
+static bool prefers_bl(const sf_sim *s)
+{
+    const Geo &g = s->g;
+    return g.ab == 1 && !s->generic && g.VW == 1 && !s->graph_on && !s->history && (s->fused_mode < 0 || s->fused_mode == 2);
+}
 static int ensure_bl(sf_sim *s)
 {
     if (s->bl_cur) return SF_OK;
     const Geo &g = s->g;
-    if (!s->cells_alloc) {
-        const size_t bytes = (size_t)g.E * g.cells_env;
-        int rc = dev_alloc(s, &s->cells_alloc, bytes);
-        if (rc) return rc;
-        s->cells = s->cells_alloc + (size_t)g.PV * 128;        // quad 0 of environment 0 (a guard quad above and below every environment)
-        HIPCHK(hipMemsetAsync(s->cells_alloc, 0, bytes, s->stream));
-    }
+    { int rc = alloc_bl(s); if (rc) return rc; }
     hipLaunchKernelGGL(k_rm_to_bl, dim3((g.PV + 63) / 64, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)s->age, s->cells);
     HIPCHK(hipGetLastError());
     s->bl_cur = true;
@@ -1267,10 +1292,8 @@ static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
     const size_t bytes = (size_t)n * g.H * g.W;
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
-    rc = ensure_rm(s);
-    if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H, n);
-    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, env0, (uint8_t *)s->stage);
+    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env0, (uint8_t *)s->stage);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1347,14 +1370,14 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
-    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     if (g.ab == 1 && !s->generic) {
         // per-tile histograms: only the tiles touched since the last query are recounted; one launch writes the whole block
         if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
         s->tdirty_all = false;
-        hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(1024), 0, s->stream, g, (const uint8_t *)s->status, s->tdirty, s->thist,
+        hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(1024), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), s->tdirty, s->thist,
                            (const EnvState *)s->commit, s->status_block, s->elapsed_dev, copy_to);
     } else {
+        { int rc0 = ensure_rm(s); if (rc0) return rc0; }
         HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
         int bx = g.H < 64 ? g.H : 64;
         hipLaunchKernelGGL(k_counts, dim3(bx, g.E), dim3(256), 0, s->stream, g, (const uint8_t *)s->status,
@@ -1434,10 +1457,15 @@ extern "C" int sf_fire_map_device(sf_sim *s, void **ptr, int64_t *row_pitch, int
 {
     if (!s || !ptr || !row_pitch || !env_stride) return fail(SF_EINVAL, "sf_fire_map_device: null argument");
     HIPCHK(hipSetDevice(s->p.device));
-    { int rc0 = ensure_rm(s); if (rc0) return rc0; }
+    if (s->bl_cur) {
+        // the resident launch keeps the cells in its blocked plane: the row-major status plane is refreshed from it (one sweep) and
+        // is a snapshot until the next call - the blocked plane stays the current one, nothing is converted back
+        const Geo &g = s->g;
+        hipLaunchKernelGGL(k_bl_to_rm, dim3((g.PV + 63) / 64, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->cells, s->status, (uint8_t *)nullptr);
+        HIPCHK(hipGetLastError());
+    } else s->tdirty_all = true;      // the caller holds a writable alias of the status plane: recount everything at the next query
     HIPCHK(hipStreamSynchronize(s->stream));
     *ptr = s->status; *row_pitch = s->g.P; *env_stride = s->g.plane_env;
-    s->tdirty_all = true;      // the caller holds a writable alias of the status plane: recount everything at the next query
     return SF_OK;
 }
 

@@ -336,8 +336,9 @@ class FireEngine:
 
     def fire_maps_torch(self):
         """Zero-copy view of all fire_maps as a torch uint8 tensor [n_envs, H, W] on this GPU (RL
-        observations without a PCIe round trip).  The bytes are the BurnStatus values.  The view
-        aliases the library's state: read it between calls, do not write to it."""
+        observations without a PCIe round trip).  The bytes are the BurnStatus values.  Read-only, and call it
+        again after stepping: the plane is refreshed by this call (a snapshot while the resident launch keeps the
+        cells in its blocked plane; same address every time)."""
         import torch
         ptr, pitch, stride = self.fire_map_device()
         self.sync()

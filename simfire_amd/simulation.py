@@ -454,7 +454,8 @@ class BatchedFireSimulation:
         return self._engine.fire_map(env)
 
     def fire_maps_device(self):
-        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no copy)."""
+        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no host copy).  Call it again after
+        stepping: the plane is refreshed by the call and is a read-only snapshot until the next one."""
         return self._engine.fire_maps_torch()
 
     def gather_results(self):

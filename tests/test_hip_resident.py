@@ -537,3 +537,59 @@ def test_c5_rollout_in_one_launch():
         o.apply_mitigation(pts[s])
         o.step(1, 32)
     _same(eng, o, E, burn_envs=(0, 11, 23), tag="c5 rollout")
+
+
+@pytest.mark.parametrize("shape", [(1, 40), (2, 17), (3, 16), (5, 300), (67, 130), (130, 1000)])
+def test_blocked_cell_plane_follows_every_entry_point(shape):
+    """In the automatic mode sf_step(n >= 2) runs in k_run on the blocked cell plane (16 cells x 2 rows of sprite masks +
+    status per 64-byte sector, sf_common.h) and sf_step(1) in the per-step kernels on the row-major planes.  Resets (all /
+    one environment), control lines, the result block and the fire-map getters work on whichever is current, everything
+    else converts: alternate all of them on grids whose height is not a multiple of 4 / width not a multiple of 16, and
+    compare with the oracle after every call."""
+    rng = np.random.default_rng(5000 + shape[0])
+    H, W = shape
+    E = 4
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)                 # the first reset already writes the blocked plane
+    _same(eng, o, E, tag="reset")
+
+    def lines(k):
+        pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(k)]
+        eng.apply_mitigation(pts)
+        o.apply_mitigation(pts)
+
+    def step(n):
+        eng.step(n)
+        o.step(n)
+
+    for i in range(4):
+        lines(12)
+        step(3 + i)                               # k_run
+        assert eng.last_launch_kind() == 2
+        _same(eng, o, E, tag=("k_run", i))
+        e0, x, y = int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H))
+        eng.reset_env(e0, x, y)                   # one environment, blocked plane current
+        o.reset_env(e0, x, y)
+        lines(5)
+        _same(eng, o, E, burn_envs=[e0], tag=("reset_env", i))
+        view = eng.fire_maps_torch().cpu().numpy()          # snapshot of the blocked plane
+        assert (view == eng.fire_maps()).all()
+        step(2)
+        assert eng.last_launch_kind() == 2
+        step(1)                                   # per-step kernels: row-major planes
+        assert eng.last_launch_kind() in (0, 1)
+        lines(7)
+        _same(eng, o, E, tag=("per step", i))
+        e0 = int(rng.integers(E))
+        new = o.fire_map(e0).copy()
+        new[rng.random((H, W)) < 0.1] = 4
+        eng.load_fire_map(e0, new)
+        o.load_fire_map(e0, new)
+        step(2)
+        _same(eng, o, E, tag=("after load_fire_map", i))
+    eng.reset(inits)
+    o.reset(inits)
+    step(6)
+    _same(eng, o, E, tag="second reset")

@@ -222,8 +222,13 @@ def test_zero_copy_observation_and_result_block():
     view = sim.fire_maps_device()
     assert view.shape == (3, 40, 50) and view.dtype == torch.uint8 and view.is_cuda
     assert (view.cpu().numpy() == maps).all()              # the status plane holds BurnStatus values, nothing else
-    sim.run(2, return_maps=False)                # the view aliases live state
-    assert (view.cpu().numpy() == sim._engine.fire_maps()).all()
+    sim.run(2, return_maps=False)
+    view2 = sim.fire_maps_device()               # refreshed by the call (a snapshot while the resident launch's blocked plane is current)
+    assert view2.data_ptr() == view.data_ptr()
+    assert (view2.cpu().numpy() == sim._engine.fire_maps()).all()
+    sim.run(1, return_maps=False)                # per-step kernels work on the row-major plane itself
+    sim.run(3, return_maps=False)
+    assert (sim.fire_maps_device().cpu().numpy() == sim._engine.fire_maps()).all()
     res = sim.gather_results()                   # no process group: the local block
     st, _ = sim.results()
     assert (res.cpu().numpy() == st).all()
