@@ -339,6 +339,7 @@ def main():
     eng.set_generic(a.generic)
     eng.set_fused(a.fused)
     result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{device}")
+    eng.set_result_sink(result.data_ptr())          # the harness's tensor of episode returns: registered once
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
     if a.warmup:

@@ -179,6 +179,14 @@ int sf_update_status_device(sf_sim *sim);
 /* Refresh the result block and copy it (device to device) into caller-owned device memory,
  * e.g. the torch tensor that is then all-gathered over RCCL. */
 int sf_copy_status_to(sf_sim *sim, void *device_dst /* int32 [n_envs][8] */);
+/* Register caller-owned device memory (int32 [n_envs][8]; NULL unregisters) as a second home of the
+ * result block: every refresh of the block also writes it there.  In particular the resident launch
+ * of sf_step(n >= 2) leaves the block behind itself (every workgroup counts its own environment when
+ * its steps are done), so a rollout `sf_step(n)` in async mode + `sf_copy_status_to(sim, same pointer)`
+ * costs one launch and one wait, and the episode returns (FireSimulation attributes of
+ * simulation.py:541-553) are already in the harness's tensor.  The buffer must stay valid until it is
+ * unregistered or the handle is destroyed. */
+int sf_set_result_sink(sf_sim *sim, void *device_dst /* int32 [n_envs][8] or NULL */);
 
 /* Drop-in for compute_rate_of_spread (rothermel.py:4-22): 17 float32 vectors of length n ->
  * R float64[n] (ft/min). */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sf_status_device": [_VP, C.POINTER(_VP)],
     "sf_update_status_device": [_VP],
     "sf_copy_status_to": [_VP, _VP],
+    "sf_set_result_sink": [_VP, _VP],
     "sf_get_counters": [_VP, _VP, _I32],
     "sf_enable_counters": [_VP, _I32],
     "sf_compute_ros": [_I64] + [_VP] * 18 + [_I32],

@@ -282,35 +282,34 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
 // clean tiles cost one round trip for all of them); the dirty tiles are collected in an LDS list and recounted by the
 // waves in turn, one wave per tile.  The result block row of the environment (and its elapsed_time) is written without
 // atomics, so nothing has to be zeroed first.
-constexpr int kCountsDirtyCap = 4096;
-__global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
-                                                       const EnvState *commit, int32_t *out, double *elapsed, int32_t *out2)
+// The body: the calling workgroup (any number of waves) produces the result row of environment e.  running / steps /
+// elapsed_time are the environment's committed state; s_tot [16][6] lives in the caller's LDS.  A wave takes 64 tiles at a time,
+// one per lane (dirty flag + cached histogram: one round trip for all of them), and recounts the dirty ones among them one after
+// the other with all its lanes; one barrier for the whole row.
+__device__ __forceinline__ void counts_env(const Geo &g, int e, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
+                                           int running, int steps, double elapsed_time, int32_t *out, double *elapsed, int32_t *out2,
+                                           int32_t (*s_tot)[6])
 {
-    __shared__ int32_t s_tot[16][6];
-    __shared__ uint16_t s_dirty[kCountsDirtyCap];
-    __shared__ uint32_t s_n;
-    const int e = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int per_env = g.TY * g.TX;
     const int c = lane & (g.LC - 1), r = lane >> g.logLC;
     int32_t tot[6] = {0, 0, 0, 0, 0, 0};
-    // (more tiles than the list holds: in rounds)
-    for (int round0 = 0; round0 < per_env; round0 += kCountsDirtyCap) {
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-        const int round1 = round0 + kCountsDirtyCap < per_env ? round0 + kCountsDirtyCap : per_env;
-        for (int t = round0 + (int)threadIdx.x; t < round1; t += (int)blockDim.x) {
+    for (int t0 = wave * 64; t0 < per_env; t0 += n_waves * 64) {
+        const int t = t0 + lane;
+        bool dirty = false;
+        if (t < per_env) {
             const long long idx = (long long)e * per_env + t;
-            if (tdirty[idx]) s_dirty[atomicAdd(&s_n, 1u)] = (uint16_t)(t - round0);
-            else {
+            dirty = tdirty[idx] != 0;
+            if (!dirty) {
                 const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
                 tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
                 tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
             }
         }
-        __syncthreads();
-        const uint32_t n_dirty = s_n;
-        for (uint32_t q = wave; q < n_dirty; q += n_waves) {
-            const int tt = round0 + s_dirty[q];
+        unsigned long long todo = __ballot(dirty);
+        while (todo) {
+            const int tt = t0 + (int)__ffsll((long long)todo) - 1;
+            todo &= todo - 1;
             const long long tidx = (long long)e * per_env + tt;
             const int tyw = tt / g.TX, chunk = tt - tyw * g.TX;
             const int cv = chunk * g.LC + c, y0 = (tyw * g.LR + r) * g.RB;
@@ -339,7 +338,6 @@ __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *sta
             if (lane >= 1 && lane < 6) thist[tidx * 8 + lane] = (uint16_t)(lane == 1 ? loc[1] : lane == 2 ? loc[2] : lane == 3 ? loc[3] : lane == 4 ? loc[4] : loc[5]);
             if (lane == 0) tdirty[tidx] = 0;
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
@@ -350,20 +348,26 @@ __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *sta
     __syncthreads();
     if (threadIdx.x == 0) {
         int32_t others = 0;
-#pragma unroll
         for (int k = 1; k < 6; ++k) {
             int32_t v = 0;
             for (int w = 0; w < n_waves; ++w) v += s_tot[w][k];
             out[e * 8 + 2 + k] = v;
+            if (out2) out2[e * 8 + 2 + k] = v;
             others += v;
         }
-        out[e * 8 + 2] = g.H * g.W - others;                                          // UNBURNED = H * W - the others
-        out[e * 8 + 0] = commit[e].running == 1;
-        out[e * 8 + 1] = commit[e].steps;
-        elapsed[e] = commit[e].elapsed;
-        if (out2)                                    // sf_copy_status_to: the caller's device buffer gets its copy right here
-            for (int k = 0; k < 8; ++k) out2[e * 8 + k] = out[e * 8 + k];
+        const int32_t unburned = g.H * g.W - others;                          // UNBURNED = H * W - the others
+        out[e * 8 + 2] = unburned; out[e * 8 + 0] = running == 1; out[e * 8 + 1] = steps;
+        elapsed[e] = elapsed_time;
+        if (out2) { out2[e * 8 + 2] = unburned; out2[e * 8 + 0] = running == 1; out2[e * 8 + 1] = steps; }    // sf_copy_status_to / sf_set_result_sink: the caller's copy
     }
+}
+
+__global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
+                                                       const EnvState *commit, int32_t *out, double *elapsed, int32_t *out2)
+{
+    __shared__ int32_t s_tot[16][6];
+    const int e = blockIdx.x;
+    counts_env(g, e, status, cells, tdirty, thist, commit[e].running, commit[e].steps, commit[e].elapsed, out, elapsed, out2, s_tot);
 }
 
 __global__ void k_elapsed(int E, const EnvState *commit, double *out)

@@ -97,6 +97,11 @@ struct StepArgs {
     const int32_t *mit;  // k_run only: control-line points [n_steps][E][mit_k][3] = (column, row, type) applied before each step, or null
     int mit_k;
     const int32_t *todo; // k_run only: steps to do per environment (what k_front left over), or null = n_steps for all
+    // k_run only: the per-environment result block written by the launch itself when its steps are done (null = not)
+    int32_t *res_block;  // [E][8] running, update() calls made, cells per BurnStatus 0..5 (sf_get_status)
+    double *res_elapsed; // [E]
+    int32_t *res_sink;   // the caller's registered copy of the block (sf_set_result_sink), or null
+    uint16_t *thist;     // [E][TY][TX][8] cached per-tile status histograms behind the block
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

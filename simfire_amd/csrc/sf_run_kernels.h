@@ -165,11 +165,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw) + n_waves * kRunWin / 2;
 
     EnvState st = a.commit[e];
-    if (!st.running && !a.mit) return;          // frozen: run() no longer calls update (uniform over the workgroup)
-    if (a.todo) {                               // the steps k_front left over for this environment (usually none)
-        n_steps = a.todo[e];
-        if (n_steps <= 0) return;
-    }
+    if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
+    if ((!st.running && !a.mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * g.VW;
     for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];
@@ -582,6 +579,13 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
         if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
         if (n_vec_done) atomicAdd(&cs[5], (unsigned long long)n_vec_done);   // 16-cell vectors visited
+    }
+    // The result block row of this environment (sf_get_status), produced by its own workgroup now that its steps are done: the
+    // status query after a rollout then costs no launch.  LDS: the strip buffers (>= 5376 bytes), free by now.
+    if (a.res_block) {
+        __syncthreads();
+        counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
+                   reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
     }
 }
 

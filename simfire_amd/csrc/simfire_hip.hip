@@ -118,6 +118,8 @@ struct sf_sim {
     uint16_t *thist = nullptr;         // per wave tile: cells per BurnStatus 1..5 (u16 [tiles][8])
     size_t n_tiles_max = 0;
     void *status_pinned = nullptr;     // pinned landing zone of the result block (int32 [E][8] + double [E])
+    bool status_fresh = false;         // status_block / elapsed_dev (and the sink) hold the current result block: the resident launch wrote it
+    int32_t *sink = nullptr;           // sf_set_result_sink: caller-owned device copy of the result block, written by every refresh
     bool tdirty_all = true;            // every histogram is stale (reset, fire_map replaced, geometry changed, per-cell kernel ran)
     unsigned long long *vbits = nullptr;   // vector bitmap of the resident launch (k_run)
     bool vbits_valid = false;          // vbits matches the sprite-mask planes (k_run / reset keep it; the per-step kernels do not)
@@ -360,6 +362,7 @@ extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // also clears the list counters of the tiled path
     choose_rows_per_band(s->g, rows);
+    s->status_fresh = false;
     s->tdirty_all = true;
     s->tiles_valid = false;            // the tile activity map is laid out per wave tile: rebuilt for the new geometry before the next tiled step
     return SF_OK;
@@ -703,6 +706,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
             return fail(SF_EINVAL, "reset: ignition (%d, %d) of environment %d is outside the %dx%d grid", xy[2 * i],
                         xy[2 * i + 1], env0 + i, g.H, g.W);
     HIPCHK(hipSetDevice(s->p.device));
+    s->status_fresh = false;
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
     if (n == g.E) {
         // everything is rewritten, nothing to convert: into the blocked plane if the resident launch is what steps this handle
@@ -763,6 +767,7 @@ static int scatter_points(sf_sim *s, const int32_t *pts_dev, int n, bool sync)
 {
     const Geo &g = s->g;
     uint8_t *cells = s->bl_cur ? s->cells : nullptr;
+    s->status_fresh = false;
     const dim3 grd((unsigned)((n + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_mitigate_clear, grd, blk, 0, s->stream, g, s->status, cells, (const uint32_t *)s->settled, s->burn,
                        (const EnvState *)s->commit, (const EnvState *)s->tmp, (const uint32_t *)s->flags, s->seq,
@@ -838,6 +843,7 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     if (rc) return rc;
     rc = ensure_rm(s);
     if (rc) return rc;
+    s->status_fresh = false;
     if (g.att)
         hipLaunchKernelGGL(k_settle_env, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, s->settled, s->burn,
                            (const EnvState *)s->commit, env, 1);
@@ -935,7 +941,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     if (ms) *ms = 0.f;
     if (n_steps == 0) return SF_OK;
     HIPCHK(hipSetDevice(s->p.device));
+    s->status_fresh = false;
     StepArgs a;
+    a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     a.parents = s->graph_on ? s->parents : nullptr;
@@ -1108,7 +1116,15 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         }
         static const int bsz_knob = getenv("SF_RUN_BATCH") ? atoi(getenv("SF_RUN_BATCH")) : 64;       // vectors per batch (<= 64)
         const int bsz = bsz_knob < 8 ? 8 : (bsz_knob > 64 ? 64 : bsz_knob);
+        // the launch leaves the result block behind (every workgroup counts its own environment when its steps are done)
+        static const int res_knob = getenv("SF_RUN_RESULT") ? atoi(getenv("SF_RUN_RESULT")) : 1;
+        if (res_knob) {
+            if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
+            s->tdirty_all = false;
+            a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink;
+        }
         hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps, run_vcap, bsz);
+        s->status_fresh = res_knob != 0;
         s->tiles_valid = false;                // the tile activity map / seam planes are not kept by k_run
         s->last_kind = 2;
         n_steps = 0;                           // nothing left for the per-step loop
@@ -1370,12 +1386,20 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
+    if (s->status_fresh) {
+        // the resident launch has left the block (and the registered sink's copy) behind: nothing to count
+        if (copy_to && copy_to != s->sink)
+            HIPCHK(hipMemcpyAsync(copy_to, s->status_block, sizeof(int32_t) * 8 * g.E, hipMemcpyDeviceToDevice, s->stream));
+        return SF_OK;
+    }
+    int32_t *sink2 = s->sink && s->sink != copy_to ? s->sink : nullptr;       // the registered sink follows every refresh
     if (g.ab == 1 && !s->generic) {
         // per-tile histograms: only the tiles touched since the last query are recounted; one launch writes the whole block
         if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
         s->tdirty_all = false;
         hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(1024), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), s->tdirty, s->thist,
-                           (const EnvState *)s->commit, s->status_block, s->elapsed_dev, copy_to);
+                           (const EnvState *)s->commit, s->status_block, s->elapsed_dev, copy_to ? copy_to : sink2);
+        if (copy_to && sink2) HIPCHK(hipMemcpyAsync(sink2, s->status_block, sizeof(int32_t) * 8 * g.E, hipMemcpyDeviceToDevice, s->stream));
     } else {
         { int rc0 = ensure_rm(s); if (rc0) return rc0; }
         HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
@@ -1386,6 +1410,7 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
         hipLaunchKernelGGL(k_elapsed, dim3((g.E + 255) / 256), dim3(256), 0, s->stream, g.E, (const EnvState *)s->commit,
                            s->elapsed_dev);
         if (copy_to) HIPCHK(hipMemcpyAsync(copy_to, s->status_block, sizeof(int32_t) * 8 * g.E, hipMemcpyDeviceToDevice, s->stream));
+        if (sink2) HIPCHK(hipMemcpyAsync(sink2, s->status_block, sizeof(int32_t) * 8 * g.E, hipMemcpyDeviceToDevice, s->stream));
     }
     HIPCHK(hipGetLastError());
     return SF_OK;
@@ -1446,6 +1471,16 @@ extern "C" int sf_copy_status_to(sf_sim *s, void *device_dst)
     return SF_OK;
 }
 
+extern "C" int sf_set_result_sink(sf_sim *s, void *device_dst)
+{
+    if (!s) return fail(SF_EINVAL, "sf_set_result_sink: null handle");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));       // nothing in flight may still write the old sink
+    s->sink = static_cast<int32_t *>(device_dst);
+    s->status_fresh = false;                       // the new sink is filled by the next refresh
+    return SF_OK;
+}
+
 extern "C" int sf_status_device(sf_sim *s, void **ptr)
 {
     if (!s || !ptr) return fail(SF_EINVAL, "sf_status_device: null argument");
@@ -1463,7 +1498,7 @@ extern "C" int sf_fire_map_device(sf_sim *s, void **ptr, int64_t *row_pitch, int
         const Geo &g = s->g;
         hipLaunchKernelGGL(k_bl_to_rm, dim3((g.PV + 63) / 64, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->cells, s->status, (uint8_t *)nullptr);
         HIPCHK(hipGetLastError());
-    } else s->tdirty_all = true;      // the caller holds a writable alias of the status plane: recount everything at the next query
+    } else { s->tdirty_all = true; s->status_fresh = false; }      // the caller holds a writable alias of the status plane: recount everything at the next query
     HIPCHK(hipStreamSynchronize(s->stream));
     *ptr = s->status; *row_pitch = s->g.P; *env_stride = s->g.plane_env;
     return SF_OK;

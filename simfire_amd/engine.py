@@ -359,6 +359,12 @@ class FireEngine:
         (int32 [n_envs, 8]), e.g. ``tensor.data_ptr()`` of a torch tensor on the same GPU."""
         _lib.check(self._L.sf_copy_status_to(self._h, C.c_void_p(int(device_ptr))))
 
+    def set_result_sink(self, device_ptr):
+        """Register device memory (int32 [n_envs, 8], e.g. ``tensor.data_ptr()``; ``None`` unregisters) that every
+        refresh of the result block also writes - the resident launch of ``step(n >= 2)`` leaves the block there
+        itself, so ``copy_status_to(same pointer)`` after a rollout is only the wait.  Keep the tensor alive."""
+        _lib.check(self._L.sf_set_result_sink(self._h, C.c_void_p(int(device_ptr) if device_ptr else None)))
+
     def enable_counters(self, on=True):
         """Statistics for the roofline accounting; off by default (they cost atomics)."""
         _lib.check(self._L.sf_enable_counters(self._h, int(bool(on))))

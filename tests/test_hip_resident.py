@@ -593,3 +593,61 @@ def test_blocked_cell_plane_follows_every_entry_point(shape):
     o.reset(inits)
     step(6)
     _same(eng, o, E, tag="second reset")
+
+
+def test_resident_launch_leaves_the_result_block_and_fills_the_sink():
+    """k_run's workgroups write their environment's result row themselves (cached tile histograms + a recount of the tiles
+    they or anything before them dirtied); a registered sink tensor receives every refresh.  Compared with the oracle's
+    counts after k_run rollouts, frozen environments, control lines only, a partial reset, a switch to the per-step
+    kernels (whose refresh is the counting kernel) and back."""
+    import torch
+    rng = np.random.default_rng(99)
+    H, W, E = 70, 210, 6
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=False)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0], size=(8, H, W))
+    R8[:, :, 150:] = 0.0
+    inits = [(5, 5), (100, 30), (205, 60), (60, 60), (140, 10), (209, 0)]      # two in barren ground: QUIT after the first updates
+    eng, o = _pair(kw, R8, inits)
+    sink = torch.full((E, 8), -1, dtype=torch.int32, device="cuda:0")
+    eng.set_result_sink(sink.data_ptr())
+
+    def check(tag, via_copy=True):
+        so, eo = o.status()
+        if via_copy:
+            eng.copy_status_to(sink.data_ptr())          # with the sink's own address: only a wait
+        else:
+            st, el = eng.status()
+            assert (st == so).all() and (el == eo).all(), tag
+        torch.cuda.synchronize()
+        assert (sink.cpu().numpy() == so).all(), tag
+
+    check("reset", via_copy=False)
+    for i, n in enumerate([4, 2, 9, 30]):
+        pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(20)]
+        eng.apply_mitigation(pts)
+        o.apply_mitigation(pts)
+        eng.set_async(True)
+        eng.step(n)
+        eng.set_async(False)
+        o.step(n)
+        assert eng.last_launch_kind() == 2
+        check(("k_run", i), via_copy=i % 2 == 0)
+    assert not o.status()[0][:, 0].all()                 # some environments are frozen by now: their rows still follow
+    pts = [(e, 20 + e, 20, 4) for e in range(E)]
+    eng.apply_mitigation(pts)
+    o.apply_mitigation(pts)
+    check("control lines only")
+    eng.reset_env(5, 30, 30)
+    o.reset_env(5, 30, 30)
+    check("reset_env")
+    eng.step(1); o.step(1)
+    check("per-step kernels")
+    eng.step(5); o.step(5)
+    other = torch.zeros((E, 8), dtype=torch.int32, device="cuda:0")
+    eng.copy_status_to(other.data_ptr())                 # another destination: a copy, the sink keeps following
+    torch.cuda.synchronize()
+    assert (other.cpu().numpy() == o.status()[0]).all() and (sink.cpu().numpy() == o.status()[0]).all()
+    eng.set_result_sink(None)
+    eng.step(3); o.step(3)
+    _same(eng, o, E, tag="sink unregistered")
+    assert (sink.cpu().numpy() != o.status()[0]).any()
