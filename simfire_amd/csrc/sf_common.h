@@ -102,6 +102,8 @@ struct StepArgs {
     double *res_elapsed; // [E]
     int32_t *res_sink;   // the caller's registered copy of the block (sf_set_result_sink), or null
     uint16_t *thist;     // [E][TY][TX][8] cached per-tile status histograms behind the block
+    const uint32_t *order; // k_run only: workgroup i takes environment order[i] (most expensive first, k_order), or null = i
+    uint32_t *cost;      // k_run only: [E] shader clocks / 16 the environment's workgroup took in this launch (the next launch's order), or null
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

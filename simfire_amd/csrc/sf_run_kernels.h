@@ -40,17 +40,17 @@ namespace {
 // The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
 // them when it switches back), the vector bitmap is not maintained there (k_rebuild_vbits).
 // ------------------------------------------------------------------------------------------
-constexpr int kRunWin = 384;       // frontier cells per walk window of a wave (u16 items in LDS)
-constexpr int kStripDw = 21;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
+constexpr int kRunWin = 384;       // frontier cells per walk window of a wave (u16 items in LDS): the usual value of the launch parameter `cwin`
+constexpr int kStripDw = 19;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
 constexpr int kRunCtl = 16;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps)
-constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row)
+constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row): k_run<4>; k_run<1> for one row of one word
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap)
+__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap, int cwin)
 {
     const int maps = g.VW == 1 ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
-    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (kRunWin * 2 + 64 * kStripDw * 4) + kRunCtl * 4;
+    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (cwin * 2 + 64 * kStripDw * 4) + kRunCtl * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;              // + phase clocks [waves][16]
 #endif
@@ -150,19 +150,21 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
     return acc;
 }
 
-__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
+template <int MAXD>
+__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz, int cwin)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
-    const int e = blockIdx.x;
+    const int e = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
+    const unsigned long long clk0 = __builtin_readcyclecounter();
     unsigned long long *vb = reinterpret_cast<unsigned long long *>(s_dyn);        // [H][VW]
     const bool fine = g.VW == 1;                                                   // refined interest rule (see below)
     unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
     uint32_t *strips = vlist + vcap + wave * (64 * kStripDw);                      // [64][kStripDw] per wave
-    uint16_t *clist = reinterpret_cast<uint16_t *>(vlist + vcap + n_waves * (64 * kStripDw)) + wave * kRunWin;   // [kRunWin] per wave
-    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw) + n_waves * kRunWin / 2;
+    uint16_t *clist = reinterpret_cast<uint16_t *>(vlist + vcap + n_waves * (64 * kStripDw)) + wave * cwin;   // [cwin] per wave (cwin even)
+    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw) + n_waves * cwin / 2;
 
     EnvState st = a.commit[e];
     if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
 
         // ---- interest: D = the bitmap dilated by one vector / one row (kept in registers: the passes below change the
         // bitmap).  Dilation distributes over OR: OR the three rows first, dilate once.
-        unsigned long long D[kRunMaxD];
+        unsigned long long D[MAXD];
         uint32_t cnt = 0;
         if (fine) {
             // Grids up to 1024 cells wide (one word per row).  A vector has to be visited if it holds a sprite bit (b1); if it
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             // vector always finds its horizontal neighbour in the list when that neighbour's column matters to it, see the
             // edge cells below - if the vector above / below it has a sprite in an edge cell (l0 | l2 | f0 | f2).
 #pragma unroll
-            for (int d = 0; d < kRunMaxD; ++d) {
+            for (int d = 0; d < MAXD; ++d) {
                 D[d] = 0;
                 const int y = tid * rpt + d;
                 if (d < rpt && y < g.H) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             }
         } else {
 #pragma unroll
-            for (int d = 0; d < kRunMaxD; ++d) {
+            for (int d = 0; d < MAXD; ++d) {
                 D[d] = 0;
                 const int i = d / g.VW, w = d - i * g.VW;           // row of this thread, word of the row
                 const int y = tid * rpt + i;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             {
                 uint32_t p = pos0;
 #pragma unroll
-                for (int d = 0; d < kRunMaxD; ++d) {
+                for (int d = 0; d < MAXD; ++d) {
                     const unsigned long long m = D[d];
                     const int i = d / g.VW, w = d - i * g.VW;
                     const uint32_t base_item = (uint32_t)(tid * rpt + i) | ((uint32_t)(w * 64) << 16);
@@ -504,26 +506,26 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 if (st_ch) ev.tdirty[(y >> th_log) * g.TX + (v >> g.logLC)] = 1;
                 pc.mark(5);      // status arrived, SWAR, stores issued
 
-                // ---- frontier cells of this batch -> the wave's list -> walk (windows of kRunWin cells: a batch holds up to 1024)
+                // ---- frontier cells of this batch -> the wave's list -> walk (windows of cwin cells: a batch holds up to 1024)
                 const uint32_t mine = (uint32_t)__popc(m16);
                 if (__ballot(mine != 0) != 0ull) {
                     const uint32_t incl_c = wave_scan_incl(mine, lane);
                     const uint32_t total = wave_last(incl_c);
                     const uint32_t excl = incl_c - mine;
 #pragma unroll 1
-                    for (uint32_t win = 0; win < total; win += (uint32_t)kRunWin) {
+                    for (uint32_t win = 0; win < total; win += (uint32_t)cwin) {
                         uint32_t pos = excl, m = m16;
                         while (m) {
                             const int b = __ffs(m) - 1;
                             m &= m - 1;
                             const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
-                            if (slot < (uint32_t)kRunWin) {
+                            if (slot < (uint32_t)cwin) {
                                 const uint32_t code = (pick(snew, b >> 2) >> (8 * (b & 3))) & 7u;
                                 clist[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)b << 6) | (code << 10));
                             }
                             pos++;
                         }
-                        const uint32_t tot = total - win < (uint32_t)kRunWin ? total - win : (uint32_t)kRunWin;
+                        const uint32_t tot = total - win < (uint32_t)cwin ? total - win : (uint32_t)cwin;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -565,7 +567,13 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
 #endif
     // ---- hand the environment back: state, vector bitmap
     __syncthreads();
-    if (tid == 0) a.commit[e] = st;
+    if (tid == 0) {
+        a.commit[e] = st;
+        if (a.cost) {            // what this environment cost: the order of the next launch (k_order)
+            const unsigned long long c = (__builtin_readcyclecounter() - clk0) >> 4;
+            a.cost[e] = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+        }
+    }
     for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
     if (fine)
         for (int i = tid; i < g.H; i += nthr) {
@@ -587,6 +595,42 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
                    reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
     }
+}
+
+// Launch order of the environments for the resident launch when there are more of them than the chip holds workgroups: the
+// most expensive first (cost = clocks of the environment's workgroup in the launch before; 1024 linear buckets, counting sort),
+// so that the launch does not end with a large fire that started late.  One workgroup.  Results never depend on the order.
+__global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uint32_t *order)
+{
+    __shared__ uint32_t s_max, s_hist[1024], s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_max = 0;
+    s_hist[tid] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int e = tid; e < E; e += 1024) mx = cost[e] > mx ? cost[e] : mx;
+    if (mx) atomicMax(&s_max, mx);
+    __syncthreads();
+    mx = s_max;
+    if (mx == 0) {                 // nothing known yet (first launch after a reset)
+        for (int e = tid; e < E; e += 1024) order[e] = (uint32_t)e;
+        return;
+    }
+    const float scale = 1023.0f / (float)mx;
+    auto bucket = [&](uint32_t c) { int b = 1023 - (int)((float)c * scale); return b < 0 ? 0 : (b > 1023 ? 1023 : b); };
+    for (int e = tid; e < E; e += 1024) atomicAdd(&s_hist[bucket(cost[e])], 1u);
+    __syncthreads();
+    // exclusive prefix sum over the 1024 buckets (one per thread)
+    const uint32_t mine = s_hist[tid];
+    const uint32_t incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    __syncthreads();
+    s_hist[tid] = base + incl - mine;
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) order[atomicAdd(&s_hist[bucket(cost[e])], 1u)] = (uint32_t)e;
 }
 
 // The vector bitmap of environments [env0, env0 + n) from their sprite-mask planes (after steps of the per-step

@@ -126,10 +126,11 @@ struct sf_sim {
     bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
     int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell, 4 k_run_tiles, 5 k_front
     int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
+    uint32_t *run_cost = nullptr, *run_order = nullptr;   // k_run: clocks / 16 an environment's workgroup took in the last resident launch [E]; launch order built from it (k_order)
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run = 0, attr_front = 0;       // dynamic LDS sizes k_run / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[3] = {0, 0, 0}, attr_front = 0;       // dynamic LDS sizes k_run<1> / <2> / <4> / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -271,6 +272,9 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.cells_env = (long long)((g.H + 3) / 4 + 2) * g.PV * 128;
     TRY(dev_alloc(s, &s->vbits, (size_t)3 * g.E * g.vb_env));
     TRY(dev_alloc(s, &s->todo, (size_t)g.E));
+    TRY(dev_alloc(s, &s->run_cost, (size_t)g.E));
+    TRY(dev_alloc(s, &s->run_order, (size_t)g.E));
+    TRYHIP(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
     if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * kFrontStartCap));
     TRYHIP(hipHostMalloc(reinterpret_cast<void **>(&s->ovf_pinned), sizeof(int32_t), hipHostMallocMapped));
     TRYHIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->ovf_mapped), s->ovf_pinned, 0));
@@ -305,7 +309,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    void *ptrs[] = {s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->wheel, s->mit_stage,
+    void *ptrs[] = {s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
@@ -714,6 +718,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
         const bool bl = prefers_bl(s) && (s->bl_cur || s->last_kind == 2 || s->last_kind == -1);
         if (bl) { int rc0 = alloc_bl(s); if (rc0) return rc0; }
         s->bl_cur = bl;
+        HIPCHK(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));      // new episodes everywhere: no launch order to carry over
     }
     if (s->bl_cur)
         HIPCHK(hipMemsetAsync(s->cells_alloc + (size_t)env0 * g.cells_env, 0, (size_t)n * g.cells_env, s->stream));
@@ -932,6 +937,22 @@ extern "C" int sf_last_step_launch(sf_sim *s, int32_t *kind)
 
 constexpr int SF_INTERNAL_NO_RESIDENT = 1;       // step_impl: the resident launch was asked for (mitigated rollout) but cannot run
 
+// The resident launch: k_run<D>, D = bitmap words a thread owns (rows per thread x words per row) rounded up to 1, 2 or 4 (grids up to
+// 1024 x 1024 in 16 waves: D = 1, thirteen registers fewer than D = 4).
+static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, int vcap, int cwin, size_t lds, int bsz)
+{
+    const int need = ((s->g.H + waves * 64 - 1) / (waves * 64)) * s->g.VW;
+    const int which = need <= 1 ? 0 : (need <= 2 ? 1 : 2);
+    void (*kern)(StepArgs, int, int, int, int) = which == 0 ? k_run<1> : (which == 1 ? k_run<2> : k_run<kRunMaxD>);
+    size_t &attr = s->attr_run[which];
+    if (lds > 64 * 1024 && lds > attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)s->g.E), dim3((unsigned)waves * 64), lds, s->stream, a, n_steps, vcap, bsz, cwin);
+    return SF_OK;
+}
+
 static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev = nullptr, int mit_k = 0)
 {
     if (!s) return fail(SF_EINVAL, "sf_step: null handle");
@@ -944,6 +965,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     s->status_fresh = false;
     StepArgs a;
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
+    a.order = nullptr; a.cost = nullptr;
     a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     a.parents = s->graph_on ? s->parents : nullptr;
@@ -962,7 +984,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     const bool generic = s->g.ab > 1 || s->generic;
     // Environment-resident launch (k_run): all n steps of an environment in one workgroup.  Not with the
     // per-step by-products (spread graph, history) and not for the wide sprite planes.
-    int run_waves = 0, run_vcap = 0;
+    int run_waves = 0, run_vcap = 0, run_cwin = kRunWin;
     size_t run_lds = 0;
     int runt_waves = 0;                        // tile flavour of the resident launch (sf_set_fused(3))
     size_t runt_lds = 0;
@@ -978,7 +1000,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     }
     int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
     size_t fr_lds = 0;
-    int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
+    int fit_waves = 0, fit_vcap = 0, fit_cwin = kRunWin;   // k_run as k_front's overflow fallback (whether or not it is the choice)
     size_t fit_lds = 0;
     if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
         static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
@@ -993,14 +1015,24 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         long long all_vec = (long long)g.H * g.PV;
         int vcap = vcap_knob < 64 ? 64 : vcap_knob;
         if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
-        const size_t lds = run_lds_bytes(g, nw, vcap);
+        int cwin = kRunWin;
+        size_t lds = run_lds_bytes(g, nw, vcap, cwin);
+        // More environments than CUs (the throughput regime): a CU works through several environments one after the other, and a
+        // workgroup of 16 waves mostly waits for memory.  Half the waves, a shorter vector list (longer ones are taken in chunks) and
+        // walk window: two workgroups fit the 160 KB of LDS and overlap each other's round trips.
+        static const int compact_knob = getenv("SF_RUN_COMPACT") ? atoi(getenv("SF_RUN_COMPACT")) : 1;
+        if (compact_knob && g.E > s->n_cu && nw > 8 && min_nw <= 8 && !getenv("SF_RUN_WAVES")) {
+            const int vcap2 = vcap > 1024 ? 1024 : vcap;
+            const size_t lds2 = run_lds_bytes(g, 8, vcap2, 256);
+            if (lds2 <= 80 * 1024) { nw = 8; vcap = vcap2; cwin = 256; lds = lds2; }
+        }
         const bool fits = nw <= 16 && g.W <= 4096 && g.H <= 65535 && g.VW <= kRunMaxD && lds <= 160 * 1024;
         // automatic: multi-step calls on grids up to 1024 cells wide (measured on 1024^2, 1 .. 1024 environments: 1.2 - 1.4 x
         // faster than the per-step launches at every batch size; on 2048^2 an environment's fire is too much work for the one
         // CU that owns it and the per-step launches, which spread tiles over the whole chip, win by 1.4 - 2 x)
         const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
-        if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
-        if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
+        if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; run_cwin = cwin; }
+        if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; fit_cwin = cwin; }
         // k_front: the frontier records of an environment in LDS.  Needs k_run as its overflow fallback; not in attenuation
         // mode, not with control lines inside the launch, not in the visit-everything cross-check mode.
         static const int front_min_steps = getenv("SF_FRONT_MIN_STEPS") ? atoi(getenv("SF_FRONT_MIN_STEPS")) : 4;
@@ -1101,19 +1133,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             a.todo = s->todo;
             { int rc0 = ensure_bl(s); if (rc0) return rc0; }       // (what k_front left in the row-major planes, for every environment)
             a.cells = s->cells;
-            if (fit_lds > 64 * 1024 && fit_lds > s->attr_run) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
-                s->attr_run = fit_lds;
-            }
-            hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)fit_waves * 64), fit_lds, s->stream, a, n_steps, fit_vcap, 64);
+            { int rc0 = launch_k_run(s, a, n_steps, fit_waves, fit_vcap, fit_cwin, fit_lds, 64); if (rc0) return rc0; }
         }
         n_steps = 0;
     } else if (run_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        if (run_lds > 64 * 1024 && run_lds > s->attr_run) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)run_lds));
-            s->attr_run = run_lds;
-        }
         static const int bsz_knob = getenv("SF_RUN_BATCH") ? atoi(getenv("SF_RUN_BATCH")) : 64;       // vectors per batch (<= 64)
         const int bsz = bsz_knob < 8 ? 8 : (bsz_knob > 64 ? 64 : bsz_knob);
         // the launch leaves the result block behind (every workgroup counts its own environment when its steps are done)
@@ -1121,9 +1145,24 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         if (res_knob) {
             if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
             s->tdirty_all = false;
-            a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink;
         }
-        hipLaunchKernelGGL(k_run, dim3((unsigned)s->g.E), dim3((unsigned)run_waves * 64), run_lds, s->stream, a, n_steps, run_vcap, bsz);
+        // More environments than the chip holds workgroups: the launch would end with whatever large fire happened to start late.
+        // The rollout is cut into segments, and every segment starts its environments in the order of what they cost in the one
+        // before (k_order: most expensive first) - the tail of a segment is then made of the cheapest environments.
+        static const int seg_knob = getenv("SF_RUN_SEGMENT") ? atoi(getenv("SF_RUN_SEGMENT")) : 64;
+        const bool balance = seg_knob > 0 && s->g.E > s->n_cu * (run_waves <= 8 ? 2 : 1);       // (with every environment resident from the start there is nothing to order)
+        a.cost = s->run_cost;
+        for (int done = 0; done < n_steps;) {
+            const int seg = balance && n_steps - done > seg_knob + seg_knob / 2 ? seg_knob : n_steps - done;
+            if (balance) {
+                hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
+                a.order = s->run_order;
+            }
+            a.mit = mit_dev ? mit_dev + (size_t)done * s->g.E * mit_k * 3 : nullptr;
+            if (res_knob && done + seg == n_steps) { a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink; }
+            { int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_cwin, run_lds, bsz); if (rc0) return rc0; }
+            done += seg;
+        }
         s->status_fresh = res_knob != 0;
         s->tiles_valid = false;                // the tile activity map / seam planes are not kept by k_run
         s->last_kind = 2;

@@ -651,3 +651,41 @@ def test_resident_launch_leaves_the_result_block_and_fills_the_sink():
     eng.step(3); o.step(3)
     _same(eng, o, E, tag="sink unregistered")
     assert (sink.cpu().numpy() != o.status()[0]).any()
+
+
+def test_more_environments_than_workgroup_slots_compact_launch_in_segments():
+    """More environments than CUs: k_run runs as 8-wave workgroups with a short vector list and walk window (two per
+    CU), and above two per CU the rollout is cut into segments whose environments start in the order of what they cost
+    in the segment before (k_order).  Neither changes a result: 1100 environments on a 600 x 48 grid (two bitmap rows
+    per thread: k_run<2>; fires that need more list entries than the short list holds: chunks), 230 steps in calls of
+    20 + 210 (= segments of 64, 64, 82), control lines between the calls, a partial reset - equal to the oracle."""
+    rng = np.random.default_rng(606)
+    H, W, E = 600, 48, 1100
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
+    R8[:, 400:, :] = rng.choice([0.0, 3.0], size=(8, 200, W))                  # slow / barren ground: costs differ a lot between environments
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    sample = [0, 1, 255, 256, 511, 512, 700, 1023, 1024, 1099]
+
+    def check(tag):
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), tag
+        for e in sample:
+            assert (eng.fire_map(e) == o.fire_map(e)).all(), (tag, e)
+            assert (eng.burn(e) == o.burn(e)).all(), (tag, e)
+
+    eng.step(20); o.step(20)
+    assert eng.last_launch_kind() == 2
+    check("first call")
+    pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(3000)]
+    eng.apply_mitigation(pts); o.apply_mitigation(pts)
+    eng.step(210); o.step(210)
+    assert eng.last_launch_kind() == 2
+    check("segments")
+    for e in (3, 600, 1099):
+        eng.reset_env(e, 7, 9); o.reset_env(e, 7, 9)
+    eng.step(100); o.step(100)
+    check("after partial resets")
+    assert not o.status()[0][:, 0].all() and o.status()[0][:, 0].any()
