@@ -1,0 +1,51 @@
+"""Development aid: the shader-clock timeline of ONE step of ONE environment inside a resident launch (k_run), wave by
+wave (library built with -DSF_PHASES: profiles/run_timeline.sh).  usage: run_timeline.py <steps> <warmup> [env|-1 = slowest]"""
+import ctypes
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from simfire_amd import workloads            # noqa: E402
+from simfire_amd.engine import FireEngine    # noqa: E402
+
+NAMES = {15: "step start", 1: "interest+ranks", 2: "list+barrierA", 3: "cursor+next fetch issued", 11: "rows arrived", 4: "nb masks, strips",
+         5: "SWAR, stores issued", 6: "prefix+frontier list", 7: "walk: winner", 8: "walk: burn/table arrived, update", 9: "walk: stores, fence",
+         10: "end of batch", 0: "barrier B (end of step)"}
+
+
+def main():
+    steps, warm = int(sys.argv[1]), int(sys.argv[2])
+    env = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+    envs = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+    w = workloads.c3(1024, envs)
+    eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    L = eng._L
+    L.sf_debug_timeline.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    L.sf_debug_wave_log.argtypes = [ctypes.c_int32, ctypes.c_void_p]
+    log = np.zeros((16384, 4), dtype=np.uint64)
+    if env < 0:       # find the slowest environment of this window first
+        eng.reset(w.init_xy)
+        eng.step(warm)
+        L.sf_debug_wave_log(1, None)
+        eng.step(steps)
+        eng.status()
+        L.sf_debug_wave_log(0, log.ctypes.data_as(ctypes.c_void_p))
+        env = int(np.argmax(log[:envs, 0]))
+        print("slowest env", env, "clocks", int(log[env, 0]), "vectors", int(log[env, 1]))
+    eng.reset(w.init_xy)
+    eng.step(warm)
+    L.sf_debug_timeline(env, steps - 1, None)
+    eng.step(steps)
+    eng.status()
+    tl = np.zeros((16, 64), dtype=np.uint64)
+    L.sf_debug_timeline(0, 0, tl.ctypes.data_as(ctypes.c_void_p))
+    t0 = min(int(v & np.uint64(0x00FFFFFFFFFFFFFF)) for v in tl[:, 0] if v)
+    for wv in range(16):
+        ev = [(int(v >> np.uint64(56)), int(v & np.uint64(0x00FFFFFFFFFFFFFF)) - t0) for v in tl[wv] if v]
+        print("wave %2d: " % wv + "  ".join("%s@%d" % (NAMES.get(k, str(k)).split(":")[0].split(",")[0][:14], t) for k, t in ev))
+
+
+if __name__ == "__main__":
+    main()

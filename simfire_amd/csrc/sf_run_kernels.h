@@ -40,17 +40,16 @@ namespace {
 // The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
 // them when it switches back), the vector bitmap is not maintained there (k_rebuild_vbits).
 // ------------------------------------------------------------------------------------------
-constexpr int kRunWin = 384;       // frontier cells per walk window of a wave (u16 items in LDS): the usual value of the launch parameter `cwin`
 constexpr int kStripDw = 19;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
 constexpr int kRunCtl = 16;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps)
 constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row): k_run<4>; k_run<1> for one row of one word
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap, int cwin)
+__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap)
 {
     const int maps = g.VW == 1 ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
-    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (cwin * 2 + 64 * kStripDw * 4) + kRunCtl * 4;
+    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (64 * kStripDw * 4) + kRunCtl * 4;
 #ifdef SF_PHASES
     b += 16 * 16 * 4;              // + phase clocks [waves][16]
 #endif
@@ -67,19 +66,58 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
     uint8_t *tdirty;               // [TY][TX] of this environment: status histogram of the wave tile is stale
 };
 
-// The walk: one frontier cell per lane.  item = lane of the vector in the batch | cell in the vector << 6 | status after the
-// prune << 10.  The 3 x 3 sprite masks come from the batch's strip buffer in LDS (the rows the vector pass has just loaded, with
-// the cell left / right of the vector): no memory round trip before the winner is known.
+// The walk: frontier cells of a batch, one (or two) per lane and pass.  There is no list: walker j finds its cell itself.
+// excl = frontier cells in the lanes below (exclusive prefix sum over the batch), w16 = the lane's 16-bit frontier mask | its
+// control-line cells << 16, s7 = its status row after the prune.  The owner of item j is the last lane with excl <= j (binary
+// search: six cross-lane reads), the cell is the (j - excl)-th set bit of the owner's mask.  (A per-lane loop over the set bits
+// into an LDS list cost 2 - 5 k clocks per batch along horizontal fronts; the search costs the same whatever the front looks like.)
+// The 3 x 3 sprite masks come from the batch's strip buffer in LDS (the rows the vector pass has just loaded, with the cell left /
+// right of the vector): no memory round trip before the winner is known.
+struct WalkCell {
+    bool cand;
+    uint32_t yx;         // y | x << 16
+    uint32_t own_spost;  // the cell's own sprite mask | status after the prune << 8 (0, 3, 4, 5: eligible by construction, fire.py:192-205)
+    uint32_t owed;
+    double bn, r_tab;
+};
+
 __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev, const Masks &mk, int complete,
-                                            uint32_t lo_mask, uint32_t hi_mask, const uint16_t *clist, const uint32_t *strips,
-                                            uint32_t pend, int lane, int th_log, PhaseClock &pc)
+                                            uint32_t lo_mask, uint32_t hi_mask, const uint32_t *strips,
+                                            uint32_t pend, int lane, int th_log, PhaseClock &pc,
+                                            uint32_t excl, uint32_t w16, uint4 s7)
 {
     const Geo &g = a.g;
     WalkAcc acc = {0u, 0u, 0u, 0u};
-    for (uint32_t j = lane; j < pend; j += 64) {
-        const uint32_t it = clist[j];
-        const int jl = it & 63, b = (it >> 6) & 15;
-        const uint32_t s_post = it >> 10;                  // 0, 3, 4, 5: eligible by construction (fire.py:192-205)
+    // first half of a cell: who, winner source, operands requested
+    auto front = [&](uint32_t j) {
+        WalkCell c;
+        const bool valid = j < pend;
+        int jl = 0;
+        uint32_t base = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int t = jl + step;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(t << 2, (int)excl);
+            if (v <= j) { jl = t; base = v; }
+        }
+        const uint32_t wl = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)w16);
+        int b = 0;
+        {
+            uint32_t r = valid ? j - base : 0u, x = wl & 0xFFFFu, n;
+            n = (uint32_t)__popc(x & 0xFFu); if (r >= n) { r -= n; b += 8; x >>= 8; }
+            n = (uint32_t)__popc(x & 0xFu); if (r >= n) { r -= n; b += 4; x >>= 4; }
+            n = (uint32_t)__popc(x & 0x3u); if (r >= n) { r -= n; b += 2; x >>= 2; }
+            if (r >= (x & 1u)) b += 1;
+            b &= 15;
+        }
+        uint32_t s_post = 0;
+        const bool on_line = valid && ((wl >> (16 + b)) & 1u);
+        if (__ballot(on_line) != 0ull) {                   // (rare) the exact line type from the owner's status row
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)s7.x), d1 = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)s7.y);
+            const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)s7.z), d3 = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)s7.w);
+            const uint32_t dd = (b >> 2) == 0 ? d0 : ((b >> 2) == 1 ? d1 : ((b >> 2) == 2 ? d2 : d3));
+            if (on_line) s_post = (dd >> (8 * (b & 3))) & 7u;
+        }
         const uint32_t *rec = strips + jl * kStripDw;
         const uint32_t hdr = rec[0];
         const int y = hdr & 0xFFFF, x = (int)(hdr >> 16) * 16 + b;
@@ -90,40 +128,46 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
         const uint32_t up3 = __builtin_amdgcn_alignbyte(rec[2 + q], rec[1 + q], sh);
         const uint32_t mid3 = __builtin_amdgcn_alignbyte(rec[8 + q], rec[7 + q], sh);
         const uint32_t dn3 = __builtin_amdgcn_alignbyte(rec[14 + q], rec[13 + q], sh);
-        const uint32_t own = (mid3 >> 8) & 0xFFu;
         const int bestk = pick_winner8(up3, mid3, dn3, mk, lo_mask, hi_mask);
-        const bool is_cand = bestk >= 0;
-        pc.mark(7);          // list item, neighbourhood, winner
+        c.cand = valid && bestk >= 0;
+        c.yx = (uint32_t)y | ((uint32_t)x << 16);
+        c.own_spost = ((mid3 >> 8) & 0xFFu) | (s_post << 8);
+        c.owed = 0; c.bn = 0.0; c.r_tab = 0.0;
         {
-            const unsigned long long cb = __ballot(is_cand);
+            const unsigned long long cb = __ballot(c.cand);
             acc.n_active += (uint32_t)__popcll(cb);
             acc.cand |= cb != 0ull;
         }
-        bool ignited = false;
-        if (is_cand) {
+        if (c.cand) {
             // both operands are requested before either is used: one memory round trip, not two
-            const double *rt_p = ev.rt + ((uint32_t)bestk * (uint32_t)(g.H * g.P) + idx);          // 8 H P < 2^29
+            c.bn = ev.burn[idx];
+            c.r_tab = ev.rt[(uint32_t)bestk * (uint32_t)(g.H * g.P) + idx];          // 8 H P < 2^29
+            if (s_post >= SF_FIRELINE && g.att) c.owed = (uint32_t)complete - ev.settled[idx];
+        }
+        return c;
+    };
+    // second half: accumulate, ignite
+    auto back = [&](const WalkCell &c) {
+        bool ignited = false;
+        if (c.cand) {
+            const int y = (int)(c.yx & 0xFFFFu), x = (int)(c.yx >> 16);
+            const uint32_t idx = (uint32_t)(y * g.P + x), s_post = c.own_spost >> 8;
             const bool line = s_post >= SF_FIRELINE;
-            double bn = ev.burn[idx];
-            double r_tab = *rt_p;
-            uint32_t owed = 0;
-            if (line && g.att) owed = (uint32_t)complete - ev.settled[idx];
-            asm volatile("" : "+v"(bn), "+v"(r_tab), "+v"(owed));     // keeps the loads from being sunk behind the first use of bn
-            double ros = r_tab * g.update_rate;                                  // fire.py:696,705
+            double bn = c.bn;
+            double ros = c.r_tab * g.update_rate;                                // fire.py:696,705
             if (line) {                                                          // fire.py:271-282
                 if (g.att) {
                     const double f = line_factor(s_post);
-                    bn = lazy_sub(bn, f, owed);          // the updates since this cell was last touched (fire.py:278, ros = 0)
+                    bn = lazy_sub(bn, f, c.owed);        // the updates since this cell was last touched (fire.py:278, ros = 0)
                     ros = ros - f;
                     ev.settled[idx] = (uint32_t)complete + 1u;                   // this update runs to the end: it has a candidate
                 } else ros = 0.0;
             }
             bn = bn + ros;                                                       // fire.py:710
             ev.burn[idx] = bn;
-            pc.mark(8);      // burn / table entry arrived
             if (bn > g.pixel_scale) {                                            // fire.py:568
                 ignited = true;
-                const uint8_t nb = (uint8_t)((own & ~mk.b_clr) | mk.b_new);       // fire.py:571-579
+                const uint8_t nb = (uint8_t)(((c.own_spost & 0xFFu) & ~mk.b_clr) | mk.b_new);       // fire.py:571-579
                 // These byte stores follow, in program order, the 16-byte stores of the vector pass to the same lines: stores of one
                 // wave reach the L2 in issue order (same line = same channel queue; profiles/store_order_probe.hip: 0 of 5.2e9
                 // inverted).  -DSF_STORE_ORDER_WAIT restores an explicit wait for the earlier stores' acknowledgements.
@@ -142,16 +186,38 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
             }
         }
         acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
+    };
+#ifndef SF_WALK1
+    // two cells per lane and pass: a second pass would be a second memory round trip behind the first
+    for (uint32_t j0 = 0; j0 < pend; j0 += 128) {
+        const bool two = j0 + 64 < pend;                   // (uniform)
+        WalkCell c0 = front(j0 + (uint32_t)lane), c1;
+        c1.cand = false; c1.yx = 0; c1.own_spost = 0; c1.owed = 0; c1.bn = 0.0; c1.r_tab = 0.0;
+        if (two) c1 = front(j0 + 64u + (uint32_t)lane);
+        pc.mark(7);          // cells found, winners, operands requested
+        asm volatile("" : "+v"(c0.bn), "+v"(c0.r_tab), "+v"(c0.owed), "+v"(c1.bn), "+v"(c1.r_tab), "+v"(c1.owed));
+        back(c0);
+        if (two) back(c1);
+        pc.mark(8);          // burn / table entries arrived, updates, ignition stores issued
     }
+#else
+    for (uint32_t j0 = 0; j0 < pend; j0 += 64) {
+        WalkCell c0 = front(j0 + (uint32_t)lane);
+        pc.mark(7);          // cell found, winner, operands requested
+        asm volatile("" : "+v"(c0.bn), "+v"(c0.r_tab), "+v"(c0.owed));     // keeps the loads from being sunk behind the first use of bn
+        back(c0);
+        pc.mark(8);          // burn / table entry arrived, update, ignition stores issued
+    }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    pc.mark(9);              // ignition stores
+    pc.mark(9);              // end of the walk
     return acc;
 }
 
 template <int MAXD>
-__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz, int cwin)
+__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
@@ -163,8 +229,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
     uint32_t *strips = vlist + vcap + wave * (64 * kStripDw);                      // [64][kStripDw] per wave
-    uint16_t *clist = reinterpret_cast<uint16_t *>(vlist + vcap + n_waves * (64 * kStripDw)) + wave * cwin;   // [cwin] per wave (cwin even)
-    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw) + n_waves * cwin / 2;
+    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw);
 
     EnvState st = a.commit[e];
     if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
@@ -239,6 +304,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             __syncthreads();
             if (!st.running) continue;          // (uniform) the fire is out: nothing to step
         }
+#ifdef SF_PHASES
+        pc.tl = (e == g_timeline_env && s == g_timeline_step) ? g_timeline + wave * 64 : nullptr;
+        pc.mark(15);         // step start
+#endif
         if (tid < 3) ctl[3 * tid + kn] = 0;     // ring slots of the next step (last read before the barrier that ended step s - 1)
         const int t = st.steps + 1;
         const Masks mk = make_masks(t, g.md, g.N);
@@ -387,8 +456,14 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             while (j_next < n_chunk) {
                 const uint32_t j0 = j_next;
                 const VecIn cur = nxt;
-                j_next = grab();
+                // (a batch that reaches the end of the list was the last one: no need to ask the cursor again)
+                j_next = j0 + (uint32_t)bsz < n_chunk ? grab() : n_chunk;
                 if (j_next < n_chunk) fetch(j_next, nxt);
+#ifdef SF_PHASES
+                pc.mark(3);      // cursor, next batch's rows requested
+                asm volatile("" :: "v"(cur.mid.x), "v"(cur.sr.x), "v"(cur.up.x), "v"(cur.dn.x));
+                pc.mark(11);     // this batch's rows have arrived
+#endif
                 const bool has = cur.item != 0xFFFFFFFFu;
                 const uint32_t item = cur.item;
                 const int y = item & 0xFFFF, v = (item >> 16) & 0xFF;
@@ -506,37 +581,25 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 if (st_ch) ev.tdirty[(y >> th_log) * g.TX + (v >> g.logLC)] = 1;
                 pc.mark(5);      // status arrived, SWAR, stores issued
 
-                // ---- frontier cells of this batch -> the wave's list -> walk (windows of cwin cells: a batch holds up to 1024)
+                // ---- frontier cells of this batch -> walk (the walkers find their cells themselves: run_walk)
                 const uint32_t mine = (uint32_t)__popc(m16);
                 if (__ballot(mine != 0) != 0ull) {
                     const uint32_t incl_c = wave_scan_incl(mine, lane);
                     const uint32_t total = wave_last(incl_c);
                     const uint32_t excl = incl_c - mine;
-#pragma unroll 1
-                    for (uint32_t win = 0; win < total; win += (uint32_t)cwin) {
-                        uint32_t pos = excl, m = m16;
-                        while (m) {
-                            const int b = __ffs(m) - 1;
-                            m &= m - 1;
-                            const uint32_t slot = pos - win;      // wraps for pos < win: not in this window
-                            if (slot < (uint32_t)cwin) {
-                                const uint32_t code = (pick(snew, b >> 2) >> (8 * (b & 3))) & 7u;
-                                clist[slot] = (uint16_t)((uint32_t)lane | ((uint32_t)b << 6) | (code << 10));
-                            }
-                            pos++;
-                        }
-                        const uint32_t tot = total - win < (uint32_t)cwin ? total - win : (uint32_t)cwin;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        pc.mark(6);  // prefix sum + frontier list
-                        const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, clist, strips, tot, lane, th_log, pc);
-                        n_active += wk.n_active;
-                        n_ignite += wk.n_ignite;
-                        if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
-                        n_items_acc += (lane == 0) ? tot : 0u;
-                        n_phase2++;
-                    }
+                    const uint4 s7n = and4(snew, 0x07070707u);
+                    const uint32_t line16 = pack4(ge3_01(s7n.x)) | (pack4(ge3_01(s7n.y)) << 4) | (pack4(ge3_01(s7n.z)) << 8) | (pack4(ge3_01(s7n.w)) << 12);
+                    // (the strip records written above are read by other lanes of this wave)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    pc.mark(6);  // prefix sum
+                    const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, strips, total, lane, th_log, pc, excl, m16 | (line16 << 16), s7n);
+                    n_active += wk.n_active;
+                    n_ignite += wk.n_ignite;
+                    if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
+                    n_items_acc += (lane == 0) ? total : 0u;
+                    n_phase2++;
                 } else {
                     // (the strip buffer is rewritten by the next batch: order this batch's LDS traffic before it)
                     __builtin_amdgcn_wave_barrier();

@@ -101,11 +101,14 @@ struct PhaseClock {
     // clocks per phase accumulate in a per-wave LDS array (k_run only; k_step / k_step_fused pass none)
     unsigned long long t, t0;
     uint32_t *acc;
+    unsigned long long *tl = nullptr;      // timeline of one step of one environment (sf_debug_timeline): [64] events = mark id << 56 | clock
+    int tl_n = 0;
     __device__ __forceinline__ void start(uint32_t *a = nullptr) { acc = a; t = t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void mark(int k)
     {
         const unsigned long long n = __builtin_readcyclecounter();
         if (acc && (threadIdx.x & 63) == 0) atomicAdd(&acc[k], (uint32_t)(n - t));
+        if (tl && (threadIdx.x & 63) == 0 && tl_n < 64) tl[tl_n++] = ((unsigned long long)k << 56) | (n & 0x00FFFFFFFFFFFFFFull);
         t = n;
     }
 #else
@@ -120,6 +123,8 @@ struct PhaseClock {
 __device__ unsigned long long g_wave_log[16384 * 4];
 __device__ unsigned long long g_phase[16];    // k_run: shader clocks per phase, summed over all waves (sf_debug_phases)
 __device__ int g_wave_log_launch = -1;       // -2: record (armed from the host through sf_debug_wave_log)
+__device__ int g_timeline_env = -1, g_timeline_step = -1;      // k_run: environment / step (of the launch) whose marks are logged
+__device__ unsigned long long g_timeline[16 * 64];
 #endif
 
 struct WalkAcc {

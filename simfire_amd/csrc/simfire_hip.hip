@@ -939,17 +939,17 @@ constexpr int SF_INTERNAL_NO_RESIDENT = 1;       // step_impl: the resident laun
 
 // The resident launch: k_run<D>, D = bitmap words a thread owns (rows per thread x words per row) rounded up to 1, 2 or 4 (grids up to
 // 1024 x 1024 in 16 waves: D = 1, thirteen registers fewer than D = 4).
-static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, int vcap, int cwin, size_t lds, int bsz)
+static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, int vcap, size_t lds, int bsz)
 {
     const int need = ((s->g.H + waves * 64 - 1) / (waves * 64)) * s->g.VW;
     const int which = need <= 1 ? 0 : (need <= 2 ? 1 : 2);
-    void (*kern)(StepArgs, int, int, int, int) = which == 0 ? k_run<1> : (which == 1 ? k_run<2> : k_run<kRunMaxD>);
+    void (*kern)(StepArgs, int, int, int) = which == 0 ? k_run<1> : (which == 1 ? k_run<2> : k_run<kRunMaxD>);
     size_t &attr = s->attr_run[which];
     if (lds > 64 * 1024 && lds > attr) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)s->g.E), dim3((unsigned)waves * 64), lds, s->stream, a, n_steps, vcap, bsz, cwin);
+    hipLaunchKernelGGL(kern, dim3((unsigned)s->g.E), dim3((unsigned)waves * 64), lds, s->stream, a, n_steps, vcap, bsz);
     return SF_OK;
 }
 
@@ -984,7 +984,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     const bool generic = s->g.ab > 1 || s->generic;
     // Environment-resident launch (k_run): all n steps of an environment in one workgroup.  Not with the
     // per-step by-products (spread graph, history) and not for the wide sprite planes.
-    int run_waves = 0, run_vcap = 0, run_cwin = kRunWin;
+    int run_waves = 0, run_vcap = 0;
     size_t run_lds = 0;
     int runt_waves = 0;                        // tile flavour of the resident launch (sf_set_fused(3))
     size_t runt_lds = 0;
@@ -1000,7 +1000,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     }
     int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
     size_t fr_lds = 0;
-    int fit_waves = 0, fit_vcap = 0, fit_cwin = kRunWin;   // k_run as k_front's overflow fallback (whether or not it is the choice)
+    int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
     size_t fit_lds = 0;
     if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
         static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
@@ -1015,24 +1015,23 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         long long all_vec = (long long)g.H * g.PV;
         int vcap = vcap_knob < 64 ? 64 : vcap_knob;
         if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
-        int cwin = kRunWin;
-        size_t lds = run_lds_bytes(g, nw, vcap, cwin);
+        size_t lds = run_lds_bytes(g, nw, vcap);
         // More environments than CUs (the throughput regime): a CU works through several environments one after the other, and a
-        // workgroup of 16 waves mostly waits for memory.  Half the waves, a shorter vector list (longer ones are taken in chunks) and
-        // walk window: two workgroups fit the 160 KB of LDS and overlap each other's round trips.
+        // workgroup of 16 waves mostly waits.  Half the waves and a shorter vector list (longer ones are taken in chunks): two
+        // workgroups fit the 160 KB of LDS and fill each other's gaps.
         static const int compact_knob = getenv("SF_RUN_COMPACT") ? atoi(getenv("SF_RUN_COMPACT")) : 1;
         if (compact_knob && g.E > s->n_cu && nw > 8 && min_nw <= 8 && !getenv("SF_RUN_WAVES")) {
             const int vcap2 = vcap > 1024 ? 1024 : vcap;
-            const size_t lds2 = run_lds_bytes(g, 8, vcap2, 256);
-            if (lds2 <= 80 * 1024) { nw = 8; vcap = vcap2; cwin = 256; lds = lds2; }
+            const size_t lds2 = run_lds_bytes(g, 8, vcap2);
+            if (lds2 <= 80 * 1024) { nw = 8; vcap = vcap2; lds = lds2; }
         }
         const bool fits = nw <= 16 && g.W <= 4096 && g.H <= 65535 && g.VW <= kRunMaxD && lds <= 160 * 1024;
         // automatic: multi-step calls on grids up to 1024 cells wide (measured on 1024^2, 1 .. 1024 environments: 1.2 - 1.4 x
         // faster than the per-step launches at every batch size; on 2048^2 an environment's fire is too much work for the one
         // CU that owns it and the per-step launches, which spread tiles over the whole chip, win by 1.4 - 2 x)
         const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
-        if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; run_cwin = cwin; }
-        if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; fit_cwin = cwin; }
+        if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
+        if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
         // k_front: the frontier records of an environment in LDS.  Needs k_run as its overflow fallback; not in attenuation
         // mode, not with control lines inside the launch, not in the visit-everything cross-check mode.
         static const int front_min_steps = getenv("SF_FRONT_MIN_STEPS") ? atoi(getenv("SF_FRONT_MIN_STEPS")) : 4;
@@ -1133,7 +1132,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             a.todo = s->todo;
             { int rc0 = ensure_bl(s); if (rc0) return rc0; }       // (what k_front left in the row-major planes, for every environment)
             a.cells = s->cells;
-            { int rc0 = launch_k_run(s, a, n_steps, fit_waves, fit_vcap, fit_cwin, fit_lds, 64); if (rc0) return rc0; }
+            { int rc0 = launch_k_run(s, a, n_steps, fit_waves, fit_vcap, fit_lds, 64); if (rc0) return rc0; }
         }
         n_steps = 0;
     } else if (run_waves) {
@@ -1160,7 +1159,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             }
             a.mit = mit_dev ? mit_dev + (size_t)done * s->g.E * mit_k * 3 : nullptr;
             if (res_knob && done + seg == n_steps) { a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink; }
-            { int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_cwin, run_lds, bsz); if (rc0) return rc0; }
+            { int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_lds, bsz); if (rc0) return rc0; }
             done += seg;
         }
         s->status_fresh = res_knob != 0;
@@ -1256,6 +1255,18 @@ extern "C" int sf_debug_wave_log(int32_t arm, unsigned long long *out)
     int v = -1;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log_launch), &v, sizeof v);
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_log), sizeof(unsigned long long) * 16384 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef SF_PHASES
+// development build only: log the marks of one step (index inside the next resident launch) of one environment / read the log
+extern "C" int sf_debug_timeline(int32_t env, int32_t step, unsigned long long *out /* [16][64] or null */)
+{
+    if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 16 * 64) == hipSuccess ? 0 : -1;
+    unsigned long long z[16 * 64] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_step), &step, sizeof step);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_env), &env, sizeof env) == hipSuccess ? 0 : -1;
 }
 #endif
 
