@@ -59,6 +59,7 @@ def parse(argv=None):
                          "multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--dense-leg", action="store_true", help="also measure the same workload with skipping off")
     ap.add_argument("--no-dense-leg", action="store_true", help="(accepted for older scripts; the dense leg is off by default)")
+    ap.add_argument("--no-rehearsal", action="store_true", help="skip the untimed dress rehearsal of the timed region")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / all-gather plumbing without touching a GPU (CPU test of --gpus N)")
     return ap.parse_args(argv)
@@ -342,33 +343,41 @@ def main():
     eng.set_result_sink(result.data_ptr())          # the harness's tensor of episode returns: registered once
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
-    if a.warmup:
-        # the W warm-up steps go through the entry points the timed rollout uses (async step calls + the result-block call): the
-        # first call of a C entry point resolves its symbol, the first launch of a kernel loads its code
-        w1 = a.warmup // 2
-        if w1:
-            run_steps(eng, w1, 0, agent_pts)
-            eng.copy_status_to(result.data_ptr())
-        run_steps(eng, a.warmup - w1, w1, agent_pts)
-    eng.copy_status_to(result.data_ptr())
-    steps_before = result[:, 1].sum().item()
-    if dist is not None:
-        # untimed warm-up of the one collective of the rollout (communicator set-up, first-use kernel load)
-        dist.all_gather_into_tensor(gathered, result.to(coll_dev))
-
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def rollout(k, first):
+        run_steps(eng, k, first, agent_pts)
+        eng.copy_status_to(result.data_ptr())            # per-env result block (episode returns)
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, result.to(coll_dev))  # RCCL over xGMI, once per rollout
+
+    if not a.no_rehearsal:
+        # Untimed dress rehearsal: the same episodes, the same W + K steps through the same calls (first calls of C entry
+        # points, first launches, the collective's set-up, the host's own cold paths cost ~50 us once per process - a quarter
+        # of a 20-step rollout), then the environments are reset and the measurement starts from scratch.
+        if a.warmup:
+            rollout(a.warmup, 0)
+        result[:, 1].sum().item()                        # (torch's own first kernel launch / first D2H copy)
+        fence()
+        rollout(a.steps, a.warmup)
+        fence()
+        eng.reset(w.init_xy)
+    if a.warmup:
+        run_steps(eng, a.warmup, 0, agent_pts)
+    eng.copy_status_to(result.data_ptr())
+    steps_before = result[:, 1].sum().item()
+    if dist is not None:
+        # untimed warm-up of the one collective of the rollout (communicator set-up, first-use kernel load)
+        dist.all_gather_into_tensor(gathered, result.to(coll_dev))
+
     # ------------------------------------------------------------------ timed region
     fence()
     t0 = time.perf_counter()
-    run_steps(eng, a.steps, a.warmup, agent_pts)
-    eng.copy_status_to(result.data_ptr())            # per-env result block (episode returns)
-    if dist is not None:
-        dist.all_gather_into_tensor(gathered, result.to(coll_dev))  # RCCL over xGMI, once per rollout
+    rollout(a.steps, a.warmup)
     fence()
     dt = time.perf_counter() - t0
     # ---------------------------------------------------------------------------------
@@ -430,7 +439,7 @@ def main():
             "ms_per_step": dt * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 status + u8 sprite masks + f64 burn_amounts", "data": "synthetic",
-            "verified": verified,
+            "verified": verified, "rehearsal": not a.no_rehearsal,
             "verification": (None if verified is None else
                              f"result block (running, steps, cells per BurnStatus) of {n_check} environments per rank + fire "
                              "maps of 3 of them after the timed rollout == oracle/fire_dense.c on the same inputs, bit for bit"),
