@@ -81,6 +81,7 @@ struct WalkCell {
     double bn, r_tab;
 };
 
+template <int ATT>
 __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev, const Masks &mk, int complete,
                                             uint32_t lo_mask, uint32_t hi_mask, const uint32_t *strips,
                                             uint32_t pend, int lane, int th_log, PhaseClock &pc,
@@ -142,7 +143,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
             // both operands are requested before either is used: one memory round trip, not two
             c.bn = ev.burn[idx];
             c.r_tab = ev.rt[(uint32_t)bestk * (uint32_t)(g.H * g.P) + idx];          // 8 H P < 2^29
-            if (s_post >= SF_FIRELINE && g.att) c.owed = (uint32_t)complete - ev.settled[idx];
+            if (ATT && s_post >= SF_FIRELINE) c.owed = (uint32_t)complete - ev.settled[idx];
         }
         return c;
     };
@@ -156,7 +157,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
             double bn = c.bn;
             double ros = c.r_tab * g.update_rate;                                // fire.py:696,705
             if (line) {                                                          // fire.py:271-282
-                if (g.att) {
+                if (ATT) {
                     const double f = line_factor(s_post);
                     bn = lazy_sub(bn, f, c.owed);        // the updates since this cell was last touched (fire.py:278, ros = 0)
                     ros = ros - f;
@@ -216,7 +217,9 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
     return acc;
 }
 
-template <int MAXD>
+// Template parameters: MAXD = bitmap words a thread owns; ATT = attenuate_line_ros (fire.py:236-284) known at compile time;
+// DIAG = 1: diagonal_spread known to be on, -1: read from the geometry (the 4-connected case is rare).
+template <int MAXD, int ATT, int DIAG>
 __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
 {
     extern __shared__ uint4 s_dyn[];
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const unsigned long long clk0 = __builtin_readcyclecounter();
     unsigned long long *vb = reinterpret_cast<unsigned long long *>(s_dyn);        // [H][VW]
     const bool fine = g.VW == 1;                                                   // refined interest rule (see below)
+    const bool diag = DIAG > 0 ? true : g.diag != 0;
     unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
     uint32_t *strips = vlist + vcap + wave * (64 * kStripDw);                      // [64][kStripDw] per wave
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
                 const int sh = (x & 3) * 8;
                 const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
-                if (g.att && old >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(old), (uint32_t)st.complete - ev.settled[o]);
+                if (ATT && old >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(old), (uint32_t)st.complete - ev.settled[o]);
             }
             __syncthreads();
             for (int i = tid; i < a.mit_k; i += nthr) {
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
                     old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
                 } while (old != seen);
-                if (g.att) ev.settled[o] = (uint32_t)st.complete;      // idempotent: every point of this step on this cell stores the same count
+                if (ATT) ev.settled[o] = (uint32_t)st.complete;      // idempotent: every point of this step on this cell stores the same count
                 ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
                 if (fine) atomicOr(&ve[y], 1ull << (x >> 4));          // a control line is an eligible cell
             }
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
         const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
         const int exp_sh = __ffs(mk.b_exp) - 1;
-        const uint32_t lo_mask = g.diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = g.diag ? L4 : (L4 & 0x00FF00FFu);
+        const uint32_t lo_mask = diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = diag ? L4 : (L4 & 0x00FF00FFu);
 
         // ---- interest: D = the bitmap dilated by one vector / one row (kept in registers: the passes below change the
         // bitmap).  Dilation distributes over OR: OR the three rows first, dilate once.
@@ -443,11 +447,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 // (the same rows of the vector to the left / right: one line = 128 bytes further along x)
                 if (has && lane == 0 && v > 0) {
                     in.l0 = *reinterpret_cast<const uint32_t *>(p_mid - 128 + 12);
-                    if (g.diag) { in.l1 = *reinterpret_cast<const uint32_t *>(p_up - 128 + 12); in.l2 = *reinterpret_cast<const uint32_t *>(p_dn - 128 + 12); }
+                    if (diag) { in.l1 = *reinterpret_cast<const uint32_t *>(p_up - 128 + 12); in.l2 = *reinterpret_cast<const uint32_t *>(p_dn - 128 + 12); }
                 }
                 if (has && (j0 + lane + 1 == n_chunk || lane == bsz - 1) && x0 + 16 < g.W) {
                     in.r0 = *reinterpret_cast<const uint32_t *>(p_mid + 128);
-                    if (g.diag) { in.r1 = *reinterpret_cast<const uint32_t *>(p_up + 128); in.r2 = *reinterpret_cast<const uint32_t *>(p_dn + 128); }
+                    if (diag) { in.r1 = *reinterpret_cast<const uint32_t *>(p_up + 128); in.r2 = *reinterpret_cast<const uint32_t *>(p_dn + 128); }
                 }
             };
             uint32_t j_next = grab();
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 n_vec_done += (lane == 0) ? (n_chunk - j0 < (uint32_t)bsz ? n_chunk - j0 : (uint32_t)bsz) : 0u;
                 const uint4 midL = and4(mid, L4);
                 const uint4 vsrc = and4(or4(up, dn), L4);
-                const uint4 hsrc = g.diag ? or4(midL, vsrc) : midL;
+                const uint4 hsrc = diag ? or4(midL, vsrc) : midL;
                 // per row: the cell left of the vector in byte 3 of l?, the cell right of it in byte 0 of r?
                 uint32_t l0 = cur.l0 & 0xFF000000u, l1 = cur.l1 & 0xFF000000u, l2 = cur.l2 & 0xFF000000u;
                 uint32_t r0 = cur.r0 & 0xFFu, r1 = cur.r1 & 0xFFu, r2 = cur.r2 & 0xFFu;
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     if (lane != 0 && item_l + 0x10000u == item) { l0 = dl0 & 0xFF000000u; l1 = dl1 & 0xFF000000u; l2 = dl2 & 0xFF000000u; }
                     if (!last_lane && item_r == item + 0x10000u) { r0 = dr0 & 0xFFu; r1 = dr1 & 0xFFu; r2 = dr2 & 0xFFu; }
                 }
-                uint32_t lin = (g.diag ? (l0 | l1 | l2) : l0) >> 24, rin = g.diag ? (r0 | r1 | r2) : r0;
+                uint32_t lin = (diag ? (l0 | l1 | l2) : l0) >> 24, rin = diag ? (r0 | r1 | r2) : r0;
                 // park the rows for the walk (this wave's strip buffer; the walk of the previous batch is over)
                 if (has) {
                     uint32_t *rec = strips + lane * kStripDw;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                         *reinterpret_cast<uint4 *>(vmask + kBlStatus) = snew;
                         // attenuation mode: a control line drawn on a burning cell ends when that sprite expires (the prune
                         // overwrites it with BURNED, fire.py:140): make up the attenuation the cell is still owed
-                        if (g.att) {
+                        if (ATT) {
                             uint32_t sp16 = pack4(ge3_01(s7.x) & em.x & 0x01010101u) | (pack4(ge3_01(s7.y) & em.y & 0x01010101u) << 4) |
                                             (pack4(ge3_01(s7.z) & em.z & 0x01010101u) << 8) | (pack4(ge3_01(s7.w) & em.w & 0x01010101u) << 12);
                             while (sp16) {
@@ -588,13 +592,15 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     const uint32_t total = wave_last(incl_c);
                     const uint32_t excl = incl_c - mine;
                     const uint4 s7n = and4(snew, 0x07070707u);
-                    const uint32_t line16 = pack4(ge3_01(s7n.x)) | (pack4(ge3_01(s7n.y)) << 4) | (pack4(ge3_01(s7n.z)) << 8) | (pack4(ge3_01(s7n.w)) << 12);
+                    uint32_t line16 = 0;                 // control-line cells of the vector (none anywhere in most batches)
+                    if (__ballot((((s7n.x | s7n.y | s7n.z | s7n.w) + 0x05050505u) & 0x08080808u) != 0) != 0ull)
+                        line16 = pack4(ge3_01(s7n.x)) | (pack4(ge3_01(s7n.y)) << 4) | (pack4(ge3_01(s7n.z)) << 8) | (pack4(ge3_01(s7n.w)) << 12);
                     // (the strip records written above are read by other lanes of this wave)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     pc.mark(6);  // prefix sum
-                    const WalkAcc wk = run_walk(a, ev, mk, st.complete, lo_mask, hi_mask, strips, total, lane, th_log, pc, excl, m16 | (line16 << 16), s7n);
+                    const WalkAcc wk = run_walk<ATT>(a, ev, mk, st.complete, lo_mask, hi_mask, strips, total, lane, th_log, pc, excl, m16 | (line16 << 16), s7n);
                     n_active += wk.n_active;
                     n_ignite += wk.n_ignite;
                     if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
