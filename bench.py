@@ -425,10 +425,13 @@ def main():
         tile_cells = geo["tile_w"] * geo["tile_h"]
         kms, env_steps_local, cnt, kind = measure(eng, w, a, agent_pts, a.dense)
         pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
+        # PMC traffic of this very window, if profiles/collect_pmc.sh has been run for it (per window: ..._s<K>_w<W>.json)
+        for pmc_path in (os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}_s{a.steps}_w{a.warmup}.json"),
+                         os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")):
+            if os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                break
         out = {
             "metric": "cell-updates/sec (grid x envs x steps)",
             # every update() call really made (environments that reached QUIT stop counting,

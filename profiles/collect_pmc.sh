@@ -2,12 +2,15 @@
 # rocprofv3 passes behind the numbers in DESIGN.md / bench.py ("roofline.traffic").
 # Run on the GPU box from the repo root:  bash profiles/collect_pmc.sh [round-tag]
 # Counters are collected in their own runs (separate --pmc passes, no trace domains besides
-# --kernel-trace), as MI355X_MICROARCH.md prescribes.  Window = bench.py's default (--steps 1000 --warmup 20).
+# --kernel-trace), as MI355X_MICROARCH.md prescribes.  usage: collect_pmc.sh [tag] [steps] [warmup]
+# (default window = bench.py's default, --steps 1000 --warmup 20; the driver's window is 20 5).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r02}
+STEPS=${2:-1000}
+WARM=${3:-20}
 O=gpurun_out/$R
 mkdir -p $O
-B="python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-extra"
+B="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/sf_mb profiles/streaming_microbench.hip
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o default -- $B > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o perstep -- $B --fused 0 > $O/bench_under_rocprof_perstep.json 2>/dev/null
@@ -17,7 +20,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc -o calib
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $O/pmc -o sq -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES -d $O/pmc -o sq2 -- $B > /dev/null 2>&1
 rm -f $O/stats/*_kernel_trace.csv
-R=$R python - <<'PY'
+R=$R STEPS=$STEPS WARM=$WARM python - <<'PY'
 import csv, glob, collections, json, os
 R=os.environ["R"]; O=f"gpurun_out/{R}"
 def launches(path, want):
@@ -30,11 +33,11 @@ def launches(path, want):
     return acc
 bench=json.load(open(f"{O}/bench_under_rocprof.json"))
 kernel=bench["roofline"]["kernel"]
-# bench.py launches k_run: warm-up (20 steps), timed rollout (1000), then measure(): warm-up, timed, warm-up, counted.
-# The 1000-step launches are the large ones: take the largest value per counter (they are identical rollouts).
+# bench.py launches k_run for: the dress rehearsal (W + K steps), the warm-up (W), the timed rollout (K), then measure(): W, K, W, K (counted).
+# The K-step launches are the large ones: take the largest value per counter (they are identical rollouts).
 out={"workload": bench["config"]["workload"], "kernel": kernel, "steps": bench["steps"], "warmup": bench["warmup"],
-     "command": "bash profiles/collect_pmc.sh (rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE | WRITE_SIZE in separate passes -- python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-extra)",
-     "per_launch": "one launch of k_run = the whole 1000-step rollout of all environments (the window bench.py times)"}
+     "command": "bash profiles/collect_pmc.sh <tag> %s %s (rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE | WRITE_SIZE in separate passes -- python bench.py --steps %s --warmup %s --no-cpu-baseline --no-extra)" % (os.environ["STEPS"], os.environ["WARM"], os.environ["STEPS"], os.environ["WARM"]),
+     "per_launch": "one launch of k_run = the whole K-step rollout of all environments (the window bench.py times)"}
 raw={}
 for cn,f in (("fetch","fetch"),("write","write")):
     acc=launches(f"{O}/pmc/{f}_counter_collection.csv", "k_run")
@@ -51,7 +54,7 @@ out["algorithmic_bytes_per_launch"]=bench["roofline"]["algorithmic_bytes_per_lau
 out["note"]="FETCH_SIZE counts L2 fills from the fabric (HBM or the 256 MB memory-side cache)"
 json.dump(out, open(f"{O}/pmc_traffic.json","w"), indent=1)
 with open(f"{O}/sq_counters.csv","w") as f:
-    f.write("kernel,counter,value_of_the_1000_step_launch\n")
+    f.write("kernel,counter,value_of_the_K_step_launch\n")
     for p in ("sq","sq2"):
         for k,v in sorted(launches(f"{O}/pmc/{p}_counter_collection.csv","k_run").items()):
             f.write(f"{kernel},{k},{max(v):.0f}\n")

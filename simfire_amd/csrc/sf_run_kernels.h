@@ -69,7 +69,7 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
 // The walk: frontier cells of a batch, one (or two) per lane and pass.  There is no list: walker j finds its cell itself.
 // excl = frontier cells in the lanes below (exclusive prefix sum over the batch), w16 = the lane's 16-bit frontier mask | its
 // control-line cells << 16, s7 = its status row after the prune.  The owner of item j is the last lane with excl <= j (binary
-// search: six cross-lane reads), the cell is the (j - excl)-th set bit of the owner's mask.  (A per-lane loop over the set bits
+// search: three scalars, then four cross-lane reads), the cell is the (j - excl)-th set bit of the owner's mask.  (A per-lane loop over the set bits
 // into an LDS list cost 2 - 5 k clocks per batch along horizontal fronts; the search costs the same whatever the front looks like.)
 // The 3 x 3 sprite masks come from the batch's strip buffer in LDS (the rows the vector pass has just loaded, with the cell left /
 // right of the vector): no memory round trip before the winner is known.
@@ -89,14 +89,17 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 {
     const Geo &g = a.g;
     WalkAcc acc = {0u, 0u, 0u, 0u};
+    const uint32_t e16 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 16), e32 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 32),
+                   e48 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 48);
     // first half of a cell: who, winner source, operands requested
     auto front = [&](uint32_t j) {
         WalkCell c;
         const bool valid = j < pend;
-        int jl = 0;
-        uint32_t base = 0;
+        // (the first two levels of the search against three scalars: lanes 16 / 32 / 48 of the prefix sums)
+        int jl = j >= e32 ? (j >= e48 ? 48 : 32) : (j >= e16 ? 16 : 0);
+        uint32_t base = j >= e32 ? (j >= e48 ? e48 : e32) : (j >= e16 ? e16 : 0u);
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
+        for (int step = 8; step >= 1; step >>= 1) {
             const int t = jl + step;
             const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(t << 2, (int)excl);
             if (v <= j) { jl = t; base = v; }
