@@ -12,10 +12,10 @@ from simfire_amd.engine import FireEngine    # noqa: E402
 from simfire_amd import _lib                 # noqa: E402
 
 NAMES = ["0 barrier at the end of the step (waiting for the slowest wave)", "1 interest bitmap + ranks",
-         "2 vector list written, barrier", "3", "4 vector item + rows + neighbour masks arrive",
-         "5 status SWAR, stores issued", "6 prefix sum + frontier list", "7 walk: item, neighbourhood, winner",
-         "8 walk: burn / table entry arrive, update", "9 walk: ignition stores, fence", "10 end of batch", "11",
-         "12 epilogue", "13", "14", "15"]
+         "2 vector list written, barrier", "3 cursor, next batch's rows requested", "4 neighbour masks, strips written",
+         "5 status SWAR, stores issued", "6 prefix sum of the frontier cells", "7 walk: cells found (search), winners, operands requested",
+         "8 walk: burn / table entries arrive, updates, ignition stores", "9 end of the walk", "10 end of batch",
+         "11 wait for this batch's rows", "12 epilogue", "13", "14", "15 step start (fold, control lines)"]
 
 
 def main():

@@ -998,12 +998,14 @@ __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t 
 }
 
 __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, uint8_t *cells, EnvState *commit, uint8_t *tflags, int ring,
-                           unsigned long long *vbits, const int32_t *xy, int env0, int n)
+                           unsigned long long *vbits, const int32_t *xy, int env0, int n, uint8_t *tdirty)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int e = env0 + i;
     const int x = xy[2 * i], y = xy[2 * i + 1];
+    // (the caller has zeroed the environment's tile histograms - all UNBURNED - and flags: only the ignition's tile is to be recounted)
+    if (tdirty) tdirty[((long long)e * g.TY + y / (g.LR * g.RB)) * g.TX + (x / 16) / g.LC] = 1;
     if (cells) {                        // the blocked cell plane is the current one (1-byte sprite masks)
         uint8_t *cell = cells + (long long)e * g.cells_env + bl_cell(g, y, x);
         cell[kBlStatus] = SF_BURNING;

@@ -737,14 +737,23 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
         HIPCHK(hipMemsetAsync(s->tflags + ((size_t)k * g.E + env0) * fplane, 0, (size_t)n * fplane, s->stream));
     for (int k = 0; k < 3; ++k)
         HIPCHK(hipMemsetAsync(s->vbits + ((size_t)k * g.E + env0) * g.vb_env, 0, (size_t)n * g.vb_env * sizeof(unsigned long long), s->stream));
+    // Result-block bookkeeping: a freshly reset environment is all UNBURNED but for its ignition cell - its tile histograms are
+    // written here (zeros) and only the ignition's tile is marked for a recount.  (A partial reset while everything is marked stale anyway leaves it at that.)
+    const bool hist_known = g.ab == 1 && !s->generic && (n == g.E || !s->tdirty_all);
+    if (hist_known) {
+        const size_t per_env = (size_t)g.TY * g.TX;
+        HIPCHK(hipMemsetAsync(s->tdirty + (size_t)env0 * per_env, 0, (size_t)n * per_env, s->stream));
+        HIPCHK(hipMemsetAsync(s->thist + (size_t)env0 * per_env * 8, 0, (size_t)n * per_env * 8 * sizeof(uint16_t), s->stream));
+    }
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->bl_cur ? s->cells : nullptr, s->commit,
-                       s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n);
+                       s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n, hist_known ? s->tdirty : nullptr);
     HIPCHK(hipGetLastError());
     if (!s->bl_cur) {                   // (the tile bookkeeping is not kept while the blocked plane is current: tiles_valid is false)
         rc = rebuild_seams(s, env0, n);
         if (rc) return rc;
     }
-    s->tdirty_all = true;
+    if (!hist_known) s->tdirty_all = true;
+    else if (n == g.E) s->tdirty_all = false;
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
