@@ -371,12 +371,18 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             }
         }
         // list positions: prefix sum inside the wave, one LDS atomic per wave for its range
-        const uint32_t incl = wave_scan_incl(cnt, lane);
-        const uint32_t wave_total = wave_last(incl);
-        uint32_t wbase = 0;
-        if (lane == 0 && wave_total) wbase = atomicAdd(&ctl[k], wave_total);
-        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-        const uint32_t pos0 = wbase + incl - cnt;
+        uint32_t pos0 = 0;
+#ifndef SF_NO_SKIP_EMPTY
+        if (__ballot(cnt != 0) != 0ull)         // (most waves of most environments own no interesting row)
+#endif
+        {
+            const uint32_t incl = wave_scan_incl(cnt, lane);
+            const uint32_t wave_total = wave_last(incl);
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&ctl[k], wave_total);
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            pos0 = wbase + incl - cnt;
+        }
         pc.mark(1);          // interest bitmap + ranks
 
         uint32_t n_all = 0;
