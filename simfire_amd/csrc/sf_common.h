@@ -239,6 +239,8 @@ __device__ __forceinline__ uint32_t eq0_01(uint32_t s7) { return ~(s7 | (s7 >> 1
 // 0/1 per byte for status bytes 0..5: eligible for ignition (fire.py:192-205) = UNBURNED or a control line = not 1, 2
 // = bit2 | ~(bit0 ^ bit1)
 __device__ __forceinline__ uint32_t elig01(uint32_t s7) { return ((s7 >> 2) | ~(s7 ^ (s7 >> 1))) & 0x01010101u; }
+// the same as ONE byte permute: a status byte (0..7) is the selector into the table {1, 0, 0, 1, 1, 1, 0, 0}
+__device__ __forceinline__ uint32_t elig01_perm(uint32_t s7) { return __builtin_amdgcn_perm(0x00000101u, 0x01000001u, s7); }
 // gather the 0/1 bytes of a dword into 4 bits
 __device__ __forceinline__ uint32_t pack4(uint32_t b01)
 {

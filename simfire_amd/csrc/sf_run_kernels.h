@@ -41,6 +41,11 @@ namespace {
 // them when it switches back), the vector bitmap is not maintained there (k_rebuild_vbits).
 // ------------------------------------------------------------------------------------------
 constexpr int kStripDw = 19;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
+#ifdef SF_NO_PERM_ELIG
+#define ELIG(x) elig01(x)
+#else
+#define ELIG(x) elig01_perm(x)      // status bytes in the cell plane are 0..5, nothing else (BurnStatus)
+#endif
 constexpr int kRunCtl = 16;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps)
 constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row): k_run<4>; k_run<1> for one row of one word
 
@@ -565,10 +570,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     }
                     if (any_nb) {
                         // frontier cells (0 / 1 per byte): eligible (fire.py:192-205) & next to a live sprite
-                        uint32_t p0 = elig01(snew.x) & nz01(nb.x);
-                        uint32_t p1 = elig01(snew.y) & nz01(nb.y);
-                        uint32_t p2 = elig01(snew.z) & nz01(nb.z);
-                        uint32_t p3 = elig01(snew.w) & nz01(nb.w);
+                        uint32_t p0 = ELIG(snew.x) & nz01(nb.x);
+                        uint32_t p1 = ELIG(snew.y) & nz01(nb.y);
+                        uint32_t p2 = ELIG(snew.z) & nz01(nb.z);
+                        uint32_t p3 = ELIG(snew.w) & nz01(nb.w);
                         // pitch padding (x >= W) never takes part
                         if (__builtin_expect(x0 + 16 > g.W, 0)) {
                             const int nv = g.W - x0;          // valid cells of this vector
@@ -580,12 +585,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 if (fine && has) {
                     // no eligible cell left in the vector (fire.py:192-205: UNBURNED or a control line)?  Then sprites next
                     // to it are no reason to visit it.  (snew still lacks this step's ignitions: found out at the next visit.)
-                    uint32_t el = elig01(snew.x) | elig01(snew.y) |
-                                  elig01(snew.z) | elig01(snew.w);
+                    uint32_t el = ELIG(snew.x) | ELIG(snew.y) |
+                                  ELIG(snew.z) | ELIG(snew.w);
                     if (__builtin_expect(x0 + 16 > g.W, 0)) {          // pitch padding is UNBURNED for ever: only real cells count
                         const int nv = g.W - x0;
-                        el = (elig01(snew.x) & first01(nv)) | (elig01(snew.y) & first01(nv - 4)) |
-                             (elig01(snew.z) & first01(nv - 8)) | (elig01(snew.w) & first01(nv - 12));
+                        el = (ELIG(snew.x) & first01(nv)) | (ELIG(snew.y) & first01(nv - 4)) |
+                             (ELIG(snew.z) & first01(nv - 8)) | (ELIG(snew.w) & first01(nv - 12));
                     }
                     if (!el) atomicAnd(&ve[y], ~(1ull << v));
                 }
