@@ -39,6 +39,7 @@ extern "C" {
 #define SF_EHIP (-3)     /* HIP runtime error                          -> RuntimeError    */
 #define SF_ENOTSUP (-4)  /* outside the supported envelope             -> NotImplementedError */
 #define SF_ESTATE (-5)   /* call sequence error (e.g. step before layers) -> RuntimeError */
+#define SF_ERCCL (-6)    /* RCCL error (library missing, communicator, collective) -> RuntimeError */
 
 /* BurnStatus (simfire/enums.py:52-69) - the values stored in fire_map */
 #define SF_UNBURNED 0
@@ -187,6 +188,19 @@ int sf_copy_status_to(sf_sim *sim, void *device_dst /* int32 [n_envs][8] */);
  * simulation.py:541-553) are already in the harness's tensor.  The buffer must stay valid until it is
  * unregistered or the handle is destroyed. */
 int sf_set_result_sink(sf_sim *sim, void *device_dst /* int32 [n_envs][8] or NULL */);
+
+/* The ONE collective of the path, for hosts that have no torch.distributed: an all-gather of the result blocks of the
+ * ranks' shards over RCCL (xGMI inside a node).  Environments never read each other's state (simulation.py:202-214: one
+ * FireSimulation object each), so nothing else is ever exchanged.  librccl is loaded on first use (dlopen), not linked: a
+ * one-GPU host needs no RCCL.  One process per GPU; every rank's handle holds the same number of environments.
+ *   rank 0:  sf_comm_unique_id(id)  -> hand the 128 bytes to the other ranks (file, socket, MPI, the launcher's store)
+ *   all:     sf_comm_init(sim, rank, world, id)          (collective: returns when every rank has called it)
+ *   rollout: sf_step(sim, n) ... sf_allgather_status(sim, out)   out = device int32 [world][n_envs][8], rank-major
+ *   end:     sf_comm_destroy(sim)                        (sf_destroy does it too) */
+int sf_comm_unique_id(void *id_out /* 128 bytes */);
+int sf_comm_init(sf_sim *sim, int32_t rank, int32_t world_size, const void *unique_id /* 128 bytes */);
+int sf_allgather_status(sf_sim *sim, void *device_out /* int32 [world_size * n_envs][8] */);
+int sf_comm_destroy(sf_sim *sim);
 
 /* Drop-in for compute_rate_of_spread (rothermel.py:4-22): 17 float32 vectors of length n ->
  * R float64[n] (ft/min). */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIMFIRE_HIP_LIB: another build of the same library (e.g. the phase-clock build of profiles/phase_profile.sh)
 LIB_PATH = os.environ.get("SIMFIRE_HIP_LIB") or os.path.join(_HERE, "csrc", "libsimfire_hip.so")
 
-SF_OK, SF_EINVAL, SF_ESHAPE, SF_EHIP, SF_ENOTSUP, SF_ESTATE = 0, -1, -2, -3, -4, -5
+SF_OK, SF_EINVAL, SF_ESHAPE, SF_EHIP, SF_ENOTSUP, SF_ESTATE, SF_ERCCL = 0, -1, -2, -3, -4, -5, -6
 
 
 class SimfireHipError(RuntimeError):
@@ -62,6 +62,10 @@ SIGNATURES = {
     "sf_update_status_device": [_VP],
     "sf_copy_status_to": [_VP, _VP],
     "sf_set_result_sink": [_VP, _VP],
+    "sf_comm_unique_id": [_VP],
+    "sf_comm_init": [_VP, _I32, _I32, _VP],
+    "sf_allgather_status": [_VP, _VP],
+    "sf_comm_destroy": [_VP],
     "sf_get_counters": [_VP, _VP, _I32],
     "sf_enable_counters": [_VP, _I32],
     "sf_compute_ros": [_I64] + [_VP] * 18 + [_I32],

@@ -52,6 +52,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>        // types only: the library is loaded with dlopen on first use (sf_comm_*)
+
 #include "../../include/simfire_hip.h"
 #include "rothermel_dev.h"
 
@@ -126,6 +129,8 @@ struct sf_sim {
     bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
     int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell, 4 k_run_tiles, 5 k_front
     int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
+    ncclComm_t comm = nullptr;         // sf_comm_init: communicator of the result-block all-gather
+    int comm_world = 0;
     uint32_t *run_cost = nullptr, *run_order = nullptr;   // k_run: clocks / 16 an environment's workgroup took in the last resident launch [E]; launch order built from it (k_order)
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
@@ -309,6 +314,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->comm) (void)sf_comm_destroy(s);
     void *ptrs[] = {s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
@@ -1544,6 +1550,91 @@ extern "C" int sf_set_result_sink(sf_sim *s, void *device_dst)
     HIPCHK(hipStreamSynchronize(s->stream));       // nothing in flight may still write the old sink
     s->sink = static_cast<int32_t *>(device_dst);
     s->status_fresh = false;                       // the new sink is filled by the next refresh
+    return SF_OK;
+}
+
+// ---- the one collective: RCCL through dlopen, so that a one-GPU host needs no librccl
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load()
+{
+    if (g_rccl.lib) return SF_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return fail(SF_ERCCL, "librccl.so could not be loaded: %s", dlerror());
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(lib, "ncclAllGather"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) {
+        dlclose(lib);
+        return fail(SF_ERCCL, "librccl.so lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy / ncclGetErrorString");
+    }
+    g_rccl = a;
+    return SF_OK;
+}
+#define RCCLCHK(x) do { ncclResult_t _r = (x); if (_r != ncclSuccess) return fail(SF_ERCCL, "%s failed: %s", #x, g_rccl.GetErrorString(_r)); } while (0)
+}  // namespace
+
+extern "C" int sf_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(SF_EINVAL, "sf_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "the header promises 128 bytes");
+    { int rc = rccl_load(); if (rc) return rc; }
+    ncclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return SF_OK;
+}
+
+extern "C" int sf_comm_destroy(sf_sim *s)
+{
+    if (!s) return fail(SF_EINVAL, "sf_comm_destroy: null handle");
+    if (s->comm) {
+        HIPCHK(hipSetDevice(s->p.device));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        ncclComm_t c = s->comm;
+        s->comm = nullptr; s->comm_world = 0;
+        RCCLCHK(g_rccl.CommDestroy(c));
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_comm_init(sf_sim *s, int32_t rank, int32_t world_size, const void *unique_id)
+{
+    if (!s || !unique_id) return fail(SF_EINVAL, "sf_comm_init: null argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SF_EINVAL, "sf_comm_init: rank %d of %d", rank, world_size);
+    { int rc = rccl_load(); if (rc) return rc; }
+    { int rc = sf_comm_destroy(s); if (rc) return rc; }
+    HIPCHK(hipSetDevice(s->p.device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    RCCLCHK(g_rccl.CommInitRank(&s->comm, world_size, id, rank));
+    s->comm_world = world_size;
+    return SF_OK;
+}
+
+extern "C" int sf_allgather_status(sf_sim *s, void *device_out)
+{
+    if (!s || !device_out) return fail(SF_EINVAL, "sf_allgather_status: null argument");
+    if (!s->comm) return fail(SF_ESTATE, "sf_allgather_status: call sf_comm_init first");
+    int rc = update_status_async(s);                // the block of this rank's shard (fresh already after a resident launch)
+    if (rc) return rc;
+    // on the handle's stream: behind the steps in flight and the refresh, no host wait in between
+    RCCLCHK(g_rccl.AllGather(s->status_block, device_out, (size_t)8 * s->g.E, ncclInt32, s->comm, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
 }
 

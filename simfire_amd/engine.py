@@ -365,6 +365,30 @@ class FireEngine:
         itself, so ``copy_status_to(same pointer)`` after a rollout is only the wait.  Keep the tensor alive."""
         _lib.check(self._L.sf_set_result_sink(self._h, C.c_void_p(int(device_ptr) if device_ptr else None)))
 
+    # ---- the one collective of the path, through the C ABI (hosts without torch.distributed; SURVEY 8e)
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes made by rank 0, to be handed to every rank's ``comm_init`` by the host's own means."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().sf_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def comm_init(self, rank, world_size, unique_id):
+        """Collective: join the RCCL communicator of the result-block all-gather (one process per GPU, the same
+        number of environments on every rank)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self._L.sf_comm_init(self._h, int(rank), int(world_size), C.cast(buf, C.c_void_p)))
+
+    def allgather_status(self, device_ptr):
+        """Refresh this rank's result block and all-gather the blocks of all ranks over RCCL into device memory
+        int32 [world_size * n_envs, 8] (rank-major), on the handle's stream; returns when it is there."""
+        _lib.check(self._L.sf_allgather_status(self._h, C.c_void_p(int(device_ptr))))
+
+    def comm_destroy(self):
+        _lib.check(self._L.sf_comm_destroy(self._h))
+
     def enable_counters(self, on=True):
         """Statistics for the roofline accounting; off by default (they cost atomics)."""
         _lib.check(self._L.sf_enable_counters(self._h, int(bool(on))))

@@ -689,3 +689,35 @@ def test_more_environments_than_workgroup_slots_compact_launch_in_segments():
     eng.step(100); o.step(100)
     check("after partial resets")
     assert not o.status()[0][:, 0].all() and o.status()[0][:, 0].any()
+
+
+def test_c_abi_collective_world_of_one():
+    """sf_comm_unique_id / sf_comm_init / sf_allgather_status / sf_comm_destroy: the result-block all-gather through the C
+    ABI (RCCL loaded with dlopen).  A one-GPU box only allows a world of one rank (RCCL refuses two ranks on one GPU), where
+    the gathered block must equal the rank's own - after a resident rollout (block written by the launch itself), after
+    control lines only (count kernel) and after the communicator has been re-created."""
+    import torch
+    from simfire_amd import _lib
+    rng = np.random.default_rng(7)
+    H, W, E = 80, 96, 5
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=False)
+    R8 = rng.choice([0.0, 7.5, 30.0, 400.0], size=(8, H, W))
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    out = torch.full((E, 8), -1, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(_lib.SimfireHipError):
+        eng.allgather_status(out.data_ptr())                 # no communicator yet: SF_ESTATE
+    for round_ in range(2):
+        eng.comm_init(0, 1, eng.comm_unique_id())
+        eng.set_async(True); eng.step(12); eng.set_async(False)
+        o.step(12)
+        eng.allgather_status(out.data_ptr())
+        assert (out.cpu().numpy() == o.status()[0]).all()
+        pts = [(e, 3 + e, 5, 4) for e in range(E)]
+        eng.apply_mitigation(pts); o.apply_mitigation(pts)
+        eng.allgather_status(out.data_ptr())
+        assert (out.cpu().numpy() == o.status()[0]).all()
+    eng.comm_destroy()
+    with pytest.raises(ValueError):
+        eng.comm_init(0, 1, b"short")
+    _same(eng, o, E, tag="after the collective")
