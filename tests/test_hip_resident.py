@@ -721,3 +721,35 @@ def test_c_abi_collective_world_of_one():
     with pytest.raises(ValueError):
         eng.comm_init(0, 1, b"short")
     _same(eng, o, E, tag="after the collective")
+
+
+def test_mitigated_rollout_in_segments_with_many_environments():
+    """sf_step_mitigated with more environments than two per CU: the rollout is cut into ordered segments and every segment
+    has to pick up its own steps of the point block.  700 environments on a 576 x 32 grid, 110 steps (segments of 64 + 46),
+    attenuation on - equal to `update_mitigation(points[s]); run(1)` pairs of the oracle."""
+    rng = np.random.default_rng(2718)
+    H, W, E, K, n = 576, 32, 700, 3, 110
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([0.0, 7.5, 30.0, 400.0, 1500.0], size=(8, H, W))
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    blk = np.zeros((n, E, K, 3), dtype=np.int32)
+    blk[..., 0] = rng.integers(0, W, (n, E, K))
+    blk[..., 1] = rng.integers(0, H, (n, E, K))
+    blk[..., 2] = rng.integers(3, 6, (n, E, K))
+    # (lines near the ignitions so that they matter)
+    near = np.array(inits, dtype=np.int32)
+    blk[:, :, 0, 0] = np.clip(near[None, :, 0] + rng.integers(-6, 7, (n, E)), 0, W - 1)
+    blk[:, :, 0, 1] = np.clip(near[None, :, 1] + rng.integers(-6, 7, (n, E)), 0, H - 1)
+    for s in range(n):
+        rows = np.concatenate([np.repeat(np.arange(E, dtype=np.int32), K)[:, None], blk[s].reshape(E * K, 3)], axis=1)
+        o.apply_mitigation(rows)
+        o.step(1)
+    eng.step_mitigated(blk)
+    assert eng.last_launch_kind() == 2
+    st, el = eng.status()
+    so, eo = o.status()
+    assert (st == so).all() and (el == eo).all()
+    for e in (0, 1, 255, 256, 512, 513, 699):
+        assert (eng.fire_map(e) == o.fire_map(e)).all(), e
+        assert (eng.burn(e) == o.burn(e)).all(), e
