@@ -15,30 +15,37 @@ namespace {
 // its workgroup sits on), no sweep over every tile of every environment, and a fast environment never
 // waits for a slow one.
 //
-// A resident workgroup does not work tile by tile.  What it keeps in LDS for the whole launch is the
-// environment's VECTOR BITMAP: one bit per 16-cell vector of the sprite-mask plane, set while the vector
-// holds any sprite bit (1024 x 1024 cells = 1024 rows x 64 bits = 8 KB).  Per step:
-//   interest  every thread dilates the bitmap rows it owns by one vector in x and one row in y (a handful
-//             of 64-bit shifts / ORs): the vectors in which anything can happen in this step.  A wave
-//             prefix sum + one LDS atomic per wave turn them into the step's vector list (y | v << 16).
-//   vectors   the waves take batches of 64 list entries off a shared cursor, one 16-cell vector per lane:
-//             3 sprite rows + the two edge cells per row + the status vector straight from the cell planes
-//             (the lines sit in this CU's L1 / the XCD's L2 from the step before), SWAR over the 16 cells
-//             (4 per VALU op): expiry -> BURNED (fire.py:116-161), slot recycling, eligible & next to a
-//             live sprite (fire.py:163-234) -> 16-bit frontier mask; changed vectors are stored at once;
-//             a vector that holds no sprite bit any more leaves the bitmap
-//   frontier  the same wave ranks the frontier cells of its batch with one DPP prefix sum into its LDS
-//             window and walks them one cell per lane: 3 x 3 sprite masks (three unaligned dword loads),
-//             winner source, one f64 table entry, burn += R dt - attenuation, burn > pixel_scale ->
-//             BURNING (fire.py:696-710, 550-589): two byte stores + the vector's bit in the bitmap
+// A resident workgroup does not work tile by tile.  What it keeps in LDS for the whole launch are the
+// environment's VECTOR BITMAPS: one bit per 16-cell vector of the sprite-mask plane (1024 x 1024 cells = 1024
+// rows x 64 bits = 8 KB each): B (holds a sprite bit), Bf / Bl (in its first / last cell), E (may hold a cell
+// eligible for ignition).  Per step:
+//   interest  every thread combines the bitmap rows it owns and their neighbours (a dozen 64-bit shifts / ORs)
+//             into the vectors in which anything can happen in this step.  A wave prefix sum + one LDS atomic
+//             per wave that owns any turn them into the step's vector list (y | v << 16, by rows).
+//   vectors   the waves take batches of 64 list entries off a shared cursor, one 16-cell vector per lane: 3
+//             sprite rows + the status row from the BLOCKED cell plane (sf_common.h: two 64-byte sectors; the next
+//             batch's are requested before the current one is worked on), the cells left / right of the vector
+//             from the neighbouring lane (DPP), SWAR over the 16 cells (4 per VALU op): expiry -> BURNED
+//             (fire.py:116-161), slot recycling, eligible & next to a live sprite (fire.py:163-234) -> a 16-bit
+//             frontier mask; changed vectors are stored at once; a vector that holds no sprite bit any more
+//             leaves the bitmaps; the rows are parked in the wave's LDS strip buffer
+//   frontier  one DPP prefix sum over the lanes' frontier counts; every walker then finds its cell itself (run_walk:
+//             a search over the prefix sums, no list), two cells per lane and pass: 3 x 3 sprite masks from the
+//             strip buffer, winner source, burn and the one f64 table entry of both cells requested together,
+//             burn += R dt - attenuation, burn > pixel_scale -> BURNING (fire.py:696-710, 550-589): two byte
+//             stores + the vector's bits in the bitmaps
 //   fold      the predicates of fire.py:637-652 are two LDS bytes; every thread folds them into its copy of
 //             the environment state
-// Two workgroup barriers per step.  What one wave writes to the cell planes is read by the others in the
-// next step through the CU's own L1 / L2 (one workgroup = one CU: workgroup-scope ordering is enough);
-// inside a step the update is in place, like in the tiled kernels: concurrent writers only touch the two
-// mask slots (t and t - md - 2) that every reader masks out.
+// Two workgroup barriers per step.  When its steps are done the workgroup counts its own environment
+// (counts_env) and writes its row of the result block.  What one wave writes to the cell planes is read by
+// the others in the next step through the CU's own L1 / L2 (one workgroup = one CU: workgroup-scope ordering
+// is enough); inside a step the update is in place, like in the tiled kernels: concurrent writers only touch
+// the two mask slots (t and t - md - 2) that every reader masks out, and a vector is written only by the wave
+// that holds it in its batch.
+// What bounds it: the busiest CUs are bound by instruction issue - ~950 instructions per batch
+// of 64 vectors and their ~70 frontier cells - not by memory; a young fire's step is one wave's dependent chain.
 // The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
-// them when it switches back), the vector bitmap is not maintained there (k_rebuild_vbits).
+// them when it switches back), the vector bitmaps are not maintained there (k_rebuild_vbits).
 // ------------------------------------------------------------------------------------------
 constexpr int kStripDw = 19;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
 #ifdef SF_NO_PERM_ELIG

@@ -22,6 +22,9 @@
 //     bit (s mod N) until it is recycled at step s + max_fire_duration + 2, so the planes are
 //     only written where something happens, and a step runs IN PLACE: every concurrent writer of
 //     a step touches only the two slots (t and t - md - 2) that readers mask out.
+//   * n steps of an sf_step(n) call = ONE launch of k_run (sf_run_kernels.h): a workgroup owns an environment for all n
+//     steps, its vector bitmaps live in LDS, the cells in a blocked plane (sf_common.h); the automatic choice for n >= 2 on
+//     grids up to 1024 cells wide.  Otherwise:
 //   * One step = k_select + k_step.  k_select (one thread per 64 x 32 wave tile) folds the
 //     per-environment predicates of fire.py:637-652 of the previous step (3-deep ring of flag
 //     words), and compacts the tiles in which anything can change into a list (ballot + mbcnt +
@@ -34,7 +37,7 @@
 //   * The whole-grid attenuation of control-line cells (fire.py:271-278) is lazy: a line cell is
 //     touched only when it becomes a candidate, is overwritten or burn_amounts is read back; the
 //     subtractions it is owed by then are made up bit for bit (lazy_sub, sf_common.h).
-//   * A step lasts as long as its slowest wave (all live tiles are resident at once), so the
+//   * A per-step launch lasts as long as its slowest wave (all live tiles are resident at once), so those
 //     kernels are organised around a short per-tile dependency chain, not around throughput.
 //
 // No MFMA: there is no dense contraction anywhere on this path; it is byte / integer work plus a
