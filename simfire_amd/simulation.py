@@ -1,9 +1,10 @@
 """``FireSimulation`` / ``BatchedFireSimulation`` - the surface an RL harness talks to.
 
 ``FireSimulation`` keeps the method names, arguments and return values of the reference class
-(simfire/sim/simulation.py:184-829) for everything that touches the fire-spread path; display,
-GIF, spread-graph and data-saving methods raise ``NotImplementedError`` (out of scope, SURVEY.md
-section 2).  The state lives on the GPU: ``run`` launches the step kernels, ``update_mitigation``
+(simfire/sim/simulation.py:184-829) for everything that touches the fire-spread path, including
+``save_data`` (``data_type: npy``: the reference's directory layout, file for file; ``h5`` needs
+h5py, which this build does not depend on); display, GIF and spread-graph rendering methods raise
+``NotImplementedError`` (out of scope).  The state lives on the GPU: ``run`` launches the step kernels, ``update_mitigation``
 is a device scatter, ``fire_map`` is copied out when ``run`` returns.
 ``BatchedFireSimulation`` adds a leading environment axis (many independent simulations that
 share terrain and wind) - the form the hardware wants.
