@@ -96,6 +96,12 @@ __global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
 
 // Development aid (build with -DSF_PHASES, see profiles/phase_profile.sh): lane 0 of every wave sums
 // the shader clocks it spends in each phase of step_tile into the statistics counters.
+#ifdef SF_TILE_LIST
+constexpr bool kTileList = true;       // frontier cells of a tile through an LDS list (every RB)
+#else
+constexpr bool kTileList = false;      // RB <= 2: the walkers find their cells by a search over the lanes' prefix sums (walk_body)
+#endif
+
 struct PhaseClock {
 #ifdef SF_PHASES
     // clocks per phase accumulate in a per-wave LDS array (k_run only; k_step / k_step_fused pass none)
@@ -181,16 +187,50 @@ __device__ __forceinline__ int pick_winner8(uint32_t up3, uint32_t mid3, uint32_
 template <int RB>
 __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk, int e, int yw, int chunk, bool spread,
                                              int complete, uint8_t *tile_lds, uint8_t *stat_lds, const uint16_t *s_list,
-                                             uint32_t pend, int lane)
+                                             uint32_t pend, int lane, uint32_t excl = 0, uint32_t fm01 = 0)
 {
     const Geo &g = a.g;
     const int LC = g.LC, row_pitch = LC * 16 + 16;
     WalkAcc acc = {0u, 0u, 0u, 0u};
     const uint32_t L4w = rep4(mk.m_live);
     const uint32_t lo_mask = g.diag ? L4w : (L4w & 0xFF00FF00u), hi_mask = g.diag ? L4w : (L4w & 0x00FF00FFu);
-    for (uint32_t j = lane; j < pend; j += 64) {
-        const uint32_t it = s_list[j];
-        const int i = it & 31, ol = (it >> 5) & 63, b = (it >> 11) & 15;
+#ifndef SF_TILE_LIST
+    // (tiles of up to two rows per lane: no list - walker j finds its cell itself, like k_run's: the owner lane is the last one whose
+    // prefix sum excl is <= j, the cell the (j - excl)-th set bit of the owner's 32-bit frontier mask fm01 = row 0 | row 1 << 16)
+    const uint32_t e16 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 16), e32 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 32),
+                   e48 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 48);
+#endif
+    for (uint32_t j0 = 0; j0 < pend; j0 += 64) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        int i, ol, b;
+        bool valid = j < pend;
+#ifndef SF_TILE_LIST
+        if (RB <= 2) {
+            ol = j >= e32 ? (j >= e48 ? 48 : 32) : (j >= e16 ? 16 : 0);
+            uint32_t base = j >= e32 ? (j >= e48 ? e48 : e32) : (j >= e16 ? e16 : 0u);
+#pragma unroll
+            for (int step = 8; step >= 1; step >>= 1) {
+                const int t = ol + step;
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(t << 2, (int)excl);
+                if (v <= j) { ol = t; base = v; }
+            }
+            uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(ol << 2, (int)fm01), r = valid ? j - base : 0u, n;
+            int p = 0;
+            n = (uint32_t)__popc(x & 0xFFFFu); if (r >= n) { r -= n; p += 16; x >>= 16; }
+            n = (uint32_t)__popc(x & 0xFFu); if (r >= n) { r -= n; p += 8; x >>= 8; }
+            n = (uint32_t)__popc(x & 0xFu); if (r >= n) { r -= n; p += 4; x >>= 4; }
+            n = (uint32_t)__popc(x & 0x3u); if (r >= n) { r -= n; p += 2; x >>= 2; }
+            if (r >= (x & 1u)) p += 1;
+            p &= 31;
+            i = p >> 4; b = p & 15;
+            if (!valid) { i = 0; b = 0; ol = 0; }
+        } else
+#endif
+        {
+            const uint32_t it = s_list[valid ? j : j0];
+            i = it & 31; ol = (it >> 5) & 63; b = (it >> 11) & 15;
+        }
+        if (valid) {
         const int oc = ol & (g.LC - 1), orr = ol >> g.logLC;
         const int x = (chunk * LC + oc) * 16 + b, y = yw + orr * RB + i;
         const uint32_t idx = (uint32_t)(y * g.P + x);
@@ -253,6 +293,7 @@ __device__ __forceinline__ WalkAcc walk_body(const StepArgs &a, const Masks &mk,
         }
         acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
         *own_st = (uint8_t)st_new;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -496,10 +537,10 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
         const uint32_t excl = incl_all - mine;          // rank of this lane's first frontier cell
         // one window unless the tile has more frontier cells than the list holds (dense control lines)
 #pragma unroll 1
-        for (uint32_t win = 0; win < total; win += (uint32_t)kListCap) {
+        for (uint32_t win = 0; win < total; win += (uint32_t)(RB <= 2 && !kTileList ? 0x7FFFFFFF : kListCap)) {
             uint32_t pos = excl;
 #pragma unroll
-            for (int k = 0; k < (RB + 1) / 2; ++k) {
+            for (int k = 0; k < (RB <= 2 && !kTileList ? 0 : (RB + 1) / 2); ++k) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * k + h;
@@ -515,12 +556,12 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, int e, int tyw, int
                     }
                 }
             }
-            const uint32_t tot = total - win < (uint32_t)kListCap ? total - win : (uint32_t)kListCap;
+            const uint32_t tot = (RB <= 2 && !kTileList) ? total : (total - win < (uint32_t)kListCap ? total - win : (uint32_t)kListCap);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             pc.mark(3);      // prefix sum + list building
-            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.complete, tile_lds, stat_lds, s_list, tot, lane);
+            const WalkAcc w = walk_body<RB>(a, mk, e, yw, chunk, spread, st.complete, tile_lds, stat_lds, s_list, tot, lane, excl, fm[0]);
             pc.mark(4);      // walk
             acc_merge(tot_acc, w);
             n_items_acc += (lane == 0) ? tot : 0u;
