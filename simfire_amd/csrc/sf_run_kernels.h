@@ -233,8 +233,9 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 }
 
 // Template parameters: MAXD = bitmap words a thread owns; ATT = attenuate_line_ros (fire.py:236-284) known at compile time;
-// DIAG = 1: diagonal_spread known to be on, -1: read from the geometry (the 4-connected case is rare).
-template <int MAXD, int ATT, int DIAG>
+// DIAG = 1: diagonal_spread known to be on, -1: read from the geometry (the 4-connected case is rare); MIT = 0: no control lines
+// inside the launch (sf_step), -1: look at the argument (sf_step_mitigated).  MAXD = 1 implies one-word rows (the refined interest rule).
+template <int MAXD, int ATT, int DIAG, int MIT>
 __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
 {
     extern __shared__ uint4 s_dyn[];
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const int e = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
     const unsigned long long clk0 = __builtin_readcyclecounter();
     unsigned long long *vb = reinterpret_cast<unsigned long long *>(s_dyn);        // [H][VW]
-    const bool fine = g.VW == 1;                                                   // refined interest rule (see below)
+    const bool fine = MAXD == 1 ? true : g.VW == 1;                                // refined interest rule (see below)
+    const int32_t *const mit = MIT == 0 ? nullptr : a.mit;                         // control lines inside the launch
     const bool diag = DIAG > 0 ? true : g.diag != 0;
     unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
 
     EnvState st = a.commit[e];
     if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
-    if ((!st.running && !a.mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
+    if ((!st.running && !mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * g.VW;
     for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];
@@ -285,15 +287,15 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
-    for (int s = 0; s < n_steps && (st.running || a.mit); ++s) {
+    for (int s = 0; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
-        if (a.mit) {
+        if (mit) {
             // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80): this
             // environment's points of step s, the same two passes as k_mitigate_clear / k_mitigate_write - clear (and make
             // up the attenuation a line cell is owed under its old type), then byte-wise atomic max of the line types
             // (FIRELINE < SCRATCHLINE < WETLINE = the reference's write order for duplicates).  Also after QUIT: the
             // harness keeps drawing lines on a fire that is out.
-            const int32_t *pts = a.mit + ((long long)s * g.E + e) * a.mit_k * 3;
+            const int32_t *pts = mit + ((long long)s * g.E + e) * a.mit_k * 3;
             for (int i = tid; i < a.mit_k; i += nthr) {
                 const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
                 if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;

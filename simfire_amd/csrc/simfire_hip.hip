@@ -138,7 +138,7 @@ struct sf_sim {
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run[12] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[16] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -962,14 +962,17 @@ static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, in
     const int need = ((s->g.H + waves * 64 - 1) / (waves * 64)) * s->g.VW;
     const int which = need <= 1 ? 0 : (need <= 2 ? 1 : 2);
     typedef void (*run_fn)(StepArgs, int, int, int);
-    // [words per thread 1 / 2 / 4][attenuation off / on][diagonal spread read at run time / known to be on]
+    // [words per thread 1 / 2 / 4][attenuation off / on][diagonal spread read at run time / known to be on]; control lines inside
+    // the launch: one word per thread has an instantiation without them (MIT = 0), the others look at the argument
     static const run_fn table[3][2][2] = {
-        {{k_run<1, 0, -1>, k_run<1, 0, 1>}, {k_run<1, 1, -1>, k_run<1, 1, 1>}},
-        {{k_run<2, 0, -1>, k_run<2, 0, 1>}, {k_run<2, 1, -1>, k_run<2, 1, 1>}},
-        {{k_run<kRunMaxD, 0, -1>, k_run<kRunMaxD, 0, 1>}, {k_run<kRunMaxD, 1, -1>, k_run<kRunMaxD, 1, 1>}}};
+        {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, -1>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, -1>}},
+        {{k_run<2, 0, -1, -1>, k_run<2, 0, 1, -1>}, {k_run<2, 1, -1, -1>, k_run<2, 1, 1, -1>}},
+        {{k_run<kRunMaxD, 0, -1, -1>, k_run<kRunMaxD, 0, 1, -1>}, {k_run<kRunMaxD, 1, -1, -1>, k_run<kRunMaxD, 1, 1, -1>}}};
+    static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, 0>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, 0>, k_run<1, 1, 1, 0>}};
     const int ia = s->g.att ? 1 : 0, id = s->g.diag ? 1 : 0;
-    const run_fn kern = table[which][ia][id];
-    size_t &attr = s->attr_run[(which * 2 + ia) * 2 + id];
+    const bool nomit = which == 0 && !a.mit;
+    const run_fn kern = nomit ? table_nomit[ia][id] : table[which][ia][id];
+    size_t &attr = s->attr_run[nomit ? 12 + ia * 2 + id : (which * 2 + ia) * 2 + id];
     if (lds > 64 * 1024 && lds > attr) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
