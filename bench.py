@@ -347,7 +347,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def rollout(k, first):
         run_steps(eng, k, first, agent_pts)
