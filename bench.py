@@ -350,8 +350,11 @@ def main():
             torch.cuda.synchronize()
 
     def rollout(k, first):
-        run_steps(eng, k, first, agent_pts)
-        eng.copy_status_to(result.data_ptr())            # per-env result block (episode returns)
+        if agent_pts is None:
+            eng.rollout(k, result.data_ptr())            # the steps (not waited for) + the per-env result block (episode returns): one call, one wait
+        else:
+            run_steps(eng, k, first, agent_pts)
+            eng.copy_status_to(result.data_ptr())
         if dist is not None:
             dist.all_gather_into_tensor(gathered, result.to(coll_dev))  # RCCL over xGMI, once per rollout
 

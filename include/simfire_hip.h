@@ -180,6 +180,10 @@ int sf_update_status_device(sf_sim *sim);
 /* Refresh the result block and copy it (device to device) into caller-owned device memory,
  * e.g. the torch tensor that is then all-gathered over RCCL. */
 int sf_copy_status_to(sf_sim *sim, void *device_dst /* int32 [n_envs][8] */);
+/* A rollout in one call: sf_step(sim, n_steps) without a host wait of its own, then sf_copy_status_to(sim, device_dst) - n calls of
+ * FireSimulation.run(1) per environment (simulation.py:501-553) and the attributes a harness reads afterwards (541-553), one
+ * launch and one wait on grids the resident launch covers.  The handle's asynchronous mode is left as it was. */
+int sf_rollout(sf_sim *sim, int32_t n_steps, void *device_dst /* int32 [n_envs][8] */);
 /* Register caller-owned device memory (int32 [n_envs][8]; NULL unregisters) as a second home of the
  * result block: every refresh of the block also writes it there.  In particular the resident launch
  * of sf_step(n >= 2) leaves the block behind itself (every workgroup counts its own environment when

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sf_status_device": [_VP, C.POINTER(_VP)],
     "sf_update_status_device": [_VP],
     "sf_copy_status_to": [_VP, _VP],
+    "sf_rollout": [_VP, _I32, _VP],
     "sf_set_result_sink": [_VP, _VP],
     "sf_comm_unique_id": [_VP],
     "sf_comm_init": [_VP, _I32, _I32, _VP],

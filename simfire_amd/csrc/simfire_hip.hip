@@ -1549,6 +1549,17 @@ extern "C" int sf_copy_status_to(sf_sim *s, void *device_dst)
     return SF_OK;
 }
 
+extern "C" int sf_rollout(sf_sim *s, int32_t n_steps, void *device_dst)
+{
+    if (!s || !device_dst) return fail(SF_EINVAL, "sf_rollout: null argument");
+    const bool was_async = s->async;
+    s->async = true;                               // (the steps are only enqueued: the one wait is the result block's)
+    int rc = step_impl(s, n_steps, nullptr);
+    s->async = was_async;
+    if (rc) return rc;
+    return sf_copy_status_to(s, device_dst);
+}
+
 extern "C" int sf_set_result_sink(sf_sim *s, void *device_dst)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_result_sink: null handle");

@@ -359,6 +359,11 @@ class FireEngine:
         (int32 [n_envs, 8]), e.g. ``tensor.data_ptr()`` of a torch tensor on the same GPU."""
         _lib.check(self._L.sf_copy_status_to(self._h, C.c_void_p(int(device_ptr))))
 
+    def rollout(self, n, device_ptr):
+        """``step(n)`` without a wait of its own + ``copy_status_to(device_ptr)`` as one call: what a harness does
+        between two policy evaluations."""
+        _lib.check(self._L.sf_rollout(self._h, int(n), C.c_void_p(int(device_ptr))))
+
     def set_result_sink(self, device_ptr):
         """Register device memory (int32 [n_envs, 8], e.g. ``tensor.data_ptr()``; ``None`` unregisters) that every
         refresh of the result block also writes - the resident launch of ``step(n >= 2)`` leaves the block there

@@ -651,6 +651,12 @@ def test_resident_launch_leaves_the_result_block_and_fills_the_sink():
     eng.step(3); o.step(3)
     _same(eng, o, E, tag="sink unregistered")
     assert (sink.cpu().numpy() != o.status()[0]).any()
+    # sf_rollout: the steps + the result block as one call (resident launch and, for one step, the per-step kernels)
+    for n in (7, 1):
+        eng.rollout(n, other.data_ptr()); o.step(n)
+        torch.cuda.synchronize()
+        assert (other.cpu().numpy() == o.status()[0]).all(), n
+    _same(eng, o, E, tag="rollout")
 
 
 def test_more_environments_than_workgroup_slots_compact_launch_in_segments():
