@@ -283,33 +283,50 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
 // waves in turn, one wave per tile.  The result block row of the environment (and its elapsed_time) is written without
 // atomics, so nothing has to be zeroed first.
 // The body: the calling workgroup (any number of waves) produces the result row of environment e.  running / steps /
-// elapsed_time are the environment's committed state; s_tot [16][6] lives in the caller's LDS.  A wave takes 64 tiles at a time,
-// one per lane (dirty flag + cached histogram: one round trip for all of them), and recounts the dirty ones among them one after
-// the other with all its lanes; one barrier for the whole row.
+// elapsed_time are the environment's committed state; s_tot [16][6] + a counter + a list of kCountsListCap u16 live in the caller's LDS.
+constexpr int kCountsListCap = 1024;          // dirty tiles per round of counts_env (u16 entries in the caller's LDS, after s_tot)
 __device__ __forceinline__ void counts_env(const Geo &g, int e, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
                                            int running, int steps, double elapsed_time, int32_t *out, double *elapsed, int32_t *out2,
                                            int32_t (*s_tot)[6])
 {
+    // LDS of the caller: s_tot [16][6] int32, then one counter, then the list of dirty tiles of the round [kCountsListCap] u16
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(&s_tot[16][0]);
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_n + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int per_env = g.TY * g.TX;
     const int c = lane & (g.LC - 1), r = lane >> g.logLC;
     int32_t tot[6] = {0, 0, 0, 0, 0, 0};
-    for (int t0 = wave * 64; t0 < per_env; t0 += n_waves * 64) {
-        const int t = t0 + lane;
-        bool dirty = false;
-        if (t < per_env) {
-            const long long idx = (long long)e * per_env + t;
-            dirty = tdirty[idx] != 0;
-            if (!dirty) {
-                const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
-                tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
-                tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+    // Rounds of kCountsListCap tiles (one round on every reference grid): a wave takes 64 tiles at a time, one per lane (dirty flag +
+    // cached histogram: one round trip for all of them); the dirty ones go to a list in LDS, which the waves then recount in turn - the
+    // tiles a fire dirties are neighbours in the map, and whoever owns their block of 64 would recount them one after the other.
+    for (int round0 = 0; round0 < per_env; round0 += kCountsListCap) {
+        if (threadIdx.x == 0) *s_n = 0;
+        __syncthreads();
+        const int round1 = round0 + kCountsListCap < per_env ? round0 + kCountsListCap : per_env;
+        for (int t0 = round0 + wave * 64; t0 < round1; t0 += n_waves * 64) {
+            const int t = t0 + lane;
+            bool dirty = false;
+            if (t < round1) {
+                const long long idx = (long long)e * per_env + t;
+                dirty = tdirty[idx] != 0;
+                if (!dirty) {
+                    const uint4 hv = *reinterpret_cast<const uint4 *>(thist + idx * 8);      // [_, 1, 2, 3, 4, 5, _, _]
+                    tot[1] += (int32_t)(hv.x >> 16); tot[2] += (int32_t)(hv.y & 0xFFFFu); tot[3] += (int32_t)(hv.y >> 16);
+                    tot[4] += (int32_t)(hv.z & 0xFFFFu); tot[5] += (int32_t)(hv.z >> 16);
+                }
+            }
+            const unsigned long long bal = __ballot(dirty);
+            if (bal) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(s_n, (uint32_t)__popcll(bal));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (dirty) s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)(t - round0);
             }
         }
-        unsigned long long todo = __ballot(dirty);
-        while (todo) {
-            const int tt = t0 + (int)__ffsll((long long)todo) - 1;
-            todo &= todo - 1;
+        __syncthreads();
+        const uint32_t n_dirty = *s_n;
+        for (uint32_t q = wave; q < n_dirty; q += n_waves) {
+            const int tt = round0 + s_list[q];
             const long long tidx = (long long)e * per_env + tt;
             const int tyw = tt / g.TX, chunk = tt - tyw * g.TX;
             const int cv = chunk * g.LC + c, y0 = (tyw * g.LR + r) * g.RB;
@@ -338,6 +355,7 @@ __device__ __forceinline__ void counts_env(const Geo &g, int e, const uint8_t *s
             if (lane >= 1 && lane < 6) thist[tidx * 8 + lane] = (uint16_t)(lane == 1 ? loc[1] : lane == 2 ? loc[2] : lane == 3 ? loc[3] : lane == 4 ? loc[4] : loc[5]);
             if (lane == 0) tdirty[tidx] = 0;
         }
+        if (round1 < per_env) __syncthreads();         // (uniform) more rounds: the list is rewritten
     }
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
@@ -365,9 +383,10 @@ __device__ __forceinline__ void counts_env(const Geo &g, int e, const uint8_t *s
 __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
                                                        const EnvState *commit, int32_t *out, double *elapsed, int32_t *out2)
 {
-    __shared__ int32_t s_tot[16][6];
+    __shared__ int32_t s_mem[16 * 6 + 1 + kCountsListCap / 2];        // s_tot [16][6], the list counter, the list (u16)
     const int e = blockIdx.x;
-    counts_env(g, e, status, cells, tdirty, thist, commit[e].running, commit[e].steps, commit[e].elapsed, out, elapsed, out2, s_tot);
+    counts_env(g, e, status, cells, tdirty, thist, commit[e].running, commit[e].steps, commit[e].elapsed, out, elapsed, out2,
+               reinterpret_cast<int32_t (*)[6]>(s_mem));
 }
 
 __global__ void k_elapsed(int E, const EnvState *commit, double *out)
