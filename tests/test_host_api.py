@@ -325,3 +325,56 @@ def test_save_data_matches_reference(tmp_path):
         assert (mine == ref).all() and (np.asarray(attr[str(name)]) == ref).all(), name
         if str(name) in ("w_0", "sigma", "delta", "M_x", "wind_speed", "wind_direction"):
             assert str(mine.dtype) == str(dt), name
+
+
+@pytest.mark.parametrize("data_type", ["jsonl", "json", "h5"])
+def test_save_data_other_formats(tmp_path, data_type):
+    """``data_type`` ``json`` / ``jsonl`` (one ``{"<elapsed_steps>": fire_map}`` line per update, appended across
+    run() calls, static planes as ``<name>.json`` = ``{"data": [...]}``) and ``h5`` (dataset ``data``): simulation.py:
+    906-958, 1077-1104.  The reference's Config accepts only npy / h5 (config.py:111), so json is set on the config
+    object, as a reference user would have to.  The maps are the ones the reference recorded for the npy run."""
+    import json
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    if data_type == "h5":
+        h5py = pytest.importorskip("h5py")
+    d = _golden.load("save_data_c1_32.npz")
+    y = yaml.safe_load(open(os.path.join(CFG, "functional_config.yml")))
+    y["area"]["screen_size"] = [32, 32]
+    y["terrain"]["topography"]["functional"]["function"] = "flat"
+    y["simulation"].update(headless=True, save_data=True, data_type="npy", sf_home=str(tmp_path))
+    y["fire"]["fire_initial_position"]["static"]["position"] = "(8, 9)"
+    sim = FireSimulation(Config(config_dict=y))
+    sim.config.simulation.data_type = data_type
+    sim._HISTORY_CHUNK = 4
+    sim.update_mitigation([tuple(int(v) for v in p) for p in d["points"]])
+    sim.run(7)
+    sim.run(5)
+    datadir = tmp_path / "data" / sim.start_time
+    meta = json.load(open(datadir / "metadata.json"))
+    ext = "h5" if data_type == "h5" else "jsonl"
+    assert meta["fire_map"] == f"fire_map.{ext}"
+    names = [str(n) for n in d["static_names"]]
+    sext = "h5" if data_type == "h5" else "json"
+    assert sorted(os.listdir(datadir)) == sorted([f"fire_map.{ext}", "metadata.json"] + [f"{n}.{sext}" for n in names])
+    assert meta["static_data"]["data"] == {n: f"{n}.{sext}" for n in meta["static_data"]["data"]}
+    if data_type == "h5":
+        with h5py.File(datadir / "fire_map.h5", "r") as f:
+            hist = np.asarray(f["data"])
+        assert (hist == d["history"]).all()
+        for n in names:
+            with h5py.File(datadir / f"{n}.h5", "r") as f:
+                assert (np.asarray(f["data"]) == d[f"attr_{n}"]).all(), n
+    else:
+        lines = open(datadir / "fire_map.jsonl").read().splitlines()
+        assert len(lines) == d["history"].shape[0]
+        for i, line in enumerate(lines):
+            rec = json.loads(line)
+            assert list(rec) == [str(i + 1)]                       # the key is elapsed_steps after the update
+            assert (np.array(rec[str(i + 1)]) == d["history"][i]).all()
+        for n in names:
+            assert (np.array(json.load(open(datadir / f"{n}.json"))["data"]) == d[f"attr_{n}"]).all(), n
+    sim.config.simulation.data_type = "csv"
+    with pytest.raises(ValueError):
+        sim.run(1)
