@@ -21,13 +21,21 @@ NAMES = ["0 barrier at the end of the step (waiting for the slowest wave)", "1 i
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     envs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    w = workloads.c3(1024, envs)
+    c5 = len(sys.argv) > 5 and sys.argv[5] == "c5"      # C5: 64 agents per environment, control lines inside the launch
+    w = workloads.c5(1024, envs) if c5 else workloads.c3(1024, envs)
     eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
     eng.set_layers(*w.layers())
     eng.reset(w.init_xy)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     eng.set_fused(mode)
-    eng.step(int(sys.argv[4]) if len(sys.argv) > 4 else 20)
+    warm = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    if c5:
+        H, W = w.shape
+        pts = np.ascontiguousarray(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, steps + warm).reshape(
+            steps + warm, w.n_envs, w.agents_per_env, 4)[..., 1:])
+        eng.step_mitigated(pts[:warm])
+    else:
+        eng.step(warm)
     eng.enable_counters(True)
     out = np.zeros(8, dtype=np.int64)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
@@ -37,7 +45,7 @@ def main():
     log = np.zeros((16384, 4), dtype=np.uint64)
     fn(0, log.ctypes.data_as(ctypes.c_void_p))      # clears nothing, but makes sure the symbol is there
     fn(1, None)
-    ms = eng.step_timed(steps)
+    ms = eng.step_mitigated(pts[warm:], timed=True) if c5 else eng.step_timed(steps)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
     fn(0, log.ctypes.data_as(ctypes.c_void_p))
     tiles = max(int(out[5]) // 64, 1)      # batches of 64 vectors (approx.)

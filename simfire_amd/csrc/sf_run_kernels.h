@@ -286,6 +286,16 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const int rpt = (g.H + nthr - 1) / nthr;                  // rows per thread (contiguous, so the list runs by rows)
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
+    // control lines inside the launch, up to 64 points per environment and step: lane i of wave 0 holds point i of the coming step
+    const bool mit_one_wave = mit && a.mit_k <= 64;
+    int32_t px = 0, py = 0, pty = 0;
+    auto load_pt = [&](int s) {
+        if (wave == 0 && lane < a.mit_k) {
+            const int32_t *p = mit + (((long long)s * g.E + e) * a.mit_k + lane) * 3;
+            px = p[0]; py = p[1]; pty = p[2];
+        }
+    };
+    if (mit_one_wave && n_steps > 0) load_pt(0);
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
     for (int s = 0; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
@@ -295,34 +305,87 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             // up the attenuation a line cell is owed under its old type), then byte-wise atomic max of the line types
             // (FIRELINE < SCRATCHLINE < WETLINE = the reference's write order for duplicates).  Also after QUIT: the
             // harness keeps drawing lines on a fire that is out.
-            const int32_t *pts = mit + ((long long)s * g.E + e) * a.mit_k * 3;
-            for (int i = tid; i < a.mit_k; i += nthr) {
-                const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
-                if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
-                const uint32_t o = (uint32_t)(y * g.P + x);
-                uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
-                const int sh = (x & 3) * 8;
-                const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
-                if (ATT && old >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(old), (uint32_t)st.complete - ev.settled[o]);
+            if (mit_one_wave) {
+                // Up to 64 points per environment and step (C5): wave 0 alone, a point per lane, no barrier between the two passes (the
+                // lanes of a wave issue the clears together and wait for them together), the write pass starts from the word the clear
+                // returned instead of loading it again, burn / settled are requested with the clear instead of after it, and the points
+                // were requested one step ahead (the block was 9.3 k clocks of a C5 step).
+                if (wave == 0) {
+                    const int ty = pty;
+                    const bool ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && px >= 0 && px < g.W && py >= 0 && py < g.H;
+                    const int x = ok ? px : 0, y = ok ? py : 0;
+                    const uint32_t o = (uint32_t)(y * g.P + x);
+                    uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
+                    const int sh = (x & 3) * 8;
+                    uint32_t w = 0, owed_since = 0;
+                    double bn = 0.0;
+                    if (ok) {
+                        w = atomicAnd(word, ~(0xFFu << sh));
+                        if (ATT) { bn = ev.burn[o]; owed_since = ev.settled[o]; }
+                    }
+                    if (s + 1 < n_steps) load_pt(s + 1);
+                    if (ok) {
+                        if (ATT) {
+                            const uint32_t was = (w >> sh) & 7u;
+                            if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)st.complete - owed_since);
+                            ev.settled[o] = (uint32_t)st.complete;      // (every lane has its old count by now; every point of this step on this cell stores the same)
+                        }
+                        ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();          // every clear of this step has returned
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (ok) {
+                        // the word as this lane's clear left it; if another point of the step changed it since (a duplicate, a neighbouring
+                        // byte) the first compare-and-swap fails and returns what it holds now
+                        uint32_t old = w & ~(0xFFu << sh), seen;
+                        do {
+                            seen = old;
+                            if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
+                            old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
+                        } while (old != seen);
+                        if (fine) atomicOr(&ve[y], 1ull << (x >> 4));
+                    }
+                }
+                // What the step reads next are the bitmaps in LDS; the cell planes are not read before the barrier behind the vector list,
+                // which waits for wave 0's stores like any __syncthreads: no wait for their acknowledgements here.
+                if (st.running) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                } else {
+                    __syncthreads();        // the fire is out: the next thing is the next step's control lines
+                }
+            } else {
+                const int32_t *pts = mit + ((long long)s * g.E + e) * a.mit_k * 3;
+                for (int i = tid; i < a.mit_k; i += nthr) {
+                    const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
+                    if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
+                    const uint32_t o = (uint32_t)(y * g.P + x);
+                    uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
+                    const int sh = (x & 3) * 8;
+                    const uint32_t old = (atomicAnd(word, ~(0xFFu << sh)) >> sh) & 7u;
+                    if (ATT && old >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(old), (uint32_t)st.complete - ev.settled[o]);
+                }
+                __syncthreads();
+                for (int i = tid; i < a.mit_k; i += nthr) {
+                    const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
+                    if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
+                    const uint32_t o = (uint32_t)(y * g.P + x);
+                    uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
+                    const int sh = (x & 3) * 8;
+                    uint32_t old = *word, seen;
+                    do {
+                        seen = old;
+                        if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
+                        old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
+                    } while (old != seen);
+                    if (ATT) ev.settled[o] = (uint32_t)st.complete;      // idempotent: every point of this step on this cell stores the same count
+                    ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                    if (fine) atomicOr(&ve[y], 1ull << (x >> 4));          // a control line is an eligible cell
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            for (int i = tid; i < a.mit_k; i += nthr) {
-                const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
-                if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
-                const uint32_t o = (uint32_t)(y * g.P + x);
-                uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
-                const int sh = (x & 3) * 8;
-                uint32_t old = *word, seen;
-                do {
-                    seen = old;
-                    if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
-                    old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
-                } while (old != seen);
-                if (ATT) ev.settled[o] = (uint32_t)st.complete;      // idempotent: every point of this step on this cell stores the same count
-                ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
-                if (fine) atomicOr(&ve[y], 1ull << (x >> 4));          // a control line is an eligible cell
-            }
-            __syncthreads();
             if (!st.running) continue;          // (uniform) the fire is out: nothing to step
         }
 #ifdef SF_PHASES

@@ -457,17 +457,19 @@ def _blk(agent_pts, E, k):
     return np.ascontiguousarray(a.reshape(a.shape[0], E, k, 4)[..., 1:])
 
 
-@pytest.mark.parametrize("mode", [-1, 0, 2, "torch"])
+@pytest.mark.parametrize("mode,K", [(-1, 12), (0, 12), (2, 12), ("torch", 12), (2, 64), (2, 80)])
 @pytest.mark.parametrize("att", [False, True])
-def test_mitigated_rollout_equals_update_mitigation_run_pairs(mode, att):
+def test_mitigated_rollout_equals_update_mitigation_run_pairs(mode, att, K):
     """sf_step_mitigated == `for s: update_mitigation(points[s]); run(1)` (simulation.py:449-478, 501-553): inside k_run
     (automatic / forced), as scatter + step pairs (forced per-step launches), from a device tensor; duplicates with
     type precedence, lines on burning cells, padding / off-grid entries, an environment that reaches QUIT half-way
-    (its lines are still drawn), lazy attenuation."""
+    (its lines are still drawn), lazy attenuation.  Up to 64 points per environment and step are handled by one wave of the
+    resident launch (K = 12, 64), more by the whole workgroup (K = 80); points in neighbouring bytes of one status word and
+    lines drawn over the lines of the step before (attenuation owed under the old type) are forced in every step."""
     import torch
     from simfire_amd.engine import FireEngine
     rng = np.random.default_rng(314 + int(att))
-    H, W, E, K, n = 90, 210, 5, 12, 60
+    H, W, E, n = 90, 210, 5, 60
     kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0,
               attenuate_line_ros=att, max_time=45.0)
     R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
@@ -488,6 +490,9 @@ def test_mitigated_rollout_equals_update_mitigation_run_pairs(mode, att):
         blk[..., 2] = rng.integers(2, 7, (chunk, E, K))                  # 2 and 6: not control lines, skipped
         blk[:, :, 0, 0] = W + 3                                           # off the grid: skipped
         blk[:, :, 1, :2] = blk[:, :, 2, :2]                              # duplicates, maybe of another type
+        blk[:, :, 5, 0] = (blk[:, :, 4, 0] & ~3) | ((blk[:, :, 4, 0] + 1) & 3)      # the neighbouring byte of the same status word
+        blk[:, :, 5, 1] = blk[:, :, 4, 1]
+        blk[1:, :, 6, :2] = blk[:-1, :, 7, :2]                          # over the line the step before drew
         for s in range(chunk):
             cur = o.fire_map(0)
             burning = np.argwhere(cur == 1)
