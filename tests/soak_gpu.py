@@ -74,8 +74,30 @@ def world(seed):
             assert (b == o.burn(e)).all(), (seed, t, e, "burn before round trip")
             eng.set_burn(e, b)
         n = int(rng.choice([1, 1, 1, 2, 5, 17]))
-        eng.step(n)
-        o.step(n)
+        if rng.random() < 0.15:
+            # sf_step_mitigated: n (control lines, update) pairs in one call; up to 64 points per environment and step go
+            # through one wave of the resident launch, more through the workgroup; duplicates, neighbouring bytes of a
+            # status word, lines over the lines of the step before, off-grid / padding entries
+            K = int(rng.choice([1, 3, 12, 64, 70]))
+            blk = np.zeros((n, E, K, 3), dtype=np.int32)
+            blk[..., 0] = rng.integers(-1, W + 1, (n, E, K))
+            blk[..., 1] = rng.integers(-1, H + 1, (n, E, K))
+            blk[..., 2] = rng.integers(2, 7, (n, E, K))
+            if K >= 3:
+                blk[:, :, 1, :2] = blk[:, :, 0, :2]
+                blk[:, :, 2, 0] = blk[:, :, 0, 0] ^ 1
+                blk[:, :, 2, 1] = blk[:, :, 0, 1]
+                blk[1:, :, 0, :2] = blk[:-1, :, 2, :2]
+            eng.step_mitigated(blk)
+            for s_ in range(n):
+                rows = [(e, int(blk[s_, e, i, 0]), int(blk[s_, e, i, 1]), int(blk[s_, e, i, 2])) for e in range(E) for i in range(K)
+                        if 3 <= blk[s_, e, i, 2] <= 5 and 0 <= blk[s_, e, i, 0] < W and 0 <= blk[s_, e, i, 1] < H]
+                if rows:
+                    o.apply_mitigation(rows)
+                o.step(1)
+        else:
+            eng.step(n)
+            o.step(n)
         if rng.random() < 0.6 or t == steps - 1:      # otherwise the states stay in the device rings
             st, el = eng.status()
             so, eo = o.status()
@@ -95,4 +117,6 @@ if __name__ == "__main__":
     cells = 0
     for s in range(s0, s0 + n):
         cells += world(s)
+        if (s - s0 + 1) % 1000 == 0:
+            print(f"  {s - s0 + 1} worlds ok, {time.time()-t0:.0f} s", flush=True)
     print(f"soak ok: {n} worlds, {cells:.3g} cell-steps, {time.time()-t0:.1f} s")
