@@ -187,68 +187,12 @@ class FireSimulation:
             self._save_data(np.concatenate(maps, axis=0))
 
     def _save_data(self, new_maps: np.ndarray) -> None:
-        """On-disk layout of simulation.py:887-959, 1059-1104: ``<sf_home>/data/<start_time>/`` with the fire-map
-        history, one ``<name>.npy`` per observation plane and ``metadata.json``.  ``data_type``:
-        ``npy``  ``fire_map.npy``, int8 [T, H, W], appended to by every run (simulation.py:932-950);
-        ``h5``   ``fire_map.h5``, dataset ``data`` [T, H, W] (simulation.py:951-953; needs h5py, as in the reference);
-        ``json`` / ``jsonl``  ``fire_map.jsonl``, one line ``{"<elapsed_steps>": [[...], ...]}`` per update, appended
-                 (simulation.py:954-958: ``jsonlines.Writer.write`` = ``json.dumps(obj, ensure_ascii=False)`` + a
-                 newline, written here with the standard library)."""
-        import json
-        dtype = self.config.simulation.data_type
-        if dtype == "npy":
-            ext = "npy"
-        elif dtype == "h5":
-            ext = "h5"
-        elif dtype in ("json", "jsonl"):
-            ext = "jsonl"
-        else:
-            raise ValueError(f"Invalid data type '{dtype}' given. Valid types are 'npy', 'h5', 'json', and 'jsonl'.")
-        if dtype == "h5":
-            import h5py                                 # the reference's own dependency for this format
-        datapath = self.sf_home / "data" / self.start_time
-        datapath.mkdir(parents=True, exist_ok=True)
-        data = self.get_attribute_data()
-        static_ext = {"npy": "npy", "h5": "h5", "jsonl": "json"}[ext]           # simulation.py:1077-1104
-        locs = {k: f"{k}.{static_ext}" for k in data}
-        for k, loc in locs.items():
-            if (datapath / loc).is_file():
-                continue
-            if ext == "npy":
-                np.save(datapath / loc, data[k])
-            elif ext == "h5":
-                with h5py.File(datapath / loc, "w") as f:
-                    f.create_dataset("data", data=data[k])
-            else:
-                with open(datapath / loc, "w") as f:
-                    json.dump({"data": np.asarray(data[k]).tolist()}, f)
-        shape = list(next(iter(data.values())).shape)
-        path = datapath / f"fire_map.{ext}"
-        metadata = {"config": self.config.yaml_data, "seeds": self.get_seeds(), "layer_types": self.get_layer_types(),
-                    "shape": shape, "static_data": {"data": locs, "shape": shape}, "fire_map": path.name}
-        with open(datapath / "metadata.json", "w") as f:
-            json.dump(metadata, f, indent=2, default=str)
-        if ext == "jsonl":
-            # self.elapsed_steps still holds the count before this run() call; the reference writes after its increment
-            with open(path, "a", encoding="utf-8") as f:
-                for i, m in enumerate(new_maps):
-                    f.write(json.dumps({self.elapsed_steps + 1 + i: m.astype(np.int64).tolist()}, ensure_ascii=False))
-                    f.write("\n")
-            return
-        if path.is_file():
-            if ext == "npy":
-                old = np.load(path)
-            else:
-                with h5py.File(path, "r") as f:
-                    old = np.asarray(f["data"])
-            if old.ndim == 2:
-                old = old[None]
-            new_maps = np.append(old, new_maps, axis=0)
-        if ext == "npy":
-            np.save(path, new_maps.astype(np.int8))
-        else:
-            with h5py.File(path, "w") as f:
-                f.create_dataset("data", data=new_maps)
+        """simulation.py:887-959: the per-update maps of this run() call go to ``<sf_home>/data/<start_time>/``
+        (``savedata.write_history``: layout and formats of the reference, file for file)."""
+        from .savedata import write_history
+        write_history(self.sf_home / "data" / self.start_time, self.config.simulation.data_type, new_maps,
+                      self.elapsed_steps, self.get_attribute_data(),
+                      {"config": self.config.yaml_data, "seeds": self.get_seeds(), "layer_types": self.get_layer_types()})
 
     # ------------------------------------------------------------------------ mitigation
     def update_mitigation(self, points: Iterable[Tuple[int, int, int]]) -> None:

@@ -214,3 +214,49 @@ def test_bench_self_launch_plumbing():
     assert j["n_gpus"] == 2 and j["gathered_rows"] == 6 and j["ok"] is True
     one = subprocess.run([sys.executable, bench, "--plumbing-only", "--envs", "3"], capture_output=True, text=True, timeout=300)
     assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+@pytest.mark.parametrize("data_type", ["npy", "jsonl", "json", "h5"])
+def test_savedata_writer_against_the_reference_run(tmp_path, data_type):
+    """simfire_amd/savedata.py (host code) fed the per-update maps and observation planes the REFERENCE produced
+    (tests/golden/save_data_c1_32.npz, recorded by make_golden_savedata.py) in two run() calls of 7 and 5 updates:
+    file list, metadata and history of simulation.py:887-959, 1059-1104 for every data_type."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _golden
+    from simfire_amd.savedata import write_history
+    if data_type == "h5":
+        h5py = pytest.importorskip("h5py")
+    d = _golden.load("save_data_c1_32.npz")
+    names = [str(n) for n in d["static_names"]]
+    static = {n: d[f"attr_{n}"] for n in names}
+    meta = {"config": {"area": {"screen_size": [32, 32]}}, "seeds": {"elevation": None}, "layer_types": {"fuel": "functional"}}
+    hist = d["history"].astype(np.int64)
+    write_history(tmp_path, data_type, hist[:7], 0, static, meta)
+    write_history(tmp_path, data_type, hist[7:], 7, static, meta)
+    ext = {"npy": "npy", "h5": "h5"}.get(data_type, "jsonl")
+    sext = {"npy": "npy", "h5": "h5"}.get(data_type, "json")
+    assert sorted(os.listdir(tmp_path)) == sorted([f"fire_map.{ext}", "metadata.json"] + [f"{n}.{sext}" for n in names])
+    m = json.load(open(tmp_path / "metadata.json"))
+    assert list(m) == ["config", "seeds", "layer_types", "shape", "static_data", "fire_map"]      # the reference's key order
+    assert sorted(m) == [str(k) for k in d["metadata_keys"]]
+    assert m["shape"] == [int(v) for v in d["metadata_shape"]] and m["fire_map"] == f"fire_map.{ext}"
+    if data_type == "npy":
+        assert sorted(os.listdir(tmp_path)) == [str(f) for f in d["files"]]
+        assert m["static_data"] == json.loads(str(d["metadata_static"])) and m["fire_map"] == str(d["metadata_fire_map"])
+        got = np.load(tmp_path / "fire_map.npy")
+        assert got.dtype == np.int8 and (got == d["history"]).all()
+        for n, dt in zip(names, d["static_dtypes"]):
+            a = np.load(tmp_path / f"{n}.npy")
+            assert (a == static[n]).all() and str(a.dtype) == str(static[n].dtype)
+    elif data_type == "h5":
+        with h5py.File(tmp_path / "fire_map.h5", "r") as f:
+            assert (np.asarray(f["data"]) == d["history"]).all()
+    else:
+        lines = open(tmp_path / "fire_map.jsonl").read().splitlines()
+        assert [list(json.loads(ln)) for ln in lines] == [[str(i + 1)] for i in range(12)]
+        assert all((np.array(json.loads(ln)[str(i + 1)]) == d["history"][i]).all() for i, ln in enumerate(lines))
+        for n in names:
+            assert (np.array(json.load(open(tmp_path / f"{n}.json"))["data"]) == static[n]).all()
+    with pytest.raises(ValueError):
+        write_history(tmp_path, "csv", hist[:1], 12, static, meta)
