@@ -256,6 +256,36 @@ int sf_set_generic(sf_sim *sim, int32_t on);
  * are kept as lists in LDS for all n steps; falls back to 2 in attenuation mode, in the visit-everything mode and when
  * control lines are applied inside the launch). */
 int sf_set_fused(sf_sim *sim, int32_t mode);
+/* (modes 3 and 4 are measured alternatives that were never the automatic choice; they are compiled only into the
+ * cross-check build, -DSF_EXPERIMENTAL -> libsimfire_hip_exp.so; the product library answers SF_ENOTSUP.) */
+
+/* Launch-geometry knobs of a handle.  RESULTS NEVER DEPEND ON THEM (the tests force several values of each against the
+ * oracle); the defaults are the measured choices of DESIGN.md section 5.  This is the only way to change them: the
+ * library does not read the environment - except that, for the measurement scripts under profiles/, a process started
+ * with SF_DEBUG_KNOBS=1 takes the initial values of new handles from variables named like the enumerators
+ * (SF_TUNE_RUN_WAVES=8 ...).  No reference counterpart (the reference has no launch geometry). */
+enum sf_tuning_knob {
+    SF_TUNE_WAVES_PER_CU = 0,   /* persistent waves per CU of k_step (default 24) */
+    SF_TUNE_RUN_WAVES = 1,      /* waves per workgroup of the resident launch k_run, 1..16 (default 16; 8 when there are more environments than CUs) */
+    SF_TUNE_RUN_MIN_ENVS = 2,   /* automatic mode picks k_run from this many environments (default 1) */
+    SF_TUNE_RUN_VCAP = 3,       /* entries of k_run's vector list in LDS (default 4096; longer lists are taken in chunks) */
+    SF_TUNE_RUN_COMPACT = 4,    /* 1 = 8-wave workgroups, two per CU, when there are more environments than CUs (default 1) */
+    SF_TUNE_RUN_BATCH = 5,      /* vectors per batch of k_run, 8..64 (default 64) */
+    SF_TUNE_RUN_RESULT = 6,     /* 1 = k_run writes the result block itself when its steps are done (default 1) */
+    SF_TUNE_RUN_SEGMENT = 7,    /* steps per k_run launch when there are more environments than workgroup slots (default 64; 0 = one launch) */
+    SF_TUNE_FRONT_MIN_STEPS = 8,/* cross-check build only: k_front knobs */
+    SF_TUNE_FRONT_AUTO = 9,
+    SF_TUNE_FRONT_WAVES = 10,
+    SF_TUNE_FRONT_RC = 11,
+    SF_TUNE_FRONT_IC = 12,
+    SF_TUNE_FRONT_TAB = 13,
+    SF_TUNE_FRONT_DEBUG = 14,
+    SF_TUNE_RUN_SOLO = 15,      /* 1 = k_run lets ONE wave step a small fire by itself (no workgroup barriers) while its vector list fits one batch (default 1) */
+    SF_TUNE_RUN_TEAM = 16,      /* workgroups per environment in k_run: -1 = chosen per launch from the recorded per-environment cost (default), 1 / 2 / 4 = forced upper bound */
+    SF_TUNE_COUNT = 17
+};
+int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
+int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
  * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay
  * QUIT in the result block, spread stays off); 0 (default) = a QUIT environment is frozen, as FireSimulation.run

@@ -78,6 +78,8 @@ SIGNATURES = {
     "sf_get_spread_parents": [_VP, _I32, _VP],
     "sf_set_generic": [_VP, _I32],
     "sf_set_fused": [_VP, _I32],
+    "sf_set_tuning": [_VP, _I32, _I32],
+    "sf_get_tuning": [_VP, _I32, C.POINTER(_I32)],
     "sf_last_step_launch": [_VP, C.POINTER(_I32)],
     "sf_set_prune_after_quit": [_VP, _I32],
     "sf_set_async": [_VP, _I32],
@@ -86,20 +88,34 @@ SIGNATURES = {
 }
 STRING_GETTERS = ("sf_last_error", "sf_version")
 
-_lib = None
+# Other builds of the same sources, loaded only by tests (python -m simfire_amd.build --all):
+#   "exp"  -DSF_EXPERIMENTAL: + the measured alternatives k_run_tiles / k_front (sf_set_fused(3 / 4))
+#   "sow"  -DSF_STORE_ORDER_WAIT: k_run with an explicit wait between a vector's 16-byte store and its ignition byte stores
+VARIANTS = {"exp": "libsimfire_hip_exp.so", "sow": "libsimfire_hip_sow.so"}
 
 
-def load():
+def variant_path(variant):
+    return os.environ.get("SIMFIRE_HIP_LIB_" + variant.upper()) or os.path.join(_HERE, "csrc", VARIANTS[variant])
+
+
+TUNE = {name: i for i, name in enumerate((
+    "waves_per_cu", "run_waves", "run_min_envs", "run_vcap", "run_compact", "run_batch", "run_result", "run_segment",
+    "front_min_steps", "front_auto", "front_waves", "front_rc", "front_ic", "front_tab", "front_debug", "run_solo", "run_team"))}
+
+_libs = {}
+
+
+def load(variant=None):
     """Load the HIP library (once).  Raises ``SimfireHipError`` if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    path = variant_path(variant) if variant else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise SimfireHipError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()' or python -m simfire_amd.build). "
-            "simfire_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+            f"{path} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python -m simfire_amd.build"
+            f"{' --all' if variant else ''}). simfire_amd has no CPU fallback.")
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -107,15 +123,15 @@ def load():
     for name in STRING_GETTERS:
         getattr(lib, name).restype = C.c_char_p
         getattr(lib, name).argtypes = []
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     """Map a C return code onto the exception type the reference raises for that failure."""
     if rc == SF_OK:
         return
-    msg = load().sf_last_error().decode("utf-8", "replace")
+    msg = (lib or load()).sf_last_error().decode("utf-8", "replace")
     if rc in (SF_EINVAL, SF_ESHAPE):
         raise ValueError(msg)
     if rc == SF_ENOTSUP:

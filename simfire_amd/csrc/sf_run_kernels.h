@@ -184,9 +184,13 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
             if (bn > g.pixel_scale) {                                            // fire.py:568
                 ignited = true;
                 const uint8_t nb = (uint8_t)(((c.own_spost & 0xFFu) & ~mk.b_clr) | mk.b_new);       // fire.py:571-579
-                // These byte stores follow, in program order, the 16-byte stores of the vector pass to the same lines: stores of one
-                // wave reach the L2 in issue order (same line = same channel queue; profiles/store_order_probe.hip: 0 of 5.2e9
-                // inverted).  -DSF_STORE_ORDER_WAIT restores an explicit wait for the earlier stores' acknowledgements.
+                // These byte stores follow the 16-byte stores of the vector pass to the same lines.  What orders them: on gfx9-class
+                // hardware loads and stores share ONE in-order completion counter (vmcnt; a store leaves it when its data has been
+                // written to the L2 - the compiler's own wait-count model for this target relies on the same fact, and it is why a
+                // wait for a load here also waits for every earlier store).  The decision `bn > pixel_scale` above
+                // depends on c.bn, a load issued AFTER the vector pass's stores: the wait in front of it has retired them.  Evidence
+                // besides the argument: profiles/store_order_probe.hip (0 of 5.2e9 inverted), the soak runs, and the
+                // -DSF_STORE_ORDER_WAIT build (explicit wait; test_store_order_wait_build runs both).
 #ifdef SF_STORE_ORDER_WAIT
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -766,6 +766,7 @@ __host__ __device__ inline int run_shared_bytes(const Geo &g)
 #endif
 }
 
+#ifdef SF_EXPERIMENTAL      // k_run_tiles: the tile kernels inside a resident workgroup (measured alternative, sf_set_fused(3); not in the product build)
 constexpr int run_max_waves(int rb) { return rb <= 4 ? 16 : 8; }      // 64 x 128 tiles need more than 128 VGPRs per lane
 template <int RB>
 __global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run_tiles(StepArgs a, int n_steps)
@@ -874,6 +875,8 @@ __global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run_tiles(StepArgs a
 #endif
     }
 }
+
+#endif  // SF_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------
 // Generic step: one thread per cell, any sprite-plane width (AgeT = uint8_t / uint16_t /

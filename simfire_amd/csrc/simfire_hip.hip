@@ -88,9 +88,31 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 #include "sf_step_kernels.h"
 #include "sf_aux_kernels.h"
 #include "sf_run_kernels.h"
+#ifdef SF_EXPERIMENTAL
+// Measured alternatives that are never the automatic choice: k_run_tiles (sf_set_fused(3)) and k_front
+// (sf_set_fused(4)).  They are compiled only into the cross-check build libsimfire_hip_exp.so (python -m simfire_amd.build
+// --experimental), which the tests of those two modes load; the product library answers SF_ENOTSUP.
 #include "sf_front_kernels.h"
+#endif
 
 constexpr int kFrontStartCap = 32768;      // k_front: sprite cells per environment at launch start it remembers (more: k_run takes over)
+
+// Launch-geometry knobs of a handle (sf_set_tuning, include/simfire_hip.h: SF_TUNE_*).  Results never depend on them; the
+// defaults are the measured choices of DESIGN.md 5.  The environment is NOT consulted - except, for the measurement scripts
+// under profiles/, when SF_DEBUG_KNOBS=1 is set: then sf_create takes initial values from variables named like the enum
+// (SF_TUNE_RUN_WAVES=8 ...).
+struct Tuning {
+    int v[SF_TUNE_COUNT];
+    bool set[SF_TUNE_COUNT];
+};
+static const int kTuneDefault[SF_TUNE_COUNT] = {
+    /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
+    /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
+    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_SOLO */ 1, /* RUN_TEAM */ -1};
+static const char *const kTuneName[SF_TUNE_COUNT] = {
+    "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
+    "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
+    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_SOLO", "SF_TUNE_RUN_TEAM"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -157,6 +179,7 @@ struct sf_sim {
     bool async = false;                // sf_set_async: calls that return no data do not synchronise
     bool have_rt = false, was_reset = false, counters_on = false;
     int seq = 0;                       // index (mod 6) of the next step launch
+    Tuning tune;                       // sf_set_tuning
     bool committed = true;             // commit[] is current (no step launch since the last k_commit / reset)
     std::vector<char> rt_set;          // per table: layers / R table supplied?
     int64_t bytes = 0;
@@ -232,7 +255,15 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.LR = 64 / g.LC;
     g.chunks_x = (g.PV + g.LC - 1) / g.LC;
     g.dense = 0;
-    if (const char *v = getenv("SF_DENSE")) g.dense = atoi(v) != 0;
+    {
+        const char *dk = getenv("SF_DEBUG_KNOBS");
+        const bool from_env = dk && atoi(dk) != 0;
+        for (int i = 0; i < SF_TUNE_COUNT; ++i) {
+            s->tune.v[i] = kTuneDefault[i]; s->tune.set[i] = false;
+            const char *v = from_env ? getenv(kTuneName[i]) : nullptr;
+            if (v) { s->tune.v[i] = atoi(v); s->tune.set[i] = true; }
+        }
+    }
     g.md = p->max_fire_duration; g.N = g.md + 3;
     g.ab = g.N <= 8 ? 1 : (g.N <= 16 ? 2 : 4);
     g.rt_env = p->per_env_terrain ? (long long)8 * g.H * P : 0;   // 1-byte plane: SWAR kernels; wider: generic per-cell kernel
@@ -283,7 +314,9 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->run_cost, (size_t)g.E));
     TRY(dev_alloc(s, &s->run_order, (size_t)g.E));
     TRYHIP(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
+#ifdef SF_EXPERIMENTAL
     if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * kFrontStartCap));
+#endif
     TRYHIP(hipHostMalloc(reinterpret_cast<void **>(&s->ovf_pinned), sizeof(int32_t), hipHostMallocMapped));
     TRYHIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->ovf_mapped), s->ovf_pinned, 0));
     *s->ovf_pinned = 0;
@@ -467,9 +500,29 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
 extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 {
     if (!s || mode < -1 || mode > 4) return fail(SF_EINVAL, "sf_set_fused: mode must be -1 ... 4");
+#ifndef SF_EXPERIMENTAL
+    if (mode == 3 || mode == 4)
+        return fail(SF_ENOTSUP, "sf_set_fused: modes 3 (k_run_tiles) and 4 (k_front) exist only in the cross-check build (libsimfire_hip_exp.so, -DSF_EXPERIMENTAL)");
+#endif
     HIPCHK(hipSetDevice(s->p.device));
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
+    return SF_OK;
+}
+
+extern "C" int sf_set_tuning(sf_sim *s, int32_t knob, int32_t value)
+{
+    if (!s || knob < 0 || knob >= SF_TUNE_COUNT) return fail(SF_EINVAL, "sf_set_tuning: unknown knob %d", knob);
+    HIPCHK(hipSetDevice(s->p.device));
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }
+    s->tune.v[knob] = value;
+    s->tune.set[knob] = true;
+    return SF_OK;
+}
+extern "C" int sf_get_tuning(sf_sim *s, int32_t knob, int32_t *value)
+{
+    if (!s || !value || knob < 0 || knob >= SF_TUNE_COUNT) return fail(SF_EINVAL, "sf_get_tuning: unknown knob %d", knob);
+    *value = s->tune.v[knob];
     return SF_OK;
 }
 
@@ -960,13 +1013,12 @@ constexpr int SF_INTERNAL_NO_RESIDENT = 1;       // step_impl: the resident laun
 static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, int vcap, size_t lds, int bsz)
 {
     const int need = ((s->g.H + waves * 64 - 1) / (waves * 64)) * s->g.VW;
-    const int which = need <= 1 ? 0 : (need <= 2 ? 1 : 2);
+    const int which = need <= 1 ? 0 : 1;       // (an instantiation for two words was not measurably faster than the one for four)
     typedef void (*run_fn)(StepArgs, int, int, int);
     // [words per thread 1 / 2 / 4][attenuation off / on][diagonal spread read at run time / known to be on]; control lines inside
     // the launch: one word per thread has an instantiation without them (MIT = 0), the others look at the argument
-    static const run_fn table[3][2][2] = {
+    static const run_fn table[2][2][2] = {
         {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, -1>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, -1>}},
-        {{k_run<2, 0, -1, -1>, k_run<2, 0, 1, -1>}, {k_run<2, 1, -1, -1>, k_run<2, 1, 1, -1>}},
         {{k_run<kRunMaxD, 0, -1, -1>, k_run<kRunMaxD, 0, 1, -1>}, {k_run<kRunMaxD, 1, -1, -1>, k_run<kRunMaxD, 1, 1, -1>}}};
     static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, 0>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, 0>, k_run<1, 1, 1, 0>}};
     const int ia = s->g.att ? 1 : 0, id = s->g.diag ? 1 : 0;
@@ -1005,7 +1057,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     const StepKernel kern = pick_step_kernel(s->g.RB, fused);
     a.tflags = s->tflags; a.tile_list = s->tile_list; a.n_active = s->n_active; a.seam = s->seam; a.settled = s->settled; a.tdirty = s->tdirty;
     const dim3 sel_grid((unsigned)((n_wave_tiles + kSelectThreads - 1) / kSelectThreads));
-    static const int waves_per_cu = getenv("SF_WAVES_PER_CU") ? atoi(getenv("SF_WAVES_PER_CU")) : 24;   // persistent grid of k_step
+    const Tuning &tn = s->tune;
+    const int waves_per_cu = tn.v[SF_TUNE_WAVES_PER_CU];   // persistent grid of k_step
     long long want = fused ? (n_wave_tiles + kWaves - 1) / kWaves : (long long)s->n_cu * waves_per_cu / kWaves;
     if (!fused && want * kWaves > n_wave_tiles) want = (n_wave_tiles + kWaves - 1) / kWaves;
     const dim3 step_grid((unsigned)(want < 1 ? 1 : want));
@@ -1016,8 +1069,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     size_t run_lds = 0;
     int runt_waves = 0;                        // tile flavour of the resident launch (sf_set_fused(3))
     size_t runt_lds = 0;
+#ifdef SF_EXPERIMENTAL
     if (!generic && !a.parents && !s->history && s->fused_mode == 3) {
-        static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
+        const int waves_knob = tn.v[SF_TUNE_RUN_WAVES];
         const int per_env = s->g.TY * s->g.TX;
         int nw = waves_knob < 1 ? 1 : waves_knob;
         if (nw > run_max_waves(s->g.RB)) nw = run_max_waves(s->g.RB);
@@ -1026,14 +1080,13 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         const size_t lds = (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g);
         if (per_env <= 65535 && lds <= 160 * 1024) { runt_waves = nw; runt_lds = lds; }
     }
+#endif
     int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
     size_t fr_lds = 0;
     int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
     size_t fit_lds = 0;
     if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
-        static const int waves_knob = getenv("SF_RUN_WAVES") ? atoi(getenv("SF_RUN_WAVES")) : 16;
-        static const int envs_knob = getenv("SF_RUN_MIN_ENVS") ? atoi(getenv("SF_RUN_MIN_ENVS")) : 1;
-        static const int vcap_knob = getenv("SF_RUN_VCAP") ? atoi(getenv("SF_RUN_VCAP")) : 4096;
+        const int waves_knob = tn.v[SF_TUNE_RUN_WAVES], envs_knob = tn.v[SF_TUNE_RUN_MIN_ENVS], vcap_knob = tn.v[SF_TUNE_RUN_VCAP];
         const Geo &g = s->g;
         int nw = waves_knob < 1 ? 1 : (waves_knob > 16 ? 16 : waves_knob);
         const int need = (g.H + 63) / 64;                     // a thread per bitmap row is all the interest pass can use
@@ -1047,8 +1100,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // More environments than CUs (the throughput regime): a CU works through several environments one after the other, and a
         // workgroup of 16 waves mostly waits.  Half the waves and a shorter vector list (longer ones are taken in chunks): two
         // workgroups fit the 160 KB of LDS and fill each other's gaps.
-        static const int compact_knob = getenv("SF_RUN_COMPACT") ? atoi(getenv("SF_RUN_COMPACT")) : 1;
-        if (compact_knob && g.E > s->n_cu && nw > 8 && min_nw <= 8 && !getenv("SF_RUN_WAVES")) {
+        if (tn.v[SF_TUNE_RUN_COMPACT] && g.E > s->n_cu && nw > 8 && min_nw <= 8 && !tn.set[SF_TUNE_RUN_WAVES]) {
             const int vcap2 = vcap > 1024 ? 1024 : vcap;
             const size_t lds2 = run_lds_bytes(g, 8, vcap2);
             if (lds2 <= 80 * 1024) { nw = 8; vcap = vcap2; lds = lds2; }
@@ -1060,16 +1112,12 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
         if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
+#ifdef SF_EXPERIMENTAL
         // k_front: the frontier records of an environment in LDS.  Needs k_run as its overflow fallback; not in attenuation
         // mode, not with control lines inside the launch, not in the visit-everything cross-check mode.
-        static const int front_min_steps = getenv("SF_FRONT_MIN_STEPS") ? atoi(getenv("SF_FRONT_MIN_STEPS")) : 4;
-        static const int front_off = getenv("SF_FRONT_OFF") ? atoi(getenv("SF_FRONT_OFF")) : 1;      // (not the automatic choice yet)
-        const bool front_wanted = s->fused_mode == 4 || (s->fused_mode < 0 && n_steps >= front_min_steps && !front_off);
+        const bool front_wanted = s->fused_mode == 4 || (s->fused_mode < 0 && n_steps >= tn.v[SF_TUNE_FRONT_MIN_STEPS] && tn.v[SF_TUNE_FRONT_AUTO]);
         if (fits && front_wanted && !g.att && !mit_dev && !g.dense && g.H <= 2048 && g.W <= 2048) {
-            static const int fw_knob = getenv("SF_FRONT_WAVES") ? atoi(getenv("SF_FRONT_WAVES")) : 0;
-            static const int frc_knob = getenv("SF_FRONT_RC") ? atoi(getenv("SF_FRONT_RC")) : 0;
-            static const int fic_knob = getenv("SF_FRONT_IC") ? atoi(getenv("SF_FRONT_IC")) : 0;
-            static const int ftab_knob = getenv("SF_FRONT_TAB") ? atoi(getenv("SF_FRONT_TAB")) : 0;
+            const int fw_knob = tn.v[SF_TUNE_FRONT_WAVES], frc_knob = tn.v[SF_TUNE_FRONT_RC], fic_knob = tn.v[SF_TUNE_FRONT_IC], ftab_knob = tn.v[SF_TUNE_FRONT_TAB];
             const bool many = g.E > s->n_cu;              // more environments than CUs: smaller workgroups, two per CU
             fr_waves = fw_knob ? fw_knob : (many ? 8 : 16);
             if (fr_waves > 16) fr_waves = 16;
@@ -1086,7 +1134,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             fr_lds = front_lds_bytes(g, fr_waves, fr_rc, fr_ic, fr_tab);
             if (fr_tab < 8 || fr_lds > 160 * 1024) fr_waves = 0;
         }
+#endif
     }
+#ifndef SF_EXPERIMENTAL
+    (void)runt_lds; (void)fr_rc; (void)fr_ic; (void)fr_tab; (void)fr_lds; (void)fit_waves; (void)fit_vcap; (void)fit_lds; (void)kFrontStartCap;
+#endif
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
     a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr;
     if (run_waves || fr_waves) {
@@ -1105,6 +1157,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     a.vbits = s->vbits;
     a.cells = s->cells;
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
+#ifdef SF_EXPERIMENTAL
     if (runt_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
         void (*krun)(StepArgs, int) = s->g.RB == 1 ? k_run_tiles<1> : s->g.RB == 2 ? k_run_tiles<2> : s->g.RB == 4 ? k_run_tiles<4> : k_run_tiles<8>;
@@ -1121,7 +1174,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             s->attr_front = fr_lds;
         }
         *s->ovf_pinned = 0;
-        static const int fdbg = getenv("SF_FRONT_DEBUG") ? atoi(getenv("SF_FRONT_DEBUG")) : 0;
+        const int fdbg = tn.v[SF_TUNE_FRONT_DEBUG];
         int32_t *dbg_dev = nullptr;
         if (fdbg) { HIPCHK(hipMalloc(reinterpret_cast<void **>(&dbg_dev), (size_t)s->g.E * 16)); HIPCHK(hipMemsetAsync(dbg_dev, 0, (size_t)s->g.E * 16, s->stream)); }
         hipLaunchKernelGGL(k_front, dim3((unsigned)s->g.E), dim3((unsigned)fr_waves * 64), fr_lds, s->stream, a, n_steps, fr_rc, fr_ic, fr_tab,
@@ -1146,7 +1199,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             // some environment outgrew its record / wheel capacity: k_run finishes its steps from the planes
             s->front_fallbacks++;
             s->last_kind = 6;
-            static const int dbg = getenv("SF_FRONT_DEBUG") ? atoi(getenv("SF_FRONT_DEBUG")) : 0;
+            const int dbg = tn.v[SF_TUNE_FRONT_DEBUG];
             if (dbg) {
                 std::vector<int32_t> td((size_t)s->g.E);
                 HIPCHK(hipMemcpy(td.data(), s->todo, td.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1163,12 +1216,14 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             { int rc0 = launch_k_run(s, a, n_steps, fit_waves, fit_vcap, fit_lds, 64); if (rc0) return rc0; }
         }
         n_steps = 0;
-    } else if (run_waves) {
+    } else
+#endif
+    if (run_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        static const int bsz_knob = getenv("SF_RUN_BATCH") ? atoi(getenv("SF_RUN_BATCH")) : 64;       // vectors per batch (<= 64)
+        const int bsz_knob = tn.v[SF_TUNE_RUN_BATCH];       // vectors per batch (<= 64)
         const int bsz = bsz_knob < 8 ? 8 : (bsz_knob > 64 ? 64 : bsz_knob);
         // the launch leaves the result block behind (every workgroup counts its own environment when its steps are done)
-        static const int res_knob = getenv("SF_RUN_RESULT") ? atoi(getenv("SF_RUN_RESULT")) : 1;
+        const int res_knob = tn.v[SF_TUNE_RUN_RESULT];
         if (res_knob) {
             if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
             s->tdirty_all = false;
@@ -1176,7 +1231,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // More environments than the chip holds workgroups: the launch would end with whatever large fire happened to start late.
         // The rollout is cut into segments, and every segment starts its environments in the order of what they cost in the one
         // before (k_order: most expensive first) - the tail of a segment is then made of the cheapest environments.
-        static const int seg_knob = getenv("SF_RUN_SEGMENT") ? atoi(getenv("SF_RUN_SEGMENT")) : 64;
+        const int seg_knob = tn.v[SF_TUNE_RUN_SEGMENT];
         const bool balance = seg_knob > 0 && s->g.E > s->n_cu * (run_waves <= 8 ? 2 : 1);       // (with every environment resident from the start there is nothing to order)
         a.cost = s->run_cost;
         for (int done = 0; done < n_steps;) {

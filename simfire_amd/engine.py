@@ -23,8 +23,9 @@ class FireEngine:
 
     def __init__(self, shape, n_envs=1, max_fire_duration=4, pixel_scale=50.0, update_rate=1.0,
                  max_time=None, attenuate_line_ros=True, diagonal_spread=True, M_f=0.03,
-                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0, per_env_terrain=False):
-        self._L = _lib.load()
+                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0, per_env_terrain=False, experimental=False, variant=None):
+        # experimental / variant: another build of the library (tests only; _lib.VARIANTS)
+        self._L = _lib.load("exp" if experimental else variant)
         self.H, self.W = int(shape[0]), int(shape[1])
         self.n_envs = int(n_envs)
         h, S_T, S_e, p_p = particle
@@ -36,7 +37,10 @@ class FireEngine:
             h=float(h), S_T=float(S_T), S_e=float(S_e), p_p=float(p_p), M_f=float(M_f),
             per_env_terrain=int(bool(per_env_terrain)))
         self._h = C.c_void_p()
-        _lib.check(self._L.sf_create(C.byref(self.params), C.byref(self._h)))
+        self._chk(self._L.sf_create(C.byref(self.params), C.byref(self._h)))
+
+    def _chk(self, rc):
+        _lib.check(rc, self._L)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -65,28 +69,28 @@ class FireEngine:
             (w_0, delta, M_x, sigma, elevation, U, U_dir),
             ("w_0", "delta", "M_x", "sigma", "elevation", "U", "U_dir"))]
         if env is None:
-            _lib.check(self._L.sf_set_layers(self._h, *[_ptr(a) for a in arrs]))
+            self._chk(self._L.sf_set_layers(self._h, *[_ptr(a) for a in arrs]))
         else:
-            _lib.check(self._L.sf_set_layers_env(self._h, int(env), *[_ptr(a) for a in arrs]))
+            self._chk(self._L.sf_set_layers_env(self._h, int(env), *[_ptr(a) for a in arrs]))
 
     def set_rtable(self, R8, env=None):
         R8 = np.ascontiguousarray(R8, dtype=np.float64)
         if R8.shape != (8, self.H, self.W):
             raise ValueError(f"R table shape {R8.shape} != {(8, self.H, self.W)}")
         if env is None:
-            _lib.check(self._L.sf_set_rtable(self._h, _ptr(R8)))
+            self._chk(self._L.sf_set_rtable(self._h, _ptr(R8)))
         else:
-            _lib.check(self._L.sf_set_rtable_env(self._h, int(env), _ptr(R8)))
+            self._chk(self._L.sf_set_rtable_env(self._h, int(env), _ptr(R8)))
 
     def get_rtable(self, env=0):
         out = np.empty((8, self.H, self.W), dtype=np.float64)
-        _lib.check(self._L.sf_get_rtable_env(self._h, int(env), _ptr(out)))
+        self._chk(self._L.sf_get_rtable_env(self._h, int(env), _ptr(out)))
         return out
 
     def get_slopes(self):
         mag = np.empty((self.H, self.W))
         dr = np.empty((self.H, self.W))
-        _lib.check(self._L.sf_get_slopes(self._h, _ptr(mag), _ptr(dr)))
+        self._chk(self._L.sf_get_slopes(self._h, _ptr(mag), _ptr(dr)))
         return mag, dr
 
     # ------------------------------------------------------------------------ running
@@ -96,16 +100,16 @@ class FireEngine:
             xy = np.ascontiguousarray(np.repeat(xy, self.n_envs, axis=0))
         if xy.shape[0] != self.n_envs:
             raise ValueError(f"need {self.n_envs} ignition points, got {xy.shape[0]}")
-        _lib.check(self._L.sf_reset(self._h, _ptr(xy)))
+        self._chk(self._L.sf_reset(self._h, _ptr(xy)))
 
     def reset_env(self, env, x, y):
-        _lib.check(self._L.sf_reset_env(self._h, int(env), int(x), int(y)))
+        self._chk(self._L.sf_reset_env(self._h, int(env), int(x), int(y)))
 
     def apply_mitigation(self, pts):
         """pts: rows (env, x, y, type)."""
         q = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 4))
         if len(q):
-            _lib.check(self._L.sf_apply_mitigation(self._h, _ptr(q), len(q)))
+            self._chk(self._L.sf_apply_mitigation(self._h, _ptr(q), len(q)))
 
     def apply_mitigation_torch(self, pts):
         """The same scatter for a torch int32 tensor [n, 4] (env, x, y, type) that already lives on this
@@ -117,7 +121,7 @@ class FireEngine:
             raise ValueError("expected a CUDA int32 tensor of shape [n, 4]")
         pts = pts.contiguous()
         if pts.shape[0]:
-            _lib.check(self._L.sf_apply_mitigation_device(self._h, C.c_void_p(pts.data_ptr()), int(pts.shape[0])))
+            self._chk(self._L.sf_apply_mitigation_device(self._h, C.c_void_p(pts.data_ptr()), int(pts.shape[0])))
             self._keep_alive = pts          # until the next call: the scatter may still be queued (async mode)
 
     def load_fire_map(self, env, fire_map):
@@ -127,15 +131,15 @@ class FireEngine:
         if m.min() < 0 or m.max() > 5:
             raise ValueError("fire_map holds values outside BurnStatus")
         m = np.ascontiguousarray(m, dtype=np.uint8)
-        _lib.check(self._L.sf_load_fire_map(self._h, int(env), _ptr(m)))
+        self._chk(self._L.sf_load_fire_map(self._h, int(env), _ptr(m)))
 
     def step(self, n=1):
-        _lib.check(self._L.sf_step(self._h, int(n)))
+        self._chk(self._L.sf_step(self._h, int(n)))
 
     def step_timed(self, n=1):
         """Returns the GPU milliseconds spent in the n step kernels."""
         ms = C.c_float(0.0)
-        _lib.check(self._L.sf_step_timed(self._h, int(n), C.byref(ms)))
+        self._chk(self._L.sf_step_timed(self._h, int(n), C.byref(ms)))
         return float(ms.value)
 
     def step_mitigated(self, pts, timed=False):
@@ -147,13 +151,13 @@ class FireEngine:
             q = np.ascontiguousarray(np.asarray(pts, dtype=np.int32))
             if q.ndim != 4 or q.shape[1] != self.n_envs or q.shape[3] != 3:
                 raise ValueError(f"expected points of shape [n_steps, {self.n_envs}, k, 3], got {q.shape}")
-            _lib.check(self._L.sf_step_mitigated(self._h, q.shape[0], _ptr(q), q.shape[2], 0, C.byref(ms) if timed else None))
+            self._chk(self._L.sf_step_mitigated(self._h, q.shape[0], _ptr(q), q.shape[2], 0, C.byref(ms) if timed else None))
         else:
             import torch
             if pts.dtype != torch.int32 or pts.dim() != 4 or pts.shape[1] != self.n_envs or pts.shape[3] != 3 or not pts.is_cuda:
                 raise ValueError(f"expected a CUDA int32 tensor of shape [n_steps, {self.n_envs}, k, 3]")
             pts = pts.contiguous()
-            _lib.check(self._L.sf_step_mitigated(self._h, int(pts.shape[0]), C.c_void_p(pts.data_ptr()), int(pts.shape[2]), 1,
+            self._chk(self._L.sf_step_mitigated(self._h, int(pts.shape[0]), C.c_void_p(pts.data_ptr()), int(pts.shape[2]), 1,
                                                  C.byref(ms) if timed else None))
             self._keep_alive = pts
         return float(ms.value) if timed else None
@@ -161,73 +165,84 @@ class FireEngine:
     # ------------------------------------------------------------------------ outputs
     def fire_map(self, env=0):
         out = np.empty((self.H, self.W), dtype=np.uint8)
-        _lib.check(self._L.sf_get_fire_map(self._h, int(env), _ptr(out)))
+        self._chk(self._L.sf_get_fire_map(self._h, int(env), _ptr(out)))
         return out
 
     def fire_maps(self):
         out = np.empty((self.n_envs, self.H, self.W), dtype=np.uint8)
-        _lib.check(self._L.sf_get_fire_maps(self._h, _ptr(out)))
+        self._chk(self._L.sf_get_fire_maps(self._h, _ptr(out)))
         return out
 
     def burn(self, env=0):
         out = np.empty((self.H, self.W), dtype=np.float64)
-        _lib.check(self._L.sf_get_burn(self._h, int(env), _ptr(out)))
+        self._chk(self._L.sf_get_burn(self._h, int(env), _ptr(out)))
         return out
 
     def set_burn(self, env, burn):
         b = np.ascontiguousarray(burn, dtype=np.float64)
         if b.shape != (self.H, self.W):
             raise ValueError(f"burn shape {b.shape} != {(self.H, self.W)}")
-        _lib.check(self._L.sf_set_burn(self._h, int(env), _ptr(b)))
+        self._chk(self._L.sf_set_burn(self._h, int(env), _ptr(b)))
 
     def status(self):
         """(int32 [E, 8]: running, steps, counts of BurnStatus 0..5; float64 [E] elapsed_time)"""
         st = np.zeros((self.n_envs, 8), dtype=np.int32)
         el = np.zeros(self.n_envs, dtype=np.float64)
-        _lib.check(self._L.sf_get_status(self._h, _ptr(st), _ptr(el)))
+        self._chk(self._L.sf_get_status(self._h, _ptr(st), _ptr(el)))
         return st, el
 
     def memory_bytes(self):
         v = C.c_int64(0)
-        _lib.check(self._L.sf_memory_bytes(self._h, C.byref(v)))
+        self._chk(self._L.sf_memory_bytes(self._h, C.byref(v)))
         return int(v.value)
 
     def geometry(self):
         """dict(tile_w, tile_h, tiles_x, tiles_y, rows_per_band, pitch, lds_wave_bytes, dense)"""
         out = np.zeros(8, dtype=np.int32)
-        _lib.check(self._L.sf_get_geometry(self._h, _ptr(out)))
+        self._chk(self._L.sf_get_geometry(self._h, _ptr(out)))
         keys = ("tile_w", "tile_h", "tiles_x", "tiles_y", "rows_per_band", "pitch", "lds_wave_bytes", "dense")
         return dict(zip(keys, (int(v) for v in out)))
 
     def set_rows_per_band(self, rows):
-        _lib.check(self._L.sf_set_rows_per_band(self._h, int(rows)))
+        self._chk(self._L.sf_set_rows_per_band(self._h, int(rows)))
 
     def set_threshold(self, pixel_scale):
         """Ignition threshold only (``manager.pixel_scale = v`` in the reference)."""
-        _lib.check(self._L.sf_set_threshold(self._h, float(pixel_scale)))
+        self._chk(self._L.sf_set_threshold(self._h, float(pixel_scale)))
         self.params.pixel_scale = float(pixel_scale)
 
     def set_async(self, on=True):
         """Rollout mode: ``step`` / ``apply_mitigation`` only enqueue work; ``sync`` or any getter waits."""
-        _lib.check(self._L.sf_set_async(self._h, int(bool(on))))
+        self._chk(self._L.sf_set_async(self._h, int(bool(on))))
 
     def sync(self):
-        _lib.check(self._L.sf_sync(self._h))
+        self._chk(self._L.sf_sync(self._h))
 
     def set_fused(self, mode=-1):
         """-1 auto, 0 always k_select + k_step, 1 always one fused launch per step, 2 one environment-resident
         launch per ``step(n)`` call (k_run)."""
-        _lib.check(self._L.sf_set_fused(self._h, int(mode)))
+        self._chk(self._L.sf_set_fused(self._h, int(mode)))
+
+    def set_tuning(self, **knobs):
+        """Launch-geometry knobs (``include/simfire_hip.h``: ``SF_TUNE_*``; results never depend on them), e.g.
+        ``set_tuning(run_waves=8, run_vcap=256)``."""
+        for name, value in knobs.items():
+            self._chk(self._L.sf_set_tuning(self._h, _lib.TUNE[name], int(value)))
+
+    def get_tuning(self, name):
+        v = C.c_int32()
+        self._chk(self._L.sf_get_tuning(self._h, _lib.TUNE[name], C.byref(v)))
+        return v.value
 
     def set_prune_after_quit(self, on=True):
         """Environments that QUIT on the runtime check keep pruning when stepped again (fire.py:631-643)."""
-        _lib.check(self._L.sf_set_prune_after_quit(self._h, int(bool(on))))
+        self._chk(self._L.sf_set_prune_after_quit(self._h, int(bool(on))))
 
     def last_launch_kind(self):
         """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, 4 k_run_tiles,
         5 frontier-resident launch (k_front), 6 k_front + k_run for left-over steps, -1 none yet."""
         v = C.c_int32(-1)
-        _lib.check(self._L.sf_last_step_launch(self._h, C.byref(v)))
+        self._chk(self._L.sf_last_step_launch(self._h, C.byref(v)))
         return int(v.value)
 
     # neighbour order of the parent masks = adj_locs of simfire/utils/graph.py:125-134
@@ -236,12 +251,12 @@ class FireEngine:
 
     def enable_spread_graph(self, on=True):
         """Record the fire-spread graph (FireSpreadGraph, simfire/utils/graph.py) as parent masks."""
-        _lib.check(self._L.sf_enable_spread_graph(self._h, int(bool(on))))
+        self._chk(self._L.sf_enable_spread_graph(self._h, int(bool(on))))
 
     def spread_parents(self, env=0):
         """uint8 [H, W]: bit j set <=> graph edge from neighbour j (GRAPH_DX/DY) into the cell."""
         out = np.zeros((self.H, self.W), dtype=np.uint8)
-        _lib.check(self._L.sf_get_spread_parents(self._h, int(env), _ptr(out)))
+        self._chk(self._L.sf_get_spread_parents(self._h, int(env), _ptr(out)))
         return out
 
     def spread_edges(self, env=0):
@@ -269,7 +284,7 @@ class FireEngine:
         lut_fuel = np.array([[table[int(c)].w_0, table[int(c)].delta, table[int(c)].M_x, table[int(c)].sigma]
                              for c in lut_codes], dtype=np.float64)
         arrs = [self._plane(a, n) for a, n in zip((elevation, U, U_dir), ("elevation", "U", "U_dir"))]
-        _lib.check(self._L.sf_set_layers_fbfm(self._h, -1 if env is None else int(env), _ptr(codes), len(lut_codes),
+        self._chk(self._L.sf_set_layers_fbfm(self._h, -1 if env is None else int(env), _ptr(codes), len(lut_codes),
                                               _ptr(lut_codes), _ptr(lut_fuel), *[_ptr(a) for a in arrs]))
 
     def attribute_data(self, env=0):
@@ -279,7 +294,7 @@ class FireEngine:
         out = {"w_0": np.empty(shp, np.float32), "sigma": np.empty(shp, np.uint32), "delta": np.empty(shp, np.float32),
                "M_x": np.empty(shp, np.float32), "elevation": np.empty(shp, np.float64),
                "wind_speed": np.empty(shp, np.float64), "wind_direction": np.empty(shp, np.float64)}
-        _lib.check(self._L.sf_get_attribute_data(self._h, int(env), *[_ptr(out[k]) for k in (
+        self._chk(self._L.sf_get_attribute_data(self._h, int(env), *[_ptr(out[k]) for k in (
             "w_0", "sigma", "delta", "M_x", "elevation", "wind_speed", "wind_direction")], 0))
         return out
 
@@ -299,7 +314,7 @@ class FireEngine:
                "wind_direction": torch.empty((n, self.H, self.W), dtype=torch.float64, device=dev)}
         torch.cuda.synchronize(dev)
         for i, e in enumerate(envs):
-            _lib.check(self._L.sf_get_attribute_data(self._h, e, *[C.c_void_p(out[k][i].data_ptr()) for k in (
+            self._chk(self._L.sf_get_attribute_data(self._h, e, *[C.c_void_p(out[k][i].data_ptr()) for k in (
                 "w_0", "sigma", "delta", "M_x", "elevation", "wind_speed", "wind_direction")], 1))
         return out
 
@@ -308,7 +323,7 @@ class FireEngine:
         """Record the fire map after every executed update (what ``_save_data`` appends to
         ``fire_map.npy``, simfire/sim/simulation.py:548-549) in GPU memory: a ring int8
         [n_envs, capacity, H, W] (update u in slot u mod capacity); 0 switches it off."""
-        _lib.check(self._L.sf_enable_history(self._h, int(capacity)))
+        self._chk(self._L.sf_enable_history(self._h, int(capacity)))
 
     def history(self, env=0, first=0, count=None):
         """int8 [count, H, W]: maps after updates ``first .. first+count-1`` of ``env`` since its reset."""
@@ -317,21 +332,21 @@ class FireEngine:
             count = int(st[env, 1]) - int(first)
         out = np.empty((max(int(count), 0), self.H, self.W), dtype=np.int8)
         if out.shape[0]:
-            _lib.check(self._L.sf_get_history(self._h, int(env), int(first), int(count), _ptr(out)))
+            self._chk(self._L.sf_get_history(self._h, int(env), int(first), int(count), _ptr(out)))
         return out
 
     def set_generic(self, on=True):
         """Per-cell kernel instead of the tiled SWAR kernels (always on for max_fire_duration > 5)."""
-        _lib.check(self._L.sf_set_generic(self._h, int(bool(on))))
+        self._chk(self._L.sf_set_generic(self._h, int(bool(on))))
 
     def set_dense(self, dense=True):
         """Visit every tile every step (cross-check of the tile activity map)."""
-        _lib.check(self._L.sf_set_dense(self._h, int(bool(dense))))
+        self._chk(self._L.sf_set_dense(self._h, int(bool(dense))))
 
     def fire_map_device(self):
         """(device pointer, row pitch, env stride) of the uint8 status plane (BurnStatus values)."""
         p, pitch, stride = C.c_void_p(), C.c_int64(), C.c_int64()
-        _lib.check(self._L.sf_fire_map_device(self._h, C.byref(p), C.byref(pitch), C.byref(stride)))
+        self._chk(self._L.sf_fire_map_device(self._h, C.byref(p), C.byref(pitch), C.byref(stride)))
         return p.value, int(pitch.value), int(stride.value)
 
     def fire_maps_torch(self):
@@ -351,24 +366,24 @@ class FireEngine:
     def status_device_ptr(self):
         """Device address of the int32 [E, 8] result block (after ``update_status_device``)."""
         p = C.c_void_p()
-        _lib.check(self._L.sf_status_device(self._h, C.byref(p)))
+        self._chk(self._L.sf_status_device(self._h, C.byref(p)))
         return p.value
 
     def copy_status_to(self, device_ptr):
         """Refresh the result block and copy it into device memory at ``device_ptr``
         (int32 [n_envs, 8]), e.g. ``tensor.data_ptr()`` of a torch tensor on the same GPU."""
-        _lib.check(self._L.sf_copy_status_to(self._h, C.c_void_p(int(device_ptr))))
+        self._chk(self._L.sf_copy_status_to(self._h, C.c_void_p(int(device_ptr))))
 
     def rollout(self, n, device_ptr):
         """``step(n)`` without a wait of its own + ``copy_status_to(device_ptr)`` as one call: what a harness does
         between two policy evaluations."""
-        _lib.check(self._L.sf_rollout(self._h, int(n), C.c_void_p(int(device_ptr))))
+        self._chk(self._L.sf_rollout(self._h, int(n), C.c_void_p(int(device_ptr))))
 
     def set_result_sink(self, device_ptr):
         """Register device memory (int32 [n_envs, 8], e.g. ``tensor.data_ptr()``; ``None`` unregisters) that every
         refresh of the result block also writes - the resident launch of ``step(n >= 2)`` leaves the block there
         itself, so ``copy_status_to(same pointer)`` after a rollout is only the wait.  Keep the tensor alive."""
-        _lib.check(self._L.sf_set_result_sink(self._h, C.c_void_p(int(device_ptr) if device_ptr else None)))
+        self._chk(self._L.sf_set_result_sink(self._h, C.c_void_p(int(device_ptr) if device_ptr else None)))
 
     # ---- the one collective of the path, through the C ABI (hosts without torch.distributed; SURVEY 8e)
     @staticmethod
@@ -384,30 +399,30 @@ class FireEngine:
         if len(unique_id) != 128:
             raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
         buf = C.create_string_buffer(bytes(unique_id), 128)
-        _lib.check(self._L.sf_comm_init(self._h, int(rank), int(world_size), C.cast(buf, C.c_void_p)))
+        self._chk(self._L.sf_comm_init(self._h, int(rank), int(world_size), C.cast(buf, C.c_void_p)))
 
     def allgather_status(self, device_ptr):
         """Refresh this rank's result block and all-gather the blocks of all ranks over RCCL into device memory
         int32 [world_size * n_envs, 8] (rank-major), on the handle's stream; returns when it is there."""
-        _lib.check(self._L.sf_allgather_status(self._h, C.c_void_p(int(device_ptr))))
+        self._chk(self._L.sf_allgather_status(self._h, C.c_void_p(int(device_ptr))))
 
     def comm_destroy(self):
-        _lib.check(self._L.sf_comm_destroy(self._h))
+        self._chk(self._L.sf_comm_destroy(self._h))
 
     def enable_counters(self, on=True):
         """Statistics for the roofline accounting; off by default (they cost atomics)."""
-        _lib.check(self._L.sf_enable_counters(self._h, int(bool(on))))
+        self._chk(self._L.sf_enable_counters(self._h, int(bool(on))))
 
     def counters(self, reset=False):
         """dict(active_cell_updates, ignitions, frontier_items) summed since the last reset."""
         out = np.zeros(8, dtype=np.int64)
-        _lib.check(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
+        self._chk(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
         return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
                     active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]),
                     records=int(out[6]), sprite_events=int(out[7]))
 
     def update_status_device(self):
-        _lib.check(self._L.sf_update_status_device(self._h))
+        self._chk(self._L.sf_update_status_device(self._h))
 
 
 def compute_ros(arrays, device=0):

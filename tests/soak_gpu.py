@@ -27,7 +27,7 @@ def world(seed):
               max_time=(None if rng.random() < 0.6 else float(rng.integers(3, 40))),
               attenuate_line_ros=att, diagonal_spread=diag)
     xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
-    eng, o = FireEngine(**kw), fire_dense.DenseOracle(**kw)
+    eng, o = FireEngine(experimental=True, **kw), fire_dense.DenseOracle(**kw)      # cross-check build: launch structures 3 / 4 are in the draw
     eng.set_fused(int(rng.integers(-1, 5)))            # automatic, two launches, fused, resident (k_run), resident tiles
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))

@@ -18,9 +18,10 @@ from oracle import fire_dense
 pytestmark = pytest.mark.gpu
 
 
-def _pair(kw, R8, inits, M_f=None):
+def _pair(kw, R8, inits, M_f=None, exp=False):
+    """exp: load the cross-check build of the library (launch structures 3 = k_run_tiles and 4 = k_front exist only there)."""
     from simfire_amd.engine import FireEngine
-    eng = FireEngine(**kw)
+    eng = FireEngine(experimental=exp, **kw)
     o = fire_dense.DenseOracle(**kw)
     for x in (eng, o):
         x.set_rtable(R8)
@@ -47,7 +48,7 @@ def test_resident_replays_golden_trajectories(name, mode):
     trajectory: fire_map / status / elapsed_time per step and the final burn_amounts equal the reference's."""
     from simfire_amd.engine import FireEngine
     d = _golden.load_traj(name)
-    eng = FireEngine(M_f=float(d["M_f"]), **_golden.engine_kwargs(d))
+    eng = FireEngine(M_f=float(d["M_f"]), experimental=mode in (3, 4), **_golden.engine_kwargs(d))
     eng.set_fused(mode)
     eng.set_rtable(d["rtable"])
     eng.reset([d["init_pos"]])
@@ -75,7 +76,7 @@ def test_resident_chunked_random_worlds(seed):
     if rng.random() < 0.5:
         R8[:, :, W // 2:] = 0.0                                  # fires die against the barren half
     inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
-    eng, o = _pair(kw, R8, inits)
+    eng, o = _pair(kw, R8, inits, exp=seed % 3 != 0)
     eng.set_fused(2 + seed % 3)
     eng.set_rows_per_band(int(rng.choice([1, 2, 2, 4, 8])))
     done = 0
@@ -118,7 +119,7 @@ def test_resident_hands_over_to_per_step_kernels_and_back():
     R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
     R8[:, :, 250:] = 0.0
     inits = [(5, 5), (160, 70), (90, 140), (320, 10), (200, 100)]      # (320, 10) sits in barren ground: QUIT early
-    eng, o = _pair(kw, R8, inits)
+    eng, o = _pair(kw, R8, inits, exp=True)
     eng.set_async(True)
     sched = [(2, 7), (0, 3), (3, 4), (4, 6), (2, 1), (1, 4), (4, 1), (2, 9), ("generic", 2), (4, 3), (3, 5), (0, 2), (2, 11), (3, 1), (1, 1), (2, 30)]
     for i, (mode, n) in enumerate(sched):
@@ -146,7 +147,7 @@ def test_resident_dense_mode_and_status_histograms(mode):
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
     w = workloads.c3(256, 3)
-    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng = FireEngine(M_f=w.M_f, experimental=mode == 3, **w.engine_kwargs())
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**w.engine_kwargs())
     o.set_rtable(eng.get_rtable())
@@ -164,77 +165,87 @@ def test_resident_dense_mode_and_status_histograms(mode):
         _same(eng, o, 3, tag=(dense, n))
 
 
+def _c3_small(fused, exp, **knobs):
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c3(512, 4)
+    kw = w.engine_kwargs()
+    eng = FireEngine(M_f=w.M_f, experimental=exp, **kw)
+    eng.set_tuning(**knobs)
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    eng.set_fused(fused)
+    kinds = []
+    for n in (70, 1, 130):
+        eng.step(n)
+        o.step(n, 4)
+        kinds.append(eng.last_launch_kind())
+    assert (eng.status()[0] == o.status()[0]).all()
+    for e in range(4):
+        assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
+    return kinds
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("waves", [1, 3, 16])
 def test_resident_any_workgroup_size(waves, mode):
     """Fewer waves than live tiles: the waves of the workgroup take several tiles per step off the shared
-    cursor (their LDS scratch is reused); the result must not depend on the workgroup size."""
-    import subprocess, sys, os, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import sys; sys.path.insert(0, %r)
-        import numpy as np
-        from oracle import fire_dense
-        from simfire_amd import workloads
-        from simfire_amd.engine import FireEngine
-        w = workloads.c3(512, 4)
-        eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
-        eng.set_layers(*w.layers())
-        o = fire_dense.DenseOracle(**w.engine_kwargs())
-        o.set_rtable(eng.get_rtable())
-        eng.reset(w.init_xy); o.reset(w.init_xy)
-        eng.set_fused(%d)
-        for n in (70, 1, 130):
-            eng.step(n); o.step(n, 4)
-        assert (eng.status()[0] == o.status()[0]).all()
-        for e in range(4):
-            assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
-        print("OK")
-    """ % (root, mode))
-    env = dict(os.environ, SF_RUN_WAVES=str(waves), SF_RUN_VCAP="256")       # read once per process: run in a child
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    cursor (their LDS scratch is reused); the result must not depend on the workgroup size (sf_set_tuning)."""
+    _c3_small(mode, mode == 3, run_waves=waves, run_vcap=256)
 
 
 @pytest.mark.parametrize("caps", [(4, 2048, 0), (144, 6, 0), (144, 2048, 12), (16, 64, 40)])
 def test_front_overflow_is_finished_by_k_run(caps):
     """k_front with tiny record / ignition-list / cell-table (tile pool) capacities: whatever overflows is derived state, the
     environment stops at a step boundary and k_run does the steps left over - same result, and the hand-over really happened."""
-    import subprocess, sys, os, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import sys; sys.path.insert(0, %r)
-        import numpy as np
-        from oracle import fire_dense
-        from simfire_amd import workloads
-        from simfire_amd.engine import FireEngine
-        w = workloads.c3(512, 4)
-        kw = w.engine_kwargs()
-        eng = FireEngine(M_f=w.M_f, **kw)
+    kinds = _c3_small(4, True, front_rc=caps[0], front_ic=caps[1], front_tab=caps[2])
+    assert 6 in kinds, kinds
+
+
+def test_store_order_wait_build():
+    """k_run's ignition byte stores follow the vector pass's 16-byte stores to the same lines (sf_run_kernels.h: run_walk, back()).
+    The product relies on the in-order vmcnt counter for that (the ignition decision depends on a load issued after those stores);
+    the -DSF_STORE_ORDER_WAIT build waits explicitly.  Both must give the oracle's result."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c3(512, 6)
+    kw = w.engine_kwargs()
+    engs = [FireEngine(M_f=w.M_f, variant=v, **kw) for v in (None, "sow")]
+    o = fire_dense.DenseOracle(**kw)
+    for eng in engs:
         eng.set_layers(*w.layers())
-        o = fire_dense.DenseOracle(**kw)
-        o.set_rtable(eng.get_rtable())
-        eng.reset(w.init_xy); o.reset(w.init_xy)
-        eng.set_fused(4)
-        kinds = []
-        for n in (70, 1, 130):
-            eng.step(n); o.step(n, 4)
-            kinds.append(eng.last_launch_kind())
-        assert (eng.status()[0] == o.status()[0]).all()
-        for e in range(4):
-            assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
-        assert 6 in kinds, kinds
-        print("OK")
-    """ % root)
-    env = dict(os.environ, SF_FRONT_RC=str(caps[0]), SF_FRONT_IC=str(caps[1]), SF_FRONT_TAB=str(caps[2]))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+        eng.reset(w.init_xy)
+        eng.set_fused(2)
+    o.set_rtable(engs[0].get_rtable())
+    o.reset(w.init_xy)
+    for n in (40, 160):
+        o.step(n, 4)
+        for eng in engs:
+            eng.step(n)
+            assert eng.last_launch_kind() == 2
+            assert (eng.status()[0] == o.status()[0]).all()
+            for e in range(6):
+                assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
+
+
+def test_product_build_refuses_the_experimental_launch_structures():
+    """sf_set_fused(3 / 4) (k_run_tiles, k_front) are compiled only into the cross-check build: the product library
+    says so instead of silently running something else."""
+    from simfire_amd.engine import FireEngine
+    eng = FireEngine((32, 48))
+    for mode in (3, 4):
+        with pytest.raises(NotImplementedError):
+            eng.set_fused(mode)
+    eng.set_fused(2)
 
 
 # ------------------------------------------------------------------ BASELINE-size batches, every launch structure
 def _workload_run(w, chunks, fused, agent_pts=None, threads=32, burn_envs=(0, 1), graph=False, dense=False, waves_per_cu=None):
     from simfire_amd.engine import FireEngine
-    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng = FireEngine(M_f=w.M_f, experimental=fused in (3, 4), **w.engine_kwargs())
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**w.engine_kwargs())
     o.set_rtable(eng.get_rtable())                    # common table: step parity must then be bit-exact
@@ -333,7 +344,7 @@ def test_update_after_runtime_quit_keeps_pruning(mode):
               attenuate_line_ros=True, diagonal_spread=True)
     R8 = rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W))
     init = (30, 20)
-    eng = FireEngine(**kw)
+    eng = FireEngine(experimental=mode == "run_tiles", **kw)
     eng.set_prune_after_quit(True)
     if mode == "generic":
         eng.set_generic(True)
@@ -393,7 +404,7 @@ def test_result_block_counts_follow_every_kind_of_status_write():
     rng = np.random.default_rng(77)
     H, W, E = 90, 200, 3
     kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0)
-    eng = FireEngine(**kw)
+    eng = FireEngine(experimental=True, **kw)      # (cross-check build: launch structure 3 exists only there)
     eng.set_rtable(rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W)))
     eng.reset([(10, 10), (100, 45), (190, 80)])
 

@@ -169,7 +169,7 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
 def test_missing_extension_fails_loudly(monkeypatch):
     """No CPU fallback: without the HIP library the product path raises, it does not degrade."""
     from simfire_amd import _lib
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsimfire_hip.so")
     with pytest.raises(_lib.SimfireHipError):
         _lib.load()
