@@ -508,7 +508,7 @@ def test_launch_structures(name, fused):
     environment-resident launches (2: k_run over the vector bitmap, 3: k_run_tiles; here with one step per
     call) are schedules of the same update: force each on the golden trajectories."""
     d = _golden.load_traj(name)
-    eng = _engine(d)
+    eng = _engine(d, experimental=fused in (3, 4))      # launch structures 3 / 4 exist only in the cross-check build
     eng.set_fused(fused)
     eng.set_rtable(d["rtable"])
     eng.reset([d["init_pos"]])
@@ -521,7 +521,7 @@ def test_c3_both_launch_structures(fused):
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
     w = workloads.c3(512, 6)
-    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
+    eng = FireEngine(M_f=w.M_f, experimental=fused in (3, 4), **w.engine_kwargs())
     eng.set_fused(fused)
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**w.engine_kwargs())
@@ -846,7 +846,7 @@ def test_frontier_larger_than_list_window(fill, fused):
     H, W = 130, 200
     kw = dict(shape=(H, W), max_fire_duration=4, pixel_scale=30.0, update_rate=1.0, attenuate_line_ros=True)
     R8 = rng.choice([12.0, 30.0, 400.0, 1500.0, 2500.0], size=(8, H, W))
-    eng = FireEngine(**kw)
+    eng = FireEngine(experimental=fused in (3, 4), **kw)
     eng.set_fused(fused)
     eng.set_rtable(R8)
     o = fire_dense.DenseOracle(**kw)
