@@ -213,7 +213,8 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
     16-cell vectors visited (k_run).  With a resident launch one launch = the whole K-step rollout."""
     H, W = w.shape
     # all K steps; k_front: one cell per frontier record visited and per sprite expiry / recycling event
-    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16 + cnt["records"] + cnt["sprite_events"]
+    front = kind in (5, 6)
+    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16 + ((cnt["records"] + cnt["sprite_events"]) if front else 0)
     active = cnt["active_cell_updates"]
     if dense:
         # the dense sweep reads 1 B (the sprite mask) of a quiescent cell and rejects it; charging the 4 B of
@@ -238,7 +239,10 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
             "cells_swept_per_step": cells / a.steps, "active_cell_updates_per_step": active / a.steps,
             "tiles_visited_per_step": cnt["active_waves"] / a.steps, "vectors_visited_per_step": cnt["vectors"] / a.steps,
             "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
-            "records_visited_per_step": cnt["records"] / a.steps, "sprite_events_per_step": cnt["sprite_events"] / a.steps,
+            "records_visited_per_step": cnt["records"] / a.steps if front else 0.0,
+            "sprite_events_per_step": cnt["sprite_events"] / a.steps if front else 0.0,
+            # k_run: environment steps that ONE wave ran by itself (small fires, no workgroup barrier), per step of the window
+            "solo_env_steps_per_step": 0.0 if front else cnt["sprite_events"] / a.steps,
             # window-independent rates (the headline counts H x W per environment step, however small the fire)
             "active_cell_updates_per_s": active / sec, "cells_swept_per_s": cells / sec,
             "dense_cell_updates_per_s_kernel": H * W * env_steps / sec,
