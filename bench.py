@@ -241,8 +241,6 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
             "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
             "records_visited_per_step": cnt["records"] / a.steps if front else 0.0,
             "sprite_events_per_step": cnt["sprite_events"] / a.steps if front else 0.0,
-            # k_run: environment steps that ONE wave ran by itself (small fires, no workgroup barrier), per step of the window
-            "solo_env_steps_per_step": 0.0 if front else cnt["sprite_events"] / a.steps,
             # window-independent rates (the headline counts H x W per environment step, however small the fire)
             "active_cell_updates_per_s": active / sec, "cells_swept_per_s": cells / sec,
             "dense_cell_updates_per_s_kernel": H * W * env_steps / sec,

@@ -280,9 +280,8 @@ enum sf_tuning_knob {
     SF_TUNE_FRONT_IC = 12,
     SF_TUNE_FRONT_TAB = 13,
     SF_TUNE_FRONT_DEBUG = 14,
-    SF_TUNE_RUN_SOLO = 15,      /* 1 = k_run lets ONE wave step a small fire by itself (no workgroup barriers) while its vector list fits one batch (default 1) */
-    SF_TUNE_RUN_TEAM = 16,      /* workgroups per environment in k_run: -1 = chosen per launch from the recorded per-environment cost (default), 1 / 2 / 4 = forced upper bound */
-    SF_TUNE_COUNT = 17
+    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in k_run: 0 = chosen per launch from the recorded per-environment cost (default), 1 / 2 / 4 = upper bound forced */
+    SF_TUNE_COUNT = 16
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
