@@ -194,6 +194,7 @@ def measure(eng, w, a, agent_pts, dense):
     st0, _ = eng.status()
     kernel_ms = timed_steps(eng, a.steps, a.warmup, agent_pts)
     kind = eng.last_launch_kind()
+    measure.last_cost = eng.run_cost() if kind == 2 else None      # clocks / 16 per environment in that launch (k_run)
     st1, _ = eng.status()
     env_steps = int((st1[:, 1] - st0[:, 1]).sum())
     eng.reset(w.init_xy)
@@ -205,6 +206,9 @@ def measure(eng, w, a, agent_pts, dense):
     cnt = eng.counters()
     eng.enable_counters(False)
     return kernel_ms, env_steps, cnt, kind
+
+
+measure.last_cost = None
 
 
 def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense):
@@ -249,6 +253,38 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
             "dense_equivalent_gbs": H * W * env_steps * 4.0 / sec / 1e9}
 
 
+def issue_block(w, a, rl, cost, n_cu=256):
+    """What bounds the resident launch is not HBM but instruction issue on the CUs of the largest fires.
+    In-run, from the kernel's own clock stamps (sf_get_run_cost: shader clocks every environment's workgroups spent in
+    the timed launch): `cu_balance` = sum(cost) / (max(cost) x min(envs, CUs)) - 1.0 would be every CU busy for the
+    whole launch - and the shader clock the launch really ran at (max(cost) / the HIP-event duration; DVFS).  The SQ
+    counters of the same window come from profiles/ (rocprofv3 --pmc, a separate run: profiles/collect_issue.sh)."""
+    if cost is None or not len(cost) or int(cost.max()) == 0 or rl.get("launches") != 1:
+        return None
+    clocks = cost.astype(np.float64) * 16.0
+    slots = min(len(cost), n_cu)
+    sec = rl["launch_ms"] * 1e-3
+    blk = {"cu_balance": float(clocks.sum() / (clocks.max() * slots)), "workgroup_slots": slots,
+           "clocks_max_env": float(clocks.max()), "clocks_median_env": float(np.median(clocks)),
+           "clock_ghz_measured": float(clocks.max() / sec / 1e9),
+           "source": "sf_get_run_cost (s_memtime stamps of the timed launch) / HIP-event duration"}
+    p = os.path.join(ROOT, "profiles", f"r03_sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            sq = json.load(f)
+        # one VALU / SALU issue slot per SIMD every 4 clocks (a SIMD is visited once per 4-clock round); SQ_WAVE_CYCLES and
+        # SQ_WAIT_ANY count quad-cycles summed over waves
+        slots4 = n_cu * 4 * (sec * blk["clock_ghz_measured"] * 1e9) / 4.0
+        blk.update({"valu_issue_util": sq["SQ_INSTS_VALU"] / slots4, "salu_issue_util": sq["SQ_INSTS_SALU"] / slots4,
+                    "wave_wait_share": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "sq_source": os.path.relpath(p, ROOT)})
+    p = os.path.join(ROOT, "profiles", f"r03_phase_clocks_k_run_{w.name}_s{a.steps}_w{a.warmup}.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            ph = json.load(f)
+        blk.update({"barrier_wait_share": ph.get("barrier_wait_share"), "phase_source": os.path.relpath(p, ROOT)})
+    return blk
+
+
 def random_access_block(traffic, kernel_ms, n_cu=256, clock_ghz=2.4):
     """The roofline a scatter of 1 - 16-byte accesses runs against: 64-byte sectors the fabric moved per
     clock and CU in the timed launch (PMC traffic of profiles/collect_pmc.sh) next to what profiles/scatter_probe.hip
@@ -272,6 +308,63 @@ def random_access_block(traffic, kernel_ms, n_cu=256, clock_ghz=2.4):
             "probe_sectors_per_clock_per_cu": probe, "clock_ghz_assumed": clock_ghz, "n_cu": n_cu,
             "frac_of_probe_loads": per_clock_cu / probe["loads_8_in_flight"] if "loads_8_in_flight" in probe else None,
             "source": "profiles/r02_scatter_probe.txt (profiles/scatter_probe.hip), profiles/pmc_traffic_*.json"}
+
+
+def side_workload(name, a, device, torch, n_check, tile_cells):
+    """One GPU's share of another BASELINE config (C4: 128 x 2048^2 with the simplex wind field; C5: 64 x 1024^2 with 64
+    agents per environment drawing control lines before every update), measured like the main line - wall time of the
+    rollout + result block, kernel time, roofline block - and checked against the oracle on the first n_check environments."""
+    from simfire_amd import workloads
+    w = make_workload(name, a.size, None, 0)
+    H, W = w.shape
+    agent_pts = None
+    if name == "c5":
+        agent_pts = AgentPoints(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup), w.n_envs,
+                                w.agents_per_env, device)
+    eng = make_engine(w, device, a.rows_per_band)
+    eng.set_fused(a.fused)
+    result = torch.zeros((w.n_envs, 8), dtype=torch.int32, device=f"cuda:{device}")
+    eng.set_result_sink(result.data_ptr())
+
+    def rollout(k, first):
+        run_steps(eng, k, first, agent_pts)
+        eng.copy_status_to(result.data_ptr())
+
+    for rehearsal in (True, False):
+        eng.reset(w.init_xy)
+        if a.warmup:
+            rollout(a.warmup, 0)
+        before = result[:, 1].sum().item()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rollout(a.steps, a.warmup)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    env_steps = result[:, 1].sum().item() - before
+    block = result.cpu().numpy()
+    verified = None
+    if not a.no_cpu_baseline:
+        n_check = min(n_check, w.n_envs)
+        sample = sorted(set([0, n_check // 2, n_check - 1]))
+        maps = {e: eng.fire_map(e) for e in sample}
+        threads = a.cpu_threads or max(1, min(os.cpu_count() or 1, 32))
+        o, ost, _, _ = oracle_rollout(w, eng.get_rtable(), a.steps, a.warmup, threads, agent_pts, n_check)
+        verified = bool((block[:n_check] == ost).all()) and all(bool((maps[e] == o.fire_map(e)).all()) for e in sample)
+        del o
+    kms, esl, cnt, kind = measure(eng, w, a, agent_pts, False)
+    rl = roofline_block(w, a, kms, cnt, tile_cells, kind, esl, None, False)
+    out = {"workload": w.name, "grid": [H, W], "envs_per_gpu": w.n_envs, "agents_per_env": w.agents_per_env,
+           "value": H * W * env_steps / dt, "unit": "cell-updates/s", "ms_per_step": dt * 1e3 / a.steps,
+           "kernel_ms_per_step": kms / a.steps, "verified": verified, "envs_checked": 0 if verified is None else n_check,
+           "env_steps_executed": env_steps,
+           "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "launch_ms",
+                                           "cells_swept_per_step", "active_cell_updates_per_step", "active_cell_updates_per_s",
+                                           "algorithmic_bytes_per_launch")}}
+    iss = issue_block(w, a, rl, measure.last_cost)
+    if iss:
+        out["roofline"]["issue"] = iss
+    eng.close()
+    return out
 
 
 def reference_python_timing():
@@ -463,6 +556,16 @@ def main():
                        "burned_cells_total": int(res[:, 4].sum())},
             "roofline": roofline_block(w, a, kms, cnt, tile_cells, kind, env_steps_local, pmc, a.dense),
         }
+        iss = issue_block(w, a, out["roofline"], measure.last_cost)
+        if iss:
+            out["roofline"]["issue"] = iss
+            ra = out["roofline"].get("random_access")
+            if ra:       # the sector rate at the clock the launch really ran at, not an assumed one
+                ra["achieved_sectors_per_clock_per_cu"] *= ra["clock_ghz_assumed"] / iss["clock_ghz_measured"]
+                ra["frac_of_probe_loads"] = (ra["achieved_sectors_per_clock_per_cu"] / ra["probe_sectors_per_clock_per_cu"]["loads_8_in_flight"]
+                                             if "loads_8_in_flight" in ra["probe_sectors_per_clock_per_cu"] else None)
+                ra["clock_ghz_measured"] = iss["clock_ghz_measured"]
+                del ra["clock_ghz_assumed"]
         out["roofline"]["note"] = ("only the tiles / 16-cell vectors / frontier records in which something can change are visited; `achieved` counts "
                                    "the cells of those" if not a.dense else "dense sweep: everything visited every step")
         if world == 1 and not a.dense and a.dense_leg:
@@ -500,7 +603,13 @@ def main():
                 "value": H * W * done / dt2, "unit": "cell-updates/s", "ms_per_step": dt2 * 1e3 / a.steps,
                 "kernel_ms_per_step": kms2 / a.steps, "steps_executed": done, "running_at_end": int(st2[0, 0]),
                 "burned_cells": int(st2[0, 4]), "kernel": LAUNCH_KINDS.get(e2.last_launch_kind(), "?")}
+            # one GPU's share of BASELINE configs C4 and C5, each checked against the oracle on a sample of its environments
+            also["c4_share"] = side_workload("c4", a, device, torch, 16, tile_cells)
+            also["c5"] = side_workload("c5", a, device, torch, 32, tile_cells)
             out["also"] = also
+        if world > 1:
+            # the all-gathered block really holds every rank's rows (rank r's environments report their own ignition seeds' fires)
+            out["ranks_seen_by_collective"] = int(sum(1 for r in range(world) if res[r * w.n_envs:(r + 1) * w.n_envs, 1].max() > 0))
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

@@ -284,6 +284,11 @@ enum sf_tuning_knob {
     SF_TUNE_COUNT = 16
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
+/* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:
+ * uint32 [n_envs].  The next launch orders / sizes its workgroups by it; bench.py turns it into the CU balance
+ * sum(cost) / (max(cost) x min(n_envs, CUs)) and, with the launch's duration, into the shader clock the launch ran at.
+ * Zeros before the first resident launch.  No reference counterpart. */
+int sf_get_run_cost(sf_sim *sim, uint32_t *cost_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
  * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay

@@ -519,6 +519,14 @@ extern "C" int sf_set_tuning(sf_sim *s, int32_t knob, int32_t value)
     s->tune.set[knob] = true;
     return SF_OK;
 }
+extern "C" int sf_get_run_cost(sf_sim *s, uint32_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_run_cost: null argument");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(out, s->run_cost, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SF_OK;
+}
 extern "C" int sf_get_tuning(sf_sim *s, int32_t knob, int32_t *value)
 {
     if (!s || !value || knob < 0 || knob >= SF_TUNE_COUNT) return fail(SF_EINVAL, "sf_get_tuning: unknown knob %d", knob);

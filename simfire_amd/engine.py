@@ -229,6 +229,12 @@ class FireEngine:
         for name, value in knobs.items():
             self._chk(self._L.sf_set_tuning(self._h, _lib.TUNE[name], int(value)))
 
+    def run_cost(self):
+        """Shader clocks / 16 every environment's workgroup(s) spent in the last resident launch (uint32 [n_envs])."""
+        out = np.zeros(self.n_envs, dtype=np.uint32)
+        self._chk(self._L.sf_get_run_cost(self._h, _ptr(out)))
+        return out
+
     def get_tuning(self, name):
         v = C.c_int32()
         self._chk(self._L.sf_get_tuning(self._h, _lib.TUNE[name], C.byref(v)))

@@ -461,6 +461,36 @@ def test_bench_two_ranks_on_one_gpu_shard_the_hip_engine():
     assert j["config"]["env_steps_executed"] > 0 and j["roofline"]["kernel"] in ("k_front", "k_run", "k_step_fused", "k_select + k_step")
 
 
+def _bench(*args, timeout=1500):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + [str(x) for x in args], capture_output=True, text=True,
+                         timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="32"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("workload,envs", [("c4", 128), ("c5", 64)])
+def test_bench_other_baseline_configs_at_their_per_gpu_batch(workload, envs):
+    """bench.py --workload c4 | c5 at one GPU's share of the BASELINE batch (128 x 2048^2 with the simplex wind field; 64 x 1024^2
+    with 64 agents per environment): the timed rollout of EVERY environment equals the oracle's (result blocks + sampled
+    fire maps) - the > CU-count scheduling at 2048^2 and C5's one-wave control-line block under 64 concurrent workgroups."""
+    j = _bench("--workload", workload, "--steps", 60, "--warmup", 5, "--no-extra")
+    assert j["verified"] is True and j["config"]["envs_per_gpu"] == envs and j["n_gpus"] == 1
+    assert j["config"]["env_steps_executed"] > 0
+
+
+@pytest.mark.parametrize("workload", ["c3", "c4", "c5"])
+def test_bench_eight_ranks_dry_run_on_one_gpu(workload):
+    """What the driver's SCALE run does with 8 GPUs, here with 8 ranks of the HIP engine on the one GPU of the box (gloo
+    instead of RCCL, tiny grids): the self-launch, the env-axis sharding with per-rank ignition seeds / agent walks, the one
+    all-gather of the result blocks and the one JSON line with n_gpus = 8 - for every workload bench.py knows."""
+    j = _bench("--gpus", 8, "--backend", "gloo", "--workload", workload, "--size", 128, "--envs", 3, "--steps", 14, "--warmup", 3,
+               "--no-extra", "--cpu-threads", 2)
+    assert j["n_gpus"] == 8 and j["config"]["envs_total"] == 24 and j["ranks_seen_by_collective"] == 8
+    assert j["verified"] is True and j["scaling"] == "weak" and j["config"]["collective_backend"] == "gloo"
+
+
 # ------------------------------------------------------------------ rollouts with control lines before every update
 def _blk(agent_pts, E, k):
     """[n][E * k][4] rows (env, x, y, type), env-major -> [n][E][k][3]"""
