@@ -280,7 +280,9 @@ enum sf_tuning_knob {
     SF_TUNE_FRONT_IC = 12,
     SF_TUNE_FRONT_TAB = 13,
     SF_TUNE_FRONT_DEBUG = 14,
-    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in k_run: 0 = chosen per launch from the recorded per-environment cost (default), 1 / 2 / 4 = upper bound forced */
+    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in the resident launch: 0 = automatic (default: teams of 1..4 sized from what the
+                                 * environments cost in the launch before, on long calls; always on grids of more than 1024 columns), 1 = never,
+                                 * 2 / 3 / 4 = every environment split into exactly that many (tests) */
     SF_TUNE_COUNT = 16
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
@@ -289,6 +291,10 @@ int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
  * sum(cost) / (max(cost) x min(n_envs, CUs)) and, with the launch's duration, into the shader clock the launch ran at.
  * Zeros before the first resident launch.  No reference counterpart. */
 int sf_get_run_cost(sf_sim *sim, uint32_t *cost_out);
+/* Workgroups every environment had in the last environment-resident launch if that was a team launch (k_run<TEAM>: the
+ * environment's rows are cut into bands, one workgroup each; the members exchange one boundary row per step): uint32 [n_envs],
+ * zeros if the last launch gave every environment one workgroup.  No reference counterpart. */
+int sf_get_team_sizes(sf_sim *sim, uint32_t *sizes_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
  * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay

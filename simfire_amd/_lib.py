@@ -81,6 +81,7 @@ SIGNATURES = {
     "sf_set_tuning": [_VP, _I32, _I32],
     "sf_get_tuning": [_VP, _I32, C.POINTER(_I32)],
     "sf_get_run_cost": [_VP, _VP],
+    "sf_get_team_sizes": [_VP, _VP],
     "sf_last_step_launch": [_VP, C.POINTER(_I32)],
     "sf_set_prune_after_quit": [_VP, _I32],
     "sf_set_async": [_VP, _I32],

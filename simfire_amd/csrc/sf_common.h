@@ -72,6 +72,10 @@ __host__ __device__ inline int bl_cell(const Geo &g, int y, int x)     // sprite
 }
 constexpr int kBlStatus = 32;      // status row = mask row + 32 inside a sector
 
+constexpr int kTeamMax = 4;                      // workgroups per environment in the resident launch (k_run<TEAM>)
+constexpr uint32_t kTeamUnused = 0xFFFFFFFFu;
+__host__ __device__ inline int team_xrow(const Geo &g) { return (64 + g.PV * 16 + 127) / 128 * 128; }
+
 struct StepArgs {
     Geo g;
     uint8_t *status;
@@ -104,6 +108,14 @@ struct StepArgs {
     uint16_t *thist;     // [E][TY][TX][8] cached per-tile status histograms behind the block
     const uint32_t *order; // k_run only: workgroup i takes environment order[i] (most expensive first, k_order), or null = i
     uint32_t *cost;      // k_run only: [E] shader clocks / 16 the environment's workgroup took in this launch (the next launch's order), or null
+    // k_run<TEAM> only: an environment served by a TEAM of 1 .. kTeamMax workgroups, each owning a band of rows (sf_run_kernels.h)
+    const uint32_t *team_tab;    // [grid] workgroup slot -> env | member << 16 | team size << 24 (kTeamUnused: the slot has nothing to do)
+    unsigned long long *xg;      // [E][kTeamMax][2] granules {step epoch << 32 | predicate bits}: a member's "step s done", by parity of s
+    uint8_t *xbuf;               // [E][kTeamMax][2 sides][2 parities][xrow] the member's first / last row as its neighbours need it (sc1 stores / loads only)
+    uint32_t *xdone;             // [E] members that have left the launch (the last one counts the environment)
+    uint32_t *xerr;              // != 0: a wait for a team member timed out (the launch's results are void)
+    int xrow;                    // bytes per published row: 64 (bitmap words) + PV * 16, rounded up to 128
+    int team_rcap;               // bitmap rows a member keeps in LDS (+ 2 halo rows); 0 = the whole grid
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

@@ -58,10 +58,14 @@ constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap)
+// team: 0 = k_run<TEAM = 0> (a workgroup holds the bitmaps of the whole grid); 1 = k_run<TEAM = 1>: all four bitmaps whatever the
+// row width, for team_rcap + 2 rows (team_rcap = 0: the whole grid), + the two halo rows of sprite masks.
+__host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap, int team = 0, int team_rcap = 0)
 {
-    const int maps = g.VW == 1 ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
-    size_t b = (size_t)maps * g.H * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (64 * kStripDw * 4) + kRunCtl * 4;
+    const int maps = (team || g.VW == 1) ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
+    const int rows = team && team_rcap ? team_rcap + 2 : g.H;
+    size_t b = (size_t)maps * rows * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (64 * kStripDw * 4) + kRunCtl * 4;
+    if (team) b += (size_t)2 * g.PV * 16 + 64 * 4;         // halo rows of sprite masks [2][PV] uint4, tile-row counts of the split
 #ifdef SF_PHASES
     b += 16 * 16 * 4;              // + phase clocks [waves][16]
 #endif
@@ -197,10 +201,11 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
                 uint8_t *cell = ev.cells + bl_cell(g, y, x);
                 cell[kBlStatus] = (uint8_t)SF_BURNING;                           // fire.py:587
                 cell[0] = nb;
-                atomicOr(&ev.vb[y * g.VW + (x >> 10)], 1ull << ((x >> 4) & 63));
+                const int bw = y * g.VW + (x >> 10);
+                atomicOr(&ev.vb[bw], 1ull << ((x >> 4) & 63));
                 if (ev.vf) {
-                    if ((x & 15) == 0) atomicOr(&ev.vf[y], 1ull << (x >> 4));
-                    if ((x & 15) == 15) atomicOr(&ev.vl[y], 1ull << (x >> 4));
+                    if ((x & 15) == 0) atomicOr(&ev.vf[bw], 1ull << ((x >> 4) & 63));
+                    if ((x & 15) == 15) atomicOr(&ev.vl[bw], 1ull << ((x >> 4) & 63));
                 }
                 ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
             }
@@ -239,36 +244,132 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 // Template parameters: MAXD = bitmap words a thread owns; ATT = attenuate_line_ros (fire.py:236-284) known at compile time;
 // DIAG = 1: diagonal_spread known to be on, -1: read from the geometry (the 4-connected case is rare); MIT = 0: no control lines
 // inside the launch (sf_step), -1: look at the argument (sf_step_mitigated).  MAXD = 1 implies one-word rows (the refined interest rule).
-template <int MAXD, int ATT, int DIAG, int MIT>
+//
+// TEAM = 1: an environment is served by a TEAM of 1 .. kTeamMax workgroups (a.team_tab: workgroup slot -> environment, member, team size;
+// k_team_plan sizes the teams from what the environments cost in the launch before).  Member m owns the rows [R0, R1) - bands cut at
+// wave-tile rows so that the members' fronts hold about the same number of vectors - and everything that belongs to them: their cells,
+// their burn_amounts, their bitmap rows (in ITS LDS: with 2048-wide rows only its own band fits, which is what puts C4 on this
+// kernel), their tiles' dirty flags.  What crosses a band boundary is one row of sprite masks each way (the row below / above the
+// neighbour's last / first row, fire.py:163-234) + its bitmap words, and the two predicates of fire.py:637-652, once per step:
+// after barrier B wave 0 PUBLISHES its first / last row (write-through sc1 stores into a.xbuf, drained, then one 8-byte granule
+// {step epoch, predicates} in a.xg), waits until every member's granule carries this step's epoch, and reads its neighbours' rows with
+// sc1 loads into the LDS halo rows - the placement-independent hand-off of the HIP guide (payload written through, ONE tagged word per
+// producer, no fence); plain loads / stores never touch another member's lines inside the launch (bands are cut at multiples of the
+// tile height, so a 128-byte line of the blocked plane has one owner).  Every member folds the same predicates into the same state,
+// so they all stop at the same step.  The last member to leave counts the environment (counts_env) behind an agent-scope release /
+// acquire.  Same update, same per-row list order inside a band: results do not depend on the team size (tests force 1 .. 4).
+template <int MAXD, int ATT, int DIAG, int MIT, int TEAM = 0>
 __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
-    const int e = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
+    int e_ = 0, tm_ = 0, tn_ = 1;
+    if (TEAM) {
+        const uint32_t tt = a.team_tab[blockIdx.x];
+        if (tt == kTeamUnused) return;
+        e_ = (int)(tt & 0xFFFFu); tm_ = (int)((tt >> 16) & 0xFFu); tn_ = (int)(tt >> 24);
+    } else e_ = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
+    const int e = e_, tm = tm_, tn = tn_;        // environment, member of its team, team size
     const unsigned long long clk0 = __builtin_readcyclecounter();
-    unsigned long long *vb = reinterpret_cast<unsigned long long *>(s_dyn);        // [H][VW]
-    const bool fine = MAXD == 1 ? true : g.VW == 1;                                // refined interest rule (see below)
+    const bool fine = TEAM ? true : (MAXD == 1 ? true : g.VW == 1);                // refined interest rule (see below)
+    const int VW = MAXD == 1 ? 1 : g.VW;                                           // 64-bit words per bitmap row
     const int32_t *const mit = MIT == 0 ? nullptr : a.mit;                         // control lines inside the launch
     const bool diag = DIAG > 0 ? true : g.diag != 0;
-    unsigned long long *vf = fine ? vb + g.H : nullptr, *vl = fine ? vb + 2 * g.H : nullptr, *ve = fine ? vb + 3 * g.H : nullptr;
-    uint32_t *vlist = reinterpret_cast<uint32_t *>(vb + (size_t)(fine ? 4 : 1) * g.H * g.VW);       // [vcap]
+    const int lds_rows = TEAM && a.team_rcap ? a.team_rcap + 2 : g.H;              // bitmap rows kept in LDS
+    unsigned long long *vb0 = reinterpret_cast<unsigned long long *>(s_dyn);       // [lds_rows][VW] x 4 (fine) or x 1
+    uint32_t *vlist = reinterpret_cast<uint32_t *>(vb0 + (size_t)(fine ? 4 : 1) * lds_rows * VW);       // [vcap]
     uint32_t *strips = vlist + vcap + wave * (64 * kStripDw);                      // [64][kStripDw] per wave
     uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw);
+#ifdef SF_PHASES
+    uint4 *halo = reinterpret_cast<uint4 *>(ctl + kRunCtl + 16 * 16);              // (behind the phase clocks)
+#else
+    uint4 *halo = reinterpret_cast<uint4 *>(ctl + kRunCtl);                        // TEAM: [2][PV] the sprite masks of the row above R0 / below R1 - 1
+#endif
+    uint32_t *tcnt = reinterpret_cast<uint32_t *>(halo + 2 * g.PV);                // TEAM: [64] vectors with sprites per tile row (the split)
 
     EnvState st = a.commit[e];
     if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
     if ((!st.running && !mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
-    const int n_words = g.H * g.VW;
-    for (int i = tid; i < n_words; i += nthr) vb[i] = vb_glob[i];
-    if (fine)
-        for (int i = tid; i < g.H; i += nthr) {
-            vf[i] = vb_glob[(long long)g.E * g.vb_env + i];           // planes 1 / 2 of the bitmap array
-            vl[i] = vb_glob[2ll * g.E * g.vb_env + i];
-            ve[i] = ~0ull;                                             // "has an eligible cell": found out as the vectors are visited
-        }
+    const int n_words = g.H * VW;
     if (tid < kRunCtl) ctl[tid] = 0;
+    // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
+    // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
+    int R0 = 0, R1 = g.H;
+    if (TEAM && tn > 1) {
+        const int th = g.LR * g.RB, ntr = (g.H + th - 1) / th;        // (the host offers teams only for <= 64 tile rows)
+        if (tid < 64) tcnt[tid] = 0;
+        __syncthreads();
+        for (int y = tid; y < g.H; y += nthr) {
+            uint32_t c = 0;
+            for (int w = 0; w < VW; ++w) c += (uint32_t)__popcll(vb_glob[y * VW + w]);
+            if (c) atomicAdd(&tcnt[y / th], c);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t ci = lane < ntr ? tcnt[lane] : 0u;
+            const uint32_t incl = wave_scan_incl(ci, lane), total = wave_last(incl);
+            const unsigned long long nzb = __ballot(ci != 0u);
+            // rows that can hold fire before the launch is over (it advances one row per update at most); with a window of
+            // team_rcap rows per member nobody has to own the rest
+            int lo = 0, hi = ntr;
+            if (a.team_rcap && nzb) {
+                const int mt = (n_steps + 1 + th - 1) / th + 1;
+                lo = __ffsll((long long)nzb) - 1 - mt; hi = 64 - __clzll((long long)nzb) + mt;
+                lo = lo < 0 ? 0 : lo; hi = hi > ntr ? ntr : hi;
+            }
+            const int cap = a.team_rcap ? a.team_rcap / th : ntr;     // tile rows a member can hold
+            int cut[kTeamMax + 1];
+            cut[0] = lo; cut[tn] = hi;
+            for (int j = 1; j < tn; ++j) {
+                // first tile row at which the running count reaches j / tn of the total: the boundary comes after it
+                const unsigned long long bal = __ballot(lane < ntr && (unsigned long long)incl * (unsigned)tn >= (unsigned long long)total * (unsigned)j);
+                int c = total ? __ffsll((long long)bal) : lo + (hi - lo) * j / tn;
+                if (c < cut[j - 1] + 1) c = cut[j - 1] + 1;            // every member owns at least one tile row ...
+                if (c > cut[j - 1] + cap) c = cut[j - 1] + cap;        // ... and no more than it can hold
+                cut[j] = c;
+            }
+            for (int j = tn - 1; j >= 1; --j) {                        // (the same two rules seen from the far end)
+                if (cut[j] > cut[j + 1] - 1) cut[j] = cut[j + 1] - 1;
+                if (cut[j] < cut[j + 1] - cap) cut[j] = cut[j + 1] - cap;
+            }
+            if (lane == 0) { tcnt[0] = (uint32_t)(cut[tm] * th); tcnt[1] = (uint32_t)(cut[tm + 1] * th); }
+        }
+        __syncthreads();
+        R0 = (int)tcnt[0]; R1 = (int)tcnt[1];
+        R0 = __builtin_amdgcn_readfirstlane(R0); R1 = __builtin_amdgcn_readfirstlane(R1);
+        if (R1 > g.H) R1 = g.H;
+        __syncthreads();
+    }
+    const bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;           // a neighbour above / below the band
+    // The bitmaps are indexed by the grid row: with a window of rows in LDS the base pointers are shifted so that row y sits where it is.
+    const int yoff = TEAM && a.team_rcap ? R0 - 1 : 0;
+    unsigned long long *vb = vb0 - (long long)yoff * VW;
+    unsigned long long *vf = fine ? vb + (size_t)lds_rows * VW : nullptr, *vl = fine ? vb + (size_t)2 * lds_rows * VW : nullptr,
+                       *ve = fine ? vb + (size_t)3 * lds_rows * VW : nullptr;
+    {
+        // rows to load: the whole grid, or the band and the rows next to it
+        const int y_lo = TEAM && a.team_rcap ? (R0 > 0 ? R0 - 1 : 0) : 0, y_hi = TEAM && a.team_rcap ? (R1 < g.H ? R1 + 1 : g.H) : g.H;
+        for (int i = y_lo * VW + tid; i < y_hi * VW; i += nthr) {
+            vb[i] = vb_glob[i];
+            if (fine) {
+                vf[i] = vb_glob[(long long)g.E * g.vb_env + i];       // planes 1 / 2 of the bitmap array
+                vl[i] = vb_glob[2ll * g.E * g.vb_env + i];
+                ve[i] = ~0ull;                                         // "has an eligible cell": found out as the vectors are visited
+            }
+        }
+    }
+    if (TEAM && tn > 1) {
+        // the neighbours' boundary rows as the launch finds them (plain loads: nobody has written anything yet)
+        for (int i = tid; i < 2 * g.PV; i += nthr) {
+            const int side = i >= g.PV, v = side ? i - g.PV : i, yh = side ? R1 : R0 - 1;
+            uint4 r = make_uint4(0, 0, 0, 0);
+            if (side ? has_dn : has_up)
+                r = *reinterpret_cast<const uint4 *>(a.cells + (long long)e * g.cells_env + bl_vec(g, yh, v) + (yh & 1) * 16);
+            halo[i] = r;
+        }
+    }
     PhaseClock pc;
 #ifdef SF_PHASES
     uint32_t *ph_acc = ctl + kRunCtl + wave * 16;
@@ -287,7 +388,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     ev.vb = vb; ev.vf = vf; ev.vl = vl;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
     const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));      // wave-tile height is a power of two
-    const int rpt = (g.H + nthr - 1) / nthr;                  // rows per thread (contiguous, so the list runs by rows)
+    const int rpt = ((TEAM ? R1 - R0 : g.H) + nthr - 1) / nthr;      // rows per thread (contiguous, so the list runs by rows)
+    const int row0 = TEAM ? R0 : 0;                                   // first row of this workgroup's rows
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
     // control lines inside the launch, up to 64 points per environment and step: lane i of wave 0 holds point i of the coming step
@@ -301,6 +403,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     };
     if (mit_one_wave && n_steps > 0) load_pt(0);
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
+    bool gave_up = false;        // TEAM: a wait for the other members timed out (the handle is void; never wait again)
     for (int s = 0; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
         if (mit) {
@@ -316,7 +419,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 // were requested one step ahead (the block was 9.3 k clocks of a C5 step).
                 if (wave == 0) {
                     const int ty = pty;
-                    const bool ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && px >= 0 && px < g.W && py >= 0 && py < g.H;
+                    const bool ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && px >= 0 && px < g.W && py >= R0 && py < R1;      // (TEAM: the points in this member's band; else R0 = 0, R1 = H)
                     const int x = ok ? px : 0, y = ok ? py : 0;
                     const uint32_t o = (uint32_t)(y * g.P + x);
                     uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
@@ -348,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                             if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
                             old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
                         } while (old != seen);
-                        if (fine) atomicOr(&ve[y], 1ull << (x >> 4));
+                        if (fine) atomicOr(&ve[y * VW + (x >> 10)], 1ull << ((x >> 4) & 63));
                     }
                 }
                 // What the step reads next are the bitmaps in LDS; the cell planes are not read before the barrier behind the vector list,
@@ -364,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const int32_t *pts = mit + ((long long)s * g.E + e) * a.mit_k * 3;
                 for (int i = tid; i < a.mit_k; i += nthr) {
                     const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
-                    if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
+                    if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < R0 || y >= R1) continue;
                     const uint32_t o = (uint32_t)(y * g.P + x);
                     uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
                     const int sh = (x & 3) * 8;
@@ -374,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 __syncthreads();
                 for (int i = tid; i < a.mit_k; i += nthr) {
                     const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
-                    if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < 0 || y >= g.H) continue;
+                    if (ty < SF_FIRELINE || ty > SF_WETLINE || x < 0 || x >= g.W || y < R0 || y >= R1) continue;
                     const uint32_t o = (uint32_t)(y * g.P + x);
                     uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
                     const int sh = (x & 3) * 8;
@@ -386,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     } while (old != seen);
                     if (ATT) ev.settled[o] = (uint32_t)st.complete;      // idempotent: every point of this step on this cell stores the same count
                     ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
-                    if (fine) atomicOr(&ve[y], 1ull << (x >> 4));          // a control line is an eligible cell
+                    if (fine) atomicOr(&ve[y * VW + (x >> 10)], 1ull << ((x >> 4) & 63));          // a control line is an eligible cell
                 }
                 __syncthreads();
             }
@@ -414,19 +517,28 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             // neighbour, rows y - 1 .. y + 1 (last cell of v - 1: l << 1; first cell of v + 1: f >> 1); and - so that a listed
             // vector always finds its horizontal neighbour in the list when that neighbour's column matters to it, see the
             // edge cells below - if the vector above / below it has a sprite in an edge cell (l0 | l2 | f0 | f2).
+            // (TEAM: the rows of this member's band; rows R0 - 1 and R1 of the bitmaps are the neighbours' boundary rows as of the
+            // end of the step before; rows of two words: the edge-cell terms carry across the word boundary)
 #pragma unroll
             for (int d = 0; d < MAXD; ++d) {
                 D[d] = 0;
-                const int y = tid * rpt + d;
-                if (d < rpt && y < g.H) {
-                    const int up_o = y > 0 ? -1 : 0, dn_o = y + 1 < g.H ? 1 : 0;
-                    const unsigned long long b1 = vb[y], l1 = vl[y], f1 = vf[y], e1 = ve[y];
+                const int i = MAXD == 1 ? 0 : d / VW, w = MAXD == 1 ? 0 : d - i * VW;
+                const int y = row0 + tid * rpt + i;
+                if (i < rpt && y < R1) {
+                    const int o = y * VW + w;
+                    const int up_o = y > 0 ? -VW : 0, dn_o = y + 1 < g.H ? VW : 0;
+                    const unsigned long long b1 = vb[o], l1 = vl[o], f1 = vf[o], e1 = ve[o];
                     unsigned long long b02 = 0, l02 = 0, f02 = 0;
-                    if (up_o) { b02 = vb[y - 1]; l02 = vl[y - 1]; f02 = vf[y - 1]; }
-                    if (dn_o) { b02 |= vb[y + 1]; l02 |= vl[y + 1]; f02 |= vf[y + 1]; }
-                    unsigned long long m = b1 | (e1 & (b02 | ((l02 | l1) << 1) | ((f02 | f1) >> 1))) | l02 | f02;
-                    m &= last_word_mask;
-                    if (g.dense) m = last_word_mask;
+                    if (up_o) { b02 = vb[o + up_o]; l02 = vl[o + up_o]; f02 = vf[o + up_o]; }
+                    if (dn_o) { b02 |= vb[o + dn_o]; l02 |= vl[o + dn_o]; f02 |= vf[o + dn_o]; }
+                    unsigned long long edge = ((l02 | l1) << 1) | ((f02 | f1) >> 1);
+                    if (MAXD > 1 && VW > 1) {
+                        if (w > 0) edge |= (vl[o - 1] | vl[o - 1 + up_o] | vl[o - 1 + dn_o]) >> 63;
+                        if (w + 1 < VW) edge |= (vf[o + 1] | vf[o + 1 + up_o] | vf[o + 1 + dn_o]) << 63;
+                    }
+                    unsigned long long m = b1 | (e1 & (b02 | edge)) | l02 | f02;
+                    if (g.dense) m = ~0ull;
+                    if (w == VW - 1) m &= last_word_mask;
                     D[d] = m;
                     cnt += (uint32_t)__popcll(m);
                 }
@@ -475,7 +587,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 for (int d = 0; d < MAXD; ++d) {
                     const unsigned long long m = D[d];
                     const int i = d / g.VW, w = d - i * g.VW;
-                    const uint32_t base_item = (uint32_t)(tid * rpt + i) | ((uint32_t)(w * 64) << 16);
+                    const uint32_t base_item = (uint32_t)(row0 + tid * rpt + i) | ((uint32_t)(w * 64) << 16);
                     // (two 32-bit loops: a row along a front holds tens of vectors, and this loop is serial per thread)
                     uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
                     while (lo) {
@@ -543,6 +655,21 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     in.r0 = *reinterpret_cast<const uint32_t *>(p_mid + 128);
                     if (diag) { in.r1 = *reinterpret_cast<const uint32_t *>(p_up + 128); in.r2 = *reinterpret_cast<const uint32_t *>(p_dn + 128); }
                 }
+                if (TEAM) {
+                    // The row above the band's first row / below its last row belongs to a neighbour: its sprite masks as of the end of
+                    // the step before come from the LDS halo rows (what the plain loads above returned for them is dropped).  Bands start
+                    // on even rows and end on odd ones: that row is always the `far` one.
+                    const bool hu = has_up && y == R0, hd = has_dn && y == R1 - 1;
+                    if (hu | hd) {
+                        const uint4 *hrow = halo + (hd ? g.PV : 0);
+                        const uint4 hv = hrow[v];
+                        if (hu) in.up = hv; else in.dn = hv;
+                        if (diag) {
+                            if (has && lane == 0 && v > 0) { const uint32_t q = hrow[v - 1].w; if (hu) in.l1 = q; else in.l2 = q; }
+                            if (has && (j0 + lane + 1 == n_chunk || lane == bsz - 1) && x0 + 16 < g.W) { const uint32_t q = hrow[v + 1].x; if (hu) in.r1 = q; else in.r2 = q; }
+                        }
+                    }
+                }
             };
             uint32_t j_next = grab();
             VecIn nxt;
@@ -609,10 +736,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 if (has && any_clr) {   // recycle the slot of sprites that were pruned one step ago
                     const uint4 av = and4(mid, ~CLR4);
                     *reinterpret_cast<uint4 *>(vmask) = av;
-                    if (!any4(av)) atomicAnd(&vb[y * g.VW + (v >> 6)], ~(1ull << (v & 63)));     // no sprite bit left in the vector
+                    if (!any4(av)) atomicAnd(&vb[y * VW + (v >> 6)], ~(1ull << (v & 63)));     // no sprite bit left in the vector
                     if (fine) {
-                        if (!(av.x & 0xFFu) && (mid.x & 0xFFu)) atomicAnd(&vf[y], ~(1ull << v));
-                        if (!(av.w >> 24) && (mid.w >> 24)) atomicAnd(&vl[y], ~(1ull << v));
+                        if (!(av.x & 0xFFu) && (mid.x & 0xFFu)) atomicAnd(&vf[y * VW + (v >> 6)], ~(1ull << (v & 63)));
+                        if (!(av.w >> 24) && (mid.w >> 24)) atomicAnd(&vl[y * VW + (v >> 6)], ~(1ull << (v & 63)));
                     }
                 }
                 uint32_t m16 = 0;
@@ -668,7 +795,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                         el = (ELIG(snew.x) & first01(nv)) | (ELIG(snew.y) & first01(nv - 4)) |
                              (ELIG(snew.z) & first01(nv - 8)) | (ELIG(snew.w) & first01(nv - 12));
                     }
-                    if (!el) atomicAnd(&ve[y], ~(1ull << v));
+                    if (!el) atomicAnd(&ve[y * VW + (v >> 6)], ~(1ull << (v & 63)));
                 }
                 // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
                 const bool st_ch = ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) != 0;
@@ -708,6 +835,81 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         }
         __syncthreads();
         pc.mark(0);          // waiting for the slowest wave of the step
+        if (TEAM && tn > 1) {
+            // ---- the team's step boundary: publish this member's boundary rows and predicates, wait for every member's, take the
+            // neighbours' rows into the LDS halo (wave 0; the other waves wait at the barrier below)
+            if (wave == 0) {
+                typedef unsigned long long u64;
+                const uint32_t epoch = (uint32_t)s + 1u, par = (uint32_t)s & 1u;
+                uint8_t *xb_me = a.xbuf + ((size_t)(e * kTeamMax + tm) * 4) * (size_t)a.xrow;      // [side][parity][xrow]
+                for (int side = 0; side < 2; ++side) {
+                    if (!(side ? has_dn : has_up)) continue;           // (uniform)
+                    const int yb = side ? R1 - 1 : R0;                 // my last row is the row above the band below, my first row the row below the band above
+                    u64 *dst = reinterpret_cast<u64 *>(xb_me + (size_t)(side * 2 + par) * a.xrow);
+                    for (int v = lane; v < g.PV; v += 64)
+                        if ((vb[yb * VW + (v >> 6)] >> (v & 63)) & 1ull) {       // (vectors without a sprite bit are zero: the reader knows from the bitmap word)
+                            const uint4 val = *reinterpret_cast<const uint4 *>(ev.cells + bl_vec(g, yb, v) + (yb & 1) * 16);
+                            __hip_atomic_store(dst + 8 + v * 2, (u64)val.x | ((u64)val.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(dst + 8 + v * 2 + 1, (u64)val.z | ((u64)val.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    if (lane < 3 * VW) {
+                        const int which = lane / VW, w = lane - which * VW;
+                        const u64 word = (which == 0 ? vb : (which == 1 ? vf : vl))[yb * VW + w];
+                        __hip_atomic_store(dst + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are written through (sc1) and acknowledged ...
+                if (lane == 0)                                          // ... before the one tagged word that says so
+                    __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 2 + par, ((u64)epoch << 32) | (u64)(ctl[3 + k] & 0xFFFFu), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                // every member's granule of this step (a member can be one step ahead at most: two granules by parity)
+                u64 x = (u64)epoch << 32;
+                {
+                    const unsigned long long t0 = __builtin_readcyclecounter();
+                    for (;;) {
+                        if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 2 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all((uint32_t)(x >> 32) == epoch)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (gave_up || __builtin_readcyclecounter() - t0 > (1ull << 29)) {       // (bounded, ~0.25 s: a lost member must not hang the GPU)
+                            if (lane == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
+                            gave_up = true;
+                            break;
+                        }
+                    }
+                }
+                const bool live_any = __ballot(lane < tn && (x & 0xFFull)) != 0ull, cand_any = __ballot(lane < tn && (x & 0xFF00ull)) != 0ull;
+                if (lane == 0) ctl[3 + k] = (live_any ? FLAG_LIVE : 0u) | (cand_any ? FLAG_CAND : 0u);     // fire.py:637, 651: over the whole environment
+                for (int side = 0; side < 2; ++side) {
+                    if (!(side ? has_dn : has_up)) continue;
+                    const int nj = side ? tm + 1 : tm - 1, yh = side ? R1 : R0 - 1;
+                    const u64 *src = reinterpret_cast<const u64 *>(a.xbuf + ((size_t)(e * kTeamMax + nj) * 4 + (size_t)((side ^ 1) * 2 + par)) * a.xrow);
+                    u64 word = 0;
+                    if (lane < 3 * VW) word = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int v0 = 0; v0 < g.PV; v0 += 64) {
+                        const int v = v0 + lane;
+                        u64 lo = 0, hi = 0;
+                        if (v < g.PV) {       // (requested before the bitmap word is known: one round trip)
+                            lo = __hip_atomic_load(src + 8 + v * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi = __hip_atomic_load(src + 8 + v * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        const int wl = v0 >> 6;        // the neighbour's "holds a sprite bit" word of these 64 vectors: lane wl
+                        const u64 bw = (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, wl) |
+                                       ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), wl) << 32);
+                        if (v < g.PV) {
+                            const bool on = (bw >> lane) & 1ull;
+                            halo[side * g.PV + v] = on ? make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)) : make_uint4(0, 0, 0, 0);
+                        }
+                    }
+                    if (lane < 3 * VW) {
+                        const int which = lane / VW, w = lane - which * VW;
+                        (which == 0 ? vb : (which == 1 ? vf : vl))[yh * VW + w] = word;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");       // (what the others read next is all in LDS)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
         // ---- fold (every thread the same arithmetic on the same values)
         st = fold_state(st, ctl[3 + k], g);
         st.running = __builtin_amdgcn_readfirstlane(st.running);
@@ -727,18 +929,29 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // ---- hand the environment back: state, vector bitmap
     __syncthreads();
     if (tid == 0) {
-        a.commit[e] = st;
-        if (a.cost) {            // what this environment cost: the order of the next launch (k_order)
+        if (!TEAM || tm == 0) a.commit[e] = st;      // (every member has folded the same predicates into the same state)
+        if (a.cost) {            // what this environment cost: the order / the team sizes of the next launch (k_order, k_team_plan)
             const unsigned long long c = (__builtin_readcyclecounter() - clk0) >> 4;
-            a.cost[e] = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+            const uint32_t c32 = c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c;
+            if (TEAM) atomicAdd(&a.cost[e], c32);     // (zeroed before the launch: the sum over the members)
+            else a.cost[e] = c32;
         }
     }
-    for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
-    if (fine)
-        for (int i = tid; i < g.H; i += nthr) {
+    if (TEAM) {
+        // this member's rows of the bitmaps (the others' rows in its LDS are not maintained)
+        for (int i = R0 * VW + tid; i < R1 * VW; i += nthr) {
+            vb_glob[i] = vb[i];
             vb_glob[(long long)g.E * g.vb_env + i] = vf[i];
             vb_glob[2ll * g.E * g.vb_env + i] = vl[i];
         }
+    } else {
+        for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
+        if (fine)
+            for (int i = tid; i < g.H; i += nthr) {
+                vb_glob[(long long)g.E * g.vb_env + i] = vf[i];
+                vb_glob[2ll * g.E * g.vb_env + i] = vl[i];
+            }
+    }
     if (a.counters && lane == 0) {
         unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
@@ -749,6 +962,21 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     }
     // The result block row of this environment (sf_get_status), produced by its own workgroup now that its steps are done: the
     // status query after a rollout then costs no launch.  LDS: the strip buffers (>= 5376 bytes), free by now.
+    if (TEAM && tn > 1) {
+        // The environment's cells, dirty flags and bitmap rows were written by several CUs: every member releases what it wrote
+        // (agent scope) before it counts itself out; the last one acquires and produces the result row (or nobody does).
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the wait behind the write-back, where the compiler cannot drop it)
+            const uint32_t before = atomicAdd(&a.xdone[e], 1u);
+            const bool last = before == (uint32_t)tn - 1u;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ctl[0] = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!ctl[0]) return;       // (uniform)
+    }
     if (a.res_block) {
         __syncthreads();
         counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
@@ -790,6 +1018,71 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
     s_hist[tid] = base + incl - mine;
     __syncthreads();
     for (int e = tid; e < E; e += 1024) order[atomicAdd(&s_hist[bucket(cost[e])], 1u)] = (uint32_t)e;
+}
+
+// Team sizes and workgroup slots of a k_run<TEAM> launch (one workgroup, E <= 1024 environments, G slots = what the chip holds
+// at once).  cost[e] = shader clocks / 16 the environment's workgroups spent in the launch before (ovh = what a member pays per
+// launch for belonging to a team of more than one, same unit).  The team of an environment is the smallest one that brings
+// cost / T (+ ovh) under a target; the target is the lowest one for which the teams fit the G slots (bisection).  Slots: block b
+// runs on XCD b mod 8 (observed; speed only), so the members of a team get slots of one residue class - their per-step exchange
+// then stays in one L2 - unless a class is full, in which case the teams simply take consecutive slots (placement never matters
+// for results).  t_min / t_max bound the sizes (forced teams: t_min = t_max; rows too wide for one member: t_min = 2).
+__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, const uint32_t *cost, uint32_t *tab, uint32_t *tsize)
+{
+    __shared__ uint32_t s_T[1024], s_sum, s_cls[8], s_over;
+    const int t = threadIdx.x;
+    for (int i = t; i < G; i += 1024) tab[i] = kTeamUnused;
+    const uint32_t c = t < E ? cost[t] : 0u;
+    auto need = [&](uint32_t tgt) -> uint32_t {
+        if (t >= E) return 0u;
+        if (c <= tgt || t_max <= 1) return (uint32_t)t_min;
+        for (int T = t_min > 2 ? t_min : 2; T < t_max; ++T)
+            if (c / (uint32_t)T + ovh <= tgt) return (uint32_t)T;
+        return (uint32_t)t_max;
+    };
+    auto total = [&](uint32_t v) -> uint32_t {
+        __syncthreads();
+        if (t == 0) s_sum = 0;
+        __syncthreads();
+        uint32_t w = v;
+        for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+        if ((t & 63) == 0 && w) atomicAdd(&s_sum, w);
+        __syncthreads();
+        return s_sum;
+    };
+    uint32_t lo = 0, hi = 0;
+    {
+        __syncthreads();
+        if (t == 0) s_sum = 0;
+        __syncthreads();
+        if (c) atomicMax(&s_sum, c);
+        __syncthreads();
+        hi = s_sum;                       // target = the largest cost: nobody is split
+    }
+    for (int it = 0; it < 28 && lo < hi; ++it) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (total(need(mid)) <= (uint32_t)G) hi = mid; else lo = mid + 1;
+    }
+    const uint32_t T = need(hi);
+    s_T[t] = T;
+    if (t < E && tsize) tsize[t] = T;
+    if (t < 8) s_cls[t] = 0;
+    if (t == 0) s_over = 0;
+    __syncthreads();
+    if (t < E) atomicAdd(&s_cls[t & 7], T);
+    __syncthreads();
+    if (t < 8 && s_cls[t] > (uint32_t)((G - t + 7) / 8)) s_over = 1;     // slots of residue class t: t, t + 8, ... < G
+    __syncthreads();
+    if (t < E) {
+        uint32_t pos = 0;
+        if (!s_over) {
+            for (int q = t & 7; q < t; q += 8) pos += s_T[q];
+            for (uint32_t j = 0; j < T; ++j) tab[(t & 7) + 8 * (pos + j)] = (uint32_t)t | (j << 16) | (T << 24);
+        } else {
+            for (int q = 0; q < t; ++q) pos += s_T[q];
+            for (uint32_t j = 0; j < T; ++j) if (pos + j < (uint32_t)G) tab[pos + j] = (uint32_t)t | (j << 16) | (T << 24);
+        }
+    }
 }
 
 // The vector bitmap of environments [env0, env0 + n) from their sprite-mask planes (after steps of the per-step

@@ -156,6 +156,14 @@ struct sf_sim {
     int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
     ncclComm_t comm = nullptr;         // sf_comm_init: communicator of the result-block all-gather
     int comm_world = 0;
+    // k_run<TEAM>: an environment served by several workgroups (sf_run_kernels.h); allocated at the first team launch
+    uint32_t *team_tab = nullptr, *team_size = nullptr, *xdone = nullptr;
+    unsigned long long *xg = nullptr;
+    uint8_t *xbuf = nullptr;
+    uint32_t *xerr_pinned = nullptr, *xerr_mapped = nullptr;
+    int team_slots = 0;                // entries of team_tab
+    int last_team_max = 0;             // upper bound of the team sizes in the last resident launch (0: it was not a team launch)
+    int cost_steps = 0;                // steps the per-environment cost array covers (0: nothing recorded since the last reset)
     uint32_t *run_cost = nullptr, *run_order = nullptr;   // k_run: clocks / 16 an environment's workgroup took in the last resident launch [E]; launch order built from it (k_order)
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
@@ -351,7 +359,8 @@ extern "C" int sf_destroy(sf_sim *s)
     hipSetDevice(s->p.device);
     if (s->stream) hipStreamSynchronize(s->stream);
     if (s->comm) (void)sf_comm_destroy(s);
-    void *ptrs[] = {s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
+    if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
+    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
@@ -448,6 +457,8 @@ extern "C" int sf_sync(sf_sim *s)
     if (!s) return fail(SF_EINVAL, "sf_sync: null handle");
     HIPCHK(hipSetDevice(s->p.device));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->xerr_pinned && *s->xerr_pinned)
+        return fail(SF_EHIP, "sf_sync: a workgroup of a team launch (k_run<TEAM>) gave up waiting for a team member; the state of this handle is void");
     return SF_OK;
 }
 
@@ -525,6 +536,15 @@ extern "C" int sf_get_run_cost(sf_sim *s, uint32_t *out)
     HIPCHK(hipSetDevice(s->p.device));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(out, s->run_cost, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SF_OK;
+}
+extern "C" int sf_get_team_sizes(sf_sim *s, uint32_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_team_sizes: null argument");
+    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (!s->last_team_max || !s->team_size) { for (int e = 0; e < s->g.E; ++e) out[e] = 0; return SF_OK; }
+    HIPCHK(hipMemcpy(out, s->team_size, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SF_OK;
 }
 extern "C" int sf_get_tuning(sf_sim *s, int32_t knob, int32_t *value)
@@ -782,6 +802,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     HIPCHK(hipSetDevice(s->p.device));
     s->status_fresh = false;
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
+    if (n == g.E) s->cost_steps = 0;                         // new episodes: what the environments cost before says nothing about them
     if (n == g.E) {
         // everything is rewritten, nothing to convert: into the blocked plane if the resident launch is what steps this handle
         // (it did last, or nothing has stepped yet and it is the automatic choice), else into the row-major planes
@@ -969,7 +990,8 @@ static int alloc_bl(sf_sim *s)
 static bool prefers_bl(const sf_sim *s)
 {
     const Geo &g = s->g;
-    return g.ab == 1 && !s->generic && g.VW == 1 && !s->graph_on && !s->history && (s->fused_mode < 0 || s->fused_mode == 2);
+    return g.ab == 1 && !s->generic && (g.VW == 1 || (g.VW == 2 && s->tune.v[SF_TUNE_RUN_TEAM] != 1)) && !s->graph_on && !s->history &&
+           (s->fused_mode < 0 || s->fused_mode == 2);
 }
 static int ensure_bl(sf_sim *s)
 {
@@ -1041,6 +1063,79 @@ static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, in
     return SF_OK;
 }
 
+// Geometry of a team launch (k_run<TEAM>, sf_run_kernels.h): waves per workgroup, list entries, bitmap rows a member keeps in LDS
+// (0 = all), dynamic LDS, workgroup slots the chip holds at once, smallest team an environment needs.
+struct TeamGeo { int waves, vcap, rcap, slots, t_min; size_t lds; bool ok; };
+static TeamGeo team_geometry(const sf_sim *s)
+{
+    const Geo &g = s->g;
+    TeamGeo t = {};
+    const int th = g.LR * g.RB;
+    if (g.ab != 1 || g.VW > 2 || g.TY > 64 || g.E > 1024 || g.dense) return t;       // (k_team_plan: one thread per environment; the split: one lane per tile row)
+    if (g.VW == 1) {
+        // rows of one word: every member keeps the whole grid's bitmaps; 8 waves, two workgroups per CU
+        t.waves = 8; t.vcap = 1024; t.rcap = 0; t.t_min = 1;
+        if ((g.H + t.waves * 64 - 1) / (t.waves * 64) * g.VW > 2) return t;       // (k_run<TEAM> is instantiated for 1 and 2 bitmap words per thread)
+    } else {
+        // rows of two words (2048-wide grids): a member keeps a window of rows; 16 waves, one workgroup per CU
+        t.waves = 16; t.vcap = 2048; t.rcap = 1024 / th * th; t.t_min = (g.H + t.rcap - 1) / t.rcap;
+        if (t.rcap < th || (t.rcap + t.waves * 64 - 1) / (t.waves * 64) * g.VW > 2) return t;
+    }
+    long long all_vec = (long long)g.H * g.PV;
+    if (t.vcap > all_vec) t.vcap = (int)((all_vec + 63) / 64 * 64);
+    t.lds = run_lds_bytes(g, t.waves, t.vcap, 1, t.rcap);
+    if (t.lds > 160 * 1024 || t.t_min > kTeamMax || t.t_min > g.TY) return t;
+    int per_cu = (int)((160 * 1024) / t.lds);
+    if (per_cu * t.waves > 32) per_cu = 32 / t.waves;
+    if (per_cu > 2) per_cu = 2;
+    t.slots = s->n_cu * per_cu;
+    t.ok = (long long)g.E * t.t_min <= t.slots;
+    return t;
+}
+
+static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo &t, int t_min, int t_max, int steps_before)
+{
+    const Geo &g = s->g;
+    if (!s->team_tab || s->team_slots < t.slots) {
+        if (s->team_tab) { HIPCHK(hipFree(s->team_tab)); s->team_tab = nullptr; }
+        { int rc = dev_alloc(s, &s->team_tab, (size_t)t.slots); if (rc) return rc; }
+        s->team_slots = t.slots;
+    }
+    if (!s->xg) {
+        int rc = dev_alloc(s, &s->xg, (size_t)g.E * kTeamMax * 2); if (rc) return rc;
+        rc = dev_alloc(s, &s->xbuf, (size_t)g.E * kTeamMax * 4 * team_xrow(g)); if (rc) return rc;
+        rc = dev_alloc(s, &s->xdone, (size_t)g.E); if (rc) return rc;
+        rc = dev_alloc(s, &s->team_size, (size_t)g.E); if (rc) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->xerr_pinned), sizeof(uint32_t), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->xerr_mapped), s->xerr_pinned, 0));
+        *s->xerr_pinned = 0;
+        HIPCHK(hipMemsetAsync(s->xbuf, 0, (size_t)g.E * kTeamMax * 4 * team_xrow(g), s->stream));
+    }
+    // what a member pays per step for belonging to a team (publish, wait, read: ~4 k clocks), in the unit of the cost array
+    const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 4000 / 16);
+    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, (const uint32_t *)s->run_cost, s->team_tab, s->team_size);
+    HIPCHK(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));      // (the members add their clocks)
+    HIPCHK(hipMemsetAsync(s->xg, 0, (size_t)g.E * kTeamMax * 2 * sizeof(unsigned long long), s->stream));     // epochs restart with every launch
+    HIPCHK(hipMemsetAsync(s->xdone, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
+    a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
+    a.xrow = team_xrow(g); a.team_rcap = t.rcap;
+    a.order = nullptr;
+    typedef void (*run_fn)(StepArgs, int, int, int);
+    // [words per thread 1 / more][attenuation off / on]; diagonal spread and control lines inside the launch are looked up at run time
+    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1, 1>, k_run<1, 1, -1, -1, 1>}, {k_run<2, 0, -1, -1, 1>, k_run<2, 1, -1, -1, 1>}};
+    const int rows = t.rcap ? t.rcap : g.H;
+    const int need = ((rows + t.waves * 64 - 1) / (t.waves * 64)) * g.VW;
+    const int which = need <= 1 ? 0 : 1, ia = g.att ? 1 : 0;
+    const run_fn kern = table[which][ia];
+    size_t &attr = s->attr_run[8 + which * 2 + ia];
+    if (t.lds > 64 * 1024 && t.lds > attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds));
+        attr = t.lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)t.slots), dim3((unsigned)t.waves * 64), t.lds, s->stream, a, n_steps, t.vcap, 64);
+    return SF_OK;
+}
+
 static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev = nullptr, int mit_k = 0)
 {
     if (!s) return fail(SF_EINVAL, "sf_step: null handle");
@@ -1091,6 +1186,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
 #endif
     int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
     size_t fr_lds = 0;
+    TeamGeo tgeo = {};
+    bool team_forced = false, team_wide = false, team_auto = false;
     int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
     size_t fit_lds = 0;
     if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
@@ -1117,7 +1214,15 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // automatic: multi-step calls on grids up to 1024 cells wide (measured on 1024^2, 1 .. 1024 environments: 1.2 - 1.4 x
         // faster than the per-step launches at every batch size; on 2048^2 an environment's fire is too much work for the one
         // CU that owns it and the per-step launches, which spread tiles over the whole chip, win by 1.4 - 2 x)
-        const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && g.VW == 1 && g.E >= envs_knob);
+        // ... which the team launch (k_run<TEAM>: several workgroups per environment, each with the bitmaps of its own band of rows) takes away:
+        // grids of two-word rows run there in the automatic mode too
+        tgeo = team_geometry(s);
+        const int team_knob = tn.v[SF_TUNE_RUN_TEAM];
+        team_forced = tgeo.ok && team_knob >= 2 && team_knob <= kTeamMax && team_knob <= g.TY && team_knob >= tgeo.t_min && (long long)g.E * team_knob <= tgeo.slots;
+        team_wide = tgeo.ok && team_knob != 1 && g.VW == 2 && !mit_dev;
+        const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
+        // (rows of one word: teams from the second 64-step segment of a long call on, sized by what the environments cost in the one before)
+        team_auto = tgeo.ok && team_knob == 0 && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4;
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
         if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
 #ifdef SF_EXPERIMENTAL
@@ -1242,15 +1347,33 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         const int seg_knob = tn.v[SF_TUNE_RUN_SEGMENT];
         const bool balance = seg_knob > 0 && s->g.E > s->n_cu * (run_waves <= 8 ? 2 : 1);       // (with every environment resident from the start there is nothing to order)
         a.cost = s->run_cost;
+        // Teams (k_run<TEAM>): forced by sf_set_tuning; always on grids of two-word rows; on one-word rows in long calls, which are then
+        // cut into segments like above - the first one runs one workgroup per environment and records what every environment costs,
+        // the following ones size the teams from that (k_team_plan) and cut the bands where the fires are by then.
+        const bool team_any = (team_forced || team_wide || team_auto) && bsz == 64;
+        const bool team_segments = team_any && seg_knob > 0 && !balance;
+        s->last_team_max = 0;
         for (int done = 0; done < n_steps;) {
-            const int seg = balance && n_steps - done > seg_knob + seg_knob / 2 ? seg_knob : n_steps - done;
+            int seg = balance && n_steps - done > seg_knob + seg_knob / 2 ? seg_knob : n_steps - done;
+            if (team_segments && n_steps - done > seg_knob + seg_knob / 2) seg = seg_knob;
+            const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
                 hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
                 a.order = s->run_order;
             }
             a.mit = mit_dev ? mit_dev + (size_t)done * s->g.E * mit_k * 3 : nullptr;
             if (res_knob && done + seg == n_steps) { a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink; }
-            { int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_lds, bsz); if (rc0) return rc0; }
+            if (use_team) {
+                const int tk = tn.v[SF_TUNE_RUN_TEAM];
+                const int t_max = team_forced ? tk : (kTeamMax < s->g.TY ? kTeamMax : s->g.TY);
+                int rc0 = launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : tgeo.t_min, t_max, s->cost_steps);
+                if (rc0) return rc0;
+                s->last_team_max = t_max;
+            } else {
+                int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_lds, bsz);
+                if (rc0) return rc0;
+            }
+            s->cost_steps = seg;
             done += seg;
         }
         s->status_fresh = res_knob != 0;
@@ -1290,6 +1413,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     HIPCHK(hipGetLastError());
     if (ms || !s->async) HIPCHK(hipStreamSynchronize(s->stream));
     if (ms) HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    if ((ms || !s->async) && s->xerr_pinned && *s->xerr_pinned)
+        return fail(SF_EHIP, "sf_step: a workgroup of a team launch (k_run<TEAM>) gave up waiting for a team member; the state of this handle is void");
     return SF_OK;
 }
 

@@ -235,6 +235,12 @@ class FireEngine:
         self._chk(self._L.sf_get_run_cost(self._h, _ptr(out)))
         return out
 
+    def team_sizes(self):
+        """Workgroups per environment in the last resident launch (zeros: it was not a team launch)."""
+        out = np.zeros(self.n_envs, dtype=np.uint32)
+        self._chk(self._L.sf_get_team_sizes(self._h, _ptr(out)))
+        return out
+
     def get_tuning(self, name):
         v = C.c_int32()
         self._chk(self._L.sf_get_tuning(self._h, _lib.TUNE[name], C.byref(v)))

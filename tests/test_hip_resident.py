@@ -108,6 +108,147 @@ def test_resident_chunked_random_worlds(seed):
         _same(eng, o, E, tag=(seed, done))
 
 
+# ------------------------------------------------------------------ teams: an environment served by several workgroups
+@pytest.mark.parametrize("T", [2, 3, 4])
+@pytest.mark.parametrize("seed", range(8))
+def test_team_split_random_worlds(seed, T):
+    """k_run<TEAM>: every environment's rows cut into T bands, one workgroup each; the members exchange one row of sprite masks
+    per boundary and step.  Random worlds as above (exact R ties, 4 / 8 connectivity, attenuation, runtime cut-off, fires that
+    die against a barren half = QUIT of one band while the other still burns), control lines anywhere (also on the rows
+    either side of a cut and on burning cells), wholesale fire_map replacement and environment resets between chunks."""
+    rng = np.random.default_rng(9300 + 17 * seed + T)
+    H, W = int(rng.integers(130, 320)), int(rng.integers(64, 300))      # (>= 64 columns: wave tiles of 64 x 32 cells, >= 5 tile rows)
+    E = int(rng.integers(1, 6))
+    md = int(rng.integers(1, 6))
+    att, diag = bool(rng.integers(2)), bool(rng.integers(2))
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=md, pixel_scale=float(rng.choice([5.0, 20.0, 50.0])),
+              update_rate=float(rng.choice([1.0, 0.5, 1.5])),
+              max_time=(None if rng.random() < 0.6 else float(rng.integers(10, 60))),
+              attenuate_line_ros=att, diagonal_spread=diag)
+    R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.1] = 0.0
+    if rng.random() < 0.5:
+        R8[:, H // 2:, :] = 0.0                                  # the lower bands' share of the fire dies
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.set_tuning(run_team=T)
+    done, saw_team = 0, False
+    while done < 110:
+        n = int(rng.integers(2, 25))
+        if rng.random() < 0.6:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(int(rng.integers(1, 30)))]
+            # rows either side of every possible cut (cuts are multiples of the 32-row wave tile)
+            for yc in range(32, H, 32):
+                pts += [(int(rng.integers(E)), int(rng.integers(W)), yc - int(rng.integers(2)), int(rng.integers(3, 6)))]
+            e0 = int(rng.integers(E))
+            burning = np.argwhere(o.fire_map(e0) == 1)
+            if len(burning):
+                y, x = burning[rng.integers(len(burning))]
+                pts += [(e0, int(x), int(y), int(rng.integers(3, 6)))]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        if rng.random() < 0.1:
+            e0 = int(rng.integers(E))
+            new = o.fire_map(e0).copy()
+            new[rng.random((H, W)) < 0.05] = 0
+            eng.load_fire_map(e0, new)
+            o.load_fire_map(e0, new)
+        if rng.random() < 0.1:
+            e0, x, y = int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H))
+            eng.reset_env(e0, x, y)
+            o.reset_env(e0, x, y)
+        eng.step(n)
+        o.step(n)
+        done += n
+        assert eng.last_launch_kind() == 2
+        saw_team |= bool((eng.team_sizes() == T).all())
+        _same(eng, o, E, tag=(seed, T, done))
+    assert saw_team
+
+
+@pytest.mark.parametrize("T", [2, 4])
+@pytest.mark.parametrize("att", [False, True])
+def test_team_split_fire_across_the_cut_with_lines_in_the_launch(T, att):
+    """A fire ignited on a band boundary (row 64 of 128: bands are cut at multiples of the 32-row tile, where the vectors with sprites
+    balance) spreads into both bands from the first step; control lines are applied INSIDE the launch (sf_step_mitigated), many of
+    them on the two rows either side of the cuts, some on burning cells; one step and many steps per call."""
+    rng = np.random.default_rng(4100 + T + att)
+    H, W, E, K = 128, 200, 4, 10
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=att)
+    R8 = rng.choice([3.0, 7.5, 12.0, 30.0, 400.0], size=(8, H, W))
+    inits = [(100, 64), (30, 63), (150, 32), (60, 96)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.set_tuning(run_team=T)
+    for n in (1, 30, 1, 2, 45):
+        blk = np.zeros((n, E, K, 3), dtype=np.int32)
+        blk[..., 0] = rng.integers(0, W, size=(n, E, K))
+        blk[..., 1] = rng.choice([31, 32, 63, 64, 95, 96, 5, 120], size=(n, E, K))
+        blk[..., 2] = rng.integers(3, 6, size=(n, E, K))
+        for s_ in range(n):
+            for e in range(E):
+                burning = np.argwhere(o.fire_map(e) == 1)
+                if len(burning) and s_ == 0:
+                    y, x = burning[rng.integers(len(burning))]
+                    blk[s_, e, 0] = (int(x), int(y), 3)
+            pts = [(e, int(p[0]), int(p[1]), int(p[2])) for e in range(E) for p in blk[s_, e]]
+            o.apply_mitigation(pts)
+            o.step(1)
+        eng.step_mitigated(blk)
+        assert eng.last_launch_kind() == 2 and (eng.team_sizes() == T).all()
+        _same(eng, o, E, tag=(T, att, n))
+
+
+@pytest.mark.parametrize("T", [0, 2, 4])
+def test_team_split_c3_grid(T):
+    """C3's grid (512^2 cut: 16 tile rows), 6 environments x 260 steps.  T = 2 / 4: every environment split into that many bands;
+    T = 0: the automatic rule - the first 64-step segment runs one workgroup per environment and records what each costs, the
+    following segments size the teams from that (k_team_plan) and cut the bands where the fires are by then."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c3(512, 6)
+    kw = w.engine_kwargs()
+    eng = FireEngine(M_f=w.M_f, **kw)
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    eng.set_tuning(run_team=T)
+    for n in (200, 60):
+        eng.step(n)
+        o.step(n, 4)
+        assert eng.last_launch_kind() == 2
+        ts = eng.team_sizes()
+        assert (ts == T).all() if T else (ts >= 1).all() and ts.max() <= 4, ts
+        _same(eng, o, 6, tag=(T, n))
+
+
+def test_team_split_two_word_rows_run_resident():
+    """BASELINE config C4's grid (2048 x 2048: bitmap rows of two words).  One workgroup cannot hold the four bitmaps of such a
+    grid, a team can: every member keeps a window of rows.  The automatic mode therefore picks the team launch (kind 2, >= 2
+    members) - the refined interest rule with the edge-cell terms carried across the word boundary at column 1024."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c4(2048, 3)
+    w.init_xy = np.array([[1020, 1030], [1040, 200], [300, 1900]], dtype=np.int32)      # across the word boundary and the row cut; near the edges
+    kw = w.engine_kwargs()
+    eng = FireEngine(M_f=w.M_f, **kw)
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    for n in (90, 1, 200):
+        eng.step(n)
+        o.step(n, 4)
+        if n > 1:
+            assert eng.last_launch_kind() == 2 and (eng.team_sizes() >= 2).all(), (eng.last_launch_kind(), eng.team_sizes())
+        _same(eng, o, 3, tag=n)
+
+
 def test_resident_hands_over_to_per_step_kernels_and_back():
     """k_run leaves the committed states and the tile activity map exactly as the per-step kernels
     expect them (and takes them over from those): alternate between all four launch structures and
