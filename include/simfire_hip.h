@@ -280,10 +280,14 @@ enum sf_tuning_knob {
     SF_TUNE_FRONT_IC = 12,
     SF_TUNE_FRONT_TAB = 13,
     SF_TUNE_FRONT_DEBUG = 14,
-    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in the resident launch: 0 = automatic (default: teams of 1..4 sized from what the
-                                 * environments cost in the launch before, on long calls; always on grids of more than 1024 columns), 1 = never,
-                                 * 2 / 3 / 4 = every environment split into exactly that many (tests) */
-    SF_TUNE_COUNT = 16
+    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in the resident launch (k_run<TEAM>: bands of rows, one boundary row exchanged per step):
+                                 * 0 = automatic (default): teams on grids of more than 1024 columns, where one workgroup cannot hold an
+                                 * environment's bitmaps; one workgroup per environment otherwise (measured faster);
+                                 * 1 = never; 2 / 3 / 4 = every environment split into exactly that many (tests);
+                                 * -1 = teams of 1..4 sized from what the environments cost in the launch before, on any grid */
+    SF_TUNE_TEAM_PLACEMENT = 16,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
+                                 * 1 = consecutive slots (spread over the XCDs), 2 = as 0 but the hand-off written through as if they were apart (tests) */
+    SF_TUNE_COUNT = 17
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
 /* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:

@@ -110,7 +110,10 @@ struct StepArgs {
     uint32_t *cost;      // k_run only: [E] shader clocks / 16 the environment's workgroup took in this launch (the next launch's order), or null
     // k_run<TEAM> only: an environment served by a TEAM of 1 .. kTeamMax workgroups, each owning a band of rows (sf_run_kernels.h)
     const uint32_t *team_tab;    // [grid] workgroup slot -> env | member << 16 | team size << 24 (kTeamUnused: the slot has nothing to do)
-    unsigned long long *xg;      // [E][kTeamMax][2] granules {step epoch << 32 | predicate bits}: a member's "step s done", by parity of s
+    unsigned long long *xg;      // [E][kTeamMax][3] granules: [0], [1] {step epoch << 32 | predicate bits}: a member's "step s done", by parity of s; [2] {1 << 32 | XCC id}: "I am here"
+    int team_far;                // 1: never take the one-L2 path of the hand-off (tests: the written-through path on every placement)
+    int32_t *todo_out;           // [E] or null: an environment whose rows do not fit the windows of the team it was given is left untouched and
+                                 // its steps are noted here (0 for the others): the host's next launch (two members, half the grid each) does them
     uint8_t *xbuf;               // [E][kTeamMax][2 sides][2 parities][xrow] the member's first / last row as its neighbours need it (sc1 stores / loads only)
     uint32_t *xdone;             // [E] members that have left the launch (the last one counts the environment)
     uint32_t *xerr;              // != 0: a wait for a team member timed out (the launch's results are void)

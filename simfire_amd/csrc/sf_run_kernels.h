@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;
-    if (TEAM && tn > 1) {
+    if (TEAM && (tn > 1 || a.team_rcap)) {
         const int th = g.LR * g.RB, ntr = (g.H + th - 1) / th;        // (the host offers teams only for <= 64 tile rows)
         if (tid < 64) tcnt[tid] = 0;
         __syncthreads();
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 lo = lo < 0 ? 0 : lo; hi = hi > ntr ? ntr : hi;
             }
             const int cap = a.team_rcap ? a.team_rcap / th : ntr;     // tile rows a member can hold
+            if (a.team_rcap && !nzb) hi = ntr < cap * tn ? ntr : cap * tn;        // (no sprite anywhere: the fire is out, any rows will do)
             int cut[kTeamMax + 1];
             cut[0] = lo; cut[tn] = hi;
             for (int j = 1; j < tn; ++j) {
@@ -334,15 +335,40 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 if (cut[j] > cut[j + 1] - 1) cut[j] = cut[j + 1] - 1;
                 if (cut[j] < cut[j + 1] - cap) cut[j] = cut[j + 1] - cap;
             }
-            if (lane == 0) { tcnt[0] = (uint32_t)(cut[tm] * th); tcnt[1] = (uint32_t)(cut[tm + 1] * th); }
+            // do the bands fit?  (a tall fire given a small team: the rows between lo and hi are more than its windows hold)
+            bool fits = true;
+            for (int j = 0; j < tn; ++j) fits = fits && cut[j + 1] - cut[j] >= 1 && cut[j + 1] - cut[j] <= cap;
+            if (lane == 0) { tcnt[0] = (uint32_t)(cut[tm] * th); tcnt[1] = (uint32_t)(cut[tm + 1] * th); tcnt[2] = fits ? 1u : 0u; }
         }
         __syncthreads();
         R0 = (int)tcnt[0]; R1 = (int)tcnt[1];
+        const bool fits = __builtin_amdgcn_readfirstlane((int)tcnt[2]) != 0;
         R0 = __builtin_amdgcn_readfirstlane(R0); R1 = __builtin_amdgcn_readfirstlane(R1);
         if (R1 > g.H) R1 = g.H;
+        if (a.todo_out && tm == 0 && tid == 0) a.todo_out[e] = fits ? 0 : n_steps;
+        if (!fits) return;          // (uniform over the team: every member sees the same bitmap) nothing has been touched
         __syncthreads();
     }
     const bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;           // a neighbour above / below the band
+    // Do all members of the team sit on one XCD (one L2)?  Then the per-step hand-off can stay in that L2: plain stores (the L1 is
+    // write-through), loads that skip the L1 - ~1 us instead of the ~4 - 5 us of a written-through hand-off between busy CUs.  This is
+    // found out at run time from the hardware's XCC id, never assumed from the slot number: either path is correct wherever the
+    // members sit.  (Third granule of every member: {1, XCC id}; also the team's start line.)
+    bool one_l2 = false;
+    if (TEAM && tn > 1 && wave == 0) {
+        typedef unsigned long long u64;
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u;      // HW_REG_XCC_ID
+        if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, (1ull << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 x = 1ull << 32 | xcc;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        for (;;) {
+            if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((uint32_t)(x >> 32) == 1u)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_readcyclecounter() - t0 > (1ull << 29)) break;        // (the first step boundary reports a member that never shows up)
+        }
+        one_l2 = __all((uint32_t)(x >> 32) == 1u && ((uint32_t)x & 15u) == xcc) && !a.team_far;
+    }
     // The bitmaps are indexed by the grid row: with a window of rows in LDS the base pointers are shifted so that row y sits where it is.
     const int yoff = TEAM && a.team_rcap ? R0 - 1 : 0;
     unsigned long long *vb = vb0 - (long long)yoff * VW;
@@ -404,6 +430,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     if (mit_one_wave && n_steps > 0) load_pt(0);
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
     bool gave_up = false;        // TEAM: a wait for the other members timed out (the handle is void; never wait again)
+    unsigned long long x_clocks = 0, x_steps = 0;      // TEAM statistics: clocks wave 0 spent at the team's step boundaries (publish + wait + read), boundaries
     for (int s = 0; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
         if (mit) {
@@ -840,6 +867,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             // neighbours' rows into the LDS halo (wave 0; the other waves wait at the barrier below)
             if (wave == 0) {
                 typedef unsigned long long u64;
+                const unsigned long long xt0 = a.counters ? __builtin_readcyclecounter() : 0ull;
                 const uint32_t epoch = (uint32_t)s + 1u, par = (uint32_t)s & 1u;
                 uint8_t *xb_me = a.xbuf + ((size_t)(e * kTeamMax + tm) * 4) * (size_t)a.xrow;      // [side][parity][xrow]
                 for (int side = 0; side < 2; ++side) {
@@ -849,25 +877,31 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     for (int v = lane; v < g.PV; v += 64)
                         if ((vb[yb * VW + (v >> 6)] >> (v & 63)) & 1ull) {       // (vectors without a sprite bit are zero: the reader knows from the bitmap word)
                             const uint4 val = *reinterpret_cast<const uint4 *>(ev.cells + bl_vec(g, yb, v) + (yb & 1) * 16);
-                            __hip_atomic_store(dst + 8 + v * 2, (u64)val.x | ((u64)val.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(dst + 8 + v * 2 + 1, (u64)val.z | ((u64)val.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (one_l2) *reinterpret_cast<uint4 *>(dst + 8 + v * 2) = val;        // (stays in the XCD's L2)
+                            else {                                                               // (written through: sc1)
+                                __hip_atomic_store(dst + 8 + v * 2, (u64)val.x | ((u64)val.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(dst + 8 + v * 2 + 1, (u64)val.z | ((u64)val.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     if (lane < 3 * VW) {
                         const int which = lane / VW, w = lane - which * VW;
                         const u64 word = (which == 0 ? vb : (which == 1 ? vf : vl))[yb * VW + w];
-                        __hip_atomic_store(dst + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (one_l2) __hip_atomic_store(dst + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else __hip_atomic_store(dst + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are written through (sc1) and acknowledged ...
-                if (lane == 0)                                          // ... before the one tagged word that says so
-                    __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 2 + par, ((u64)epoch << 32) | (u64)(ctl[3 + k] & 0xFFFFu), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are acknowledged (by the L2 / written through) ...
+                if (lane == 0) {                                        // ... before the one tagged word that says so
+                    const u64 gv = ((u64)epoch << 32) | (u64)(ctl[3 + k] & 0xFFFFu);
+                    if (one_l2) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + par, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + par, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 // every member's granule of this step (a member can be one step ahead at most: two granules by parity)
                 u64 x = (u64)epoch << 32;
                 {
                     const unsigned long long t0 = __builtin_readcyclecounter();
                     for (;;) {
-                        if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 2 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (skips the L1)
                         if (__all((uint32_t)(x >> 32) == epoch)) break;
                         __builtin_amdgcn_s_sleep(1);
                         if (gave_up || __builtin_readcyclecounter() - t0 > (1ull << 29)) {       // (bounded, ~0.25 s: a lost member must not hang the GPU)
@@ -905,6 +939,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                         (which == 0 ? vb : (which == 1 ? vf : vl))[yh * VW + w] = word;
                     }
                 }
+                if (a.counters && lane == 0) { x_clocks += __builtin_readcyclecounter() - xt0; x_steps++; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");       // (what the others read next is all in LDS)
             __builtin_amdgcn_s_barrier();
@@ -959,6 +994,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
         if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
         if (n_vec_done) atomicAdd(&cs[5], (unsigned long long)n_vec_done);   // 16-cell vectors visited
+        if (TEAM && x_steps) {     // (the two slots k_front uses for its records / sprite events)
+            atomicAdd(&cs[6], x_steps | ((unsigned long long)(one_l2 ? x_steps : 0ull) << 32));      // team step boundaries | those through one L2 << 32
+            atomicAdd(&cs[7], x_clocks);
+        }
     }
     // The result block row of this environment (sf_get_status), produced by its own workgroup now that its steps are done: the
     // status query after a rollout then costs no launch.  LDS: the strip buffers (>= 5376 bytes), free by now.
@@ -1027,7 +1066,7 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
 // runs on XCD b mod 8 (observed; speed only), so the members of a team get slots of one residue class - their per-step exchange
 // then stays in one L2 - unless a class is full, in which case the teams simply take consecutive slots (placement never matters
 // for results).  t_min / t_max bound the sizes (forced teams: t_min = t_max; rows too wide for one member: t_min = 2).
-__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, const uint32_t *cost, uint32_t *tab, uint32_t *tsize)
+__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, int scatter, const uint32_t *cost, uint32_t *tab, uint32_t *tsize)
 {
     __shared__ uint32_t s_T[1024], s_sum, s_cls[8], s_over;
     const int t = threadIdx.x;
@@ -1067,7 +1106,7 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
     s_T[t] = T;
     if (t < E && tsize) tsize[t] = T;
     if (t < 8) s_cls[t] = 0;
-    if (t == 0) s_over = 0;
+    if (t == 0) s_over = scatter ? 1u : 0u;          // (scatter: consecutive slots = a team spread over the XCDs; tests)
     __syncthreads();
     if (t < E) atomicAdd(&s_cls[t & 7], T);
     __syncthreads();

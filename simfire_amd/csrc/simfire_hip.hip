@@ -108,11 +108,11 @@ struct Tuning {
 static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
     /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
-    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0};
+    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0};
 static const char *const kTuneName[SF_TUNE_COUNT] = {
     "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
     "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
-    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM"};
+    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -1093,7 +1093,8 @@ static TeamGeo team_geometry(const sf_sim *s)
     return t;
 }
 
-static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo &t, int t_min, int t_max, int steps_before)
+// keep_cost: the launch neither reads nor records what the environments cost (the catch-up launch behind a windowed one)
+static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo &t, int t_min, int t_max, int steps_before, bool keep_cost = false)
 {
     const Geo &g = s->g;
     if (!s->team_tab || s->team_slots < t.slots) {
@@ -1102,7 +1103,7 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
         s->team_slots = t.slots;
     }
     if (!s->xg) {
-        int rc = dev_alloc(s, &s->xg, (size_t)g.E * kTeamMax * 2); if (rc) return rc;
+        int rc = dev_alloc(s, &s->xg, (size_t)g.E * kTeamMax * 3); if (rc) return rc;
         rc = dev_alloc(s, &s->xbuf, (size_t)g.E * kTeamMax * 4 * team_xrow(g)); if (rc) return rc;
         rc = dev_alloc(s, &s->xdone, (size_t)g.E); if (rc) return rc;
         rc = dev_alloc(s, &s->team_size, (size_t)g.E); if (rc) return rc;
@@ -1111,14 +1112,20 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
         *s->xerr_pinned = 0;
         HIPCHK(hipMemsetAsync(s->xbuf, 0, (size_t)g.E * kTeamMax * 4 * team_xrow(g), s->stream));
     }
-    // what a member pays per step for belonging to a team (publish, wait, read: ~4 k clocks), in the unit of the cost array
-    const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 4000 / 16);
-    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, (const uint32_t *)s->run_cost, s->team_tab, s->team_size);
-    HIPCHK(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));      // (the members add their clocks)
-    HIPCHK(hipMemsetAsync(s->xg, 0, (size_t)g.E * kTeamMax * 2 * sizeof(unsigned long long), s->stream));     // epochs restart with every launch
+    // what a member pays per step for belonging to a team (publish, wait for the slowest member, read: ~7 k clocks measured), in the unit of the cost array
+    const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 7000 / 16);
+    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0,
+                       (const uint32_t *)s->run_cost, s->team_tab, s->team_size);
+    if (!keep_cost) HIPCHK(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));      // (the members add their clocks)
+    a.cost = keep_cost ? nullptr : s->run_cost;
+    HIPCHK(hipMemsetAsync(s->xg, 0, (size_t)g.E * kTeamMax * 3 * sizeof(unsigned long long), s->stream));     // epochs restart with every launch
     HIPCHK(hipMemsetAsync(s->xdone, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
     a.xrow = team_xrow(g); a.team_rcap = t.rcap;
+    // placement of the members: 0 (default) = the slots of one XCD, 1 = consecutive slots (eight XCDs in turn), 2 = as 0 but the
+    // hand-off written through as if they were apart - results never depend on it (tests run all three)
+    const int place = s->tune.v[SF_TUNE_TEAM_PLACEMENT];
+    a.team_far = place == 2;
     a.order = nullptr;
     typedef void (*run_fn)(StepArgs, int, int, int);
     // [words per thread 1 / more][attenuation off / on]; diagonal spread and control lines inside the launch are looked up at run time
@@ -1219,10 +1226,13 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         tgeo = team_geometry(s);
         const int team_knob = tn.v[SF_TUNE_RUN_TEAM];
         team_forced = tgeo.ok && team_knob >= 2 && team_knob <= kTeamMax && team_knob <= g.TY && team_knob >= tgeo.t_min && (long long)g.E * team_knob <= tgeo.slots;
-        team_wide = tgeo.ok && team_knob != 1 && g.VW == 2 && !mit_dev;
+        team_wide = tgeo.ok && team_knob != 1 && g.VW == 2 && !mit_dev;      // (control lines inside the launch: every row needs an owner, a window of rows leaves some without)
         const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
-        // (rows of one word: teams from the second 64-step segment of a long call on, sized by what the environments cost in the one before)
-        team_auto = tgeo.ok && team_knob == 0 && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4;
+        // Rows of one word: NOT automatic.  Measured on C3 / C5 (profiles/r03_team/): a member's step is a latency chain that does not get
+        // shorter with half the rows, and a team's step boundary costs 5 - 10 k clocks (publish, wait for the slowest member, read), so
+        // teams of 8-wave members lose to one 16-wave workgroup per environment until a fire is far larger than these get (C3: 11.0 ->
+        // 15.0 us per step with teams sized by cost).  sf_set_tuning(SF_TUNE_RUN_TEAM, -1) turns the cost-sized teams on.
+        team_auto = tgeo.ok && team_knob == -1 && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4;
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
         if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
 #ifdef SF_EXPERIMENTAL
@@ -1253,7 +1263,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     (void)runt_lds; (void)fr_rc; (void)fr_ic; (void)fr_tab; (void)fr_lds; (void)fit_waves; (void)fit_vcap; (void)fit_lds; (void)kFrontStartCap;
 #endif
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
-    a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr;
+    a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr; a.todo_out = nullptr;
     if (run_waves || fr_waves) {
         int rc0 = ensure_commit(s);            // k_run / k_front start from commit[] and leave the new states there
         if (rc0) return rc0;
@@ -1366,8 +1376,23 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             if (use_team) {
                 const int tk = tn.v[SF_TUNE_RUN_TEAM];
                 const int t_max = team_forced ? tk : (kTeamMax < s->g.TY ? kTeamMax : s->g.TY);
-                int rc0 = launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : tgeo.t_min, t_max, s->cost_steps);
+                // Windows of rows (two-word rows): a fire that is small enough runs in ONE workgroup with the window around it, the largest ones
+                // get up to four; whoever was given too small a team for its fire (known only on the device) is left untouched, noted in
+                // todo[] and done by the second launch - two members, half the grid each, which always fits.
+                // (Only with SF_TUNE_RUN_TEAM = -1: measured on C4's share, 128 x 2048^2, the cost-sized teams lose to two members for every
+                // environment - 55 against 37 us per step around step 1000 - because teams of different sizes do not pack into the slots of one
+                // XCD and their step boundaries then go through memory, 16 k instead of 12 k clocks each.)
+                const bool windows = tgeo.rcap > 0 && !team_forced && tk == -1;
+                a.todo = nullptr; a.todo_out = windows ? s->todo : nullptr;
+                int rc0 = launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : (windows ? 1 : tgeo.t_min), t_max, s->cost_steps);
                 if (rc0) return rc0;
+                if (windows) {
+                    a.todo = s->todo; a.todo_out = nullptr;
+                    rc0 = launch_k_run_team(s, a, seg, tgeo, tgeo.t_min, tgeo.t_min, 0, true);
+                    if (rc0) return rc0;
+                    a.todo = nullptr;
+                }
+                a.cost = s->run_cost;
                 s->last_team_max = t_max;
             } else {
                 int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_lds, bsz);

@@ -132,7 +132,8 @@ def test_team_split_random_worlds(seed, T):
     inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
     eng, o = _pair(kw, R8, inits)
     eng.set_fused(2)
-    eng.set_tuning(run_team=T)
+    # members on one XCD (hand-off through its L2) / spread over the XCDs / on one XCD but written through: same results
+    eng.set_tuning(run_team=T, team_placement=(seed + T) % 3)
     done, saw_team = 0, False
     while done < 110:
         n = int(rng.integers(2, 25))
@@ -170,7 +171,8 @@ def test_team_split_random_worlds(seed, T):
 
 @pytest.mark.parametrize("T", [2, 4])
 @pytest.mark.parametrize("att", [False, True])
-def test_team_split_fire_across_the_cut_with_lines_in_the_launch(T, att):
+@pytest.mark.parametrize("place", [0, 1, 2])
+def test_team_split_fire_across_the_cut_with_lines_in_the_launch(T, att, place):
     """A fire ignited on a band boundary (row 64 of 128: bands are cut at multiples of the 32-row tile, where the vectors with sprites
     balance) spreads into both bands from the first step; control lines are applied INSIDE the launch (sf_step_mitigated), many of
     them on the two rows either side of the cuts, some on burning cells; one step and many steps per call."""
@@ -181,7 +183,7 @@ def test_team_split_fire_across_the_cut_with_lines_in_the_launch(T, att):
     inits = [(100, 64), (30, 63), (150, 32), (60, 96)]
     eng, o = _pair(kw, R8, inits)
     eng.set_fused(2)
-    eng.set_tuning(run_team=T)
+    eng.set_tuning(run_team=T, team_placement=place)
     for n in (1, 30, 1, 2, 45):
         blk = np.zeros((n, E, K, 3), dtype=np.int32)
         blk[..., 0] = rng.integers(0, W, size=(n, E, K))
@@ -201,10 +203,10 @@ def test_team_split_fire_across_the_cut_with_lines_in_the_launch(T, att):
         _same(eng, o, E, tag=(T, att, n))
 
 
-@pytest.mark.parametrize("T", [0, 2, 4])
-def test_team_split_c3_grid(T):
+@pytest.mark.parametrize("T,place", [(-1, 0), (2, 0), (4, 0), (-1, 1), (3, 1), (4, 2)])
+def test_team_split_c3_grid(T, place):
     """C3's grid (512^2 cut: 16 tile rows), 6 environments x 260 steps.  T = 2 / 4: every environment split into that many bands;
-    T = 0: the automatic rule - the first 64-step segment runs one workgroup per environment and records what each costs, the
+    T = -1: teams sized by cost - the first 64-step segment runs one workgroup per environment and records what each costs, the
     following segments size the teams from that (k_team_plan) and cut the bands where the fires are by then."""
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
@@ -216,13 +218,13 @@ def test_team_split_c3_grid(T):
     o.set_rtable(eng.get_rtable())
     eng.reset(w.init_xy)
     o.reset(w.init_xy)
-    eng.set_tuning(run_team=T)
+    eng.set_tuning(run_team=T, team_placement=place)
     for n in (200, 60):
         eng.step(n)
         o.step(n, 4)
         assert eng.last_launch_kind() == 2
         ts = eng.team_sizes()
-        assert (ts == T).all() if T else (ts >= 1).all() and ts.max() <= 4, ts
+        assert (ts == T).all() if T > 0 else (ts >= 1).all() and ts.max() <= 4, ts
         _same(eng, o, 6, tag=(T, n))
 
 
@@ -247,6 +249,14 @@ def test_team_split_two_word_rows_run_resident():
         if n > 1:
             assert eng.last_launch_kind() == 2 and (eng.team_sizes() >= 2).all(), (eng.last_launch_kind(), eng.team_sizes())
         _same(eng, o, 3, tag=n)
+    # teams sized by cost (SF_TUNE_RUN_TEAM = -1): a small fire runs in ONE workgroup with a window of rows around it; an
+    # environment given too small a team for its fire is left to the catch-up launch (two members, half the grid each)
+    eng.set_tuning(run_team=-1)
+    for n in (70, 150):
+        eng.step(n)
+        o.step(n, 4)
+        assert eng.last_launch_kind() == 2
+        _same(eng, o, 3, tag=("cost-sized", n))
 
 
 def test_resident_hands_over_to_per_step_kernels_and_back():
