@@ -19,6 +19,15 @@ from typing import Dict
 import numpy as np
 
 
+def validate(data_type: str) -> None:
+    """Raise what ``write_history`` would raise for this ``data_type`` - BEFORE anything is stepped (``FireSimulation.run``
+    calls it first: a bad ``data_type`` or a missing h5py must not leave host and device state apart)."""
+    if data_type not in ("npy", "h5", "json", "jsonl"):
+        raise ValueError(f"Invalid data type '{data_type}' given. Valid types are 'npy', 'h5', 'json', and 'jsonl'.")
+    if data_type == "h5":
+        import h5py  # noqa: F401  (the reference's own dependency for this format)
+
+
 def write_history(datapath: Path, data_type: str, new_maps: np.ndarray, elapsed_steps_before: int,
                   static: Dict[str, np.ndarray], metadata: dict) -> None:
     """``new_maps``: [n, H, W], the fire maps after updates ``elapsed_steps_before + 1 ... + n``; ``static``: the
@@ -73,4 +82,4 @@ def write_history(datapath: Path, data_type: str, new_maps: np.ndarray, elapsed_
         np.save(path, new_maps.astype(np.int8))
     else:
         with h5py.File(path, "w") as f:
-            f.create_dataset("data", data=new_maps)
+            f.create_dataset("data", data=np.asarray(new_maps, dtype=np.int64))       # (the reference stores its int64 fire_map unchanged, simulation.py:951-953)

@@ -75,6 +75,19 @@ _SHARED_FIELDS = (("area", "screen_size"), ("area", "pixel_scale"), ("fire", "ma
                   ("mitigation", "ros_attenuation"), ("environment", "moisture"))
 
 
+def _fingerprint(a) -> int:
+    """Content fingerprint of a layer for ``FireSimulation.reset``'s "did anything change" test."""
+    import zlib
+    if a is None:
+        return 0
+    a = np.asarray(a)
+    if a.dtype != object:
+        return zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 4096)
+    return hash(tuple((f.w_0, f.delta, f.M_x, f.sigma) for f in flat[::step]))
+
+
 class FireSimulation:
     def __init__(self, config: Config, device: int = 0) -> None:
         self.config = config
@@ -91,9 +104,13 @@ class FireSimulation:
         cfg = self.config
         # The device handle (layers in HBM, R table) is rebuilt only if something it was built from changed:
         # an RL harness that calls reset() per episode with a new ignition pays one sf_reset, not k_rtable again.
+        # "Changed" = another object OR other contents: numeric planes are fingerprinted in full (crc32, a few ms at 1024^2), so an
+        # in-place edit such as ``config.wind.speed[...] = x`` rebuilds the handle like the reference's reset() rebuilds its
+        # terrain and fire manager (simulation.py:202-214); an object array of ``Fuel`` by a strided sample of its elements -
+        # after editing single elements of such an array in place call ``invalidate_layers()``.
         key_objs = (cfg.terrain.fuel_layer.data, cfg.terrain.topography_layer.data, cfg.wind.speed, cfg.wind.direction,
                     getattr(cfg, "fuel_codes", None))
-        key_vals = tuple(getattr(getattr(cfg, a), b) for a, b in _SHARED_FIELDS)
+        key_vals = tuple(getattr(getattr(cfg, a), b) for a, b in _SHARED_FIELDS) + tuple(_fingerprint(o) for o in key_objs)
         prev = getattr(self, "_engine_key", None)
         if (prev is None or len(prev[0]) != len(key_objs) or any(a is not b for a, b in zip(prev[0], key_objs))
                 or prev[1] != key_vals):
@@ -120,6 +137,11 @@ class FireSimulation:
         self.elapsed_time = 0.0
         self.fire_status = GameStatus.RUNNING
         self.active = True
+
+    def invalidate_layers(self) -> None:
+        """Forget the device copy of the layers: the next ``reset()`` rebuilds the handle (layers, slopes, R table) from the
+        config whatever the change test says."""
+        self._engine_key = None
 
     @property
     def fire_manager(self):
@@ -150,6 +172,8 @@ class FireSimulation:
         if self.fire_status == GameStatus.RUNNING and total > 0:
             before = int(self._engine.status()[0][0, 1])
             if self.config.simulation.save_data:
+                from .savedata import validate
+                validate(self.config.simulation.data_type)      # (raises before the device is stepped)
                 self._run_saving(before, total)
             else:
                 self._engine.step(total)
@@ -421,7 +445,23 @@ class BatchedFireSimulation:
         """``for s in range(n): update_mitigation(points[s]); run(1)`` for every environment as one device call
         (``sf_step_mitigated``): ``points`` int32 [n, n_envs, k, 3] = (column, row, type) per step, environment and
         agent - NumPy or a torch CUDA tensor; entries with a type outside FIRELINE / SCRATCHLINE / WETLINE are padding.
-        Returns (fire maps or None, active [n_envs]) like ``run``."""
+        Returns (fire maps or None, active [n_envs]) like ``run``.
+
+        Coordinates: a host array is treated like ``update_mitigation`` treats its rows - negative column / row count from
+        the end (the NumPy indexing of mitigation.py:75-78), anything further out raises IndexError - so that the rollout
+        equals the ``update_mitigation`` + ``run(1)`` loop for every input.  A CUDA tensor is not read on the host: its
+        entries outside [0, W) x [0, H) are dropped by the kernel, like padding."""
+        if isinstance(points, np.ndarray) or not hasattr(points, "data_ptr"):
+            q = np.array(points, dtype=np.int64)
+            if q.ndim == 4 and q.shape[-1] == 3 and q.size:
+                H, W = self.config.area.screen_size
+                real = (q[..., 2] >= int(BurnStatus.FIRELINE)) & (q[..., 2] <= int(BurnStatus.WETLINE))
+                bad = real & ((q[..., 0] < -W) | (q[..., 0] >= W) | (q[..., 1] < -H) | (q[..., 1] >= H))
+                if bad.any():
+                    raise IndexError(f"mitigation point out of bounds for a {H}x{W} fire_map")
+                q[..., 0] = np.where(real, q[..., 0] % W, q[..., 0])
+                q[..., 1] = np.where(real, q[..., 1] % H, q[..., 1])
+                points = q.astype(np.int32)
         self._engine.step_mitigated(points)
         st, _ = self._engine.status()
         return (self._engine.fire_maps() if return_maps else None), st[:, 0].astype(bool)
@@ -434,9 +474,17 @@ class BatchedFireSimulation:
         return self._engine.fire_map(env)
 
     def fire_maps_device(self):
-        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no host copy).  Call it again after
-        stepping: the plane is refreshed by the call and is a read-only snapshot until the next one."""
+        """torch uint8 [n_envs, H, W] view of the fire maps in GPU memory (no host copy).  A SNAPSHOT: the resident
+        launch keeps the cells in its own blocked plane, and this call converts them into the row-major plane the tensor
+        points at (one sweep over all environments) - the address is the same every time, the contents are those of the
+        last call.  A harness that keeps the tensor across ``run()`` calls must call this (or ``refresh_fire_maps_device``)
+        again before it reads."""
         return self._engine.fire_maps_torch()
+
+    def refresh_fire_maps_device(self) -> None:
+        """Bring the plane behind ``fire_maps_device()``'s tensor up to date (the same tensor then shows the current maps)."""
+        self._engine.fire_map_device()
+        self._engine.sync()
 
     def gather_results(self):
         """All ranks' result blocks (torch int32 [n_envs_total, 8]) - one all-gather over the

@@ -141,8 +141,10 @@ _GRAD2 = np.array([[1, 1], [-1, 1], [1, -1], [-1, -1], [1, 0], [-1, 0], [1, 0], 
 
 
 def simplex2(x, y, base=0):
-    """2-D simplex noise (Perlin 2001 / Gustavson 2005) on arrays, in [-1, 1]; ``base`` offsets the permutation
-    lookups like the ``base`` argument of ``noise.snoise2``."""
+    """2-D simplex noise (Perlin 2001 / Gustavson 2005) on arrays, in [-1, 1].  ``base`` offsets the permutation
+    INDICES (another field for another seed); note that ``noise.snoise2`` adds its ``base`` to the input coordinates
+    instead, which is not the same on the skewed lattice: the C4 wind fields are this build's own (an input, fed
+    identically to the oracle), not the reference generator's values."""
     F2, G2 = 0.5 * (np.sqrt(3.0) - 1.0), (3.0 - np.sqrt(3.0)) / 6.0
     s = (x + y) * F2
     i, j = np.floor(x + s), np.floor(y + s)

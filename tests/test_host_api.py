@@ -378,3 +378,102 @@ def test_save_data_other_formats(tmp_path, data_type):
     sim.config.simulation.data_type = "csv"
     with pytest.raises(ValueError):
         sim.run(1)
+
+
+@pytest.mark.parametrize("extra", ["plain", "history", "graph"])
+def test_reset_reuses_the_handle_only_while_nothing_changed(extra, tmp_path):
+    """FireSimulation.reset() keeps the device handle (layers, slopes, R table) while the config's layers and shared scalars are
+    unchanged - by identity AND by content: run, reset, run again == a fresh simulation (also with save_data / the spread graph
+    on); an in-place edit of the wind field is noticed and rebuilds the handle like the reference's reset() rebuilds its
+    terrain and fire manager (simulation.py:202-214)."""
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    y = yaml.safe_load(open(os.path.join(CFG, "functional_config.yml")))
+    y["area"]["screen_size"] = [48, 64]
+    y["terrain"]["topography"]["functional"]["function"] = "gaussian"
+    y["simulation"]["headless"] = True
+    y["simulation"]["sf_home"] = str(tmp_path)
+    if extra == "history":
+        y["simulation"]["save_data"] = True
+    if extra == "graph":
+        y["simulation"]["draw_spread_graph"] = True
+
+    def fresh():
+        return FireSimulation(Config(config_dict=yaml.safe_load(yaml.safe_dump(y))))
+
+    sim = fresh()
+    sim.run(12)
+    eng = sim._engine
+    sim.reset()
+    assert sim._engine is eng                                  # nothing changed: the handle is kept
+    m1, _ = sim.run(20)
+    ref = fresh()
+    m2, _ = ref.run(20)
+    assert (m1 == m2).all() and sim.elapsed_steps == ref.elapsed_steps == 20 and sim.elapsed_time == ref.elapsed_time
+    assert (sim._engine.burn(0) == ref._engine.burn(0)).all()
+    if extra == "graph":
+        assert sorted(sim.spread_graph_edges()) == sorted(ref.spread_graph_edges())
+    # an in-place edit of a layer: same object, other contents
+    sim.config.wind.speed[...] = sim.config.wind.speed * 3.0 + 88.0
+    sim.reset()
+    assert sim._engine is not eng                              # rebuilt
+    y2 = yaml.safe_load(yaml.safe_dump(y))
+    ref2 = FireSimulation(Config(config_dict=y2))
+    ref2.config.wind.speed[...] = sim.config.wind.speed
+    ref2.invalidate_layers()
+    ref2.reset()
+    a, _ = sim.run(15)
+    b, _ = ref2.run(15)
+    assert (a == b).all() and not (a == m1).all()
+
+
+def test_save_data_bad_type_raises_before_anything_is_stepped(tmp_path):
+    """An invalid data_type raises the reference's ValueError (simulation.py:958-962) - and before the device is stepped: host
+    and device state stay together."""
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import FireSimulation
+    y = yaml.safe_load(open(os.path.join(CFG, "functional_config.yml")))
+    y["area"]["screen_size"] = [32, 32]
+    y["terrain"]["topography"]["functional"]["function"] = "flat"
+    y["simulation"]["headless"] = True
+    y["simulation"]["save_data"] = True
+    y["simulation"]["sf_home"] = str(tmp_path)
+    sim = FireSimulation(Config(config_dict=y))
+    sim.config.simulation.data_type = "parquet"
+    with pytest.raises(ValueError):
+        sim.run(3)
+    assert sim.elapsed_steps == 0 and int(sim._engine.status()[0][0, 1]) == 0
+    sim.config.simulation.data_type = "npy"
+    sim.run(3)
+    assert sim.elapsed_steps == 3
+
+
+def test_batched_rollout_treats_coordinates_like_update_mitigation():
+    """BatchedFireSimulation.rollout(points) == the update_mitigation + run(1) loop also for negative coordinates (NumPy-style,
+    mitigation.py:75-78); anything further out raises IndexError in both."""
+    import yaml
+    from simfire_amd.config import Config
+    from simfire_amd.simulation import BatchedFireSimulation
+    y = yaml.safe_load(open(os.path.join(CFG, "test_config_flat_simple.yml")))
+    y["area"]["screen_size"] = [40, 56]
+    rng = np.random.default_rng(3)
+    E, K, n = 3, 5, 7
+    pts = np.zeros((n, E, K, 3), dtype=np.int32)
+    pts[..., 0] = rng.integers(-56, 56, size=(n, E, K))
+    pts[..., 1] = rng.integers(-40, 40, size=(n, E, K))
+    pts[..., 2] = rng.integers(2, 7, size=(n, E, K))            # 2 and 6: padding
+    a = BatchedFireSimulation(Config(config_dict=y), E)
+    b = BatchedFireSimulation(Config(config_dict=y), E)
+    a.rollout(pts)
+    for s in range(n):
+        rows = [(e, int(p[0]), int(p[1]), int(p[2])) for e in range(E) for p in pts[s, e] if 3 <= p[2] <= 5]
+        b.update_mitigation(rows)
+        b.run(1, return_maps=False)
+    assert (a._engine.fire_maps() == b._engine.fire_maps()).all()
+    sa, sb = a.results(), b.results()
+    assert (sa[0] == sb[0]).all() and (sa[1] == sb[1]).all()
+    pts[0, 0, 0] = (56, 0, 3)
+    with pytest.raises(IndexError):
+        a.rollout(pts)
