@@ -313,6 +313,20 @@ int sf_set_prune_after_quit(sf_sim *sim, int32_t on);
  * environment's points are applied inside the kernel right before that environment's update; otherwise the call enqueues
  * n_steps scatter + step pairs.  ms_out (may be null): GPU milliseconds of the call. */
 int sf_step_mitigated(sf_sim *sim, int32_t n_steps, const int32_t *pts, int32_t k, int32_t device_pointer, float *ms_out);
+/* The closed loop of an RL harness - FireSimulation.update_mitigation(actions that depend on the last observation) followed
+ * by run(1), simulation.py:449-478 and 501-553 - without a launch per step.  sf_loop_start leaves the environment-resident
+ * launch on the GPU (one workgroup per environment, so: grids up to 1024 x 1024, no more environments than CUs); sf_loop_step
+ * posts one step's points (int32 [n_envs][k][3] = column, row, type; k <= 64 as given to sf_loop_start; a type outside 3..5 is
+ * padding; null = none) into host-mapped memory, rings a doorbell, waits until every environment has made
+ * `update_mitigation(points); run(1)` and returns the result block of sf_get_status (either pointer may be null).
+ * sf_loop_stop - or any other call on the handle - ends the loop: the workgroups commit their environments and leave.  A launch
+ * that hears nothing for ~0.2 s leaves by itself (a host that went away cannot hang the GPU); the next sf_loop_step starts it
+ * again, every environment resumes from the last step IT finished (sf_loop_restarts counts these).  While the loop is on the
+ * GPU's CUs are taken: a policy network on the SAME GPU cannot run beside it (use sf_apply_mitigation_device + sf_step there). */
+int sf_loop_start(sf_sim *sim, int32_t k);
+int sf_loop_step(sf_sim *sim, const int32_t *points, int32_t *status_out, double *elapsed_out);
+int sf_loop_stop(sf_sim *sim);
+int sf_loop_restarts(sf_sim *sim, int32_t *count_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
  * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = k_run_tiles, 5 = one
  * frontier-resident launch (k_front), 6 = k_front, and k_run for the steps of environments that outgrew k_front's

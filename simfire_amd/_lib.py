@@ -81,6 +81,10 @@ SIGNATURES = {
     "sf_set_tuning": [_VP, _I32, _I32],
     "sf_get_tuning": [_VP, _I32, C.POINTER(_I32)],
     "sf_get_run_cost": [_VP, _VP],
+    "sf_loop_start": [_VP, _I32],
+    "sf_loop_step": [_VP, _VP, _VP, _VP],
+    "sf_loop_stop": [_VP],
+    "sf_loop_restarts": [_VP, C.POINTER(_I32)],
     "sf_get_team_sizes": [_VP, _VP],
     "sf_last_step_launch": [_VP, C.POINTER(_I32)],
     "sf_set_prune_after_quit": [_VP, _I32],

@@ -72,6 +72,7 @@ __host__ __device__ inline int bl_cell(const Geo &g, int y, int x)     // sprite
 }
 constexpr int kBlStatus = 32;      // status row = mask row + 32 inside a sector
 
+constexpr uint32_t kLoopStop = 0x80000000u;     // doorbell bit: the host ends the loop
 constexpr int kTeamMax = 4;                      // workgroups per environment in the resident launch (k_run<TEAM>)
 constexpr uint32_t kTeamUnused = 0xFFFFFFFFu;
 __host__ __device__ inline int team_xrow(const Geo &g) { return (64 + g.PV * 16 + 127) / 128 * 128; }
@@ -119,6 +120,16 @@ struct StepArgs {
     uint32_t *xerr;              // != 0: a wait for a team member timed out (the launch's results are void)
     int xrow;                    // bytes per published row: 64 (bitmap words) + PV * 16, rounded up to 128
     int team_rcap;               // bitmap rows a member keeps in LDS (+ 2 halo rows); 0 = the whole grid
+    // k_run in LOOP mode (sf_loop_start / sf_loop_step): the launch stays resident and is driven step by step by the host
+    const uint32_t *loop_db;     // HOST-mapped doorbell: sequence number of the newest step the host has posted | kLoopStop = leave
+    const int32_t *loop_pts_host;// HOST-mapped [2][E][k][3]: the points of the two newest steps (slot = sequence number & 1)
+    uint32_t *loop_done_host;    // HOST-mapped [E]: sequence number of the last step this environment has finished (its result row is there first)
+    int32_t *loop_res_host;      // HOST-mapped [E][8] + double [E] behind it: the result block of that step
+    // (device memory; all of it touched with agent-scope accesses only)
+    uint32_t *loop_seq;          // what the relay workgroup (environment 0's) forwards from the doorbell
+    int32_t *loop_pts;           // [2][E][k][3] the relay's copy of the points
+    uint32_t *loop_done;         // [E] sequence number of the last step this environment has finished
+    unsigned long long loop_timeout;   // shader clocks without a ring after which the launch leaves by itself (the host starts it again)
     int launch;          // running index of this step launch, modulo 6 (parity for tmp / n_active, mod 3 for the flag ring)
     int from_commit;     // 1: the state entering this launch is commit[e] (first step after a reset / a commit)
 };

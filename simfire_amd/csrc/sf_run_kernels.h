@@ -421,18 +421,106 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // control lines inside the launch, up to 64 points per environment and step: lane i of wave 0 holds point i of the coming step
     const bool mit_one_wave = mit && a.mit_k <= 64;
     int32_t px = 0, py = 0, pty = 0;
+    const bool loop = MIT != 0 && !TEAM && a.loop_db != nullptr;      // LOOP mode: steps on the host's doorbell (see below)
+    const int loop_slot_ints = (g.E * a.mit_k * 3 * 4 + 15) / 16 * 4;          // LOOP mode: a slot of the points ring, padded to 16 bytes
     auto load_pt = [&](int s) {
         if (wave == 0 && lane < a.mit_k) {
-            const int32_t *p = mit + (((long long)s * g.E + e) * a.mit_k + lane) * 3;
-            px = p[0]; py = p[1]; pty = p[2];
+            const int32_t *p = loop ? a.loop_pts + (long long)s * loop_slot_ints + ((long long)e * a.mit_k + lane) * 3
+                                    : mit + (((long long)s * g.E + e) * a.mit_k + lane) * 3;
+            if (loop) {      // the relay's copy, rewritten every other step: loads that skip the L1
+                px = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); py = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pty = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else { px = p[0]; py = p[1]; pty = p[2]; }
         }
     };
-    if (mit_one_wave && n_steps > 0) load_pt(0);
+    if (mit_one_wave && n_steps > 0 && !loop) load_pt(0);
+    // LOOP mode (sf_loop_start): the closed loop of an RL harness - update_mitigation(actions that depend on the last observation),
+    // run(1), look at the result (simulation.py:449-478, 501-553) - without a launch per step.  The launch stays resident.  Host
+    // memory is touched by ONE workgroup per step in each direction (hundreds of workgroups polling or reading it dword by dword
+    // drown in PCIe round trips: measured 320 - 620 us per step that way):
+    //   relay      environment 0's workgroup polls the host's doorbell (a sequence number), copies the step's points of ALL
+    //              environments from the host's two-slot ring into device memory (16 bytes per lane, written through) and
+    //              forwards the number (loop_seq); everybody waits on that word
+    //   step       the environment's points from the device copy, update_mitigation, the update, counts_env
+    //   result     every environment writes its row of the result block and then its "done" number into host memory (posted writes)
+    // A workgroup leaves on the stop bit, or by itself after loop_timeout clocks without a ring (a host that went away cannot hang
+    // the GPU; the relay forwards that as a stop); started again, every environment resumes from ITS OWN done number.
+    uint32_t lseq = 0;
+    if (loop) {
+        if (tid == 0) ctl[18] = __hip_atomic_load(a.loop_done + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        lseq = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[18]);
+        n_steps = 0x7FFFFFFF;
+    }
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
     bool gave_up = false;        // TEAM: a wait for the other members timed out (the handle is void; never wait again)
     unsigned long long x_clocks = 0, x_steps = 0;      // TEAM statistics: clocks wave 0 spent at the team's step boundaries (publish + wait + read), boundaries
     for (int s = 0; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
+        auto loop_finish = [&]() {
+            // the step is done: this environment's row of the result block goes straight to the host (posted writes are cheap, it is
+            // reads of host memory that are not), then its "done" number - to the host, and to device memory for a restarted launch
+            __syncthreads();
+            counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, nullptr,
+                       reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
+            ++lseq;
+            if (tid == 0) {
+                typedef unsigned long long u64;
+                const int32_t *row = a.res_block + e * 8;      // (what this thread has just stored)
+                u64 *dst = reinterpret_cast<u64 *>(a.loop_res_host);
+                for (int q = 0; q < 4; ++q)
+                    __hip_atomic_store(dst + e * 4 + q, (u64)(uint32_t)row[2 * q] | ((u64)(uint32_t)row[2 * q + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dst + (size_t)g.E * 4 + e, (u64)__double_as_longlong(st.elapsed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.loop_done + e, lseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row has left before the number that says so
+                __hip_atomic_store(a.loop_done_host + e, lseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        };
+        if (loop) {
+            if (e == 0) {
+                // ---- the relay: doorbell, points, forward
+                if (tid == 0) {
+                    const unsigned long long t0 = __builtin_readcyclecounter();
+                    uint32_t db;
+                    for (;;) {
+                        db = __hip_atomic_load(a.loop_db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if ((db & ~kLoopStop) > lseq || (db & kLoopStop)) break;
+                        if (__builtin_readcyclecounter() - t0 > a.loop_timeout) { db = lseq | kLoopStop; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    ctl[19] = db;
+                }
+                __syncthreads();
+                const uint32_t db = ctl[19];
+                if ((db & ~kLoopStop) > lseq && a.mit_k > 0) {
+                    const int n16 = loop_slot_ints / 4;                        // the slot in 16-byte pieces
+                    const size_t off = (size_t)((lseq + 1u) & 1u) * (size_t)n16 * 2;       // in 8-byte words
+                    typedef unsigned long long u64;
+                    // (system-scope loads, 8 bytes each: wide plain / nontemporal loads of the host's ring were measured to return the
+                    // slot's contents of two steps before now and then, and made the step no faster)
+                    const u64 *src = reinterpret_cast<const u64 *>(a.loop_pts_host) + off;
+                    u64 *dstp = reinterpret_cast<u64 *>(a.loop_pts) + off;
+                    for (int i = tid; i < n16 * 2; i += nthr)
+                        __hip_atomic_store(dstp + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(a.loop_seq, db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) {
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                uint32_t go = 0;
+                for (;;) {
+                    const uint32_t q = __hip_atomic_load(a.loop_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((q & ~kLoopStop) > lseq) { go = 1; break; }          // a step this environment has not made yet
+                    if ((q & kLoopStop) || __builtin_readcyclecounter() - t0 > 2 * a.loop_timeout) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                ctl[17] = go;
+            }
+            __syncthreads();
+            if (!ctl[17]) break;            // (uniform)
+        }
         if (mit) {
             // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80): this
             // environment's points of step s, the same two passes as k_mitigate_clear / k_mitigate_write - clear (and make
@@ -444,6 +532,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 // lanes of a wave issue the clears together and wait for them together), the write pass starts from the word the clear
                 // returned instead of loading it again, burn / settled are requested with the clear instead of after it, and the points
                 // were requested one step ahead (the block was 9.3 k clocks of a C5 step).
+                if (loop) load_pt((int)((lseq + 1u) & 1u));      // (LOOP mode: the slot of the step the host has just posted)
                 if (wave == 0) {
                     const int ty = pty;
                     const bool ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && px >= 0 && px < g.W && py >= R0 && py < R1;      // (TEAM: the points in this member's band; else R0 = 0, R1 = H)
@@ -457,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                         w = atomicAnd(word, ~(0xFFu << sh));
                         if (ATT) { bn = ev.burn[o]; owed_since = ev.settled[o]; }
                     }
-                    if (s + 1 < n_steps) load_pt(s + 1);
+                    if (s + 1 < n_steps && !loop) load_pt(s + 1);
                     if (ok) {
                         if (ATT) {
                             const uint32_t was = (w >> sh) & 7u;
@@ -520,7 +609,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 }
                 __syncthreads();
             }
-            if (!st.running) continue;          // (uniform) the fire is out: nothing to step
+            if (!st.running) {                  // (uniform) the fire is out: nothing to step
+                if (loop) loop_finish();
+                continue;
+            }
         }
 #ifdef SF_PHASES
         pc.tl = (e == g_timeline_env && s == g_timeline_step) ? g_timeline + wave * 64 : nullptr;
@@ -951,6 +1043,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         st.steps = __builtin_amdgcn_readfirstlane(st.steps);
         st.complete = __builtin_amdgcn_readfirstlane(st.complete);
         st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
+        if (loop) loop_finish();
     }
 #ifdef SF_PHASES
     pc.mark(12);

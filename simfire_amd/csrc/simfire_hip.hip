@@ -162,6 +162,18 @@ struct sf_sim {
     uint8_t *xbuf = nullptr;
     uint32_t *xerr_pinned = nullptr, *xerr_mapped = nullptr;
     int team_slots = 0;                // entries of team_tab
+    // LOOP mode (sf_loop_start): the resident launch driven step by step through host-mapped memory
+    bool loop_on = false;
+    int loop_k = 0;                    // points per environment and step
+    uint32_t loop_seq = 0;             // sequence number of the last step posted
+    uint32_t *loop_db = nullptr, *loop_db_dev = nullptr;         // (pinned, device-mapped) [0] doorbell, [16 ...] "done" numbers [E] (other cache lines)
+    int32_t *loop_res = nullptr, *loop_res_dev = nullptr;        // int32 [E][8] + double [E] (pinned, device-mapped)
+    int32_t *loop_pts = nullptr, *loop_pts_dev = nullptr;        // [2][slot] points ring (pinned, device-mapped)
+    size_t loop_pts_cap = 0, loop_slot_ints = 0;
+    uint32_t *loop_mem = nullptr;                                // device: [0] forwarded sequence number, [32 ...] done [E]
+    int32_t *loop_pts_mem = nullptr;                             // device copy of the ring
+    size_t loop_pts_mem_cap = 0;
+    int loop_restarts = 0;             // times the launch had left by itself (timeout) and was started again
     int last_team_max = 0;             // upper bound of the team sizes in the last resident launch (0: it was not a team launch)
     int cost_steps = 0;                // steps the per-environment cost array covers (0: nothing recorded since the last reset)
     uint32_t *run_cost = nullptr, *run_order = nullptr;   // k_run: clocks / 16 an environment's workgroup took in the last resident launch [E]; launch order built from it (k_order)
@@ -194,6 +206,9 @@ struct sf_sim {
 };
 
 static int ensure_commit(sf_sim *s);
+extern "C" int sf_loop_stop(sf_sim *s);
+// every entry point except sf_loop_step ends the closed loop (sf_loop_start) first: the handle's stream is busy with the resident launch
+#define LOOP_QUIESCE(s) do { if ((s)->loop_on) { int _rq = sf_loop_stop(s); if (_rq) return _rq; } } while (0)
 static int ensure_rm(sf_sim *s);
 static int alloc_bl(sf_sim *s);
 static bool prefers_bl(const sf_sim *s);
@@ -357,9 +372,12 @@ extern "C" int sf_destroy(sf_sim *s)
 {
     if (!s) return SF_OK;
     hipSetDevice(s->p.device);
+    if (s->loop_on) (void)sf_loop_stop(s);
     if (s->stream) hipStreamSynchronize(s->stream);
     if (s->comm) (void)sf_comm_destroy(s);
     if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
+    for (void *hp : {(void *)s->loop_db, (void *)s->loop_res, (void *)s->loop_pts}) if (hp) (void)hipHostFree(hp);
+    for (void *dp : {(void *)s->loop_mem, (void *)s->loop_pts_mem}) if (dp) (void)hipFree(dp);
     void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
@@ -414,7 +432,7 @@ static int rebuild_seams(sf_sim *s, int env0, int n)
 extern "C" int sf_set_rows_per_band(sf_sim *s, int32_t rows)
 {
     if (!s || rows < 1 || rows > 4096) return fail(SF_EINVAL, "sf_set_rows_per_band: rows must be in [1, 4096]");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // also clears the list counters of the tiled path
     choose_rows_per_band(s->g, rows);
     s->status_fresh = false;
@@ -447,7 +465,7 @@ extern "C" int sf_set_async(sf_sim *s, int32_t on)
 extern "C" int sf_set_prune_after_quit(sf_sim *s, int32_t on)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_prune_after_quit: null handle");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->g.prune_after_quit = on != 0;
     return SF_OK;
@@ -455,7 +473,7 @@ extern "C" int sf_set_prune_after_quit(sf_sim *s, int32_t on)
 extern "C" int sf_sync(sf_sim *s)
 {
     if (!s) return fail(SF_EINVAL, "sf_sync: null handle");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->xerr_pinned && *s->xerr_pinned)
         return fail(SF_EHIP, "sf_sync: a workgroup of a team launch (k_run<TEAM>) gave up waiting for a team member; the state of this handle is void");
@@ -468,7 +486,7 @@ extern "C" int sf_sync(sf_sim *s)
 extern "C" int sf_enable_spread_graph(sf_sim *s, int32_t on)
 {
     if (!s) return fail(SF_EINVAL, "sf_enable_spread_graph: null handle");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     if (on && !s->parents) {
         const size_t n = (size_t)s->g.E * s->g.plane_env;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->parents), n));
@@ -486,7 +504,7 @@ extern "C" int sf_get_spread_parents(sf_sim *s, int32_t env, uint8_t *out)
     const Geo &g = s->g;
     if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_spread_parents: environment %d out of range", env);
     if (!s->parents) return fail(SF_ESTATE, "sf_get_spread_parents: call sf_enable_spread_graph first");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipMemcpy2DAsync(out, (size_t)g.W, s->parents + (size_t)env * g.plane_env, (size_t)g.P, (size_t)g.W,
                             (size_t)g.H, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -498,7 +516,7 @@ extern "C" int sf_get_spread_parents(sf_sim *s, int32_t env, uint8_t *out)
 extern "C" int sf_set_generic(sf_sim *s, int32_t on)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_generic: null handle");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the list counters of the tiled path restart clean
     s->generic = on != 0;
     s->tdirty_all = true;
@@ -515,7 +533,7 @@ extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
     if (mode == 3 || mode == 4)
         return fail(SF_ENOTSUP, "sf_set_fused: modes 3 (k_run_tiles) and 4 (k_front) exist only in the cross-check build (libsimfire_hip_exp.so, -DSF_EXPERIMENTAL)");
 #endif
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
     return SF_OK;
@@ -524,7 +542,7 @@ extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 extern "C" int sf_set_tuning(sf_sim *s, int32_t knob, int32_t value)
 {
     if (!s || knob < 0 || knob >= SF_TUNE_COUNT) return fail(SF_EINVAL, "sf_set_tuning: unknown knob %d", knob);
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->tune.v[knob] = value;
     s->tune.set[knob] = true;
@@ -533,7 +551,7 @@ extern "C" int sf_set_tuning(sf_sim *s, int32_t knob, int32_t value)
 extern "C" int sf_get_run_cost(sf_sim *s, uint32_t *out)
 {
     if (!s || !out) return fail(SF_EINVAL, "sf_get_run_cost: null argument");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(out, s->run_cost, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SF_OK;
@@ -541,7 +559,7 @@ extern "C" int sf_get_run_cost(sf_sim *s, uint32_t *out)
 extern "C" int sf_get_team_sizes(sf_sim *s, uint32_t *out)
 {
     if (!s || !out) return fail(SF_EINVAL, "sf_get_team_sizes: null argument");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     if (!s->last_team_max || !s->team_size) { for (int e = 0; e < s->g.E; ++e) out[e] = 0; return SF_OK; }
     HIPCHK(hipMemcpy(out, s->team_size, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -558,7 +576,7 @@ extern "C" int sf_get_tuning(sf_sim *s, int32_t knob, int32_t *value)
 extern "C" int sf_set_dense(sf_sim *s, int32_t dense)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_dense: null handle");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->g.dense = dense != 0;
     return SF_OK;
@@ -587,7 +605,7 @@ static int set_layers_impl(sf_sim *s, int env, const double *const src[7])
 {
     int lo, hi, rc = table_range(s, env, "sf_set_layers", &lo, &hi);
     if (rc) return rc;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const Geo &g = s->g;
     const size_t n = (size_t)g.H * g.W;
     for (int i = 0; i < 7; ++i)
@@ -640,7 +658,7 @@ extern "C" int sf_set_layers_fbfm(sf_sim *s, int32_t env, const int32_t *codes, 
     if (n_lut < 1 || n_lut > kMaxFuelLut) return fail(SF_EINVAL, "sf_set_layers_fbfm: n_lut must be 1..%d", kMaxFuelLut);
     int lo, hi, rc = table_range(s, env, "sf_set_layers_fbfm", &lo, &hi);
     if (rc) return rc;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const Geo &g = s->g;
     const size_t n = (size_t)g.H * g.W;
     rc = ensure_stage(s, n * sizeof(int32_t) + sizeof(int32_t));
@@ -676,7 +694,7 @@ extern "C" int sf_get_attribute_data(sf_sim *s, int32_t env, float *w_0, uint32_
     const int n_tab = (int)s->rt_set.size();
     if (env < 0 || env >= s->g.E) return fail(SF_EINVAL, "sf_get_attribute_data: environment %d out of range", env);
     const int t = n_tab == 1 ? 0 : env;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const Geo &g = s->g;
     const size_t n = (size_t)g.H * g.W;
     const hipMemcpyKind kind = device_pointers ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -709,7 +727,7 @@ static int set_rtable_impl(sf_sim *s, int env, const double *R8)
 {
     int lo, hi, rc = table_range(s, env, "sf_set_rtable", &lo, &hi);
     if (rc) return rc;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const Geo &g = s->g;
     const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
     rc = ensure_stage(s, n);
@@ -744,7 +762,7 @@ static int get_rtable_impl(sf_sim *s, int env, double *out)
     const int t = n_tab == 1 ? 0 : env;
     if (t < 0 || t >= n_tab) return fail(SF_EINVAL, "sf_get_rtable: environment %d out of range", env);
     if (!s->rt_set[t]) return fail(SF_ESTATE, "sf_get_rtable: no layers / table set");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const Geo &g = s->g;
     const size_t n = (size_t)8 * g.H * g.W * sizeof(double);
     int rc = ensure_stage(s, n);
@@ -772,7 +790,7 @@ extern "C" int sf_get_rtable_env(sf_sim *s, int32_t env, double *out)
 extern "C" int sf_get_slopes(sf_sim *s, double *mag, double *dir)
 {
     if (!s || !mag || !dir) return fail(SF_EINVAL, "sf_get_slopes: null argument");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const size_t n = (size_t)s->g.H * s->g.W * sizeof(double);
     HIPCHK(hipMemcpyAsync(mag, s->smag, n, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(dir, s->sdir, n, hipMemcpyDeviceToHost, s->stream));
@@ -784,6 +802,7 @@ extern "C" int sf_get_slopes(sf_sim *s, double *mag, double *dir)
 // into commit[] only when something needs them (status queries, resets, burn_amounts transfers).
 static int ensure_commit(sf_sim *s)
 {
+    LOOP_QUIESCE(s);
     if (s->committed) return SF_OK;
     hipLaunchKernelGGL(k_commit, dim3((s->g.E + 255) / 256), dim3(256), 0, s->stream, s->g, s->commit,
                        (const EnvState *)s->tmp, s->flags, (s->seq + 5) % 6, s->n_active);
@@ -799,7 +818,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
         if (xy[2 * i] < 0 || xy[2 * i] >= g.W || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= g.H)
             return fail(SF_EINVAL, "reset: ignition (%d, %d) of environment %d is outside the %dx%d grid", xy[2 * i],
                         xy[2 * i + 1], env0 + i, g.H, g.W);
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     s->status_fresh = false;
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
     if (n == g.E) s->cost_steps = 0;                         // new episodes: what the environments cost before says nothing about them
@@ -896,7 +915,7 @@ extern "C" int sf_apply_mitigation(sf_sim *s, const int32_t *pts, int32_t n)
         if (q[0] < 0 || q[0] >= g.E || q[1] < 0 || q[1] >= g.W || q[2] < 0 || q[2] >= g.H)
             return fail(SF_EINVAL, "sf_apply_mitigation: point %d = (env %d, x %d, y %d) is out of range", i, q[0], q[1], q[2]);
     }
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const size_t bytes = (size_t)4 * n * sizeof(int32_t);
     if ((size_t)4 * n > s->pts_cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -928,7 +947,7 @@ extern "C" int sf_apply_mitigation_device(sf_sim *s, const int32_t *device_pts, 
     if (!s) return fail(SF_EINVAL, "sf_apply_mitigation_device: null handle");
     if (n < 0 || (n > 0 && !device_pts)) return fail(SF_EINVAL, "sf_apply_mitigation_device: bad point list");
     if (n == 0) return SF_OK;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     return scatter_points(s, device_pts, n, true);
 }
 
@@ -940,7 +959,7 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     const size_t n = (size_t)g.H * g.W;
     for (size_t i = 0; i < n; ++i)
         if (map[i] > SF_WETLINE) return fail(SF_EINVAL, "sf_load_fire_map: value %d at cell %zu is not a BurnStatus", map[i], i);
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     int rc = ensure_stage(s, n);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
@@ -1151,9 +1170,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     if (!s->was_reset) return fail(SF_ESTATE, "sf_step: call sf_reset first");
     if (ms) *ms = 0.f;
     if (n_steps == 0) return SF_OK;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     s->status_fresh = false;
     StepArgs a;
+    a.loop_db = nullptr;      // (not the closed loop of sf_loop_start)
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.order = nullptr; a.cost = nullptr;
     a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
@@ -1449,7 +1469,7 @@ extern "C" int sf_enable_history(sf_sim *s, int32_t capacity)
 {
     if (!s) return fail(SF_EINVAL, "sf_enable_history: null handle");
     if (capacity < 0) return fail(SF_EINVAL, "sf_enable_history: capacity must be >= 0");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     const size_t per = (size_t)s->g.E * s->g.H * s->g.W;
     if (s->history) { HIPCHK(hipFree(s->history)); s->bytes -= (int64_t)(per * s->history_cap); }
@@ -1470,7 +1490,7 @@ extern "C" int sf_get_history(sf_sim *s, int32_t env, int32_t first, int32_t cou
     if (env < 0 || env >= s->g.E) return fail(SF_EINVAL, "sf_get_history: environment %d out of range", env);
     if (first < 0 || count < 0 || count > s->history_cap)
         return fail(SF_EINVAL, "sf_get_history: %d updates from %d do not fit the capacity %d", count, first, s->history_cap);
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const size_t map = (size_t)s->g.H * s->g.W;
     const int8_t *base = s->history + (size_t)env * s->history_cap * map;
     const int slot = first % s->history_cap;
@@ -1551,7 +1571,7 @@ extern "C" int sf_step_mitigated(sf_sim *s, int32_t n_steps, const int32_t *pts,
     if (k == 0) return step_impl(s, n_steps, ms_out);
     if (!s->have_rt) return fail(SF_ESTATE, "sf_step: call sf_set_layers or sf_set_rtable first");
     if (!s->was_reset) return fail(SF_ESTATE, "sf_step: call sf_reset first");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const Geo &g = s->g;
     const size_t per_step = (size_t)g.E * k * 3, rows_bytes = (size_t)g.E * k * 4 * sizeof(int32_t);
     const size_t blk_bytes = device_pointer ? 0 : (size_t)n_steps * per_step * sizeof(int32_t);
@@ -1592,10 +1612,156 @@ extern "C" int sf_step_mitigated(sf_sim *s, int32_t n_steps, const int32_t *pts,
     return SF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- closed loop
+// FireSimulation.update_mitigation(actions) + run(1) with actions that depend on the last observation (simulation.py:449-478,
+// 501-553), without a launch per step: sf_loop_start leaves k_run resident, sf_loop_step posts one step's points into
+// host-mapped memory, rings the doorbell and waits for every environment's "done" number; the result block arrives with it.
+static int loop_launch(sf_sim *s)
+{
+    const Geo &g = s->g;
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.g = g; a.status = s->status; a.age = s->age; a.cells = s->cells; a.burn = s->burn; a.rt = s->rt;
+    a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = nullptr; a.tflags = s->tflags; a.tile_list = s->tile_list;
+    a.n_active = s->n_active; a.seam = s->seam; a.settled = s->settled; a.tdirty = s->tdirty; a.thist = s->thist; a.vbits = s->vbits;
+    a.launch = 0; a.from_commit = 1; a.ring = s->ring;
+    a.mit = s->loop_pts_mem; a.mit_k = s->loop_k;
+    a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink;
+    a.cost = s->run_cost;
+    a.loop_db = s->loop_db_dev; a.loop_pts_host = s->loop_pts_dev; a.loop_done_host = s->loop_db_dev + 16; a.loop_res_host = s->loop_res_dev;
+    a.loop_seq = s->loop_mem; a.loop_done = s->loop_mem + 32; a.loop_pts = s->loop_pts_mem;
+    a.loop_timeout = 400000000ull;             // ~0.2 s without a ring: the workgroups leave, the next sf_loop_step starts them again
+    HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t), s->stream));       // nothing forwarded yet (the word may hold the stop of the launch before)
+    const int nw = (g.H + 63) / 64 < 16 ? (g.H + 63) / 64 : 16;
+    long long all_vec = (long long)g.H * g.PV;
+    int vcap = 4096;
+    if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
+    const size_t lds = run_lds_bytes(g, nw, vcap);
+    return launch_k_run(s, a, 0x7FFFFFFF, nw, vcap, lds, 64);
+}
+
+extern "C" int sf_loop_start(sf_sim *s, int32_t k)
+{
+    if (!s) return fail(SF_EINVAL, "sf_loop_start: null handle");
+    if (k < 0 || k > 64) return fail(SF_EINVAL, "sf_loop_start: 0 .. 64 points per environment and step (got %d)", k);
+    if (!s->have_rt || !s->was_reset) return fail(SF_ESTATE, "sf_loop_start: call sf_set_layers / sf_set_rtable and sf_reset first");
+    HIPCHK(hipSetDevice(s->p.device));
+    const Geo &g = s->g;
+    // the resident launch with one workgroup per environment, every environment resident at once
+    if (g.ab != 1 || s->generic || g.VW != 1 || s->graph_on || s->history || g.dense || g.H > 16 * 64 || g.E > s->n_cu ||
+        (s->fused_mode >= 0 && s->fused_mode != 2))
+        return fail(SF_ENOTSUP, "sf_loop_start: needs the environment-resident launch with every environment resident at once "
+                                "(grids up to 1024 x 1024, max_fire_duration <= 5, no more environments than CUs, no spread graph / history)");
+    if (s->loop_on) { int rc0 = sf_loop_stop(s); if (rc0) return rc0; }
+    { int rc0 = ensure_commit(s); if (rc0) return rc0; }
+    { int rc0 = ensure_vbits(s); if (rc0) return rc0; }
+    { int rc0 = ensure_bl(s); if (rc0) return rc0; }
+    auto pin = [&](void **host, void **dev, size_t bytes) -> int {
+        HIPCHK(hipHostMalloc(host, bytes, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(dev, *host, 0));
+        memset(*host, 0, bytes);
+        return SF_OK;
+    };
+    if (!s->loop_db) {
+        int rc = pin((void **)&s->loop_db, (void **)&s->loop_db_dev, sizeof(uint32_t) * (16 + (size_t)g.E)); if (rc) return rc;
+        rc = pin((void **)&s->loop_res, (void **)&s->loop_res_dev, (sizeof(int32_t) * 8 + sizeof(double)) * g.E); if (rc) return rc;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->loop_mem), sizeof(uint32_t) * (32 + (size_t)g.E)));
+    }
+    s->loop_slot_ints = ((size_t)g.E * k * 3 * 4 + 15) / 16 * 4;
+    const size_t pts_bytes = sizeof(int32_t) * 2 * (s->loop_slot_ints ? s->loop_slot_ints : 4);
+    if (pts_bytes > s->loop_pts_cap) {
+        if (s->loop_pts) HIPCHK(hipHostFree(s->loop_pts));
+        if (s->loop_pts_mem) HIPCHK(hipFree(s->loop_pts_mem));
+        s->loop_pts = nullptr; s->loop_pts_mem = nullptr; s->loop_pts_cap = 0;
+        int rc = pin((void **)&s->loop_pts, (void **)&s->loop_pts_dev, pts_bytes); if (rc) return rc;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->loop_pts_mem), pts_bytes));
+        s->loop_pts_cap = pts_bytes;
+    }
+    s->loop_k = k; s->loop_seq = 0; s->loop_restarts = 0;
+    volatile uint32_t *db = s->loop_db;
+    for (int i = 0; i < 16 + g.E; ++i) db[i] = 0;
+    __sync_synchronize();
+    HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t) * (32 + (size_t)g.E), s->stream));
+    HIPCHK(hipMemsetAsync(s->loop_pts_mem, 0, pts_bytes, s->stream));
+    if (s->tdirty_all) HIPCHK(hipMemsetAsync(s->tdirty, 1, s->n_tiles_max, s->stream));
+    s->tdirty_all = false;
+    s->status_fresh = false;
+    { int rc0 = loop_launch(s); if (rc0) return rc0; }
+    HIPCHK(hipGetLastError());
+    s->loop_on = true;
+    s->tiles_valid = false;
+    s->last_kind = 2;
+    return SF_OK;
+}
+
+/* pts: int32 [n_envs][k][3] = (column, row, type) of this step (k as given to sf_loop_start; entries with a type outside 3..5 are
+ * padding), or null = no points.  status_out: int32 [n_envs][8] (like sf_get_status) or null; elapsed_out: double [n_envs] or null. */
+extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, double *elapsed_out)
+{
+    if (!s) return fail(SF_EINVAL, "sf_loop_step: null handle");
+    if (!s->loop_on) return fail(SF_ESTATE, "sf_loop_step: call sf_loop_start first");
+    const Geo &g = s->g;
+    const uint32_t seq = s->loop_seq + 1;
+    if (seq >= 0x7FFFFFF0u) return fail(SF_ESTATE, "sf_loop_step: sequence numbers exhausted; sf_loop_stop and start again");
+    if (s->loop_k > 0) {
+        int32_t *slot = s->loop_pts + (size_t)(seq & 1u) * s->loop_slot_ints;
+        const size_t n = (size_t)g.E * s->loop_k * 3;
+        if (pts) memcpy(slot, pts, sizeof(int32_t) * n);
+        else memset(slot, 0, sizeof(int32_t) * n);
+    }
+    volatile uint32_t *db = s->loop_db;
+    __sync_synchronize();                                    // the points are in memory before the number that announces them
+    db[0] = seq;
+    s->loop_seq = seq;
+    // wait for the "done" number; should the launch have left by itself (no ring for loop_timeout clocks), start it again: every
+    // workgroup resumes from its own "done" number, the points of this step are still in their slot
+    int e = 0;
+    for (unsigned long long spins = 0;; ++spins) {
+        while (e < g.E && db[16 + e] == seq) ++e;
+        if (e == g.E) break;
+        if ((spins & 0x3FFF) == 0x3FFF && hipStreamQuery(s->stream) == hipSuccess) {
+            bool all = true;
+            for (int q = 0; q < g.E; ++q) all = all && db[16 + q] == seq;
+            if (all) break;
+            if (s->xerr_pinned && *s->xerr_pinned) return fail(SF_EHIP, "sf_loop_step: the resident launch failed");
+            HIPCHK(hipSetDevice(s->p.device));
+            s->loop_restarts++;
+            { int rc0 = loop_launch(s); if (rc0) return rc0; }
+            HIPCHK(hipGetLastError());
+        }
+    }
+    __sync_synchronize();
+    if (status_out) memcpy(status_out, s->loop_res, sizeof(int32_t) * 8 * g.E);
+    if (elapsed_out) memcpy(elapsed_out, reinterpret_cast<const char *>(s->loop_res) + sizeof(int32_t) * 8 * g.E, sizeof(double) * g.E);
+    return SF_OK;
+}
+
+extern "C" int sf_loop_stop(sf_sim *s)
+{
+    if (!s) return fail(SF_EINVAL, "sf_loop_stop: null handle");
+    if (!s->loop_on) return SF_OK;
+    HIPCHK(hipSetDevice(s->p.device));
+    volatile uint32_t *db = s->loop_db;
+    __sync_synchronize();
+    db[0] = s->loop_seq | kLoopStop;
+    __sync_synchronize();
+    s->loop_on = false;
+    HIPCHK(hipStreamSynchronize(s->stream));      // the workgroups commit their environments and leave the result block behind
+    s->status_fresh = true;
+    return SF_OK;
+}
+
+extern "C" int sf_loop_restarts(sf_sim *s, int32_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_loop_restarts: null argument");
+    *out = s->loop_restarts;
+    return SF_OK;
+}
+
 static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
 {
     const Geo &g = s->g;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const size_t bytes = (size_t)n * g.H * g.W;
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
@@ -1631,7 +1797,7 @@ extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
     if (!s || !out) return fail(SF_EINVAL, "sf_get_burn: null argument");
     const Geo &g = s->g;
     if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_burn: environment %d out of range", env);
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const size_t bytes = (size_t)g.H * g.W * sizeof(double);
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
@@ -1653,7 +1819,7 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
     if (!s || !burn) return fail(SF_EINVAL, "sf_set_burn: null argument");
     const Geo &g = s->g;
     if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_set_burn: environment %d out of range", env);
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     const size_t bytes = (size_t)g.H * g.W * sizeof(double);
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
@@ -1675,7 +1841,7 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
 static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
 {
     const Geo &g = s->g;
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     if (s->status_fresh) {
         // the resident launch has left the block (and the registered sink's copy) behind: nothing to count
@@ -1742,7 +1908,7 @@ extern "C" int sf_enable_counters(sf_sim *s, int32_t on)
 extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
 {
     if (!s || !out) return fail(SF_EINVAL, "sf_get_counters: null argument");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<unsigned long long> h((size_t)kCounterShards * 8);
     HIPCHK(hipMemcpy(h.data(), s->counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1776,7 +1942,7 @@ extern "C" int sf_rollout(sf_sim *s, int32_t n_steps, void *device_dst)
 extern "C" int sf_set_result_sink(sf_sim *s, void *device_dst)
 {
     if (!s) return fail(SF_EINVAL, "sf_set_result_sink: null handle");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));       // nothing in flight may still write the old sink
     s->sink = static_cast<int32_t *>(device_dst);
     s->status_fresh = false;                       // the new sink is filled by the next refresh
@@ -1833,7 +1999,7 @@ extern "C" int sf_comm_destroy(sf_sim *s)
 {
     if (!s) return fail(SF_EINVAL, "sf_comm_destroy: null handle");
     if (s->comm) {
-        HIPCHK(hipSetDevice(s->p.device));
+        HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
         HIPCHK(hipStreamSynchronize(s->stream));
         ncclComm_t c = s->comm;
         s->comm = nullptr; s->comm_world = 0;
@@ -1848,7 +2014,7 @@ extern "C" int sf_comm_init(sf_sim *s, int32_t rank, int32_t world_size, const v
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SF_EINVAL, "sf_comm_init: rank %d of %d", rank, world_size);
     { int rc = rccl_load(); if (rc) return rc; }
     { int rc = sf_comm_destroy(s); if (rc) return rc; }
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
     RCCLCHK(g_rccl.CommInitRank(&s->comm, world_size, id, rank));
@@ -1878,7 +2044,7 @@ extern "C" int sf_status_device(sf_sim *s, void **ptr)
 extern "C" int sf_fire_map_device(sf_sim *s, void **ptr, int64_t *row_pitch, int64_t *env_stride)
 {
     if (!s || !ptr || !row_pitch || !env_stride) return fail(SF_EINVAL, "sf_fire_map_device: null argument");
-    HIPCHK(hipSetDevice(s->p.device));
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     if (s->bl_cur) {
         // the resident launch keeps the cells in its blocked plane: the row-major status plane is refreshed from it (one sweep) and
         // is a snapshot until the next call - the blocked plane stays the current one, nothing is converted back

@@ -229,6 +229,32 @@ class FireEngine:
         for name, value in knobs.items():
             self._chk(self._L.sf_set_tuning(self._h, _lib.TUNE[name], int(value)))
 
+    # ---- closed loop: update_mitigation(actions) + run(1) per call without a launch per step (sf_loop_*)
+    def loop_start(self, k):
+        """Leave the resident launch on the GPU, driven by ``loop_step``; ``k`` = points per environment and step (<= 64)."""
+        self._loop_k = int(k)
+        self._loop_status = np.zeros((self.n_envs, 8), dtype=np.int32)
+        self._loop_elapsed = np.zeros(self.n_envs, dtype=np.float64)
+        self._chk(self._L.sf_loop_start(self._h, int(k)))
+
+    def loop_step(self, pts=None):
+        """``update_mitigation(pts); run(1)`` for every environment; ``pts`` int32 [n_envs, k, 3] = (column, row, type) or None.
+        Returns (status int32 [n_envs, 8], elapsed_time float64 [n_envs]) - views that the next call overwrites."""
+        if pts is not None:
+            pts = np.ascontiguousarray(np.asarray(pts, dtype=np.int32))
+            if pts.shape != (self.n_envs, self._loop_k, 3):
+                raise ValueError(f"expected points of shape {(self.n_envs, self._loop_k, 3)}, got {pts.shape}")
+        self._chk(self._L.sf_loop_step(self._h, _ptr(pts) if pts is not None else None, _ptr(self._loop_status), _ptr(self._loop_elapsed)))
+        return self._loop_status, self._loop_elapsed
+
+    def loop_stop(self):
+        self._chk(self._L.sf_loop_stop(self._h))
+
+    def loop_restarts(self):
+        v = C.c_int32()
+        self._chk(self._L.sf_loop_restarts(self._h, C.byref(v)))
+        return v.value
+
     def run_cost(self):
         """Shader clocks / 16 every environment's workgroup(s) spent in the last resident launch (uint32 [n_envs])."""
         out = np.zeros(self.n_envs, dtype=np.uint32)

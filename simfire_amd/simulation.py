@@ -466,6 +466,20 @@ class BatchedFireSimulation:
         st, _ = self._engine.status()
         return (self._engine.fire_maps() if return_maps else None), st[:, 0].astype(bool)
 
+    # ---- closed loop: actions that depend on the last observation, one update per call, no launch per call (sf_loop_*)
+    def loop_start(self, points_per_env: int) -> None:
+        """Leave the resident launch on the GPU; ``loop_step`` then drives it.  Any other call on the simulation ends the loop."""
+        self._engine.loop_start(points_per_env)
+
+    def loop_step(self, points=None):
+        """``update_mitigation(points); run(1)`` for every environment (simulation.py:449-478, 501-553); ``points`` int32
+        [n_envs, k, 3] = (column, row, type), type outside FIRELINE..WETLINE = padding, or None.  Returns (result block int32
+        [n_envs, 8] = running, elapsed_steps, cells per BurnStatus; elapsed_time float64 [n_envs])."""
+        return self._engine.loop_step(points)
+
+    def loop_stop(self) -> None:
+        self._engine.loop_stop()
+
     def results(self):
         """int32 [E, 8]: running, elapsed_steps, cell counts per BurnStatus; float64 [E] elapsed_time."""
         return self._engine.status()

@@ -642,6 +642,57 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(workload):
     assert j["verified"] is True and j["scaling"] == "weak" and j["config"]["collective_backend"] == "gloo"
 
 
+# ------------------------------------------------------------------ closed loop: one step per call on a resident launch
+@pytest.mark.parametrize("att", [False, True])
+def test_closed_loop_steps_equal_update_mitigation_run_pairs(att):
+    """sf_loop_start / sf_loop_step: update_mitigation(points) + run(1) per call on a launch that stays resident (doorbell and
+    points in host-mapped memory).  The points of a step DEPEND on the result block of the step before (a line is drawn next to
+    a burning cell found in the returned counts' environment), some land on burning cells, some are padding; one environment
+    runs out of fuel half-way (QUIT: lines keep being drawn); a pause longer than the launch's patience makes it leave and the
+    next call start it again; other calls on the handle end the loop.  Equal to the oracle after every step."""
+    import time
+    rng = np.random.default_rng(77 + att)
+    H, W, E, K = 150, 260, 5, 6
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=att, max_time=60.0)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0], size=(8, H, W))
+    R8[:, :, 200:] = 0.0
+    inits = [(10, 10), (120, 70), (60, 140), (255, 5), (199, 100)]      # (255, 5): barren ground, out at once
+    eng, o = _pair(kw, R8, inits)
+    eng.step(3)
+    o.step(3)
+    eng.loop_start(K)
+    last = None
+    for s_ in range(70):
+        pts = np.zeros((E, K, 3), dtype=np.int32)
+        pts[..., 0] = rng.integers(0, W, size=(E, K))
+        pts[..., 1] = rng.integers(0, H, size=(E, K))
+        pts[..., 2] = rng.integers(2, 7, size=(E, K))
+        for e in range(E):
+            burning = np.argwhere(o.fire_map(e) == 1)
+            if len(burning) and (last is None or last[e, 3] > 0):          # (last[e, 3]: BURNING cells in the block of the step before)
+                y, x = burning[rng.integers(len(burning))]
+                pts[e, 0] = (int(x), int(y), 3 + s_ % 3)
+                pts[e, 1] = (min(int(x) + 1, W - 1), int(y), 4)
+        o.apply_mitigation([(e, int(p[0]), int(p[1]), int(p[2])) for e in range(E) for p in pts[e]])
+        o.step(1)
+        status, elapsed = eng.loop_step(pts)
+        so, eo = o.status()
+        assert (status == so).all() and (elapsed == eo).all(), s_
+        last = status.copy()
+        if s_ == 20:
+            time.sleep(0.6)                 # longer than the launch waits for a ring: it leaves; the next call starts it again
+        if s_ == 40:
+            assert eng.loop_restarts() >= 1      # (the pause at step 20)
+            _same(eng, o, E, tag=("mid", s_))   # any other call ends the loop (fire maps, burn_amounts are read back) ...
+            eng.loop_start(K)                    # ... and it can be started again
+    assert eng.loop_restarts() >= 0
+    eng.loop_stop()
+    _same(eng, o, E, tag="end")
+    eng.step(5)
+    o.step(5)
+    _same(eng, o, E, tag="after the loop")
+
+
 # ------------------------------------------------------------------ rollouts with control lines before every update
 def _blk(agent_pts, E, k):
     """[n][E * k][4] rows (env, x, y, type), env-major -> [n][E][k][3]"""
