@@ -243,7 +243,8 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 
 // Template parameters: MAXD = bitmap words a thread owns; ATT = attenuate_line_ros (fire.py:236-284) known at compile time;
 // DIAG = 1: diagonal_spread known to be on, -1: read from the geometry (the 4-connected case is rare); MIT = 0: no control lines
-// inside the launch (sf_step), -1: look at the argument (sf_step_mitigated).  MAXD = 1 implies one-word rows (the refined interest rule).
+// inside the launch (sf_step), -1: look at the argument (sf_step_mitigated), -2: the closed loop of sf_loop_start (points per step from
+// the host's ring).  MAXD = 1 implies one-word rows (the refined interest rule).
 //
 // TEAM = 1: an environment is served by a TEAM of 1 .. kTeamMax workgroups (a.team_tab: workgroup slot -> environment, member, team size;
 // k_team_plan sizes the teams from what the environments cost in the launch before).  Member m owns the rows [R0, R1) - bands cut at
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // control lines inside the launch, up to 64 points per environment and step: lane i of wave 0 holds point i of the coming step
     const bool mit_one_wave = mit && a.mit_k <= 64;
     int32_t px = 0, py = 0, pty = 0;
-    const bool loop = MIT != 0 && !TEAM && a.loop_db != nullptr;      // LOOP mode: steps on the host's doorbell (see below)
+    constexpr bool loop = MIT == -2;       // LOOP mode: steps on the host's doorbell (see below); its own instantiation, so that the others do not carry it
     const int loop_slot_ints = (g.E * a.mit_k * 3 * 4 + 15) / 16 * 4;          // LOOP mode: a slot of the points ring, padded to 16 bytes
     auto load_pt = [&](int s) {
         if (wave == 0 && lane < a.mit_k) {

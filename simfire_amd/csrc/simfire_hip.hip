@@ -180,7 +180,7 @@ struct sf_sim {
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run[16] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[24] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -1066,10 +1066,11 @@ static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, in
     typedef void (*run_fn)(StepArgs, int, int, int);
     // [words per thread 1 / 2 / 4][attenuation off / on][diagonal spread read at run time / known to be on]; control lines inside
     // the launch: one word per thread has an instantiation without them (MIT = 0), the others look at the argument
+    // (specialised for diagonal spread known to be on - every reference config - where it is worth the compile time: one word per thread)
     static const run_fn table[2][2][2] = {
         {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, -1>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, -1>}},
-        {{k_run<kRunMaxD, 0, -1, -1>, k_run<kRunMaxD, 0, 1, -1>}, {k_run<kRunMaxD, 1, -1, -1>, k_run<kRunMaxD, 1, 1, -1>}}};
-    static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, 0>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, 0>, k_run<1, 1, 1, 0>}};
+        {{k_run<kRunMaxD, 0, -1, -1>, k_run<kRunMaxD, 0, -1, -1>}, {k_run<kRunMaxD, 1, -1, -1>, k_run<kRunMaxD, 1, -1, -1>}}};
+    static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, 0>}};
     const int ia = s->g.att ? 1 : 0, id = s->g.diag ? 1 : 0;
     const bool nomit = which == 0 && !a.mit;
     const run_fn kern = nomit ? table_nomit[ia][id] : table[which][ia][id];
@@ -1637,7 +1638,16 @@ static int loop_launch(sf_sim *s)
     int vcap = 4096;
     if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
     const size_t lds = run_lds_bytes(g, nw, vcap);
-    return launch_k_run(s, a, 0x7FFFFFFF, nw, vcap, lds, 64);
+    typedef void (*run_fn)(StepArgs, int, int, int);
+    static const run_fn loop_table[2][2] = {{k_run<1, 0, -1, -2>, k_run<1, 0, 1, -2>}, {k_run<1, 1, -1, -2>, k_run<1, 1, 1, -2>}};       // (the closed loop's own instantiations)
+    const run_fn kern = loop_table[g.att ? 1 : 0][g.diag ? 1 : 0];
+    size_t &attr = s->attr_run[16 + (g.att ? 2 : 0) + (g.diag ? 1 : 0)];
+    if (lds > 64 * 1024 && lds > attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.E), dim3((unsigned)nw * 64), lds, s->stream, a, 0x7FFFFFFF, vcap, 64);
+    return SF_OK;
 }
 
 extern "C" int sf_loop_start(sf_sim *s, int32_t k)
