@@ -195,6 +195,7 @@ def measure(eng, w, a, agent_pts, dense):
     kernel_ms = timed_steps(eng, a.steps, a.warmup, agent_pts)
     kind = eng.last_launch_kind()
     measure.last_cost = eng.run_cost() if kind == 2 else None      # clocks / 16 per environment in that launch (k_run)
+    measure.last_teams = eng.team_sizes() if kind == 2 else None   # workgroups per environment (zeros: one each, one launch for the whole rollout)
     st1, _ = eng.status()
     env_steps = int((st1[:, 1] - st0[:, 1]).sum())
     eng.reset(w.init_xy)
@@ -209,6 +210,7 @@ def measure(eng, w, a, agent_pts, dense):
 
 
 measure.last_cost = None
+measure.last_teams = None
 
 
 def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense):
@@ -261,6 +263,20 @@ def issue_block(w, a, rl, cost, n_cu=256):
     counters of the same window come from profiles/ (rocprofv3 --pmc, a separate run: profiles/collect_issue.sh)."""
     if cost is None or not len(cost) or int(cost.max()) == 0 or rl.get("launches") != 1:
         return None
+    teams = measure.last_teams
+    if teams is not None and int(teams.max()) > 0:
+        # a team launch (k_run<TEAM>): the rollout is cut into 64-step launches, an environment's cost is the sum over its members
+        # (their waits for each other included) and covers the last launch only - no clock, no balance figure from that
+        n, launches = a.steps, 0
+        while n > 0:
+            n -= 64 if n > 96 else n
+            launches += 1
+        rl["launches"] = launches
+        rl["launch_ms"] = rl["kernel_ms_per_step"] * a.steps / launches
+        rl["steps_per_launch"] = a.steps / launches
+        rl["algorithmic_bytes_per_launch"] = rl["algorithmic_bytes_per_launch"] / launches
+        return {"team_launch": True, "workgroups_per_environment": {int(k): int(v) for k, v in zip(*np.unique(teams, return_counts=True))},
+                "note": "k_run<TEAM>: bands of rows, one workgroup each; the rollout in launches of 64 steps (profiles/r03_team/README.md)"}
     clocks = cost.astype(np.float64) * 16.0
     slots = min(len(cost), n_cu)
     sec = rl["launch_ms"] * 1e-3
@@ -353,6 +369,7 @@ def side_workload(name, a, device, torch, n_check, tile_cells):
         del o
     kms, esl, cnt, kind = measure(eng, w, a, agent_pts, False)
     rl = roofline_block(w, a, kms, cnt, tile_cells, kind, esl, None, False)
+    iss = issue_block(w, a, rl, measure.last_cost)          # (a team launch: also corrects the launch count of rl)
     out = {"workload": w.name, "grid": [H, W], "envs_per_gpu": w.n_envs, "agents_per_env": w.agents_per_env,
            "value": H * W * env_steps / dt, "unit": "cell-updates/s", "ms_per_step": dt * 1e3 / a.steps,
            "kernel_ms_per_step": kms / a.steps, "verified": verified, "envs_checked": 0 if verified is None else n_check,
@@ -360,7 +377,6 @@ def side_workload(name, a, device, torch, n_check, tile_cells):
            "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "launch_ms",
                                            "cells_swept_per_step", "active_cell_updates_per_step", "active_cell_updates_per_s",
                                            "algorithmic_bytes_per_launch")}}
-    iss = issue_block(w, a, rl, measure.last_cost)
     if iss:
         out["roofline"]["issue"] = iss
     eng.close()

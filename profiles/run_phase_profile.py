@@ -60,7 +60,9 @@ def main():
         tiles = max(int(out[6]) // 64, 1)       # batches of 64 records (approx.)
     res = {"steps": steps, "envs": envs, "ms_per_step": ms / steps, "vector_batches_per_step": tiles / steps, "vectors_per_step": int(out[5]) / steps, "frontier_cells_per_step": int(out[2]) / steps, "walks_per_step": int(out[4]) / steps,
            "clocks_per_batch": {n: round(p / tiles, 1) for n, p in zip(NAMES, ph)},
-           "clocks_per_batch_total": round(sum(ph) / tiles, 1)}
+           "clocks_per_batch_total": round(sum(ph) / tiles, 1),
+           # share of all wave clocks spent waiting at the barrier that ends a step (phase 0): bench.py's roofline.issue reads it
+           "barrier_wait_share": (ph[0] / sum(ph)) if sum(ph) else None}
     clk = log[:envs, 0].astype(np.float64)
     til = log[:envs, 1].astype(np.float64)
     stp = log[:envs, 2].astype(np.float64)
