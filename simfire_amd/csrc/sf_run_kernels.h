@@ -53,7 +53,7 @@ constexpr int kStripDw = 19;       // dwords per lane in a wave's strip buffer: 
 #else
 #define ELIG(x) elig01_perm(x)      // status bytes in the cell plane are 0..5, nothing else (BurnStatus)
 #endif
-constexpr int kRunCtl = 16;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps)
+constexpr int kRunCtl = 24;        // control words: [0..2] list length, [3..5] predicate bytes, [6..8] batch cursor (rings of 3 steps), [17..19] the closed loop's (go, done number, doorbell)
 constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row): k_run<4>; k_run<1> for one row of one word
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -66,6 +66,8 @@ __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int v
     const int rows = team && team_rcap ? team_rcap + 2 : g.H;
     size_t b = (size_t)maps * rows * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (64 * kStripDw * 4) + kRunCtl * 4;
     if (team) b += (size_t)2 * g.PV * 16 + 64 * 4;         // halo rows of sprite masks [2][PV] uint4, tile-row counts of the split
+    // (LDS comes in granules of 1 280 bytes on gfx950, requests are rounded up - profiles/lds_granule_probe.hip; words behind the
+    // request are only there by that luck: out-of-range LDS stores are dropped and loads give 0, silently)
 #ifdef SF_PHASES
     b += 16 * 16 * 4;              // + phase clocks [waves][16]
 #endif

@@ -166,7 +166,7 @@ struct sf_sim {
     bool loop_on = false;
     int loop_k = 0;                    // points per environment and step
     uint32_t loop_seq = 0;             // sequence number of the last step posted
-    uint32_t *loop_db = nullptr, *loop_db_dev = nullptr;         // (pinned, device-mapped) [0] doorbell, [16 ...] "done" numbers [E] (other cache lines)
+    uint32_t *loop_db = nullptr, *loop_db_dev = nullptr;         // (pinned, device-mapped) [0] doorbell, [64 ...] "done" numbers [E] (other cache lines)
     int32_t *loop_res = nullptr, *loop_res_dev = nullptr;        // int32 [E][8] + double [E] (pinned, device-mapped)
     int32_t *loop_pts = nullptr, *loop_pts_dev = nullptr;        // [2][slot] points ring (pinned, device-mapped)
     size_t loop_pts_cap = 0, loop_slot_ints = 0;
@@ -1629,7 +1629,7 @@ static int loop_launch(sf_sim *s)
     a.mit = s->loop_pts_mem; a.mit_k = s->loop_k;
     a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink;
     a.cost = s->run_cost;
-    a.loop_db = s->loop_db_dev; a.loop_pts_host = s->loop_pts_dev; a.loop_done_host = s->loop_db_dev + 16; a.loop_res_host = s->loop_res_dev;
+    a.loop_db = s->loop_db_dev; a.loop_pts_host = s->loop_pts_dev; a.loop_done_host = s->loop_db_dev + 64; a.loop_res_host = s->loop_res_dev;
     a.loop_seq = s->loop_mem; a.loop_done = s->loop_mem + 32; a.loop_pts = s->loop_pts_mem;
     a.loop_timeout = 400000000ull;             // ~0.2 s without a ring: the workgroups leave, the next sf_loop_step starts them again
     HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t), s->stream));       // nothing forwarded yet (the word may hold the stop of the launch before)
@@ -1667,13 +1667,13 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
     { int rc0 = ensure_vbits(s); if (rc0) return rc0; }
     { int rc0 = ensure_bl(s); if (rc0) return rc0; }
     auto pin = [&](void **host, void **dev, size_t bytes) -> int {
-        HIPCHK(hipHostMalloc(host, bytes, hipHostMallocMapped));
+        HIPCHK(hipHostMalloc(host, bytes, hipHostMallocMapped | hipHostMallocCoherent));      // fine-grained: no GPU cache may hold these lines
         HIPCHK(hipHostGetDevicePointer(dev, *host, 0));
         memset(*host, 0, bytes);
         return SF_OK;
     };
     if (!s->loop_db) {
-        int rc = pin((void **)&s->loop_db, (void **)&s->loop_db_dev, sizeof(uint32_t) * (16 + (size_t)g.E)); if (rc) return rc;
+        int rc = pin((void **)&s->loop_db, (void **)&s->loop_db_dev, sizeof(uint32_t) * (64 + (size_t)g.E)); if (rc) return rc;
         rc = pin((void **)&s->loop_res, (void **)&s->loop_res_dev, (sizeof(int32_t) * 8 + sizeof(double)) * g.E); if (rc) return rc;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->loop_mem), sizeof(uint32_t) * (32 + (size_t)g.E)));
     }
@@ -1689,7 +1689,7 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
     }
     s->loop_k = k; s->loop_seq = 0; s->loop_restarts = 0;
     volatile uint32_t *db = s->loop_db;
-    for (int i = 0; i < 16 + g.E; ++i) db[i] = 0;
+    for (int i = 0; i < 64 + g.E; ++i) db[i] = 0;
     __sync_synchronize();
     HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t) * (32 + (size_t)g.E), s->stream));
     HIPCHK(hipMemsetAsync(s->loop_pts_mem, 0, pts_bytes, s->stream));
@@ -1727,11 +1727,11 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
     // workgroup resumes from its own "done" number, the points of this step are still in their slot
     int e = 0;
     for (unsigned long long spins = 0;; ++spins) {
-        while (e < g.E && db[16 + e] == seq) ++e;
+        while (e < g.E && db[64 + e] == seq) ++e;
         if (e == g.E) break;
         if ((spins & 0x3FFF) == 0x3FFF && hipStreamQuery(s->stream) == hipSuccess) {
             bool all = true;
-            for (int q = 0; q < g.E; ++q) all = all && db[16 + q] == seq;
+            for (int q = 0; q < g.E; ++q) all = all && db[64 + q] == seq;
             if (all) break;
             if (s->xerr_pinned && *s->xerr_pinned) return fail(SF_EHIP, "sf_loop_step: the resident launch failed");
             HIPCHK(hipSetDevice(s->p.device));

@@ -29,6 +29,8 @@ def world(seed):
     xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
     eng, o = FireEngine(experimental=True, **kw), fire_dense.DenseOracle(**kw)      # cross-check build: launch structures 3 / 4 are in the draw
     eng.set_fused(int(rng.integers(-1, 5)))            # automatic, two launches, fused, resident (k_run), resident tiles
+    # teams (k_run<TEAM>): never / cost-sized / every environment split in 2 .. 4; members on one XCD, spread, written through
+    eng.set_tuning(run_team=int(rng.choice([0, 0, 1, -1, 2, 3, 4])), team_placement=int(rng.integers(3)))
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
@@ -68,12 +70,36 @@ def world(seed):
             eng.set_generic(bool(rng.integers(2)))
         elif r < 0.56:
             eng.set_fused(int(rng.integers(-1, 5)))        # hand-over between the launch structures mid-run
+            eng.set_tuning(run_team=int(rng.choice([0, 1, -1, 2, 3, 4])), team_placement=int(rng.integers(3)))
         elif r < 0.59:
             e = int(rng.integers(E))       # burn_amounts round trip: settles whatever is owed, must change nothing
             b = eng.burn(e)
             assert (b == o.burn(e)).all(), (seed, t, e, "burn before round trip")
             eng.set_burn(e, b)
         n = int(rng.choice([1, 1, 1, 2, 5, 17]))
+        if rng.random() < 0.06 and md <= 5:
+            # the closed loop (sf_loop_*): n calls of update_mitigation(points) + run(1) on a launch that stays resident
+            K = int(rng.choice([0, 2, 9, 64]))
+            try:
+                eng.loop_start(K)
+            except NotImplementedError:
+                K = -1                                      # (spread graph / generic kernel forced ...: not offered)
+            if K >= 0:
+                for s_ in range(n):
+                    pts = np.column_stack([rng.integers(-1, W + 1, E * max(K, 1)), rng.integers(-1, H + 1, E * max(K, 1)),
+                                           rng.integers(2, 7, E * max(K, 1))]).astype(np.int32).reshape(E, max(K, 1), 3)[:, :K]
+                    if os.environ.get("SOAK_DEBUG"):
+                        print("loop_step", "t", t, "s_", s_, "of", n, "K", K, "restarts", eng.loop_restarts(), flush=True)
+                    st, el = eng.loop_step(pts if K else None)
+                    rows = [(e, int(p[0]), int(p[1]), int(p[2])) for e in range(E) for p in pts[e]
+                            if 3 <= p[2] <= 5 and 0 <= p[0] < W and 0 <= p[1] < H]
+                    if rows:
+                        o.apply_mitigation(rows)
+                    o.step(1)
+                    so, eo = o.status()
+                    assert (st == so).all() and (el == eo).all(), (seed, t, s_, "loop status")
+                eng.loop_stop()
+                continue
         if rng.random() < 0.15:
             # sf_step_mitigated: n (control lines, update) pairs in one call; up to 64 points per environment and step go
             # through one wave of the resident launch, more through the workgroup; duplicates, neighbouring bytes of a
