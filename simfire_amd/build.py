@@ -5,7 +5,8 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["simfire_hip.hip"]
+# two translation units, compiled side by side (the second holds the k_run instantiations only some handles launch)
+SOURCES = ["simfire_hip.hip", "simfire_hip_run2.hip"]
 OUT = os.path.join(CSRC, "libsimfire_hip.so")
 # builds of the same sources that only tests load (simfire_amd/_lib.py: VARIANTS)
 VARIANT_FLAGS = {"exp": ["-DSF_EXPERIMENTAL"], "sow": ["-DSF_STORE_ORDER_WAIT"]}
@@ -22,9 +23,15 @@ def needs_build(out=OUT):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _cmd(out, extra=()):
+def _compile_cmds(out, extra=()):
+    """One `hipcc -c` per translation unit + the link."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    return [hipcc] + FLAGS + list(extra) + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    tag = os.path.splitext(os.path.basename(out))[0]
+    objs = [os.path.join(CSRC, f".{tag}.{os.path.splitext(src)[0]}.o") for src in SOURCES]
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    compiles = [[hipcc] + compile_flags + list(extra) + ["-c", "-o", obj, os.path.join(CSRC, src)] for src, obj in zip(SOURCES, objs)]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    return compiles, link, objs
 
 
 def variant_out(v):
@@ -33,21 +40,29 @@ def variant_out(v):
 
 
 def build(force=False, verbose=False, variants=()):
-    """Product library + the named test-only variants (the compiles run side by side)."""
-    jobs = []
+    """Product library + the named test-only variants (all compiles run side by side, then the links)."""
+    targets = []
     if force or needs_build(OUT):
-        jobs.append(_cmd(OUT))
+        targets.append((OUT, ()))
     for v in variants:
         if force or needs_build(variant_out(v)):
-            jobs.append(_cmd(variant_out(v), VARIANT_FLAGS[v]))
+            targets.append((variant_out(v), VARIANT_FLAGS[v]))
+    plans = [_compile_cmds(out, extra) for out, extra in targets]
     procs = []
-    for cmd in jobs:
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
+    for compiles, _, _ in plans:
+        for cmd in compiles:
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    for _, link, objs in plans:
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
+        for o in objs:
+            os.remove(o)
     return OUT
 
 

@@ -47,6 +47,7 @@ namespace {
 // The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
 // them when it switches back), the vector bitmaps are not maintained there (k_rebuild_vbits).
 // ------------------------------------------------------------------------------------------
+constexpr int kMarkDw = 32;       // per wave: owner markers of one walk pass, a byte per frontier cell (128), behind its strip buffer
 constexpr int kStripDw = 19;       // dwords per lane in a wave's strip buffer: header + 3 rows x (left cell, 16 cells, right cell); odd: no bank conflicts
 #ifdef SF_NO_PERM_ELIG
 #define ELIG(x) elig01(x)
@@ -64,7 +65,7 @@ __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int v
 {
     const int maps = (team || g.VW == 1) ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
     const int rows = team && team_rcap ? team_rcap + 2 : g.H;
-    size_t b = (size_t)maps * rows * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * (64 * kStripDw * 4) + kRunCtl * 4;
+    size_t b = (size_t)maps * rows * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * ((64 * kStripDw + kMarkDw) * 4) + kRunCtl * 4;
     if (team) b += (size_t)2 * g.PV * 16 + 64 * 4;         // halo rows of sprite masks [2][PV] uint4, tile-row counts of the split
     // (LDS comes in granules of 1 280 bytes on gfx950, requests are rounded up - profiles/lds_granule_probe.hip; words behind the
     // request are only there by that luck: out-of-range LDS stores are dropped and loads give 0, silently)
@@ -86,9 +87,11 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
 
 // The walk: frontier cells of a batch, one (or two) per lane and pass.  There is no list: walker j finds its cell itself.
 // excl = frontier cells in the lanes below (exclusive prefix sum over the batch), w16 = the lane's 16-bit frontier mask | its
-// control-line cells << 16, s7 = its status row after the prune.  The owner of item j is the last lane with excl <= j (binary
-// search: three scalars, then four cross-lane reads), the cell is the (j - excl)-th set bit of the owner's mask.  (A per-lane loop over the set bits
-// into an LDS list cost 2 - 5 k clocks per batch along horizontal fronts; the search costs the same whatever the front looks like.)
+// control-line cells << 16, s7 = its status row after the prune.  The owner of item j is the last lane with excl <= j: the lanes that own
+// cells put their lane number at the rank of their first cell into 128 LDS bytes of the wave (cleared first), and the owner of j is the prefix MAXIMUM
+// up to j (one LDS write, one read, a DPP scan; round 2 searched the prefix sums with six dependent cross-lane reads per cell: -1 ... 2 %);
+// the cell is the (j - excl)-th set bit of the owner's mask.  (A per-lane loop over the set bits into an LDS list cost 2 - 5 k clocks per
+// batch along horizontal fronts; this costs the same whatever the front looks like.)
 // The 3 x 3 sprite masks come from the batch's strip buffer in LDS (the rows the vector pass has just loaded, with the cell left /
 // right of the vector): no memory round trip before the winner is known.
 struct WalkCell {
@@ -107,21 +110,13 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 {
     const Geo &g = a.g;
     WalkAcc acc = {0u, 0u, 0u, 0u};
-    const uint32_t e16 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 16), e32 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 32),
-                   e48 = (uint32_t)__builtin_amdgcn_readlane((int)excl, 48);
     // first half of a cell: who, winner source, operands requested
-    auto front = [&](uint32_t j) {
+    auto front = [&](uint32_t j, int own) {
         WalkCell c;
         const bool valid = j < pend;
-        // (the first two levels of the search against three scalars: lanes 16 / 32 / 48 of the prefix sums)
-        int jl = j >= e32 ? (j >= e48 ? 48 : 32) : (j >= e16 ? 16 : 0);
-        uint32_t base = j >= e32 ? (j >= e48 ? e48 : e32) : (j >= e16 ? e16 : 0u);
-#pragma unroll
-        for (int step = 8; step >= 1; step >>= 1) {
-            const int t = jl + step;
-            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(t << 2, (int)excl);
-            if (v <= j) { jl = t; base = v; }
-        }
+        // the owner lane comes from the pass's markers (below): its rank and mask by two independent cross-lane reads
+        const int jl = own;
+        const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)excl);
         const uint32_t wl = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)w16);
         int b = 0;
         {
@@ -214,28 +209,38 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
         }
         acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
     };
-#ifndef SF_WALK1
     // two cells per lane and pass: a second pass would be a second memory round trip behind the first
     for (uint32_t j0 = 0; j0 < pend; j0 += 128) {
         const bool two = j0 + 64 < pend;                   // (uniform)
-        WalkCell c0 = front(j0 + (uint32_t)lane), c1;
+        int own0 = 0, own1 = 0;
+        {
+            // Who owns frontier cell j of this pass?  The lanes that own any put their number (+ 1) at the rank of their first cell of the
+            // pass; the owner of j is the prefix maximum up to j.  Two LDS writes, one read, a DPP scan - instead of six dependent
+            // cross-lane reads per cell.
+            uint8_t *marks = reinterpret_cast<uint8_t *>(const_cast<uint32_t *>(strips) + 64 * kStripDw);
+            reinterpret_cast<uint16_t *>(marks)[lane] = 0;            // (the wave's LDS instructions execute in order: cleared before marked)
+            const uint32_t mine_n = (uint32_t)__popc(w16 & 0xFFFFu);
+            if (mine_n && excl < j0 + 128u && excl + mine_n > j0) marks[excl < j0 ? 0u : excl - j0] = (uint8_t)(lane + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t m0 = wave_scan_max(marks[lane]);
+            own0 = (int)((m0 - 1u) & 63u);
+            if (two) {
+                const uint32_t carry = wave_last(m0);
+                const uint32_t m1 = wave_scan_max(marks[64 + lane]);
+                own1 = (int)(((m1 > carry ? m1 : carry) - 1u) & 63u);
+            }
+        }
+        WalkCell c0 = front(j0 + (uint32_t)lane, own0), c1;
         c1.cand = false; c1.yx = 0; c1.own_spost = 0; c1.owed = 0; c1.bn = 0.0; c1.r_tab = 0.0;
-        if (two) c1 = front(j0 + 64u + (uint32_t)lane);
+        if (two) c1 = front(j0 + 64u + (uint32_t)lane, own1);
         pc.mark(7);          // cells found, winners, operands requested
         asm volatile("" : "+v"(c0.bn), "+v"(c0.r_tab), "+v"(c0.owed), "+v"(c1.bn), "+v"(c1.r_tab), "+v"(c1.owed));
         back(c0);
         if (two) back(c1);
         pc.mark(8);          // burn / table entries arrived, updates, ignition stores issued
     }
-#else
-    for (uint32_t j0 = 0; j0 < pend; j0 += 64) {
-        WalkCell c0 = front(j0 + (uint32_t)lane);
-        pc.mark(7);          // cell found, winner, operands requested
-        asm volatile("" : "+v"(c0.bn), "+v"(c0.r_tab), "+v"(c0.owed));     // keeps the loads from being sunk behind the first use of bn
-        back(c0);
-        pc.mark(8);          // burn / table entry arrived, update, ignition stores issued
-    }
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const int lds_rows = TEAM && a.team_rcap ? a.team_rcap + 2 : g.H;              // bitmap rows kept in LDS
     unsigned long long *vb0 = reinterpret_cast<unsigned long long *>(s_dyn);       // [lds_rows][VW] x 4 (fine) or x 1
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb0 + (size_t)(fine ? 4 : 1) * lds_rows * VW);       // [vcap]
-    uint32_t *strips = vlist + vcap + wave * (64 * kStripDw);                      // [64][kStripDw] per wave
-    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw);
+    uint32_t *strips = vlist + vcap + wave * (64 * kStripDw + kMarkDw);           // [64][kStripDw] per wave (+ the walk's owner markers)
+    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw + kMarkDw);
 #ifdef SF_PHASES
     uint4 *halo = reinterpret_cast<uint4 *>(ctl + kRunCtl + 16 * 16);              // (behind the phase clocks)
 #else
@@ -737,10 +742,14 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             // works on the current one: the walk's memory round trips hide the next batch's.  (Reading a neighbour
             // vector before or after the current batch rewrites it makes no difference: in-place update, see above.)
             struct VecIn { uint32_t item; uint4 up, mid, dn, sr; uint32_t l0, l1, l2, r0, r1, r2; };
+            // (a young fire's one or two batches: wave w takes batch w, no round trip to the cursor on the way - driver window - 3 %; longer
+            // lists are handed out by the cursor from the start: dealing the first round out by wave number cost C4 and the 1024-environment
+            // batch 5 - 8 %)
+            const bool dealt = n_waves == 16 && n_chunk <= 2u * (uint32_t)bsz;      // (16 waves = alone on its CU: with two workgroups per CU "always wave 0" means both on one SIMD)
             auto grab = [&]() {
                 uint32_t j = 0;
                 if (lane == 0) j = atomicAdd(&ctl[6 + k], (uint32_t)bsz);
-                return (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)j) + (dealt ? (uint32_t)(n_waves * bsz) : 0u);
             };
             auto fetch = [&](uint32_t j0, VecIn &in) {
                 const bool has = lane < bsz && j0 + lane < n_chunk;
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     }
                 }
             };
-            uint32_t j_next = grab();
+            uint32_t j_next = dealt ? (uint32_t)(wave * bsz) : grab();
             VecIn nxt;
             if (j_next < n_chunk) fetch(j_next, nxt);
             while (j_next < n_chunk) {

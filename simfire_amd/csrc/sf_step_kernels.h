@@ -155,6 +155,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int /*lane*/)
     return v;
 }
 __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+// inclusive prefix MAXIMUM over the 64 lanes (unsigned; same DPP steps: lanes shifted in from outside a row read 0)
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));    // row_shr:1
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));    // row_shr:2
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));    // row_shr:4
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));    // row_shr:8
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
 
 // Winner source of a destination cell from its 3 x 3 neighbourhood (bytes 0..2 of
 // up3 / mid3 / dn3 = cells x-1, x, x+1 of the rows y-1, y, y+1), byte-parallel: the 8 neighbour masks are

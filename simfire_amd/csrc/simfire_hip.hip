@@ -207,6 +207,11 @@ struct sf_sim {
 
 static int ensure_commit(sf_sim *s);
 extern "C" int sf_loop_stop(sf_sim *s);
+// simfire_hip_run2.hip: the launches of the team and closed-loop instantiations of k_run (StepArgs crosses as bytes)
+hipError_t sf_run2_launch_team(int which, int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                               const void *args, size_t args_bytes, int n_steps, int vcap);
+hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                               const void *args, size_t args_bytes, int vcap);
 // every entry point except sf_loop_step ends the closed loop (sf_loop_start) first: the handle's stream is busy with the resident launch
 #define LOOP_QUIESCE(s) do { if ((s)->loop_on) { int _rq = sf_loop_stop(s); if (_rq) return _rq; } } while (0)
 static int ensure_rm(sf_sim *s);
@@ -1062,19 +1067,20 @@ constexpr int SF_INTERNAL_NO_RESIDENT = 1;       // step_impl: the resident laun
 static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, int vcap, size_t lds, int bsz)
 {
     const int need = ((s->g.H + waves * 64 - 1) / (waves * 64)) * s->g.VW;
-    const int which = need <= 1 ? 0 : 1;       // (an instantiation for two words was not measurably faster than the one for four)
+    const int which = need <= 1 ? 0 : (need <= 2 ? 1 : 2);      // (two words per thread = 1024 rows in 8 waves: the many-environments regime; the kernel for four spills there, +7 %)
     typedef void (*run_fn)(StepArgs, int, int, int);
     // [words per thread 1 / 2 / 4][attenuation off / on][diagonal spread read at run time / known to be on]; control lines inside
     // the launch: one word per thread has an instantiation without them (MIT = 0), the others look at the argument
     // (specialised for diagonal spread known to be on - every reference config - where it is worth the compile time: one word per thread)
-    static const run_fn table[2][2][2] = {
+    static const run_fn table[3][2][2] = {
         {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, -1>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, -1>}},
+        {{k_run<2, 0, -1, -1>, k_run<2, 0, 1, -1>}, {k_run<2, 1, -1, -1>, k_run<2, 1, 1, -1>}},
         {{k_run<kRunMaxD, 0, -1, -1>, k_run<kRunMaxD, 0, -1, -1>}, {k_run<kRunMaxD, 1, -1, -1>, k_run<kRunMaxD, 1, -1, -1>}}};
     static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, 0>}};
     const int ia = s->g.att ? 1 : 0, id = s->g.diag ? 1 : 0;
     const bool nomit = which == 0 && !a.mit;
     const run_fn kern = nomit ? table_nomit[ia][id] : table[which][ia][id];
-    size_t &attr = s->attr_run[nomit ? 12 + ia * 2 + id : (which * 2 + ia) * 2 + id];
+    size_t &attr = s->attr_run[nomit ? 12 + ia * 2 + id : (which == 2 ? 20 + ia : (which * 2 + ia) * 2 + id)];
     if (lds > 64 * 1024 && lds > attr) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
@@ -1147,19 +1153,15 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int place = s->tune.v[SF_TUNE_TEAM_PLACEMENT];
     a.team_far = place == 2;
     a.order = nullptr;
-    typedef void (*run_fn)(StepArgs, int, int, int);
-    // [words per thread 1 / more][attenuation off / on]; diagonal spread and control lines inside the launch are looked up at run time
-    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1, 1>, k_run<1, 1, -1, -1, 1>}, {k_run<2, 0, -1, -1, 1>, k_run<2, 1, -1, -1, 1>}};
+    // (the team kernels are instantiated in the library's second translation unit, simfire_hip_run2.hip: [words per thread 1 / 2]
+    // [attenuation off / on]; diagonal spread and control lines inside the launch are looked up at run time)
     const int rows = t.rcap ? t.rcap : g.H;
     const int need = ((rows + t.waves * 64 - 1) / (t.waves * 64)) * g.VW;
     const int which = need <= 1 ? 0 : 1, ia = g.att ? 1 : 0;
-    const run_fn kern = table[which][ia];
     size_t &attr = s->attr_run[8 + which * 2 + ia];
-    if (t.lds > 64 * 1024 && t.lds > attr) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds));
-        attr = t.lds;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)t.slots), dim3((unsigned)t.waves * 64), t.lds, s->stream, a, n_steps, t.vcap, 64);
+    const bool set_lds = t.lds > 64 * 1024 && t.lds > attr;
+    HIPCHK(sf_run2_launch_team(which, ia, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
+    if (set_lds) attr = t.lds;
     return SF_OK;
 }
 
@@ -1638,15 +1640,11 @@ static int loop_launch(sf_sim *s)
     int vcap = 4096;
     if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
     const size_t lds = run_lds_bytes(g, nw, vcap);
-    typedef void (*run_fn)(StepArgs, int, int, int);
-    static const run_fn loop_table[2][2] = {{k_run<1, 0, -1, -2>, k_run<1, 0, 1, -2>}, {k_run<1, 1, -1, -2>, k_run<1, 1, 1, -2>}};       // (the closed loop's own instantiations)
-    const run_fn kern = loop_table[g.att ? 1 : 0][g.diag ? 1 : 0];
+    // (the closed loop's own instantiations of k_run live in simfire_hip_run2.hip)
     size_t &attr = s->attr_run[16 + (g.att ? 2 : 0) + (g.diag ? 1 : 0)];
-    if (lds > 64 * 1024 && lds > attr) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)g.E), dim3((unsigned)nw * 64), lds, s->stream, a, 0x7FFFFFFF, vcap, 64);
+    const bool set_lds = lds > 64 * 1024 && lds > attr;
+    HIPCHK(sf_run2_launch_loop(g.att ? 1 : 0, g.diag ? 1 : 0, (unsigned)g.E, (unsigned)nw * 64, lds, set_lds, s->stream, &a, sizeof a, vcap));
+    if (set_lds) attr = lds;
     return SF_OK;
 }
 

@@ -1,0 +1,53 @@
+// Second translation unit of libsimfire_hip.so: the instantiations of k_run that only some handles ever launch - the team launch
+// (k_run<TEAM = 1>) and the closed loop (k_run<MIT = -2>) - compiled beside simfire_hip.hip so that the library builds in the time of
+// the larger of the two (python -m simfire_amd.build runs the two compiles side by side).  Everything it shares with the first unit
+// comes from the same headers (all in anonymous namespaces: each unit has its own copy of the device helpers); the launch arguments
+// cross the boundary as bytes.
+// Replaces (like sf_run_kernels.h): n calls of RothermelFireManager.update per environment, simfire/game/managers/fire.py:616-719.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/simfire_hip.h"
+#include "sf_common.h"
+#include "sf_step_kernels.h"
+#include "sf_aux_kernels.h"
+#include "sf_run_kernels.h"
+
+namespace {
+typedef void (*run_fn)(StepArgs, int, int, int);
+}
+
+// which: 0 / 1 = one / two bitmap words per thread; att: attenuate_line_ros.  set_lds: raise the kernel's dynamic-LDS limit first.
+hipError_t sf_run2_launch_team(int which, int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                               const void *args, size_t args_bytes, int n_steps, int vcap)
+{
+    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1, 1>, k_run<1, 1, -1, -1, 1>}, {k_run<2, 0, -1, -1, 1>, k_run<2, 1, -1, -1, 1>}};
+    if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
+    StepArgs a;
+    memcpy(&a, args, sizeof a);
+    const run_fn kern = table[which ? 1 : 0][att ? 1 : 0];
+    if (set_lds) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, n_steps, vcap, 64);
+    return hipSuccess;
+}
+
+// the closed loop of sf_loop_start: one workgroup per environment, steps until the host's stop
+hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                               const void *args, size_t args_bytes, int vcap)
+{
+    static const run_fn table[2][2] = {{k_run<1, 0, -1, -2>, k_run<1, 0, 1, -2>}, {k_run<1, 1, -1, -2>, k_run<1, 1, 1, -2>}};
+    if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
+    StepArgs a;
+    memcpy(&a, args, sizeof a);
+    const run_fn kern = table[att ? 1 : 0][diag ? 1 : 0];
+    if (set_lds) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, 0x7FFFFFFF, vcap, 64);
+    return hipSuccess;
+}
