@@ -1171,12 +1171,17 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
 // runs on XCD b mod 8 (observed; speed only), so the members of a team get slots of one residue class - their per-step exchange
 // then stays in one L2 - unless a class is full, in which case the teams simply take consecutive slots (placement never matters
 // for results).  t_min / t_max bound the sizes (forced teams: t_min = t_max; rows too wide for one member: t_min = 2).
-__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, int scatter, const uint32_t *cost, uint32_t *tab, uint32_t *tsize)
+// It also clears what the launch behind it counts in (three fill launches less per 64-step segment: they cost 20 us each): the members'
+// granules (epochs restart with every launch), the "members that have left" counters and - unless keep_cost - the cost array it has just read.
+__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, int scatter, uint32_t *cost, uint32_t *tab, uint32_t *tsize,
+                                                    unsigned long long *xg, uint32_t *xdone, int keep_cost)
 {
     __shared__ uint32_t s_T[1024], s_sum, s_cls[8], s_over;
     const int t = threadIdx.x;
     for (int i = t; i < G; i += 1024) tab[i] = kTeamUnused;
     const uint32_t c = t < E ? cost[t] : 0u;
+    for (int i = t; i < E * kTeamMax * 3; i += 1024) xg[i] = 0ull;
+    if (t < E) { xdone[t] = 0u; if (!keep_cost) cost[t] = 0u; }
     auto need = [&](uint32_t tgt) -> uint32_t {
         if (t >= E) return 0u;
         if (c <= tgt || t_max <= 1) return (uint32_t)t_min;

@@ -1140,12 +1140,10 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     }
     // what a member pays per step for belonging to a team (publish, wait for the slowest member, read: ~7 k clocks measured), in the unit of the cost array
     const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 7000 / 16);
+    // (the plan also clears the granules, the "left" counters and the cost array it has read: the members add their clocks)
     hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0,
-                       (const uint32_t *)s->run_cost, s->team_tab, s->team_size);
-    if (!keep_cost) HIPCHK(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));      // (the members add their clocks)
+                       s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, keep_cost ? 1 : 0);
     a.cost = keep_cost ? nullptr : s->run_cost;
-    HIPCHK(hipMemsetAsync(s->xg, 0, (size_t)g.E * kTeamMax * 3 * sizeof(unsigned long long), s->stream));     // epochs restart with every launch
-    HIPCHK(hipMemsetAsync(s->xdone, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
     a.xrow = team_xrow(g); a.team_rcap = t.rcap;
     // placement of the members: 0 (default) = the slots of one XCD, 1 = consecutive slots (eight XCDs in turn), 2 = as 0 but the
@@ -1388,7 +1386,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         s->last_team_max = 0;
         for (int done = 0; done < n_steps;) {
             int seg = balance && n_steps - done > seg_knob + seg_knob / 2 ? seg_knob : n_steps - done;
-            if (team_segments && n_steps - done > seg_knob + seg_knob / 2) seg = seg_knob;
+            // (two-word rows: twice the segment - every launch costs a plan, a prologue that reads the environment's whole bitmap and an
+            // epilogue; measured on C4's share: 64 / 128 / 256 steps per launch = 26.3 / 26.1 / 26.8 us per step - the cuts have to follow the fires)
+            const int tseg = team_wide && !team_forced ? 2 * seg_knob : seg_knob;
+            if (team_segments && n_steps - done > tseg + tseg / 2) seg = tseg;
             const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
                 hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
