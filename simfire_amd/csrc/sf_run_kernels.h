@@ -58,6 +58,7 @@ constexpr int kRunCtl = 24;        // control words: [0..2] list length, [3..5] 
 constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers (rows per thread x words per row): k_run<4>; k_run<1> for one row of one word
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (the nontemporal builtins take native vectors, not HIP's uint4 struct)
 
 // team: 0 = k_run<TEAM = 0> (a workgroup holds the bitmaps of the whole grid); 1 = k_run<TEAM = 1>: all four bitmaps whatever the
 // row width, for team_rcap + 2 rows (team_rcap = 0: the whole grid), + the two halo rows of sprite masks.
@@ -504,12 +505,28 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     const int n16 = loop_slot_ints / 4;                        // the slot in 16-byte pieces
                     const size_t off = (size_t)((lseq + 1u) & 1u) * (size_t)n16 * 2;       // in 8-byte words
                     typedef unsigned long long u64;
-                    // (system-scope loads, 8 bytes each: wide plain / nontemporal loads of the host's ring were measured to return the
-                    // slot's contents of two steps before now and then, and made the step no faster)
-                    const u64 *src = reinterpret_cast<const u64 *>(a.loop_pts_host) + off;
+                    // 16 bytes per lane with SYSTEM-scope loads (sc0 sc1: no cache may answer; plain and nontemporal 16-byte loads of the ring
+                    // were measured to return a slot's contents of two steps earlier now and then).  There is no 16-byte atomic load in
+                    // HIP: inline assembly, four loads in flight per lane, one wait.
+                    const u32x4 *src = reinterpret_cast<const u32x4 *>(reinterpret_cast<const u64 *>(a.loop_pts_host) + off);
                     u64 *dstp = reinterpret_cast<u64 *>(a.loop_pts) + off;
-                    for (int i = tid; i < n16 * 2; i += nthr)
-                        __hip_atomic_store(dstp + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i0 = tid; i0 < n16; i0 += 4 * nthr) {
+                        u32x4 v[4] = {};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = i0 + q * nthr;
+                            if (i < n16) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q]) : "v"(src + i) : "memory");
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = i0 + q * nthr;
+                            if (i < n16) {
+                                __hip_atomic_store(dstp + 2 * i, (u64)v[q].x | ((u64)v[q].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(dstp + 2 * i + 1, (u64)v[q].z | ((u64)v[q].w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
