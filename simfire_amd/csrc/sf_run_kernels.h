@@ -1190,7 +1190,10 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
 // for results).  t_min / t_max bound the sizes (forced teams: t_min = t_max; rows too wide for one member: t_min = 2).
 // It also clears what the launch behind it counts in (three fill launches less per 64-step segment: they cost 20 us each): the members'
 // granules (epochs restart with every launch), the "members that have left" counters and - unless keep_cost - the cost array it has just read.
-__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, int scatter, uint32_t *cost, uint32_t *tab, uint32_t *tsize,
+// What a member of a team of T costs: max(floor, cost / T) + ovh - a step is a latency chain that does not get shorter than `floor`
+// however few rows a member has (measured: ~12 k clocks), and belonging to a team costs `ovh` per step (~6.5 k clocks: publish, wait
+// for the slowest member, read).  An environment is split only where that beats its cost in one workgroup.
+__global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, uint32_t floor_c, int scatter, uint32_t *cost, uint32_t *tab, uint32_t *tsize,
                                                     unsigned long long *xg, uint32_t *xdone, int keep_cost)
 {
     __shared__ uint32_t s_T[1024], s_sum, s_cls[8], s_over;
@@ -1199,12 +1202,17 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
     const uint32_t c = t < E ? cost[t] : 0u;
     for (int i = t; i < E * kTeamMax * 3; i += 1024) xg[i] = 0ull;
     if (t < E) { xdone[t] = 0u; if (!keep_cost) cost[t] = 0u; }
+    auto member = [&](int T) -> uint32_t { const uint32_t share = c / (uint32_t)T; return T <= 1 ? c : (share > floor_c ? share : floor_c) + ovh; };
     auto need = [&](uint32_t tgt) -> uint32_t {
         if (t >= E) return 0u;
-        if (c <= tgt || t_max <= 1) return (uint32_t)t_min;
-        for (int T = t_min > 2 ? t_min : 2; T < t_max; ++T)
-            if (c / (uint32_t)T + ovh <= tgt) return (uint32_t)T;
-        return (uint32_t)t_max;
+        if (t_min >= t_max) return (uint32_t)t_min;
+        // the smallest team that brings the environment under the target; if none does, the team in which it is cheapest
+        int best = t_min;
+        for (int T = t_min; T <= t_max; ++T) {
+            if (member(T) <= tgt) return (uint32_t)T;
+            if (member(T) < member(best)) best = T;
+        }
+        return (uint32_t)best;
     };
     auto total = [&](uint32_t v) -> uint32_t {
         __syncthreads();

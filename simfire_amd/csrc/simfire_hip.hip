@@ -1099,8 +1099,10 @@ static TeamGeo team_geometry(const sf_sim *s)
     const int th = g.LR * g.RB;
     if (g.ab != 1 || g.VW > 2 || g.TY > 64 || g.E > 1024 || g.dense) return t;       // (k_team_plan: one thread per environment; the split: one lane per tile row)
     if (g.VW == 1) {
-        // rows of one word: every member keeps the whole grid's bitmaps; 8 waves, two workgroups per CU
-        t.waves = 8; t.vcap = 1024; t.rcap = 0; t.t_min = 1;
+        // rows of one word: every member keeps the whole grid's bitmaps.  Few environments (at most half as many as CUs: C5's 64): members
+        // of 16 waves, one workgroup per CU - the CUs a team takes would idle otherwise; more: 8 waves, two workgroups per CU
+        const bool roomy = g.E * 2 <= s->n_cu && g.H <= 16 * 64;
+        t.waves = roomy ? 16 : 8; t.vcap = roomy ? 4096 : 1024; t.rcap = 0; t.t_min = 1;
         if ((g.H + t.waves * 64 - 1) / (t.waves * 64) * g.VW > 2) return t;       // (k_run<TEAM> is instantiated for 1 and 2 bitmap words per thread)
     } else {
         // rows of two words (2048-wide grids): a member keeps a window of rows; 16 waves, one workgroup per CU
@@ -1138,10 +1140,12 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
         *s->xerr_pinned = 0;
         HIPCHK(hipMemsetAsync(s->xbuf, 0, (size_t)g.E * kTeamMax * 4 * team_xrow(g), s->stream));
     }
-    // what a member pays per step for belonging to a team (publish, wait for the slowest member, read: ~7 k clocks measured), in the unit of the cost array
-    const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 7000 / 16);
+    // what a member pays per step for belonging to a team (publish, wait for the slowest member, read: ~6.5 k clocks measured) and the
+    // latency chain no member's step gets shorter than (~12 k clocks), in the unit of the cost array
+    const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 6500 / 16);
+    const uint32_t floor_c = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 12000 / 16);
     // (the plan also clears the granules, the "left" counters and the cost array it has read: the members add their clocks)
-    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0,
+    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, floor_c, s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0,
                        s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, keep_cost ? 1 : 0);
     a.cost = keep_cost ? nullptr : s->run_cost;
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
@@ -1253,7 +1257,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // shorter with half the rows, and a team's step boundary costs 5 - 10 k clocks (publish, wait for the slowest member, read), so
         // teams of 8-wave members lose to one 16-wave workgroup per environment until a fire is far larger than these get (C3: 11.0 ->
         // 15.0 us per step with teams sized by cost).  sf_set_tuning(SF_TUNE_RUN_TEAM, -1) turns the cost-sized teams on.
-        team_auto = tgeo.ok && team_knob == -1 && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4;
+        // Except where most CUs idle anyway: with at most a quarter as many environments as CUs the members are 16-wave workgroups on CUs
+        // of their own, and teams sized by cost are automatic from the second 64-step segment on (C5, 64 environments: 18.2 -> 17.3 us per
+        // step; 128 environments: 9.9 -> 10.6, not automatic).  The gain is small because a member's step is never shorter than the ~12 k
+        // clocks of the chain and the team kernel itself is ~10 % slower for an environment that stays whole.
+        team_auto = tgeo.ok && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4 && (team_knob == -1 || (team_knob == 0 && g.E * 4 <= s->n_cu && tgeo.waves == 16));
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
         if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
 #ifdef SF_EXPERIMENTAL
