@@ -180,7 +180,7 @@ struct sf_sim {
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run[24] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[24] = {}, attr_team[8] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -208,7 +208,7 @@ struct sf_sim {
 static int ensure_commit(sf_sim *s);
 extern "C" int sf_loop_stop(sf_sim *s);
 // simfire_hip_run2.hip: the launches of the team and closed-loop instantiations of k_run (StepArgs crosses as bytes)
-hipError_t sf_run2_launch_team(int which, int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+hipError_t sf_run2_launch_team(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int n_steps, int vcap);
 hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int vcap);
@@ -1160,9 +1160,10 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int rows = t.rcap ? t.rcap : g.H;
     const int need = ((rows + t.waves * 64 - 1) / (t.waves * 64)) * g.VW;
     const int which = need <= 1 ? 0 : 1, ia = g.att ? 1 : 0;
-    size_t &attr = s->attr_run[8 + which * 2 + ia];
+    const int id = g.diag ? 1 : 0;
+    size_t &attr = s->attr_team[(which * 2 + ia) * 2 + id];
     const bool set_lds = t.lds > 64 * 1024 && t.lds > attr;
-    HIPCHK(sf_run2_launch_team(which, ia, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
+    HIPCHK(sf_run2_launch_team(which, ia, id, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
     if (set_lds) attr = t.lds;
     return SF_OK;
 }

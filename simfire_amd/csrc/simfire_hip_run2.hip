@@ -18,15 +18,17 @@ namespace {
 typedef void (*run_fn)(StepArgs, int, int, int);
 }
 
-// which: 0 / 1 = one / two bitmap words per thread; att: attenuate_line_ros.  set_lds: raise the kernel's dynamic-LDS limit first.
-hipError_t sf_run2_launch_team(int which, int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+// which: 0 / 1 = one / two bitmap words per thread; att: attenuate_line_ros; diag: diagonal_spread.  set_lds: raise the kernel's dynamic-LDS limit first.
+hipError_t sf_run2_launch_team(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int n_steps, int vcap)
 {
-    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1, 1>, k_run<1, 1, -1, -1, 1>}, {k_run<2, 0, -1, -1, 1>, k_run<2, 1, -1, -1, 1>}};
+    // [words per thread][attenuation][diagonal spread read at run time / known to be on]
+    static const run_fn table[2][2][2] = {{{k_run<1, 0, -1, -1, 1>, k_run<1, 0, 1, -1, 1>}, {k_run<1, 1, -1, -1, 1>, k_run<1, 1, 1, -1, 1>}},
+                                          {{k_run<2, 0, -1, -1, 1>, k_run<2, 0, 1, -1, 1>}, {k_run<2, 1, -1, -1, 1>, k_run<2, 1, 1, -1, 1>}}};
     if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
     StepArgs a;
     memcpy(&a, args, sizeof a);
-    const run_fn kern = table[which ? 1 : 0][att ? 1 : 0];
+    const run_fn kern = table[which ? 1 : 0][att ? 1 : 0][diag ? 1 : 0];
     if (set_lds) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
