@@ -180,7 +180,7 @@ struct sf_sim {
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run[24] = {}, attr_team[8] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -1161,7 +1161,7 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int need = ((rows + t.waves * 64 - 1) / (t.waves * 64)) * g.VW;
     const int which = need <= 1 ? 0 : 1, ia = g.att ? 1 : 0;
     const int id = g.diag ? 1 : 0;
-    size_t &attr = s->attr_team[(which * 2 + ia) * 2 + id];
+    size_t &attr = (which && id && !a.mit) ? s->attr_team_c4[ia] : s->attr_team[(which * 2 + ia) * 2 + id];
     const bool set_lds = t.lds > 64 * 1024 && t.lds > attr;
     HIPCHK(sf_run2_launch_team(which, ia, id, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
     if (set_lds) attr = t.lds;

@@ -28,7 +28,10 @@ hipError_t sf_run2_launch_team(int which, int att, int diag, unsigned grid, unsi
     if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
     StepArgs a;
     memcpy(&a, args, sizeof a);
-    const run_fn kern = table[which ? 1 : 0][att ? 1 : 0][diag ? 1 : 0];
+    // (two words per thread, diagonal spread on, no control lines inside the launch = BASELINE config C4: its own instantiations, without
+    // the control-line code and its registers)
+    static const run_fn table_c4[2] = {k_run<2, 0, 1, 0, 1>, k_run<2, 1, 1, 0, 1>};
+    const run_fn kern = (which && diag && !a.mit) ? table_c4[att ? 1 : 0] : table[which ? 1 : 0][att ? 1 : 0][diag ? 1 : 0];
     if (set_lds) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
