@@ -827,7 +827,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const VecIn cur = nxt;
                 // (a batch that reaches the end of the list was the last one: no need to ask the cursor again)
                 j_next = j0 + (uint32_t)bsz < n_chunk ? grab() : n_chunk;
-                if (j_next < n_chunk) fetch(j_next, nxt);
+                // (the team kernel for two-word rows has no registers for two batches' rows at once - it would spill 16 of them to
+                // scratch -: it asks for the next batch's rows when it is done with this one's)
+                constexpr bool kEarly = !(TEAM && MAXD == 2);
+                if (kEarly && j_next < n_chunk) fetch(j_next, nxt);
 #ifdef SF_PHASES
                 pc.mark(3);      // cursor, next batch's rows requested
                 asm volatile("" :: "v"(cur.mid.x), "v"(cur.sr.x), "v"(cur.up.x), "v"(cur.dn.x));
@@ -976,6 +979,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                     __builtin_amdgcn_wave_barrier();
                 }
                 pc.mark(10);
+                if (!kEarly && j_next < n_chunk) fetch(j_next, nxt);
             }
             if (cb + (uint32_t)vcap >= n_all) break;       // (uniform) the usual case: one chunk
             __syncthreads();                               // everybody is done with this chunk's list
