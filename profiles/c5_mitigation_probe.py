@@ -2,7 +2,7 @@
 """What the in-launch control lines cost on C5 (64 environments x 64 agents, attenuation on): the same 1000-step rollout
 (after 20) as (a) the product, sf_step_mitigated with the agents' points; (b) sf_step_mitigated with every point's type
 set to 0 (skipped: the loads of the points and the two barriers stay, the atomics go); (c) sf_step, no control lines.
-(b) and (c) are different fires by 64 cells per step - timing only.  python profiles/c5_mitigation_probe.py [steps]"""
+(b) and (c) are different fires by 64 cells per step - timing only.  python profiles/c5_mitigation_probe.py [steps] [warm-up steps] [run_team knob]"""
 import os
 import sys
 
@@ -14,7 +14,8 @@ import bench  # noqa: E402
 from simfire_amd import workloads  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-warm = 20
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+team = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 w = workloads.c5(1024, 64)
 H, W = w.shape
 rows = workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, steps + warm)
@@ -25,6 +26,7 @@ for name, block in (("a product", pts.block), ("b points skipped", none), ("c no
     best = []
     for rep in range(3):
         eng = bench.make_engine(w, 0)
+        eng.set_tuning(run_team=team)
         if block is None:
             eng.step(warm)
             ms = eng.step_timed(steps)

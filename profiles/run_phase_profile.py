@@ -15,7 +15,8 @@ NAMES = ["0 barrier at the end of the step (waiting for the slowest wave)", "1 i
          "2 vector list written, barrier", "3 cursor, next batch's rows requested", "4 neighbour masks, strips written",
          "5 status SWAR, stores issued", "6 prefix sum of the frontier cells", "7 walk: cells found (search), winners, operands requested",
          "8 walk: burn / table entries arrive, updates, ignition stores", "9 end of the walk", "10 end of batch",
-         "11 wait for this batch's rows", "12 epilogue", "13", "14", "15 step start (fold, control lines)"]
+         "11 wait for this batch's rows", "12 epilogue", "13 fold, control lines: eligible bits, barrier", "14 control lines: the wave's plane work issued",
+         "15 step start (fold; with control lines: what is left of their block)"]
 
 
 def main():

@@ -1,5 +1,5 @@
 """Development aid: the shader-clock timeline of ONE step of ONE environment inside a resident launch (k_run), wave by
-wave (library built with -DSF_PHASES: profiles/run_timeline.sh).  usage: run_timeline.py <steps> <warmup> [env|-1 = slowest]"""
+wave (library built with -DSF_PHASES: profiles/run_timeline.sh).  usage: run_timeline.py <steps> <warmup> [env|-1 = slowest] [envs] [c5]"""
 import ctypes
 import sys
 
@@ -11,14 +11,26 @@ from simfire_amd.engine import FireEngine    # noqa: E402
 
 NAMES = {15: "step start", 1: "interest+ranks", 2: "list+barrierA", 3: "cursor+next fetch issued", 11: "rows arrived", 4: "nb masks, strips",
          5: "SWAR, stores issued", 6: "prefix+frontier list", 7: "walk: winner", 8: "walk: burn/table arrived, update", 9: "walk: stores, fence",
-         10: "end of batch", 0: "barrier B (end of step)"}
+         10: "end of batch", 0: "barrier B (end of step)", 12: "fold", 13: "lines: eligible bits + barrier", 14: "lines: plane work issued"}
 
 
 def main():
     steps, warm = int(sys.argv[1]), int(sys.argv[2])
     env = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     envs = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-    w = workloads.c3(1024, envs)
+    c5 = len(sys.argv) > 5 and sys.argv[5] == "c5"      # C5: 64 agents per environment, control lines inside the launch
+    w = workloads.c5(1024, envs) if c5 else workloads.c3(1024, envs)
+    pts = None
+    if c5:
+        H, W = w.shape
+        pts = np.ascontiguousarray(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, steps + warm).reshape(
+            steps + warm, w.n_envs, w.agents_per_env, 4)[..., 1:])
+
+    def run(eng, a, b):
+        if c5:
+            eng.step_mitigated(pts[a:b])
+        else:
+            eng.step(b - a)
     eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
     eng.set_layers(*w.layers())
     L = eng._L
@@ -27,17 +39,17 @@ def main():
     log = np.zeros((16384, 4), dtype=np.uint64)
     if env < 0:       # find the slowest environment of this window first
         eng.reset(w.init_xy)
-        eng.step(warm)
+        run(eng, 0, warm)
         L.sf_debug_wave_log(1, None)
-        eng.step(steps)
+        run(eng, warm, warm + steps)
         eng.status()
         L.sf_debug_wave_log(0, log.ctypes.data_as(ctypes.c_void_p))
         env = int(np.argmax(log[:envs, 0]))
         print("slowest env", env, "clocks", int(log[env, 0]), "vectors", int(log[env, 1]))
     eng.reset(w.init_xy)
-    eng.step(warm)
+    run(eng, 0, warm)
     L.sf_debug_timeline(env, steps - 1, None)
-    eng.step(steps)
+    run(eng, warm, warm + steps)
     eng.status()
     tl = np.zeros((16, 64), dtype=np.uint64)
     L.sf_debug_timeline(0, 0, tl.ctypes.data_as(ctypes.c_void_p))

@@ -427,13 +427,15 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     const int row0 = TEAM ? R0 : 0;                                   // first row of this workgroup's rows
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
-    // control lines inside the launch, up to 64 points per environment and step: lane i of wave 0 holds point i of the coming step
+    // control lines inside the launch, up to 64 points per environment and step: lane i of the LAST wave holds point i of the coming
+    // step (a young fire's one batch is dealt to wave 0: the control lines' plane work runs beside it, not in front of it)
     const bool mit_one_wave = mit && a.mit_k <= 64;
+    const int mit_wave = n_waves - 1;
     int32_t px = 0, py = 0, pty = 0;
     constexpr bool loop = MIT == -2;       // LOOP mode: steps on the host's doorbell (see below); its own instantiation, so that the others do not carry it
     const int loop_slot_ints = (g.E * a.mit_k * 3 * 4 + 15) / 16 * 4;          // LOOP mode: a slot of the points ring, padded to 16 bytes
     auto load_pt = [&](int s) {
-        if (wave == 0 && lane < a.mit_k) {
+        if (wave == mit_wave && lane < a.mit_k) {
             const int32_t *p = loop ? a.loop_pts + (long long)s * loop_slot_ints + ((long long)e * a.mit_k + lane) * 3
                                     : mit + (((long long)s * g.E + e) * a.mit_k + lane) * 3;
             if (loop) {      // the relay's copy, rewritten every other step: loads that skip the L1
@@ -466,6 +468,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     unsigned long long x_clocks = 0, x_steps = 0;      // TEAM statistics: clocks wave 0 spent at the team's step boundaries (publish + wait + read), boundaries
     for (int s = 0; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
+#ifdef SF_PHASES
+        pc.tl = (e == g_timeline_env && s == g_timeline_step) ? g_timeline + wave * 64 : nullptr;
+#endif
         auto loop_finish = [&]() {
             // the step is done: this environment's row of the result block goes straight to the host (posted writes are cheap, it is
             // reads of host memory that are not), then its "done" number - to the host, and to device memory for a restarted launch
@@ -553,56 +558,74 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             // (FIRELINE < SCRATCHLINE < WETLINE = the reference's write order for duplicates).  Also after QUIT: the
             // harness keeps drawing lines on a fire that is out.
             if (mit_one_wave) {
-                // Up to 64 points per environment and step (C5): wave 0 alone, a point per lane, no barrier between the two passes (the
-                // lanes of a wave issue the clears together and wait for them together), the write pass starts from the word the clear
-                // returned instead of loading it again, burn / settled are requested with the clear instead of after it, and the points
-                // were requested one step ahead (the block was 9.3 k clocks of a C5 step).
+                // Up to 64 points per environment and step (C5): one wave alone, a point per lane.  One wave has all the points of the step in
+                // its registers, so nothing here needs an atomic on the plane: update_mitigation ASSIGNS the type (mitigation.py:60-80), a
+                // status byte has one owner at this point of the step (every other wave is busy with LDS until the barrier behind the
+                // vector list), and byte stores leave the neighbouring cells of the word alone.  Two points of a step on one cell:
+                // the reference writes FIRELINE, then SCRATCHLINE, then WETLINE, so the highest type stands - every point stores the
+                // highest type of the step's points on ITS cell.  With attenuation the cell's old type, burn and settled
+                // count are read first (plain loads; duplicates read the same values and store the same results).
+                // The other waves are released as soon as the "eligible" bitmap has the new lines (what they read next is LDS; the cell
+                // planes are not read before the barrier behind the vector list, which orders this wave's stores before every wave's
+                // row loads - one CU, one L1: workgroup scope): the plane work runs beside their interest pass.  (Round 2: two atomic
+                // round trips with every wave waiting, 7.5 k clocks of a C5 step.  Measured and dropped: asking for the cells' old
+                // contents before the wave's own interest pass and storing behind it - the state held across the pass cost more in
+                // spilled registers than the hidden latency gave.)
                 if (loop) load_pt((int)((lseq + 1u) & 1u));      // (LOOP mode: the slot of the step the host has just posted)
-                if (wave == 0) {
+                bool ok = false;
+                int x = 0, y = 0;
+                if (wave == mit_wave) {
                     const int ty = pty;
-                    const bool ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && px >= 0 && px < g.W && py >= R0 && py < R1;      // (TEAM: the points in this member's band; else R0 = 0, R1 = H)
-                    const int x = ok ? px : 0, y = ok ? py : 0;
-                    const uint32_t o = (uint32_t)(y * g.P + x);
-                    uint32_t *word = reinterpret_cast<uint32_t *>(ev.cells + bl_cell(g, y, x & ~3) + kBlStatus);
-                    const int sh = (x & 3) * 8;
-                    uint32_t w = 0, owed_since = 0;
-                    double bn = 0.0;
-                    if (ok) {
-                        w = atomicAnd(word, ~(0xFFu << sh));
-                        if (ATT) { bn = ev.burn[o]; owed_since = ev.settled[o]; }
-                    }
-                    if (s + 1 < n_steps && !loop) load_pt(s + 1);
-                    if (ok) {
-                        if (ATT) {
-                            const uint32_t was = (w >> sh) & 7u;
-                            if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)st.complete - owed_since);
-                            ev.settled[o] = (uint32_t)st.complete;      // (every lane has its old count by now; every point of this step on this cell stores the same)
-                        }
-                        ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();          // every clear of this step has returned
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (ok) {
-                        // the word as this lane's clear left it; if another point of the step changed it since (a duplicate, a neighbouring
-                        // byte) the first compare-and-swap fails and returns what it holds now
-                        uint32_t old = w & ~(0xFFu << sh), seen;
-                        do {
-                            seen = old;
-                            if (((seen >> sh) & 0xFFu) >= (uint32_t)ty) break;
-                            old = atomicCAS(word, seen, (seen & ~(0xFFu << sh)) | ((uint32_t)ty << sh));
-                        } while (old != seen);
-                        if (fine) atomicOr(&ve[y * VW + (x >> 10)], 1ull << ((x >> 4) & 63));
-                    }
+                    ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && px >= 0 && px < g.W && py >= R0 && py < R1;      // (TEAM: the points in this member's band; else R0 = 0, R1 = H)
+                    x = ok ? px : 0;
+                    y = ok ? py : R0;
+                    if (ok && fine) atomicOr(&ve[y * VW + (x >> 10)], 1ull << ((x >> 4) & 63));          // a control line is an eligible cell
                 }
-                // What the step reads next are the bitmaps in LDS; the cell planes are not read before the barrier behind the vector list,
-                // which waits for wave 0's stores like any __syncthreads: no wait for their acknowledgements here.
-                if (st.running) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                } else {
-                    __syncthreads();        // the fire is out: the next thing is the next step's control lines
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                pc.mark(13);     // control lines: eligible bits, barrier
+                if (wave == mit_wave) {
+                    const int ty = pty;
+                    const uint32_t o = (uint32_t)(y * g.P + x);
+                    uint8_t *cell = ev.cells + bl_cell(g, y, x & ~3) + kBlStatus + (x & 3);
+                    // (the coming step's points first: nothing issued behind them has to have returned when they are read)
+                    if (s + 1 < n_steps && !loop) load_pt(s + 1);
+                    uint32_t was = 0, owed_since = 0;
+                    double bn = 0.0;
+                    if (ATT && ok) { was = *cell & 7u; bn = ev.burn[o]; owed_since = ev.settled[o]; }
+                    // Two points of the step on one cell: every one of them stores the highest of their types (the reference's write
+                    // order).  Whether any two points MAY share a cell: a 32 768-bit table in this wave's strip buffer (free between the
+                    // steps), a bit per hashed cell; only then the exact answer, a scalar loop over the lanes that hold a higher type.
+                    int fin = ty;
+                    const unsigned long long above = __ballot(ok && ty > SF_FIRELINE);
+                    if (above && (__ballot(ok && ty != SF_WETLINE) != 0ull)) {            // (all of one type: nothing to settle)
+                        const uint32_t h = (o * 2654435761u) >> 17, bit = 1u << (h & 31);
+                        if (ok) strips[h >> 5] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const uint32_t clash = ok ? (atomicOr(&strips[h >> 5], bit) & bit) : 0u;
+                        if (__ballot(clash != 0) != 0ull) {
+                            const uint32_t key = ok ? o : 0xFFFFFFFFu;
+                            for (unsigned long long hi = above; hi; hi &= hi - 1) {
+                                const int j = __ffsll((long long)hi) - 1;
+                                const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+                                const int tj = __builtin_amdgcn_readlane(ty, j);
+                                if (key == kj && tj > fin) fin = tj;
+                            }
+                        }
+                    }
+                    if (ATT && ok && was != (uint32_t)fin) {
+                        // (a line drawn over a line of ITS type - an agent back on its own track - changes nothing: the cell goes on owing
+                        // under the same factor, k1 + k2 subtractions are k1 and then k2.  Making up what is owed is a loop with an f64
+                        // division per binade crossed: 3 - 4 k clocks of this wave whenever one lane of the 64 had to)
+                        if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)st.complete - owed_since);
+                        ev.settled[o] = (uint32_t)st.complete;
+                    }
+                    if (ok) *cell = (uint8_t)fin;
+                    if (ok) ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                    pc.mark(14); // control lines: the wave's plane work issued
                 }
             } else {
                 const int32_t *pts = mit + ((long long)s * g.E + e) * a.mit_k * 3;
@@ -639,10 +662,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 continue;
             }
         }
-#ifdef SF_PHASES
-        pc.tl = (e == g_timeline_env && s == g_timeline_step) ? g_timeline + wave * 64 : nullptr;
         pc.mark(15);         // step start
-#endif
         if (tid < 3) ctl[3 * tid + kn] = 0;     // ring slots of the next step (last read before the barrier that ended step s - 1)
         const int t = st.steps + 1;
         const Masks mk = make_masks(t, g.md, g.N);
