@@ -230,7 +230,10 @@ __device__ inline double lazy_sub(double x, double f, uint32_t k)
         const int ex = (int)((__double_as_longlong(x) >> 52) & 0x7FF);
         if (ex == 0 || ex == 0x7FF) { x = x - f; --k; continue; }          // subnormal / not finite: plain steps
         const double limit = __longlong_as_double((long long)(ex + 1) << 52);   // 2^(E+1)
-        const double room = (x + limit) / f;                  // j * f < x + limit; rounded, hence the margin of 2
+        // j * f < x + limit.  A product with the rounded reciprocal instead of a quotient (an f64 division is ~25 instructions, four
+        // of them quarter-rate, in a loop that whole waves wait for): off by a few 1e-7 at most below the 4e9 cap - the margin of 2
+        // covers it, and any n that is too SMALL only means another turn of the loop.
+        const double room = (x + limit) * (f == 980.0 ? 1.0 / 980.0 : (f == 490.0 ? 1.0 / 490.0 : 1.0 / 245.0));      // (f is one of line_factor's three)
         long long n = (room < 4.0e9 ? (long long)room : 4000000000ll) - 2;
         if (n > (long long)k) n = k;
         if (n >= 1) { x = x - (double)n * f; k -= (uint32_t)n; }
