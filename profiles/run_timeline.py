@@ -11,7 +11,7 @@ from simfire_amd.engine import FireEngine    # noqa: E402
 
 NAMES = {15: "step start", 1: "interest+ranks", 2: "list+barrierA", 3: "cursor+next fetch issued", 11: "rows arrived", 4: "nb masks, strips",
          5: "SWAR, stores issued", 6: "prefix+frontier list", 7: "walk: winner", 8: "walk: burn/table arrived, update", 9: "walk: stores, fence",
-         10: "end of batch", 0: "barrier B (end of step)", 12: "fold", 13: "lines: eligible bits + barrier", 14: "lines: plane work issued"}
+         10: "end of batch", 0: "barrier B (end of step)", 12: "fold", 13: "lines: eligible bits + barrier", 14: "lines: plane work issued", 16: "first batch known", 17: "its rows requested", 18: "next batch known"}
 
 
 def main():

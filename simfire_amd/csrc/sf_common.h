@@ -123,8 +123,8 @@ struct StepArgs {
     // k_run in LOOP mode (sf_loop_start / sf_loop_step): the launch stays resident and is driven step by step by the host
     const uint32_t *loop_db;     // HOST-mapped doorbell: sequence number of the newest step the host has posted | kLoopStop = leave
     const int32_t *loop_pts_host;// HOST-mapped [2][E][k][3]: the points of the two newest steps (slot = sequence number & 1)
-    uint32_t *loop_done_host;    // HOST-mapped [E]: sequence number of the last step this environment has finished (its result row is there first)
-    int32_t *loop_res_host;      // HOST-mapped [E][8] + double [E] behind it: the result block of that step
+    int32_t *loop_res_host;      // HOST-mapped [E][16] u32: per environment one 64-byte line = its result row, elapsed time and, at the end of
+                                 // each 16-byte piece, the number of the step they belong to (k_run, loop_finish)
     // (device memory; all of it touched with agent-scope accesses only)
     uint32_t *loop_seq;          // what the relay workgroup (environment 0's) forwards from the doorbell
     int32_t *loop_pts;           // [2][E][k][3] the relay's copy of the points

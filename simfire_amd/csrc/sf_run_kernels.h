@@ -473,21 +473,32 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
 #endif
         auto loop_finish = [&]() {
             // the step is done: this environment's row of the result block goes straight to the host (posted writes are cheap, it is
-            // reads of host memory that are not), then its "done" number - to the host, and to device memory for a restarted launch
+            // reads of host memory that are not) together with its "done" number (which also goes to device memory for a restarted launch)
             __syncthreads();
             counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, nullptr,
                        reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
             ++lseq;
-            if (tid == 0) {
-                typedef unsigned long long u64;
-                const int32_t *row = a.res_block + e * 8;      // (what this thread has just stored)
-                u64 *dst = reinterpret_cast<u64 *>(a.loop_res_host);
-                for (int q = 0; q < 4; ++q)
-                    __hip_atomic_store(dst + e * 4 + q, (u64)(uint32_t)row[2 * q] | ((u64)(uint32_t)row[2 * q + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(dst + (size_t)g.E * 4 + e, (u64)__double_as_longlong(st.elapsed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(a.loop_done + e, lseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row has left before the number that says so
-                __hip_atomic_store(a.loop_done_host + e, lseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // ONE 64-byte line per environment and step, written by one store instruction of 16 lanes (one PCIe write instead of six,
+            // no drain between "row" and "done"): four 16-byte pieces, each ends in the step's number - the host takes the line
+            // when all four carry it, whatever the granularity and order in which the pieces arrive.
+            //   [running, steps, UNBURNED, n] [BURNING, BURNED, FIRELINE, n] [SCRATCHLINE, WETLINE, elapsed lo, n] [elapsed hi, 0, 0, n]
+            if (wave == 0) {
+                uint32_t *stage = strips;            // (wave 0's strip buffer: counts_env's scratch, free again)
+                if (lane == 0) {
+                    const int32_t *row = a.res_block + e * 8;      // (what this thread has just stored)
+                    const unsigned long long el = (unsigned long long)__double_as_longlong(st.elapsed);
+                    stage[0] = (uint32_t)row[0]; stage[1] = (uint32_t)row[1]; stage[2] = (uint32_t)row[2];
+                    stage[4] = (uint32_t)row[3]; stage[5] = (uint32_t)row[4]; stage[6] = (uint32_t)row[5];
+                    stage[8] = (uint32_t)row[6]; stage[9] = (uint32_t)row[7]; stage[10] = (uint32_t)el;
+                    stage[12] = (uint32_t)(el >> 32); stage[13] = 0u; stage[14] = 0u;
+                    stage[3] = stage[7] = stage[11] = stage[15] = lseq;
+                    __hip_atomic_store(a.loop_done + e, lseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for a launch that is started again)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 16)
+                    __hip_atomic_store(reinterpret_cast<uint32_t *>(a.loop_res_host) + (size_t)e * 16 + lane, stage[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         };
         if (loop) {
@@ -840,13 +851,16 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 }
             };
             uint32_t j_next = dealt ? (uint32_t)(wave * bsz) : grab();
+            pc.note(16);     // first batch known
             VecIn nxt;
             if (j_next < n_chunk) fetch(j_next, nxt);
+            pc.note(17);     // its rows requested
             while (j_next < n_chunk) {
                 const uint32_t j0 = j_next;
                 const VecIn cur = nxt;
                 // (a batch that reaches the end of the list was the last one: no need to ask the cursor again)
                 j_next = j0 + (uint32_t)bsz < n_chunk ? grab() : n_chunk;
+                pc.note(18); // next batch known
                 // (the team kernel for two-word rows has no registers for two batches' rows at once - it would spill 16 of them to
                 // scratch -: it asks for the next batch's rows when it is done with this one's)
                 constexpr bool kEarly = !(TEAM && MAXD == 2);

@@ -117,9 +117,14 @@ struct PhaseClock {
         if (tl && (threadIdx.x & 63) == 0 && tl_n < 64) tl[tl_n++] = ((unsigned long long)k << 56) | (n & 0x00FFFFFFFFFFFFFFull);
         t = n;
     }
+    __device__ __forceinline__ void note(int k)       // timeline only (ids from 16 on: no phase sum)
+    {
+        if (tl && (threadIdx.x & 63) == 0 && tl_n < 64) tl[tl_n++] = ((unsigned long long)k << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull);
+    }
 #else
     __device__ __forceinline__ void start(uint32_t * = nullptr) {}
     __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void note(int) {}
 #endif
 };
 

@@ -167,7 +167,7 @@ struct sf_sim {
     int loop_k = 0;                    // points per environment and step
     uint32_t loop_seq = 0;             // sequence number of the last step posted
     uint32_t *loop_db = nullptr, *loop_db_dev = nullptr;         // (pinned, device-mapped) [0] doorbell, [64 ...] "done" numbers [E] (other cache lines)
-    int32_t *loop_res = nullptr, *loop_res_dev = nullptr;        // int32 [E][8] + double [E] (pinned, device-mapped)
+    int32_t *loop_res = nullptr, *loop_res_dev = nullptr;        // u32 [E][16]: one 64-byte line per environment (pinned, device-mapped; k_run, loop_finish)
     int32_t *loop_pts = nullptr, *loop_pts_dev = nullptr;        // [2][slot] points ring (pinned, device-mapped)
     size_t loop_pts_cap = 0, loop_slot_ints = 0;
     uint32_t *loop_mem = nullptr;                                // device: [0] forwarded sequence number, [32 ...] done [E]
@@ -1641,7 +1641,7 @@ static int loop_launch(sf_sim *s)
     a.mit = s->loop_pts_mem; a.mit_k = s->loop_k;
     a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink;
     a.cost = s->run_cost;
-    a.loop_db = s->loop_db_dev; a.loop_pts_host = s->loop_pts_dev; a.loop_done_host = s->loop_db_dev + 64; a.loop_res_host = s->loop_res_dev;
+    a.loop_db = s->loop_db_dev; a.loop_pts_host = s->loop_pts_dev; a.loop_res_host = s->loop_res_dev;
     a.loop_seq = s->loop_mem; a.loop_done = s->loop_mem + 32; a.loop_pts = s->loop_pts_mem;
     a.loop_timeout = 400000000ull;             // ~0.2 s without a ring: the workgroups leave, the next sf_loop_step starts them again
     HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t), s->stream));       // nothing forwarded yet (the word may hold the stop of the launch before)
@@ -1681,8 +1681,8 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
         return SF_OK;
     };
     if (!s->loop_db) {
-        int rc = pin((void **)&s->loop_db, (void **)&s->loop_db_dev, sizeof(uint32_t) * (64 + (size_t)g.E)); if (rc) return rc;
-        rc = pin((void **)&s->loop_res, (void **)&s->loop_res_dev, (sizeof(int32_t) * 8 + sizeof(double)) * g.E); if (rc) return rc;
+        int rc = pin((void **)&s->loop_db, (void **)&s->loop_db_dev, sizeof(uint32_t) * 64); if (rc) return rc;
+        rc = pin((void **)&s->loop_res, (void **)&s->loop_res_dev, (size_t)64 * g.E); if (rc) return rc;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->loop_mem), sizeof(uint32_t) * (32 + (size_t)g.E)));
     }
     s->loop_slot_ints = ((size_t)g.E * k * 3 * 4 + 15) / 16 * 4;
@@ -1697,7 +1697,8 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
     }
     s->loop_k = k; s->loop_seq = 0; s->loop_restarts = 0;
     volatile uint32_t *db = s->loop_db;
-    for (int i = 0; i < 64 + g.E; ++i) db[i] = 0;
+    for (int i = 0; i < 64; ++i) db[i] = 0;
+    memset(s->loop_res, 0, (size_t)64 * g.E);
     __sync_synchronize();
     HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t) * (32 + (size_t)g.E), s->stream));
     HIPCHK(hipMemsetAsync(s->loop_pts_mem, 0, pts_bytes, s->stream));
@@ -1733,13 +1734,15 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
     s->loop_seq = seq;
     // wait for the "done" number; should the launch have left by itself (no ring for loop_timeout clocks), start it again: every
     // workgroup resumes from its own "done" number, the points of this step are still in their slot
+    const volatile uint32_t *res = reinterpret_cast<const volatile uint32_t *>(s->loop_res);
+    auto arrived = [&](int q) { const volatile uint32_t *l = res + (size_t)q * 16; return l[3] == seq && l[7] == seq && l[11] == seq && l[15] == seq; };
     int e = 0;
     for (unsigned long long spins = 0;; ++spins) {
-        while (e < g.E && db[64 + e] == seq) ++e;
+        while (e < g.E && arrived(e)) ++e;
         if (e == g.E) break;
         if ((spins & 0x3FFF) == 0x3FFF && hipStreamQuery(s->stream) == hipSuccess) {
             bool all = true;
-            for (int q = 0; q < g.E; ++q) all = all && db[64 + q] == seq;
+            for (int q = 0; q < g.E; ++q) all = all && arrived(q);
             if (all) break;
             if (s->xerr_pinned && *s->xerr_pinned) return fail(SF_EHIP, "sf_loop_step: the resident launch failed");
             HIPCHK(hipSetDevice(s->p.device));
@@ -1749,8 +1752,18 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
         }
     }
     __sync_synchronize();
-    if (status_out) memcpy(status_out, s->loop_res, sizeof(int32_t) * 8 * g.E);
-    if (elapsed_out) memcpy(elapsed_out, reinterpret_cast<const char *>(s->loop_res) + sizeof(int32_t) * 8 * g.E, sizeof(double) * g.E);
+    for (int q = 0; q < g.E; ++q) {
+        const volatile uint32_t *l = res + (size_t)q * 16;
+        if (status_out) {
+            int32_t *o = status_out + (size_t)q * 8;
+            o[0] = (int32_t)l[0]; o[1] = (int32_t)l[1]; o[2] = (int32_t)l[2]; o[3] = (int32_t)l[4]; o[4] = (int32_t)l[5]; o[5] = (int32_t)l[6];
+            o[6] = (int32_t)l[8]; o[7] = (int32_t)l[9];
+        }
+        if (elapsed_out) {
+            const unsigned long long el = (unsigned long long)l[10] | ((unsigned long long)l[12] << 32);
+            memcpy(elapsed_out + q, &el, sizeof el);
+        }
+    }
     return SF_OK;
 }
 
