@@ -265,9 +265,9 @@ def issue_block(w, a, rl, cost, n_cu=256):
         return None
     teams = measure.last_teams
     if teams is not None and int(teams.max()) > 0:
-        # a team launch (k_run<TEAM>): the rollout is cut into 64-step launches, an environment's cost is the sum over its members
+        # a team launch (k_run<TEAM>): the rollout is cut into 128-step launches, an environment's cost is the sum over its members
         # (their waits for each other included) and covers the last launch only - no clock, no balance figure from that
-        seg = 128 if w.shape[1] > 1024 else 64          # (step_impl: segments of 2 x 64 steps on grids of two-word rows)
+        seg = 128                                       # (step_impl: teams chosen by the library run in segments of 2 x 64 steps)
         n, launches = a.steps, 0
         while n > 0:
             n -= seg if n > seg + seg // 2 else n
@@ -277,7 +277,7 @@ def issue_block(w, a, rl, cost, n_cu=256):
         rl["steps_per_launch"] = a.steps / launches
         rl["algorithmic_bytes_per_launch"] = rl["algorithmic_bytes_per_launch"] / launches
         return {"team_launch": True, "workgroups_per_environment": {int(k): int(v) for k, v in zip(*np.unique(teams, return_counts=True))},
-                "note": "k_run<TEAM>: bands of rows, one workgroup each; the rollout in launches of 64 (two-word rows: 128) steps (profiles/r03_team/README.md)"}
+                "note": "k_run<TEAM>: bands of rows, one workgroup each; the rollout in launches of 128 steps (profiles/r03_team/README.md)"}
     clocks = cost.astype(np.float64) * 16.0
     slots = min(len(cost), n_cu)
     sec = rl["launch_ms"] * 1e-3

@@ -1262,7 +1262,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // of their own, and teams sized by cost are automatic from the second 64-step segment on (C5, 64 environments: 18.2 -> 17.3 us per
         // step; 128 environments: 9.9 -> 10.6, not automatic).  The gain is small because a member's step is never shorter than the ~12 k
         // clocks of the chain and the team kernel itself is ~10 % slower for an environment that stays whole.
-        team_auto = tgeo.ok && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4 && (team_knob == -1 || (team_knob == 0 && g.E * 4 <= s->n_cu && tgeo.waves == 16));
+        team_auto = tgeo.ok && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4 && (team_knob == -1 || (team_knob == 0 && g.E >= 2 && g.E * 4 <= s->n_cu && tgeo.waves == 16));
+        // (one environment - FireSimulation.run(), C2 -: its fire fits one workgroup for hundreds of steps, and the segments of a team rollout -
+        // a plan, a prologue that reads the bitmaps and an epilogue per launch - cost a lone young fire 16 %: 3.23 against 3.74 us per step)
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
         if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
 #ifdef SF_EXPERIMENTAL
@@ -1397,7 +1399,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             int seg = balance && n_steps - done > seg_knob + seg_knob / 2 ? seg_knob : n_steps - done;
             // (two-word rows: twice the segment - every launch costs a plan, a prologue that reads the environment's whole bitmap and an
             // epilogue; measured on C4's share: 64 / 128 / 256 steps per launch = 26.3 / 26.1 / 26.8 us per step - the cuts have to follow the fires)
-            const int tseg = team_wide && !team_forced ? 2 * seg_knob : seg_knob;
+            // (one-word rows, teams sized by cost: C5 10.56 / 10.23 / 10.31 us per step with 64 / 128 / 256)
+            const int tseg = (team_wide || team_auto) && !team_forced ? 2 * seg_knob : seg_knob;
             if (team_segments && n_steps - done > tseg + tseg / 2) seg = tseg;
             const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
