@@ -18,4 +18,17 @@ done
 bash profiles/run_phase_profile.sh 1000 256 2 20 > $O/phase_clocks_k_run_c3_s1000.json 2>/dev/null
 bash profiles/run_phase_profile.sh 20 256 2 5 > $O/phase_clocks_k_run_c3_s20.json 2>/dev/null
 bash profiles/run_phase_profile.sh 1000 64 2 20 c5 > $O/phase_clocks_k_run_c5_s1000.json 2>/dev/null
+bash profiles/run_phase_profile.sh 20 64 2 5 c5 > $O/phase_clocks_k_run_c5_s20.json 2>/dev/null
+# one step, wave by wave (instrumented build): a young fire, a medium one, a young C5 fire with its control-line wave
+bash profiles/run_timeline.sh 20 5 -1 2>/dev/null | grep -v amdgpu.ids > $O/timeline_step25.txt
+bash profiles/run_timeline.sh 300 20 -1 2>/dev/null | grep -v amdgpu.ids > $O/timeline_step320.txt
+bash profiles/run_timeline.sh 20 5 -1 64 c5 2>/dev/null | grep -v amdgpu.ids > $O/timeline_c5_step25.txt
+# the bench lines as the driver runs them (its window, and bench.py's default), every `also` entry included
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_window.json
+python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
+# probes quoted in DESIGN.md
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/latency_probe profiles/latency_probe.hip 2>/dev/null && /tmp/latency_probe > $O/latency_probe.txt 2>&1
+( python profiles/c5_mitigation_probe.py 20 5; python profiles/c5_mitigation_probe.py 1000 20 ) 2>&1 | grep -v amdgpu.ids > $O/c5_mitigation_probe.txt
+( python profiles/loop_probe.py c3 300 0 4; python profiles/loop_probe.py c5 300 0 64 ) 2>&1 | grep -v amdgpu.ids > $O/loop_probe.txt
 ls -la $O gpurun_out/r03_c3_s1000 gpurun_out/r03_c3_s20
+# then, in the build container: python profiles/install_r03.py
