@@ -763,6 +763,53 @@ def test_mitigated_rollout_equals_update_mitigation_run_pairs(mode, att, K):
     assert eng.last_launch_kind() in (want, 1 if want == 0 else want)
 
 
+@pytest.mark.parametrize("mode", [-1, 2, 0])
+def test_agents_back_on_their_own_lines_keep_owing_under_the_same_factor(mode):
+    """Attenuation mode: a line redrawn in ITS OWN type - an agent walking back and forth on its track, what a random walk does all the
+    time - is not settled again inside the resident launch (k1 + k2 subtractions are k1 and then k2); a line
+    redrawn in ANOTHER type is.  Agents that oscillate between two cells, agents that cross each other's tracks in other types,
+    two agents of different types on one cell in one step - with a fire that reaches the lines (the walk then needs the exact
+    burn value) - against the oracle's eager subtraction, burn_amounts bit for bit every few steps."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(2718)
+    H, W, E, K, n = 72, 130, 3, 64, 90
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
+    eng = FireEngine(**kw)
+    o = fire_dense.DenseOracle(**kw)
+    inits = [(20, 20), (64, 36), (100, 50)]
+    for x in (eng, o):
+        x.set_rtable(R8)
+        x.reset(inits)
+    eng.set_fused(mode)
+    ax = rng.integers(4, W - 4, (E, K))
+    ay = rng.integers(4, H - 4, (E, K))
+    ty = 3 + np.arange(K) % 3
+    blk = np.zeros((n, E, K, 3), dtype=np.int32)
+    for s in range(n):
+        dx = np.where(np.arange(K) < 40, s & 1, 0)                        # agents 0 .. 39 oscillate between two cells: back on their own line every other step
+        x = ax + dx
+        y = ay.copy()
+        x[:, 40:52] = (ax[:, 40:52] + s) % W                              # agents 40 .. 51 walk east and cross the others' tracks in their own types
+        y[:, 52:58] = ay[:, 0:6]                                          # agents 52 .. 57 stand on the cells of agents 0 .. 5 (types differ: 52 % 3 = 1 against 0 % 3 = 0, ...)
+        x[:, 52:58] = ax[:, 0:6] + (s & 1)
+        blk[s, :, :, 0], blk[s, :, :, 1], blk[s, :, :, 2] = x, y, ty
+    done = 0
+    for chunk in (1, 9, 10, 20, 50):
+        eng.step_mitigated(blk[done:done + chunk])
+        for s in range(done, done + chunk):
+            o.apply_mitigation([(e, int(blk[s, e, i, 0]), int(blk[s, e, i, 1]), int(blk[s, e, i, 2])) for e in range(E) for i in range(K)])
+            o.step(1)
+        done += chunk
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), (mode, done)
+        for e in range(E):
+            assert (eng.fire_map(e) == o.fire_map(e)).all(), (mode, done, e)
+            assert (eng.burn(e) == o.burn(e)).all(), (mode, done, e)
+    assert eng.status()[0][:, 3].max() > 200            # the fires did reach the lines
+
+
 def test_c5_rollout_in_one_launch():
     """BASELINE config C5 at its grid (1024^2, 64 agents per environment, attenuation on), 24 environments, 150 steps: the
     whole rollout - control lines before every update - as one resident launch, against the oracle's scatter + step loop."""
