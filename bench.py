@@ -577,7 +577,7 @@ def main():
         if iss:
             out["roofline"]["issue"] = iss
             ra = out["roofline"].get("random_access")
-            if ra:       # the sector rate at the clock the launch really ran at, not an assumed one
+            if ra and "clock_ghz_measured" in iss:       # the sector rate at the clock the launch really ran at, not an assumed one
                 ra["achieved_sectors_per_clock_per_cu"] *= ra["clock_ghz_assumed"] / iss["clock_ghz_measured"]
                 ra["frac_of_probe_loads"] = (ra["achieved_sectors_per_clock_per_cu"] / ra["probe_sectors_per_clock_per_cu"]["loads_8_in_flight"]
                                              if "loads_8_in_flight" in ra["probe_sectors_per_clock_per_cu"] else None)
