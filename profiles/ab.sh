@@ -6,7 +6,7 @@ i=0
 for flags in "$@"; do
     i=$((i+1)); so=$PWD/profiles/_variants/ab$i/libsimfire_hip.so; mkdir -p "$(dirname "$so")"
     if [ "$flags" = base ]; then cp profiles/_variants/base/libsimfire_hip.so "$so"; continue; fi
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -o "$so" simfire_amd/csrc/simfire_hip.hip simfire_amd/csrc/simfire_hip_run2.hip 2>/dev/null &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -o "$so" simfire_amd/csrc/simfire_hip*.hip 2>/dev/null &
 done
 wait
 for round in 1 2; do

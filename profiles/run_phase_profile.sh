@@ -4,5 +4,5 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p profiles/_phase
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DSF_PHASES \
-    -o profiles/_phase/libsimfire_hip.so simfire_amd/csrc/simfire_hip.hip simfire_amd/csrc/simfire_hip_run2.hip 2>/dev/null
+    -o profiles/_phase/libsimfire_hip.so simfire_amd/csrc/simfire_hip*.hip 2>/dev/null
 SIMFIRE_HIP_LIB=$PWD/profiles/_phase/libsimfire_hip.so python profiles/run_phase_profile.py "$@"

@@ -5,8 +5,9 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# two translation units, compiled side by side (the second holds the k_run instantiations only some handles launch)
-SOURCES = ["simfire_hip.hip", "simfire_hip_run2.hip"]
+# four translation units, compiled side by side (the first: host code + every kernel every handle launches; the others: k_run
+# instantiations only some handles launch - teams / the closed loop, several bitmap words per thread, two-word teams)
+SOURCES = ["simfire_hip.hip", "simfire_hip_run2.hip", "simfire_hip_run3.hip", "simfire_hip_run4.hip"]
 OUT = os.path.join(CSRC, "libsimfire_hip.so")
 # builds of the same sources that only tests load (simfire_amd/_lib.py: VARIANTS)
 VARIANT_FLAGS = {"exp": ["-DSF_EXPERIMENTAL"], "sow": ["-DSF_STORE_ORDER_WAIT"]}

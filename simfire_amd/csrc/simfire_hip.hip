@@ -207,9 +207,14 @@ struct sf_sim {
 
 static int ensure_commit(sf_sim *s);
 extern "C" int sf_loop_stop(sf_sim *s);
-// simfire_hip_run2.hip: the launches of the team and closed-loop instantiations of k_run (StepArgs crosses as bytes)
-hipError_t sf_run2_launch_team(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+// simfire_hip_run2.hip / _run3.hip / _run4.hip: the launches of the k_run instantiations that live in the library's other translation units
+// (teams and the closed loop; two / four bitmap words per thread; two-word teams).  StepArgs crosses as bytes.
+hipError_t sf_run2_launch_team(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int n_steps, int vcap);
+hipError_t sf_run4_launch_team2(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                                const void *args, size_t args_bytes, int n_steps, int vcap);
+hipError_t sf_run3_launch_plain(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                                const void *args, size_t args_bytes, int n_steps, int vcap, int bsz);
 hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int vcap);
 // every entry point except sf_loop_step ends the closed loop (sf_loop_start) first: the handle's stream is busy with the resident launch
@@ -1069,18 +1074,22 @@ static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, in
     const int need = ((s->g.H + waves * 64 - 1) / (waves * 64)) * s->g.VW;
     const int which = need <= 1 ? 0 : (need <= 2 ? 1 : 2);      // (two words per thread = 1024 rows in 8 waves: the many-environments regime; the kernel for four spills there, +7 %)
     typedef void (*run_fn)(StepArgs, int, int, int);
-    // [words per thread 1 / 2 / 4][attenuation off / on][diagonal spread read at run time / known to be on]; control lines inside
-    // the launch: one word per thread has an instantiation without them (MIT = 0), the others look at the argument
-    // (specialised for diagonal spread known to be on - every reference config - where it is worth the compile time: one word per thread)
-    static const run_fn table[3][2][2] = {
-        {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, -1>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, -1>}},
-        {{k_run<2, 0, -1, -1>, k_run<2, 0, 1, -1>}, {k_run<2, 1, -1, -1>, k_run<2, 1, 1, -1>}},
-        {{k_run<kRunMaxD, 0, -1, -1>, k_run<kRunMaxD, 0, -1, -1>}, {k_run<kRunMaxD, 1, -1, -1>, k_run<kRunMaxD, 1, -1, -1>}}};
-    static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, 0>}};
     const int ia = s->g.att ? 1 : 0, id = s->g.diag ? 1 : 0;
-    const bool nomit = which == 0 && !a.mit;
-    const run_fn kern = nomit ? table_nomit[ia][id] : table[which][ia][id];
-    size_t &attr = s->attr_run[nomit ? 12 + ia * 2 + id : (which == 2 ? 20 + ia : (which * 2 + ia) * 2 + id)];
+    if (which > 0) {
+        // two / four words per thread: instantiated in the library's third translation unit (simfire_hip_run3.hip)
+        size_t &attr3 = s->attr_run[which == 2 ? 20 + ia : (which * 2 + ia) * 2 + id];
+        const bool set_lds = lds > 64 * 1024 && lds > attr3;
+        HIPCHK(sf_run3_launch_plain(which, ia, id, (unsigned)s->g.E, (unsigned)waves * 64, lds, set_lds, s->stream, &a, sizeof a, n_steps, vcap, bsz));
+        if (set_lds) attr3 = lds;
+        return SF_OK;
+    }
+    // one word per thread: [attenuation off / on][diagonal spread read at run time / known to be on - every reference config]; control
+    // lines inside the launch: an instantiation without them (MIT = 0) where diagonal spread is known to be on, the others look at the argument
+    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, -1>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, -1>}};
+    static const run_fn table_nomit[2][2] = {{k_run<1, 0, -1, -1>, k_run<1, 0, 1, 0>}, {k_run<1, 1, -1, -1>, k_run<1, 1, 1, 0>}};
+    const bool nomit = !a.mit;
+    const run_fn kern = nomit ? table_nomit[ia][id] : table[ia][id];
+    size_t &attr = s->attr_run[nomit ? 12 + ia * 2 + id : ia * 2 + id];
     if (lds > 64 * 1024 && lds > attr) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
@@ -1155,7 +1164,7 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int place = s->tune.v[SF_TUNE_TEAM_PLACEMENT];
     a.team_far = place == 2;
     a.order = nullptr;
-    // (the team kernels are instantiated in the library's second translation unit, simfire_hip_run2.hip: [words per thread 1 / 2]
+    // (the team kernels are instantiated in the library's other translation units, simfire_hip_run2.hip / _run4.hip: [words per thread 1 / 2]
     // [attenuation off / on]; diagonal spread and control lines inside the launch are looked up at run time)
     const int rows = t.rcap ? t.rcap : g.H;
     const int need = ((rows + t.waves * 64 - 1) / (t.waves * 64)) * g.VW;
@@ -1163,7 +1172,8 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int id = g.diag ? 1 : 0;
     size_t &attr = (which && id && !a.mit) ? s->attr_team_c4[ia] : s->attr_team[(which * 2 + ia) * 2 + id];
     const bool set_lds = t.lds > 64 * 1024 && t.lds > attr;
-    HIPCHK(sf_run2_launch_team(which, ia, id, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
+    if (which) HIPCHK(sf_run4_launch_team2(ia, id, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
+    else HIPCHK(sf_run2_launch_team(ia, id, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
     if (set_lds) attr = t.lds;
     return SF_OK;
 }

@@ -1,6 +1,7 @@
-// Second translation unit of libsimfire_hip.so: the instantiations of k_run that only some handles ever launch - the team launch
-// (k_run<TEAM = 1>) and the closed loop (k_run<MIT = -2>) - compiled beside simfire_hip.hip so that the library builds in the time of
-// the larger of the two (python -m simfire_amd.build runs the two compiles side by side).  Everything it shares with the first unit
+// Second translation unit of libsimfire_hip.so: instantiations of k_run that only some handles ever launch - the team launch on one-word
+// rows (k_run<1, ..., TEAM = 1>) and the closed loop (k_run<MIT = -2>) - compiled beside simfire_hip.hip so that the library builds in the
+// time of the largest unit (python -m simfire_amd.build runs the compiles side by side; simfire_hip_run3.hip: the plain kernels for
+// several bitmap words per thread, simfire_hip_run4.hip: the team kernels for two).  Everything it shares with the first unit
 // comes from the same headers (all in anonymous namespaces: each unit has its own copy of the device helpers); the launch arguments
 // cross the boundary as bytes.
 // Replaces (like sf_run_kernels.h): n calls of RothermelFireManager.update per environment, simfire/game/managers/fire.py:616-719.
@@ -18,20 +19,17 @@ namespace {
 typedef void (*run_fn)(StepArgs, int, int, int);
 }
 
-// which: 0 / 1 = one / two bitmap words per thread; att: attenuate_line_ros; diag: diagonal_spread.  set_lds: raise the kernel's dynamic-LDS limit first.
-hipError_t sf_run2_launch_team(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+// One bitmap word per thread.  att: attenuate_line_ros; diag: diagonal_spread.  set_lds: raise the kernel's dynamic-LDS limit first.
+// (two words per thread: sf_run4_launch_team2, simfire_hip_run4.hip)
+hipError_t sf_run2_launch_team(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int n_steps, int vcap)
 {
-    // [words per thread][attenuation][diagonal spread read at run time / known to be on]
-    static const run_fn table[2][2][2] = {{{k_run<1, 0, -1, -1, 1>, k_run<1, 0, 1, -1, 1>}, {k_run<1, 1, -1, -1, 1>, k_run<1, 1, 1, -1, 1>}},
-                                          {{k_run<2, 0, -1, -1, 1>, k_run<2, 0, 1, -1, 1>}, {k_run<2, 1, -1, -1, 1>, k_run<2, 1, 1, -1, 1>}}};
+    // [attenuation][diagonal spread read at run time / known to be on]
+    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1, 1>, k_run<1, 0, 1, -1, 1>}, {k_run<1, 1, -1, -1, 1>, k_run<1, 1, 1, -1, 1>}};
     if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
     StepArgs a;
     memcpy(&a, args, sizeof a);
-    // (two words per thread, diagonal spread on, no control lines inside the launch = BASELINE config C4: its own instantiations, without
-    // the control-line code and its registers)
-    static const run_fn table_c4[2] = {k_run<2, 0, 1, 0, 1>, k_run<2, 1, 1, 0, 1>};
-    const run_fn kern = (which && diag && !a.mit) ? table_c4[att ? 1 : 0] : table[which ? 1 : 0][att ? 1 : 0][diag ? 1 : 0];
+    const run_fn kern = table[att ? 1 : 0][diag ? 1 : 0];
     if (set_lds) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

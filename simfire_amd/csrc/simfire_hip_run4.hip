@@ -1,0 +1,38 @@
+// Fourth translation unit of libsimfire_hip.so (see simfire_hip_run2.hip): the team kernels for two bitmap words per thread - grids of
+// 1025 .. 2048 columns, BASELINE config C4.  Everything it shares with the first unit
+// comes from the same headers (all in anonymous namespaces: each unit has its own copy of the device helpers); the launch arguments
+// cross the boundary as bytes.
+// Replaces (like sf_run_kernels.h): n calls of RothermelFireManager.update per environment, simfire/game/managers/fire.py:616-719.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/simfire_hip.h"
+#include "sf_common.h"
+#include "sf_step_kernels.h"
+#include "sf_aux_kernels.h"
+#include "sf_run_kernels.h"
+
+namespace {
+typedef void (*run_fn)(StepArgs, int, int, int);
+}
+
+hipError_t sf_run4_launch_team2(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                                const void *args, size_t args_bytes, int n_steps, int vcap)
+{
+    // [attenuation][diagonal spread read at run time / known to be on]
+    static const run_fn table[2][2] = {{k_run<2, 0, -1, -1, 1>, k_run<2, 0, 1, -1, 1>}, {k_run<2, 1, -1, -1, 1>, k_run<2, 1, 1, -1, 1>}};
+    if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
+    StepArgs a;
+    memcpy(&a, args, sizeof a);
+    // (diagonal spread on, no control lines inside the launch = BASELINE config C4: its own instantiations, without the control-line
+    // code and its registers)
+    static const run_fn table_c4[2] = {k_run<2, 0, 1, 0, 1>, k_run<2, 1, 1, 0, 1>};
+    const run_fn kern = (diag && !a.mit) ? table_c4[att ? 1 : 0] : table[att ? 1 : 0][diag ? 1 : 0];
+    if (set_lds) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, n_steps, vcap, 64);
+    return hipSuccess;
+}
