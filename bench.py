@@ -196,6 +196,7 @@ def measure(eng, w, a, agent_pts, dense):
     kind = eng.last_launch_kind()
     measure.last_cost = eng.run_cost() if kind == 2 else None      # clocks / 16 per environment in that launch (k_run)
     measure.last_teams = eng.team_sizes() if kind == 2 else None   # workgroups per environment (zeros: one each, one launch for the whole rollout)
+    measure.last_launches = eng.last_launches() if kind == 2 else 0
     st1, _ = eng.status()
     env_steps = int((st1[:, 1] - st0[:, 1]).sum())
     eng.reset(w.init_xy)
@@ -211,6 +212,7 @@ def measure(eng, w, a, agent_pts, dense):
 
 measure.last_cost = None
 measure.last_teams = None
+measure.last_launches = 0
 
 
 def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense):
@@ -265,19 +267,15 @@ def issue_block(w, a, rl, cost, n_cu=256):
         return None
     teams = measure.last_teams
     if teams is not None and int(teams.max()) > 0:
-        # a team launch (k_run<TEAM>): the rollout is cut into 128-step launches, an environment's cost is the sum over its members
+        # a team launch (k_run<TEAM>): the rollout may be cut into 128-step launches, an environment's cost is the sum over its members
         # (their waits for each other included) and covers the last launch only - no clock, no balance figure from that
-        seg = 128                                       # (step_impl: teams chosen by the library run in segments of 2 x 64 steps)
-        n, launches = a.steps, 0
-        while n > 0:
-            n -= seg if n > seg + seg // 2 else n
-            launches += 1
+        launches = max(int(measure.last_launches), 1)      # (sf_get_last_launches: teams of a fixed size make the whole rollout in one launch)
         rl["launches"] = launches
         rl["launch_ms"] = rl["kernel_ms_per_step"] * a.steps / launches
         rl["steps_per_launch"] = a.steps / launches
         rl["algorithmic_bytes_per_launch"] = rl["algorithmic_bytes_per_launch"] / launches
         return {"team_launch": True, "workgroups_per_environment": {int(k): int(v) for k, v in zip(*np.unique(teams, return_counts=True))},
-                "note": "k_run<TEAM>: bands of rows, one workgroup each; the rollout in launches of 128 steps (profiles/r03_team/README.md)"}
+                "note": "k_run<TEAM>: bands of rows, one workgroup each; teams of a fixed size: one launch, new bands every 128 steps inside it; sized by cost: launches of 128 steps (profiles/r03_team/README.md)"}
     clocks = cost.astype(np.float64) * 16.0
     slots = min(len(cost), n_cu)
     sec = rl["launch_ms"] * 1e-3

@@ -288,7 +288,10 @@ enum sf_tuning_knob {
                                  * -1 = teams of 1..4 sized from what the environments cost in the launch before, on any grid */
     SF_TUNE_TEAM_PLACEMENT = 16,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
                                  * 1 = consecutive slots (spread over the XCDs), 2 = as 0 but the hand-off written through as if they were apart (tests) */
-    SF_TUNE_COUNT = 17
+    SF_TUNE_TEAM_RECUT = 17,    /* teams of a fixed size (forced; or all the chip's workgroup slots taken at the smallest size: C4's share): 1 (default) =
+                                 * the whole rollout is ONE launch whose teams cut their bands anew every 2 x SF_TUNE_RUN_SEGMENT steps inside it,
+                                 * 0 = one launch per segment (the bands are cut by each launch's prologue) */
+    SF_TUNE_COUNT = 18
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
 /* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:
@@ -300,6 +303,10 @@ int sf_get_run_cost(sf_sim *sim, uint32_t *cost_out);
  * environment's rows are cut into bands, one workgroup each; the members exchange one boundary row per step): uint32 [n_envs],
  * zeros if the last launch gave every environment one workgroup.  No reference counterpart. */
 int sf_get_team_sizes(sf_sim *sim, uint32_t *sizes_out);
+/* How many environment-resident launches (k_run) the last sf_step / sf_step_mitigated / sf_rollout call was made of (0: it ran
+ * on the per-step kernels).  bench.py divides a rollout's algorithmic bytes and duration by it, so that its per-launch figures
+ * are those of the rocprofv3 kernel statistics.  No reference counterpart. */
+int sf_get_last_launches(sf_sim *sim, int32_t *n_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
  * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay

@@ -120,6 +120,8 @@ struct StepArgs {
     uint32_t *xerr;              // != 0: a wait for a team member timed out (the launch's results are void)
     int xrow;                    // bytes per published row: 64 (bitmap words) + PV * 16, rounded up to 128
     int team_rcap;               // bitmap rows a member keeps in LDS (+ 2 halo rows); 0 = the whole grid
+    int team_recut;              // > 0: the members of a team cut their bands anew every team_recut steps INSIDE the launch (teams of a fixed size: the whole
+                                 // rollout is one launch; cut into launches it lasts the sum of the launches' slowest environments - 12 % more on C4's share)
     // k_run in LOOP mode (sf_loop_start / sf_loop_step): the launch stays resident and is driven step by step by the host
     const uint32_t *loop_db;     // HOST-mapped doorbell: sequence number of the newest step the host has posted | kLoopStop = leave
     const int32_t *loop_pts_host;// HOST-mapped [2][E][k][3]: the points of the two newest steps (slot = sequence number & 1)

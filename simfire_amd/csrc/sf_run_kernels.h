@@ -306,7 +306,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;
-    if (TEAM && (tn > 1 || a.team_rcap)) {
+    // (steps_ahead: the updates until the bands are cut again - the fire advances one row per update at most)
+    auto cut_bands = [&](int steps_ahead) -> bool {
         const int th = g.LR * g.RB, ntr = (g.H + th - 1) / th;        // (the host offers teams only for <= 64 tile rows)
         if (tid < 64) tcnt[tid] = 0;
         __syncthreads();
@@ -320,16 +321,20 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             const uint32_t ci = lane < ntr ? tcnt[lane] : 0u;
             const uint32_t incl = wave_scan_incl(ci, lane), total = wave_last(incl);
             const unsigned long long nzb = __ballot(ci != 0u);
-            // rows that can hold fire before the launch is over (it advances one row per update at most); with a window of
+            // rows that can hold fire before the bands are cut again (it advances one row per update at most); with a window of
             // team_rcap rows per member nobody has to own the rest
             int lo = 0, hi = ntr;
-            if (a.team_rcap && nzb) {
-                const int mt = (n_steps + 1 + th - 1) / th + 1;
+            // (control lines inside the launch fall anywhere: then every row needs an owner - the host offers that only where the
+            // members' windows hold the whole grid between them)
+            if (a.team_rcap && nzb && !mit) {
+                const int mt = (steps_ahead + 1 + th - 1) / th + 1;
                 lo = __ffsll((long long)nzb) - 1 - mt; hi = 64 - __clzll((long long)nzb) + mt;
                 lo = lo < 0 ? 0 : lo; hi = hi > ntr ? ntr : hi;
+                // (every member owns at least one tile row: a small fire under a short look-ahead spans fewer tile rows than the team has members)
+                if (hi - lo < tn) { hi = lo + tn < ntr ? lo + tn : ntr; lo = hi - tn > 0 ? hi - tn : 0; }
             }
             const int cap = a.team_rcap ? a.team_rcap / th : ntr;     // tile rows a member can hold
-            if (a.team_rcap && !nzb) hi = ntr < cap * tn ? ntr : cap * tn;        // (no sprite anywhere: the fire is out, any rows will do)
+            if (a.team_rcap && !nzb && !mit) hi = ntr < cap * tn ? ntr : cap * tn;        // (no sprite anywhere: the fire is out, any rows will do)
             int cut[kTeamMax + 1];
             cut[0] = lo; cut[tn] = hi;
             for (int j = 1; j < tn; ++j) {
@@ -354,9 +359,13 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         const bool fits = __builtin_amdgcn_readfirstlane((int)tcnt[2]) != 0;
         R0 = __builtin_amdgcn_readfirstlane(R0); R1 = __builtin_amdgcn_readfirstlane(R1);
         if (R1 > g.H) R1 = g.H;
+        __syncthreads();
+        return fits;
+    };
+    if (TEAM && (tn > 1 || a.team_rcap)) {
+        const bool fits = cut_bands(a.team_recut > 0 && a.team_recut < n_steps ? a.team_recut : n_steps);
         if (a.todo_out && tm == 0 && tid == 0) a.todo_out[e] = fits ? 0 : n_steps;
         if (!fits) return;          // (uniform over the team: every member sees the same bitmap) nothing has been touched
-        __syncthreads();
     }
     const bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;           // a neighbour above / below the band
     // Do all members of the team sit on one XCD (one L2)?  Then the per-step hand-off can stay in that L2: plain stores (the L1 is
@@ -379,11 +388,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         one_l2 = __all((uint32_t)(x >> 32) == 1u && ((uint32_t)x & 15u) == xcc) && !a.team_far;
     }
     // The bitmaps are indexed by the grid row: with a window of rows in LDS the base pointers are shifted so that row y sits where it is.
-    const int yoff = TEAM && a.team_rcap ? R0 - 1 : 0;
-    unsigned long long *vb = vb0 - (long long)yoff * VW;
-    unsigned long long *vf = fine ? vb + (size_t)lds_rows * VW : nullptr, *vl = fine ? vb + (size_t)2 * lds_rows * VW : nullptr,
-                       *ve = fine ? vb + (size_t)3 * lds_rows * VW : nullptr;
-    {
+    unsigned long long *vb = vb0, *vf = nullptr, *vl = nullptr, *ve = nullptr;
+    auto load_band = [&]() {
+        const int yoff = TEAM && a.team_rcap ? R0 - 1 : 0;
+        vb = vb0 - (long long)yoff * VW;
+        vf = fine ? vb + (size_t)lds_rows * VW : nullptr; vl = fine ? vb + (size_t)2 * lds_rows * VW : nullptr;
+        ve = fine ? vb + (size_t)3 * lds_rows * VW : nullptr;
         // rows to load: the whole grid, or the band and the rows next to it
         const int y_lo = TEAM && a.team_rcap ? (R0 > 0 ? R0 - 1 : 0) : 0, y_hi = TEAM && a.team_rcap ? (R1 < g.H ? R1 + 1 : g.H) : g.H;
         for (int i = y_lo * VW + tid; i < y_hi * VW; i += nthr) {
@@ -394,17 +404,18 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 ve[i] = ~0ull;                                         // "has an eligible cell": found out as the vectors are visited
             }
         }
-    }
-    if (TEAM && tn > 1) {
-        // the neighbours' boundary rows as the launch finds them (plain loads: nobody has written anything yet)
-        for (int i = tid; i < 2 * g.PV; i += nthr) {
-            const int side = i >= g.PV, v = side ? i - g.PV : i, yh = side ? R1 : R0 - 1;
-            uint4 r = make_uint4(0, 0, 0, 0);
-            if (side ? has_dn : has_up)
-                r = *reinterpret_cast<const uint4 *>(a.cells + (long long)e * g.cells_env + bl_vec(g, yh, v) + (yh & 1) * 16);
-            halo[i] = r;
+        if (TEAM && tn > 1) {
+            // the neighbours' boundary rows as the launch (or the new cut) finds them (plain loads: nobody is writing)
+            for (int i = tid; i < 2 * g.PV; i += nthr) {
+                const int side = i >= g.PV, v = side ? i - g.PV : i, yh = side ? R1 : R0 - 1;
+                uint4 r = make_uint4(0, 0, 0, 0);
+                if (side ? has_dn : has_up)
+                    r = *reinterpret_cast<const uint4 *>(a.cells + (long long)e * g.cells_env + bl_vec(g, yh, v) + (yh & 1) * 16);
+                halo[i] = r;
+            }
         }
-    }
+    };
+    load_band();
     PhaseClock pc;
 #ifdef SF_PHASES
     uint32_t *ph_acc = ctl + kRunCtl + wave * 16;
@@ -423,8 +434,16 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     ev.vb = vb; ev.vf = vf; ev.vl = vl;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
     const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));      // wave-tile height is a power of two
-    const int rpt = ((TEAM ? R1 - R0 : g.H) + nthr - 1) / nthr;      // rows per thread (contiguous, so the list runs by rows)
-    const int row0 = TEAM ? R0 : 0;                                   // first row of this workgroup's rows
+    int rpt = ((TEAM ? R1 - R0 : g.H) + nthr - 1) / nthr;            // rows per thread (contiguous, so the list runs by rows)
+    int row0 = TEAM ? R0 : 0;                                         // first row of this workgroup's rows
+    // this member's rows of the bitmaps -> the global array (the others' rows in its LDS are not maintained)
+    auto store_band = [&]() {
+        for (int i = R0 * VW + tid; i < R1 * VW; i += nthr) {
+            vb_glob[i] = vb[i];
+            vb_glob[(long long)g.E * g.vb_env + i] = vf[i];
+            vb_glob[2ll * g.E * g.vb_env + i] = vl[i];
+        }
+    };
     const unsigned long long last_word_mask = (g.PV & 63) ? ((1ull << (g.PV & 63)) - 1ull) : ~0ull;
 
     // control lines inside the launch, up to 64 points per environment and step: lane i of the LAST wave holds point i of the coming
@@ -1037,6 +1056,18 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         }
         __syncthreads();
         pc.mark(0);          // waiting for the slowest wave of the step
+        // ---- TEAM: new bands every team_recut steps, inside the launch (teams of a fixed size).  What a launch boundary does for the
+        // members is done here by hand: every member writes its bitmap rows back and RELEASES what all its waves have stored (agent
+        // scope: the members may sit on different XCDs) before it publishes this step's granule; behind the wait for every
+        // member's granule it ACQUIRES, cuts the bands from the global bitmap like the prologue - every member the same cut from
+        // the same data -, loads its new band and lines up once more (a member that started the next step early would be writing
+        // rows whose old contents a slower one is still loading as its halo).
+        const bool recut_now = TEAM && tn > 1 && a.team_recut > 0 && (s + 1) % a.team_recut == 0 && s + 1 < n_steps;      // (uniform over the team)
+        if (recut_now) {
+            store_band();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+        }
         if (TEAM && tn > 1) {
             // ---- the team's step boundary: publish this member's boundary rows and predicates, wait for every member's, take the
             // neighbours' rows into the LDS halo (wave 0; the other waves wait at the barrier below)
@@ -1127,6 +1158,35 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         st.complete = __builtin_amdgcn_readfirstlane(st.complete);
         st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
         if (loop) loop_finish();
+        if (recut_now && (st.running || mit)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int left = n_steps - (s + 1);
+            cut_bands(a.team_recut < left ? a.team_recut : left);        // (fits: the host offers this only where t_min members hold the whole grid)
+            load_band();
+            ev.vb = vb; ev.vf = vf; ev.vl = vl;
+            rpt = (R1 - R0 + nthr - 1) / nthr;
+            row0 = R0;
+            __syncthreads();
+            if (wave == 0) {
+                // the second line-up: granule [2] (the start line's), tagged with the number of the cut
+                typedef unsigned long long u64;
+                const uint32_t tag = 2u + (uint32_t)((s + 1) / a.team_recut);
+                if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, (u64)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u64 x = (u64)tag << 32;
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                for (;;) {
+                    if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((uint32_t)(x >> 32) >= tag)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (gave_up || __builtin_readcyclecounter() - t0 > (1ull << 29)) {       // (bounded like every wait for a member)
+                        if (lane == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
+                        gave_up = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 #ifdef SF_PHASES
     pc.mark(12);
@@ -1149,12 +1209,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         }
     }
     if (TEAM) {
-        // this member's rows of the bitmaps (the others' rows in its LDS are not maintained)
-        for (int i = R0 * VW + tid; i < R1 * VW; i += nthr) {
-            vb_glob[i] = vb[i];
-            vb_glob[(long long)g.E * g.vb_env + i] = vf[i];
-            vb_glob[2ll * g.E * g.vb_env + i] = vl[i];
-        }
+        store_band();
     } else {
         for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
         if (fine)

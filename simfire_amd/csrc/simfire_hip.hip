@@ -108,11 +108,11 @@ struct Tuning {
 static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
     /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
-    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0};
+    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1};
 static const char *const kTuneName[SF_TUNE_COUNT] = {
     "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
     "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
-    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT"};
+    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -149,8 +149,11 @@ struct sf_sim {
     bool status_fresh = false;         // status_block / elapsed_dev (and the sink) hold the current result block: the resident launch wrote it
     int32_t *sink = nullptr;           // sf_set_result_sink: caller-owned device copy of the result block, written by every refresh
     bool tdirty_all = true;            // every histogram is stale (reset, fire_map replaced, geometry changed, per-cell kernel ran)
+    int last_launches = 0;             // k_run launches of the last step call (sf_get_last_launches)
     unsigned long long *vbits = nullptr;   // vector bitmap of the resident launch (k_run)
     bool vbits_valid = false;          // vbits matches the sprite-mask planes (k_run / reset keep it; the per-step kernels do not)
+    bool vbits_fl_valid = true;        // ... planes 1 / 2 of it too (first / last cell of the vector holds a sprite bit): k_run on rows of several words keeps only
+                                       // plane 0 (plain dilation) unless it runs as teams - which need all three (rebuilt when a team launch follows such a launch)
     bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
     int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell, 4 k_run_tiles, 5 k_front
     int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
@@ -575,6 +578,12 @@ extern "C" int sf_get_team_sizes(sf_sim *s, uint32_t *out)
     HIPCHK(hipMemcpy(out, s->team_size, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SF_OK;
 }
+extern "C" int sf_get_last_launches(sf_sim *s, int32_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_last_launches: null argument");
+    *out = s->last_launches;
+    return SF_OK;
+}
 extern "C" int sf_get_tuning(sf_sim *s, int32_t knob, int32_t *value)
 {
     if (!s || !value || knob < 0 || knob >= SF_TUNE_COUNT) return fail(SF_EINVAL, "sf_get_tuning: unknown knob %d", knob);
@@ -882,7 +891,7 @@ extern "C" int sf_reset(sf_sim *s, const int32_t *init_xy)
 {
     if (!s || !init_xy) return fail(SF_EINVAL, "sf_reset: null argument");
     int rc = reset_range(s, 0, s->g.E, init_xy);
-    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->tiles_valid = !s->bl_cur; }     // every environment freshly written
+    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->vbits_fl_valid = true; s->tiles_valid = !s->bl_cur; }     // every environment freshly written
     return rc;
 }
 
@@ -1055,6 +1064,7 @@ static int ensure_vbits(sf_sim *s)
     hipLaunchKernelGGL(k_rebuild_vbits, dim3(g.VW, g.H, g.E), dim3(64), 0, s->stream, g, (const uint8_t *)s->age, s->vbits, 0);
     HIPCHK(hipGetLastError());
     s->vbits_valid = true;
+    s->vbits_fl_valid = true;
     return SF_OK;
 }
 
@@ -1190,6 +1200,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     s->status_fresh = false;
     StepArgs a;
     a.loop_db = nullptr;      // (not the closed loop of sf_loop_start)
+    a.team_recut = 0;
+    s->last_launches = 0;
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.order = nullptr; a.cost = nullptr;
     a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
@@ -1262,6 +1274,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         tgeo = team_geometry(s);
         const int team_knob = tn.v[SF_TUNE_RUN_TEAM];
         team_forced = tgeo.ok && team_knob >= 2 && team_knob <= kTeamMax && team_knob <= g.TY && team_knob >= tgeo.t_min && (long long)g.E * team_knob <= tgeo.slots;
+        // (control lines inside the launch: every row needs an owner, so the members' windows of rows have to hold the whole grid between them)
+        if (mit_dev && tgeo.rcap > 0 && (long long)team_knob * tgeo.rcap < g.H) team_forced = false;
         team_wide = tgeo.ok && team_knob != 1 && g.VW == 2 && !mit_dev;      // (control lines inside the launch: every row needs an owner, a window of rows leaves some without)
         const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
         // Rows of one word: NOT automatic.  Measured on C3 / C5 (profiles/r03_team/): a member's step is a latency chain that does not get
@@ -1309,6 +1323,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     if (run_waves || fr_waves) {
         int rc0 = ensure_commit(s);            // k_run / k_front start from commit[] and leave the new states there
         if (rc0) return rc0;
+        // (a team launch reads all three planes of the vector bitmap; a launch of the plain kernel on rows of several words has kept only the first)
+        if ((team_forced || team_wide || team_auto) && !s->vbits_fl_valid) s->vbits_valid = false;
         rc0 = ensure_vbits(s);
         if (rc0) return rc0;
         rc0 = (run_waves && !fr_waves && !runt_waves) ? ensure_bl(s) : ensure_rm(s);
@@ -1411,7 +1427,16 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             // epilogue; measured on C4's share: 64 / 128 / 256 steps per launch = 26.3 / 26.1 / 26.8 us per step - the cuts have to follow the fires)
             // (one-word rows, teams sized by cost: C5 10.56 / 10.23 / 10.31 us per step with 64 / 128 / 256)
             const int tseg = (team_wide || team_auto) && !team_forced ? 2 * seg_knob : seg_knob;
-            if (team_segments && n_steps - done > tseg + tseg / 2) seg = tseg;
+            // Teams of a fixed size - forced, or every workgroup slot taken at the smallest size (C4's share: 128 x 2 = 256) -: nothing to
+            // plan between segments, so the rollout is ONE launch and the teams cut their bands anew inside it (k_run, team_recut).  Cut
+            // into launches a rollout lasts the sum of the launches' slowest environments instead of the slowest sum (measured on C4's
+            // share: + 12 %, profiles/segment_penalty_probe.py) and pays a plan, a prologue and an epilogue per segment.
+            const int tk0 = tn.v[SF_TUNE_RUN_TEAM];
+            const bool team_fixed = team_segments && tn.v[SF_TUNE_TEAM_RECUT] != 0 && !(tgeo.rcap > 0 && tk0 == -1) &&
+                                    (long long)tgeo.t_min * (tgeo.rcap ? tgeo.rcap : s->g.H) >= s->g.H &&
+                                    (team_forced || (team_wide && tgeo.slots - (long long)s->g.E * tgeo.t_min < (s->g.E + 3) / 4));
+            if (team_segments && !team_fixed && n_steps - done > tseg + tseg / 2) seg = tseg;
+            a.team_recut = team_fixed ? (team_forced ? 2 * seg_knob : tseg) : 0;
             const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
                 hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
@@ -1430,7 +1455,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                 // XCD and their step boundaries then go through memory, 16 k instead of 12 k clocks each.)
                 const bool windows = tgeo.rcap > 0 && !team_forced && tk == -1;
                 a.todo = nullptr; a.todo_out = windows ? s->todo : nullptr;
-                int rc0 = launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : (windows ? 1 : tgeo.t_min), t_max, s->cost_steps);
+                int rc0 = launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : (windows ? 1 : tgeo.t_min), team_fixed && !team_forced ? tgeo.t_min : t_max, s->cost_steps);
                 if (rc0) return rc0;
                 if (windows) {
                     a.todo = s->todo; a.todo_out = nullptr;
@@ -1443,9 +1468,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             } else {
                 int rc0 = launch_k_run(s, a, seg, run_waves, run_vcap, run_lds, bsz);
                 if (rc0) return rc0;
+                if (s->g.VW > 1) s->vbits_fl_valid = false;
             }
             s->cost_steps = seg;
             done += seg;
+            s->last_launches++;
         }
         s->status_fresh = res_knob != 0;
         s->tiles_valid = false;                // the tile activity map / seam planes are not kept by k_run

@@ -267,6 +267,12 @@ class FireEngine:
         self._chk(self._L.sf_get_team_sizes(self._h, _ptr(out)))
         return out
 
+    def last_launches(self):
+        """Environment-resident launches the last step / step_mitigated / rollout call was made of (0: per-step kernels)."""
+        v = C.c_int32()
+        self._chk(self._L.sf_get_last_launches(self._h, C.byref(v)))
+        return int(v.value)
+
     def get_tuning(self, name):
         v = C.c_int32()
         self._chk(self._L.sf_get_tuning(self._h, _lib.TUNE[name], C.byref(v)))

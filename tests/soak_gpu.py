@@ -16,6 +16,8 @@ def world(seed):
     rng = np.random.default_rng(seed)
     big = rng.random() < 0.25
     H, W = (int(rng.integers(60, 300)), int(rng.integers(60, 300))) if big else (int(rng.integers(1, 70)), int(rng.integers(1, 70)))
+    if rng.random() < 0.04:
+        H, W = int(rng.integers(70, 170)), int(rng.integers(1030, 1200))       # two-word rows: the resident launch runs as teams with windows of rows
     E = int(rng.integers(1, 5))
     md = int(rng.integers(1, 6)) if rng.random() < 0.8 else int(rng.integers(6, 29))
     att, diag = bool(rng.integers(2)), bool(rng.integers(2))
@@ -31,6 +33,10 @@ def world(seed):
     eng.set_fused(int(rng.integers(-1, 5)))            # automatic, two launches, fused, resident (k_run), resident tiles
     # teams (k_run<TEAM>): never / cost-sized / every environment split in 2 .. 4; members on one XCD, spread, written through
     eng.set_tuning(run_team=int(rng.choice([0, 0, 1, -1, 2, 3, 4])), team_placement=int(rng.integers(3)))
+    # teams of a fixed size: new bands inside the launch every 2 .. 10 steps (or the default 128), or one launch per segment
+    eng.set_tuning(run_segment=int(rng.choice([64, 64, 1, 2, 5])), team_recut=int(rng.random() < 0.8))
+    if os.environ.get("SOAK_DEBUG"):
+        print("world", seed, "H W E", H, W, E, "md", md, "att diag", att, diag, "fused", eng.get_tuning("run_team"), {k: eng.get_tuning(k) for k in ("run_team", "team_placement", "run_segment", "team_recut")}, flush=True)
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))

@@ -169,6 +169,94 @@ def test_team_split_random_worlds(seed, T):
     assert saw_team
 
 
+@pytest.mark.parametrize("rows_per_band", [2, 8])
+def test_two_word_rows_plain_launches_and_team_launches_take_turns(rows_per_band):
+    """Grids of 1025 .. 2048 columns: sf_step runs as teams (which read all three planes of the vector bitmap: any sprite bit / in
+    the first cell / in the last cell), sf_step_mitigated - control lines inside the launch - as the plain kernel, which keeps only
+    the first plane.  A team launch behind a plain one has to find the other two rebuilt (found by the soak once it drew such
+    grids: a frontier cell whose only burning neighbour sat in the first cell of the next vector, one row down, was missed)."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(990148)
+    H, W, E = 123, 1094, 3
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W))
+    eng, o = _pair(kw, R8, [(900, 20), (400, 100), (1000, 60)])
+    eng.set_fused(2)
+    eng.set_rows_per_band(rows_per_band)
+    kinds = set()
+    for t in range(24):
+        if t % 3 == 1:
+            blk = np.zeros((1, E, 2, 3), dtype=np.int32)
+            blk[..., 0] = rng.integers(0, W, (1, E, 2)); blk[..., 1] = rng.integers(0, H, (1, E, 2)); blk[..., 2] = rng.integers(3, 6, (1, E, 2))
+            eng.step_mitigated(blk)
+            o.apply_mitigation([(e, int(blk[0, e, i, 0]), int(blk[0, e, i, 1]), int(blk[0, e, i, 2])) for e in range(E) for i in range(2)])
+            o.step(1)
+        else:
+            n = int(rng.integers(1, 4))
+            eng.step(n)
+            o.step(n)
+        kinds.add(int(eng.team_sizes().max()) > 0)
+        _same(eng, o, E, tag=(rows_per_band, t))
+    assert kinds == {False, True}            # both kinds of launch took part
+
+
+@pytest.mark.parametrize("T", [2, 3, 4])
+@pytest.mark.parametrize("seed", range(6))
+def test_team_bands_cut_anew_inside_the_launch(seed, T):
+    """Teams of a fixed size make a whole call in ONE launch and cut their bands anew every 2 x SF_TUNE_RUN_SEGMENT steps inside it
+    (k_run: team_recut - every member writes its bitmap rows back and releases, all line up, acquire, cut from the global bitmap
+    like the prologue, load the new band, line up again).  Here every 2 .. 10 steps, in calls of up to 70 steps, with the fires
+    moving across the cuts, dying on one side of them, control lines inside the launch (sf_step_mitigated) and between calls,
+    one-word and two-word rows, three placements of the members - against the oracle; and the same with one launch per segment
+    (SF_TUNE_TEAM_RECUT = 0)."""
+    rng = np.random.default_rng(4400 + 31 * seed + T)
+    wide = seed % 3 == 2                                             # two-word rows: windows of rows in LDS
+    H, W = int(rng.integers(130, 300)), (int(rng.integers(1030, 1300)) if wide else int(rng.integers(64, 300)))
+    E = int(rng.integers(1, 4))
+    att, diag = bool(rng.integers(2)), bool(rng.integers(2))
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=int(rng.integers(2, 6)), pixel_scale=float(rng.choice([5.0, 20.0])),
+              update_rate=1.0, max_time=(None if rng.random() < 0.7 else float(rng.integers(30, 90))),
+              attenuate_line_ros=att, diagonal_spread=diag)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.08] = 0.0
+    if rng.random() < 0.4:
+        R8[:, :H // 2, :] = 0.0                                      # the upper bands' share of the fire dies
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    recut = seed % 2 == 0 or T != 3                                  # (a few cases with one launch per segment)
+    eng.set_tuning(run_team=T, team_placement=(seed + T) % 3, run_segment=int(rng.integers(1, 6)), team_recut=int(recut))
+    done, launches = 0, set()
+    while done < 160:
+        n = int(rng.integers(9, 70))
+        if rng.random() < 0.5 and not wide:
+            K = int(rng.choice([3, 20]))
+            blk = np.zeros((n, E, K, 3), dtype=np.int32)
+            blk[..., 0] = rng.integers(-1, W + 1, (n, E, K))
+            blk[..., 1] = rng.integers(-1, H + 1, (n, E, K))
+            blk[..., 2] = rng.integers(2, 7, (n, E, K))
+            blk[:, :, 0, 1] = (rng.integers(1, max(H // 32, 2), (n, E)) * 32 - rng.integers(0, 2, (n, E))).clip(0, H - 1)   # rows either side of a possible cut
+            eng.step_mitigated(blk)
+            for s_ in range(n):
+                rows = [(e, int(blk[s_, e, i, 0]), int(blk[s_, e, i, 1]), int(blk[s_, e, i, 2])) for e in range(E) for i in range(K)
+                        if 3 <= blk[s_, e, i, 2] <= 5 and 0 <= blk[s_, e, i, 0] < W and 0 <= blk[s_, e, i, 1] < H]
+                if rows:
+                    o.apply_mitigation(rows)
+                o.step(1)
+        else:
+            if rng.random() < 0.5:
+                pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(12)]
+                eng.apply_mitigation(pts)
+                o.apply_mitigation(pts)
+            eng.step(n)
+            o.step(n)
+        done += n
+        assert eng.last_launch_kind() == 2
+        launches.add(eng.last_launches())
+        _same(eng, o, E, tag=(seed, T, done))
+    assert (launches == {1}) == recut, launches                      # one launch per call, or one per segment
+
+
 @pytest.mark.parametrize("T", [2, 4])
 @pytest.mark.parametrize("att", [False, True])
 @pytest.mark.parametrize("place", [0, 1, 2])
