@@ -267,6 +267,11 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 // tile height, so a 128-byte line of the blocked plane has one owner).  Every member folds the same predicates into the same state,
 // so they all stop at the same step.  The last member to leave counts the environment (counts_env) behind an agent-scope release /
 // acquire.  Same update, same per-row list order inside a band: results do not depend on the team size (tests force 1 .. 4).
+// "plain loads / stores never touch another member's lines inside the launch" has one exception, a.team_recut > 0 (teams of a fixed size:
+// the whole rollout is one launch - a rollout cut into launches lasts the SUM of the launches' slowest environments): every team_recut
+// steps the members cut their bands anew - each writes its bitmap rows back and releases (agent scope) before that step's granule, acquires
+// behind the wait for everybody's, cuts the bands from the global bitmap as the prologue does, loads its new band and halo rows, and
+// lines up once more before anyone writes again (cut_bands / load_band / store_band below).
 template <int MAXD, int ATT, int DIAG, int MIT, int TEAM = 0>
 __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
 {
