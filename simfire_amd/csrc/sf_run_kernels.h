@@ -368,8 +368,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         return fits;
     };
     if (TEAM && (tn > 1 || a.team_rcap)) {
-        const bool fits = cut_bands(a.team_recut > 0 && a.team_recut < n_steps ? a.team_recut : n_steps);
+        const bool fits = cut_bands(tn > 1 && a.team_recut > 0 && a.team_recut < n_steps ? a.team_recut : n_steps);
         if (a.todo_out && tm == 0 && tid == 0) a.todo_out[e] = fits ? 0 : n_steps;
+        if (!fits && !a.todo_out && tid == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;      // (the host promised a fit and made no catch-up launch: fail loudly)
         if (!fits) return;          // (uniform over the team: every member sees the same bitmap) nothing has been touched
     }
     const bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;           // a neighbour above / below the band

@@ -150,6 +150,8 @@ struct sf_sim {
     int32_t *sink = nullptr;           // sf_set_result_sink: caller-owned device copy of the result block, written by every refresh
     bool tdirty_all = true;            // every histogram is stale (reset, fire_map replaced, geometry changed, per-cell kernel ran)
     int last_launches = 0;             // k_run launches of the last step call (sf_get_last_launches)
+    int fire_rows = 0;                 // no environment's fire spans more rows than this (0: not known): 1 after sf_reset, + 2 per update (a fire
+                                       // advances one row per update at most, fire.py:163-234), the grid's height after sf_load_fire_map
     unsigned long long *vbits = nullptr;   // vector bitmap of the resident launch (k_run)
     bool vbits_valid = false;          // vbits matches the sprite-mask planes (k_run / reset keep it; the per-step kernels do not)
     bool vbits_fl_valid = true;        // ... planes 1 / 2 of it too (first / last cell of the vector holds a sprite bit): k_run on rows of several words keeps only
@@ -891,7 +893,7 @@ extern "C" int sf_reset(sf_sim *s, const int32_t *init_xy)
 {
     if (!s || !init_xy) return fail(SF_EINVAL, "sf_reset: null argument");
     int rc = reset_range(s, 0, s->g.E, init_xy);
-    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->vbits_fl_valid = true; s->tiles_valid = !s->bl_cur; }     // every environment freshly written
+    if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->vbits_fl_valid = true; s->tiles_valid = !s->bl_cur; s->fire_rows = 1; }     // every environment freshly written
     return rc;
 }
 
@@ -979,6 +981,7 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
     for (size_t i = 0; i < n; ++i)
         if (map[i] > SF_WETLINE) return fail(SF_EINVAL, "sf_load_fire_map: value %d at cell %zu is not a BurnStatus", map[i], i);
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    s->fire_rows = 0;                  // (a map from outside: its fire may be of any size)
     int rc = ensure_stage(s, n);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
@@ -1202,6 +1205,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     a.loop_db = nullptr;      // (not the closed loop of sf_loop_start)
     a.team_recut = 0;
     s->last_launches = 0;
+    const int n_requested = n_steps;
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.order = nullptr; a.cost = nullptr;
     a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
@@ -1437,6 +1441,20 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                                     (team_forced || (team_wide && tgeo.slots - (long long)s->g.E * tgeo.t_min < (s->g.E + 3) / 4));
             if (team_segments && !team_fixed && n_steps - done > tseg + tseg / 2) seg = tseg;
             a.team_recut = team_fixed ? (team_forced ? 2 * seg_knob : tseg) : 0;
+            // Two-word rows, YOUNG fires: one member holds any fire whose rows (+ what it can grow during the launch + the cut's margins)
+            // fit its window of team_rcap rows - and a young fire cut in two only pays the step boundary (C4's share, the driver's
+            // window: 8.7 us per step with two members).  The host knows an upper bound without asking the device: a fire spans one row
+            // after sf_reset and advances one row per update at most.  A call that ends with every fire still under 192 rows gives every
+            // environment ONE member.
+            bool young = false;
+            if (team_wide && !team_forced && tk0 == 0 && tgeo.rcap > 0 && s->fire_rows > 0) {
+                // (cut_bands: the fire's tile rows, + ceil((updates + 1) / tile height) + 1 tile rows either side)
+                const long long room = (long long)tgeo.rcap - s->fire_rows - 2LL * done - 7LL * s->g.LR * s->g.RB - 2;
+                const long long fit = room / 2;              // updates the window is sure to hold
+                // (only where the whole call stays young - measured on C4's share: one member for the first ~ 380 of 1000 updates and two
+                // for the rest loses to two members throughout, 23.5 against 21.9 us per step; the driver's 20 after 5: 7.0 against 8.7)
+                if (fit >= n_steps - done && s->fire_rows + 2LL * (n_steps - done) <= 192) { young = true; seg = n_steps - done; a.team_recut = 0; }
+            }
             const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
                 hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
@@ -1455,7 +1473,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                 // XCD and their step boundaries then go through memory, 16 k instead of 12 k clocks each.)
                 const bool windows = tgeo.rcap > 0 && !team_forced && tk == -1;
                 a.todo = nullptr; a.todo_out = windows ? s->todo : nullptr;
-                int rc0 = launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : (windows ? 1 : tgeo.t_min), team_fixed && !team_forced ? tgeo.t_min : t_max, s->cost_steps);
+                int rc0 = young ? launch_k_run_team(s, a, seg, tgeo, 1, 1, s->cost_steps)
+                                : launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : (windows ? 1 : tgeo.t_min), team_fixed && !team_forced ? tgeo.t_min : t_max, s->cost_steps);
                 if (rc0) return rc0;
                 if (windows) {
                     a.todo = s->todo; a.todo_out = nullptr;
@@ -1506,6 +1525,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         s->seq = (s->seq + 1) % 6;
         s->committed = false;
     }
+    if (s->fire_rows > 0) { const long long fr = (long long)s->fire_rows + 2LL * n_requested; s->fire_rows = fr > s->g.H ? s->g.H : (int)fr; }
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     // no commit here: the states stay in the rings until something asks for them (ensure_commit)
     HIPCHK(hipGetLastError());
@@ -1772,6 +1792,7 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
     __sync_synchronize();                                    // the points are in memory before the number that announces them
     db[0] = seq;
     s->loop_seq = seq;
+    if (s->fire_rows > 0 && s->fire_rows < g.H) s->fire_rows = s->fire_rows + 2 > g.H ? g.H : s->fire_rows + 2;
     // wait for the "done" number; should the launch have left by itself (no ring for loop_timeout clocks), start it again: every
     // workgroup resumes from its own "done" number, the points of this step are still in their slot
     const volatile uint32_t *res = reinterpret_cast<const volatile uint32_t *>(s->loop_res);
