@@ -1444,7 +1444,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             // Two-word rows, YOUNG fires: one member holds any fire whose rows (+ what it can grow during the launch + the cut's margins)
             // fit its window of team_rcap rows - and a young fire cut in two only pays the step boundary (C4's share, the driver's
             // window: 8.7 us per step with two members).  The host knows an upper bound without asking the device: a fire spans one row
-            // after sf_reset and advances one row per update at most.  A call that ends with every fire still under 192 rows gives every
+            // after sf_reset and advances one row per update at most.  A call that ends with every fire still under 480 rows gives every
             // environment ONE member.
             bool young = false;
             if (team_wide && !team_forced && tk0 == 0 && tgeo.rcap > 0 && s->fire_rows > 0) {
@@ -1453,7 +1453,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                 const long long fit = room / 2;              // updates the window is sure to hold
                 // (only where the whole call stays young - measured on C4's share: one member for the first ~ 380 of 1000 updates and two
                 // for the rest loses to two members throughout, 23.5 against 21.9 us per step; the driver's 20 after 5: 7.0 against 8.7)
-                if (fit >= n_steps - done && s->fire_rows + 2LL * (n_steps - done) <= 192) { young = true; seg = n_steps - done; a.team_recut = 0; }
+                // (C4's share, calls of 60 / 100 / 150 / 250 / 350 updates after 20: one member 7.8 / 8.3 / 9.6 / 11.9 / 15.8 us per step, two 9.1 / 9.3 / 10.8 / 12.1 / 14.1)
+                if (done == 0 && fit >= n_steps && s->fire_rows + 2LL * n_steps <= 480) { young = true; seg = n_steps - done; a.team_recut = 0; }
             }
             const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {

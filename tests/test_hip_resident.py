@@ -320,7 +320,7 @@ def test_team_split_two_word_rows_run_resident():
     """BASELINE config C4's grid (2048 x 2048: bitmap rows of two words).  One workgroup cannot hold the four bitmaps of such a
     grid, a team can: every member keeps a window of rows.  The automatic mode therefore picks the team launch (kind 2) - the refined
     interest rule with the edge-cell terms carried across the word boundary at column 1024: ONE member with a window around the
-    fire while the call ends with every fire surely under 192 rows (one row after the reset, one more either way per update: the host
+    fire while the call ends with every fire surely under 480 rows (one row after the reset, one more either way per update: the host
     needs no answer from the device for that), two and more after that; a wholesale map replacement voids the bound."""
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
