@@ -282,8 +282,10 @@ enum sf_tuning_knob {
     SF_TUNE_FRONT_DEBUG = 14,
     SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in the resident launch (k_run<TEAM>: bands of rows, one boundary row exchanged per step):
                                  * 0 = automatic (default): teams on grids of more than 1024 columns, where one workgroup cannot hold an
-                                 * environment's bitmaps, and - sized by cost, in long calls - where at most a quarter as many environments as
-                                 * CUs leave most of the chip idle; one workgroup per environment otherwise (measured faster);
+                                 * environment's bitmaps (one member with a window of rows while a call ends with every fire surely young -
+                                 * the library keeps an upper bound on the fires' extent since the last reset -, two and more after that),
+                                 * and - sized by cost, in long calls - where two to a quarter as many environments as CUs leave most of the
+                                 * chip idle; one workgroup per environment otherwise (measured faster);
                                  * 1 = never; 2 / 3 / 4 = every environment split into exactly that many (tests);
                                  * -1 = teams of 1..4 sized from what the environments cost in the launch before, on any grid */
     SF_TUNE_TEAM_PLACEMENT = 16,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
