@@ -150,6 +150,12 @@ struct sf_sim {
     int32_t *sink = nullptr;           // sf_set_result_sink: caller-owned device copy of the result block, written by every refresh
     bool tdirty_all = true;            // every histogram is stale (reset, fire_map replaced, geometry changed, per-cell kernel ran)
     int last_launches = 0;             // k_run launches of the last step call (sf_get_last_launches)
+    // run(1) loops (one update per call, the result block looked at after each - FireSimulation.run(1) in a harness): after two such
+    // pairs in a row the single update runs as the resident launch too, which leaves the block behind itself (measured, step(1) +
+    // status() per call: 41 against 46 us on one environment, 47 against 58 on C3's 256; a loop that only enqueues step(1) calls, or
+    // looks at the maps after each, is faster on the per-step kernels and keeps them)
+    bool last_was_step1 = false;       // the last step call was one update and nothing has looked at its result yet
+    int step1_polls = 0;               // step(1) + status pairs in a row
     int fire_rows = 0;                 // no environment's fire spans more rows than this (0: not known): 1 after sf_reset, + 2 per update (a fire
                                        // advances one row per update at most, fire.py:163-234), the grid's height after sf_load_fire_map
     unsigned long long *vbits = nullptr;   // vector bitmap of the resident launch (k_run)
@@ -1206,6 +1212,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     a.team_recut = 0;
     s->last_launches = 0;
     const int n_requested = n_steps;
+    if (n_steps != 1 || mit_dev || s->last_was_step1) s->step1_polls = 0;       // (another kind of call, or nobody looked at the last update's result)
+    const bool polled = n_steps == 1 && !mit_dev && s->step1_polls >= 2;
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.order = nullptr; a.cost = nullptr;
     a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
@@ -1281,7 +1289,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // (control lines inside the launch: every row needs an owner, so the members' windows of rows have to hold the whole grid between them)
         if (mit_dev && tgeo.rcap > 0 && (long long)team_knob * tgeo.rcap < g.H) team_forced = false;
         team_wide = tgeo.ok && team_knob != 1 && g.VW == 2 && !mit_dev;      // (control lines inside the launch: every row needs an owner, a window of rows leaves some without)
-        const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
+        const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev || polled) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
         // Rows of one word: NOT automatic.  Measured on C3 / C5 (profiles/r03_team/): a member's step is a latency chain that does not get
         // shorter with half the rows, and a team's step boundary costs 5 - 10 k clocks (publish, wait for the slowest member, read), so
         // teams of 8-wave members lose to one 16-wave workgroup per environment until a fire is far larger than these get (C3: 11.0 ->
@@ -1527,6 +1535,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         s->committed = false;
     }
     if (s->fire_rows > 0) { const long long fr = (long long)s->fire_rows + 2LL * n_requested; s->fire_rows = fr > s->g.H ? s->g.H : (int)fr; }
+    s->last_was_step1 = n_requested == 1 && !mit_dev;
     if (ms) HIPCHK(hipEventRecord(s->ev1, s->stream));
     // no commit here: the states stay in the rings until something asks for them (ensure_commit)
     HIPCHK(hipGetLastError());
@@ -1855,6 +1864,7 @@ static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
 {
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    if (s->last_was_step1) { s->last_was_step1 = false; s->step1_polls = 0; }      // (a loop that looks at the maps after every update: per-step kernels)
     const size_t bytes = (size_t)n * g.H * g.W;
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
@@ -1935,6 +1945,7 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
 {
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    if (s->last_was_step1) { s->last_was_step1 = false; if (s->step1_polls < 1000) s->step1_polls++; }
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     if (s->status_fresh) {
         // the resident launch has left the block (and the registered sink's copy) behind: nothing to count

@@ -361,6 +361,38 @@ def test_team_split_two_word_rows_run_resident():
         _same(eng, o, 3, tag=("cost-sized", n))
 
 
+def test_run1_loops_move_to_the_resident_launch():
+    """`run(1)` the way a harness uses the reference - one update per call, the result looked at after each: after two such pairs
+    in a row the single update runs as the resident launch too (it leaves the result block behind itself); a loop that looks at
+    the maps after every update, or only enqueues updates, stays on the per-step kernels; results are the oracle's either way."""
+    rng = np.random.default_rng(77)
+    H, W, E = 96, 160, 3
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=True)
+    R8 = rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W))
+    eng, o = _pair(kw, R8, [(20, 20), (100, 50), (150, 90)])
+    kinds = []
+    for i in range(7):                                   # step(1) + status()
+        eng.step(1); o.step(1)
+        st, el = eng.status()
+        so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), i
+        kinds.append(eng.last_launch_kind())
+    assert all(k in (0, 1) for k in kinds[:2]) and all(k == 2 for k in kinds[2:]), kinds
+    _same(eng, o, E, tag="status loop")
+    kinds = []
+    for i in range(5):                                   # step(1) + a look at the maps
+        eng.step(1); o.step(1)
+        assert (eng.fire_map(1) == o.fire_map(1)).all(), i
+        kinds.append(eng.last_launch_kind())
+    assert all(k in (0, 1) for k in kinds[1:]), kinds    # (the first still belonged to the loop before)
+    kinds = []
+    for i in range(5):                                   # step(1) only
+        eng.step(1); o.step(1)
+        kinds.append(eng.last_launch_kind())
+    assert all(k in (0, 1) for k in kinds), kinds
+    _same(eng, o, E, tag="end")
+
+
 def test_resident_hands_over_to_per_step_kernels_and_back():
     """k_run leaves the committed states and the tile activity map exactly as the per-step kernels
     expect them (and takes them over from those): alternate between all four launch structures and
