@@ -293,7 +293,9 @@ enum sf_tuning_knob {
     SF_TUNE_TEAM_RECUT = 17,    /* teams of a fixed size (forced; or all the chip's workgroup slots taken at the smallest size: C4's share): 1 (default) =
                                  * the whole rollout is ONE launch whose teams cut their bands anew every 2 x SF_TUNE_RUN_SEGMENT steps inside it,
                                  * 0 = one launch per segment (the bands are cut by each launch's prologue) */
-    SF_TUNE_COUNT = 18
+    SF_TUNE_RUN_WINDOW = 18,    /* the window phase of the resident launch (a young fire's cells held in registers while the fire fits 64 x 64 cells): 1 (default) = on,
+                                 * 0 = off, k > 1 = on, but the window is left after k updates (tests: forces the hand-over to the general loop anywhere) */
+    SF_TUNE_COUNT = 19
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
 /* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:

@@ -101,6 +101,8 @@ struct StepArgs {
                                  // holds one in its first cell / in its last cell
     const int32_t *mit;  // k_run only: control-line points [n_steps][E][mit_k][3] = (column, row, type) applied before each step, or null
     int mit_k;
+    int win;             // k_run only: 0 = no window phase (sf_win_kernels.h), 1 = young fires are stepped inside a window of cells held in registers,
+                         // k > 1 = the same, but the window is left after k updates (tests)
     const int32_t *todo; // k_run only: steps to do per environment (what k_front left over), or null = n_steps for all
     // k_run only: the per-environment result block written by the launch itself when its steps are done (null = not)
     int32_t *res_block;  // [E][8] running, update() calls made, cells per BurnStatus 0..5 (sf_get_status)

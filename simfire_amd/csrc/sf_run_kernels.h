@@ -76,6 +76,10 @@ __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int v
     return b;
 }
 
+}  // namespace
+#include "sf_win_kernels.h"
+namespace {
+
 struct RunEnv {                    // per-environment bases (wave-uniform)
     uint8_t *cells;                // blocked cell plane (sf_common.h, bl_vec): sprite masks + status
     double *burn;
@@ -308,6 +312,26 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * VW;
     if (tid < kRunCtl) ctl[tid] = 0;
+    const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));      // wave-tile height is a power of two
+    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
+    // ---- a young fire: as many updates as it stays inside a window of cells held in registers (sf_win_kernels.h); the loop below
+    // takes over where updates are left.  (The instantiations of sf_step on one-word rows: no teams, no control lines inside the launch.)
+    constexpr bool kWin = TEAM == 0 && MAXD == 1 && MIT == 0;
+    int s_begin = 0;
+    if (kWin) {
+        WinEnv we;
+        we.cells = a.cells + (long long)e * g.cells_env;
+        we.burn = a.burn + (long long)e * g.plane_env;
+        we.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
+        we.rt = a.rt + (long long)e * g.rt_env;
+        we.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+        we.vb_glob = vb_glob;
+        we.vb_plane = (long long)g.E * g.vb_env;
+        s_begin = run_window<ATT>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done);
+        if (a.counters && tid == 0 && s_begin)           // (statistics slot 6 of the plain kernel: updates made inside a window)
+            atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * 8 + 6, (unsigned long long)s_begin);
+    }
+    const bool general = !kWin || (s_begin < n_steps && st.running);       // (uniform) the bitmaps in LDS, the loop over the vector list
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;
@@ -421,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             }
         }
     };
-    load_band();
+    if (general) load_band();
     PhaseClock pc;
 #ifdef SF_PHASES
     uint32_t *ph_acc = ctl + kRunCtl + wave * 16;
@@ -439,7 +463,6 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     ev.rt = a.rt + (long long)e * g.rt_env;
     ev.vb = vb; ev.vf = vf; ev.vl = vl;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
-    const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));      // wave-tile height is a power of two
     int rpt = ((TEAM ? R1 - R0 : g.H) + nthr - 1) / nthr;            // rows per thread (contiguous, so the list runs by rows)
     int row0 = TEAM ? R0 : 0;                                         // first row of this workgroup's rows
     // this member's rows of the bitmaps -> the global array (the others' rows in its LDS are not maintained)
@@ -488,10 +511,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         lseq = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[18]);
         n_steps = 0x7FFFFFFF;
     }
-    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
     bool gave_up = false;        // TEAM: a wait for the other members timed out (the handle is void; never wait again)
     unsigned long long x_clocks = 0, x_steps = 0;      // TEAM statistics: clocks wave 0 spent at the team's step boundaries (publish + wait + read), boundaries
-    for (int s = 0; s < n_steps && (st.running || mit); ++s) {
+    for (int s = s_begin; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
 #ifdef SF_PHASES
         pc.tl = (e == g_timeline_env && s == g_timeline_step) ? g_timeline + wave * 64 : nullptr;
@@ -1216,7 +1238,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     }
     if (TEAM) {
         store_band();
-    } else {
+    } else if (general) {              // (a launch that never left the window phase has kept the bitmaps in memory)
         for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
         if (fine)
             for (int i = tid; i < g.H; i += nthr) {

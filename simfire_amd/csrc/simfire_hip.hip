@@ -108,11 +108,11 @@ struct Tuning {
 static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
     /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
-    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1};
+    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1};
 static const char *const kTuneName[SF_TUNE_COUNT] = {
     "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
     "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
-    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT"};
+    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -1332,6 +1332,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
 #endif
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
     a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr; a.todo_out = nullptr;
+    a.win = tn.v[SF_TUNE_RUN_WINDOW] < 0 ? 0 : tn.v[SF_TUNE_RUN_WINDOW];
     if (run_waves || fr_waves) {
         int rc0 = ensure_commit(s);            // k_run / k_front start from commit[] and leave the new states there
         if (rc0) return rc0;

@@ -1188,3 +1188,70 @@ def test_mitigated_rollout_in_segments_with_many_environments():
     for e in (0, 1, 255, 256, 512, 513, 699):
         assert (eng.fire_map(e) == o.fire_map(e)).all(), e
         assert (eng.burn(e) == o.burn(e)).all(), e
+
+
+# ------------------------------------------------------------------ the window phase of the resident launch (young fires)
+def _window_world(rng, H, W, E, att=None, burn0=False):
+    md = int(rng.integers(1, 6))
+    att = bool(rng.integers(2)) if att is None else att
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=md, pixel_scale=float(rng.choice([5.0, 20.0, 50.0])),
+              update_rate=float(rng.choice([1.0, 0.5, 1.5])),
+              max_time=(None if rng.random() < 0.7 else float(rng.integers(10, 60))),
+              attenuate_line_ros=att, diagonal_spread=True)
+    R8 = rng.choice([0.0, 3.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.1] = 0.0
+    return kw, R8
+
+
+@pytest.mark.parametrize("win", [1, 2, 3, 7, 0])
+@pytest.mark.parametrize("seed", range(10))
+def test_window_phase_random_worlds(seed, win):
+    """Young fires are stepped inside a window of cells held in registers (sf_win_kernels.h) until they reach its edge; the
+    general loop of k_run takes over inside the same launch.  Random worlds (exact R ties, attenuation on / off, runtime cut-off,
+    barren cells, ignitions anywhere - also right at the grid's edges and corners -, control lines and lines on burning
+    cells between calls, resets), calls of random length; SF_TUNE_RUN_WINDOW = k leaves the window after k updates, so the
+    hand-over happens at every age of a fire.  Equal to the oracle after every call, whatever the knob says."""
+    rng = np.random.default_rng(41000 + seed)
+    H, W = int(rng.integers(64, 400)), int(rng.integers(64, 400))
+    E = int(rng.integers(1, 6))
+    kw, R8 = _window_world(rng, H, W, E)
+    inits = []
+    for _ in range(E):
+        q = rng.random()
+        if q < 0.25:      # at an edge / in a corner of the grid
+            inits.append((int(rng.choice([0, 1, W - 2, W - 1])), int(rng.choice([0, 1, H - 2, H - 1]))))
+        elif q < 0.4:
+            inits.append((int(rng.choice([0, W - 1])), int(rng.integers(H))))
+        else:
+            inits.append((int(rng.integers(W)), int(rng.integers(H))))
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.set_tuning(run_window=win)
+    eng.enable_counters(True)
+    done = 0
+    while done < 80:
+        n = int(rng.integers(2, 30))
+        if rng.random() < 0.4:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(int(rng.integers(1, 30)))]
+            e0 = int(rng.integers(E))
+            burning = np.argwhere(o.fire_map(e0) == 1)
+            if len(burning):
+                y, x = burning[rng.integers(len(burning))]
+                pts += [(e0, int(x), int(y), int(rng.integers(3, 6))), (e0, int(x) + 1, int(y), int(rng.integers(3, 6)))]
+                pts = [p for p in pts if p[1] < W]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        if rng.random() < 0.15:
+            e0, x, y = int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H))
+            eng.reset_env(e0, x, y)
+            o.reset_env(e0, x, y)
+        eng.step(n)
+        o.step(n)
+        done += n
+        _same(eng, o, E, tag=(seed, win, done))
+    cnt = eng.counters()
+    if win == 0:
+        assert cnt["window_updates"] == 0
+    else:
+        assert cnt["window_updates"] > 0, "the window phase never ran"
