@@ -11,7 +11,10 @@ from simfire_amd.engine import FireEngine    # noqa: E402
 
 NAMES = {15: "step start", 1: "interest+ranks", 2: "list+barrierA", 3: "cursor+next fetch issued", 11: "rows arrived", 4: "nb masks, strips",
          5: "SWAR, stores issued", 6: "prefix+frontier list", 7: "walk: winner", 8: "walk: burn/table arrived, update", 9: "walk: stores, fence",
-         10: "end of batch", 0: "barrier B (end of step)", 12: "fold", 13: "lines: eligible bits + barrier", 14: "lines: plane work issued", 16: "first batch known", 17: "its rows requested", 18: "next batch known"}
+         10: "end of batch", 0: "barrier B (end of step)", 12: "fold", 13: "lines: eligible bits + barrier", 14: "lines: plane work issued", 16: "first batch known", 17: "its rows requested", 18: "next batch known",
+         20: "win start", 21: "win rows arrived", 22: "win frontier known", 23: "win winners+req", 24: "win table arrived", 25: "win updated", 26: "win at barrier",
+         27: "win thru barrier", 28: "win folded", 30: "launch start", 31: "fire found", 32: "window loaded", 33: "updates done", 34: "written back",
+         35: "steps done", 36: "handed back", 37: "result block"}
 
 
 def main():
@@ -48,7 +51,7 @@ def main():
         print("slowest env", env, "clocks", int(log[env, 0]), "vectors", int(log[env, 1]))
     eng.reset(w.init_xy)
     run(eng, 0, warm)
-    L.sf_debug_timeline(env, steps - 1, None)
+    L.sf_debug_timeline(env, -1 if len(sys.argv) > 6 and sys.argv[6] == "launch" else steps - 1, None)
     run(eng, warm, warm + steps)
     eng.status()
     tl = np.zeros((16, 64), dtype=np.uint64)

@@ -318,6 +318,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // takes over where updates are left.  (The instantiations of sf_step on one-word rows: no teams, no control lines inside the launch.)
     constexpr bool kWin = TEAM == 0 && MAXD == 1 && MIT == 0;
     int s_begin = 0;
+    bool win_result = false;  // the window phase has written this environment's row of the result block
+    PhaseClock wpc;          // (timeline of the launch as a whole: sf_debug_timeline(env, -1))
     if (kWin) {
         WinEnv we;
         we.cells = a.cells + (long long)e * g.cells_env;
@@ -325,9 +327,15 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         we.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
         we.rt = a.rt + (long long)e * g.rt_env;
         we.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+        we.thist = a.thist + (long long)e * g.TY * g.TX * 8;
         we.vb_glob = vb_glob;
         we.vb_plane = (long long)g.E * g.vb_env;
-        s_begin = run_window<ATT>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done);
+        wpc.start();
+#ifdef SF_PHASES
+        wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
+#endif
+        wpc.note(30);        // launch: state read
+        s_begin = run_window<ATT>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result);
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 6 of the plain kernel: updates made inside a window)
             atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * 8 + 6, (unsigned long long)s_begin);
     }
@@ -1226,6 +1234,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     }
 #endif
     // ---- hand the environment back: state, vector bitmap
+    wpc.note(35);            // steps done
     __syncthreads();
     if (tid == 0) {
         if (!TEAM || tm == 0) a.commit[e] = st;      // (every member has folded the same predicates into the same state)
@@ -1275,10 +1284,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         __syncthreads();
         if (!ctl[0]) return;       // (uniform)
     }
-    if (a.res_block) {
+    if (a.res_block && !(win_result && !general)) {
         __syncthreads();
+        wpc.note(36);        // state / bitmaps handed back
         counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
                    reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
+        wpc.note(37);        // result block written
     }
 }
 

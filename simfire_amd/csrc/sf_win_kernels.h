@@ -11,17 +11,22 @@ namespace {
 // A young fire's step on the general path of k_run is ONE wave's dependent chain of ~1 800 instructions (interest sweep over all
 // bitmap rows, a list, a batch of vectors, a walk) whatever the size of the fire: 12 k clocks per update while
 // fifteen waves wait at a barrier.  As long as the whole fire fits a WINDOW of (threads / 16) rows x 64 cells, the workgroup
-// instead keeps the window in REGISTERS for as many steps as it stays inside:
-//   lane (r, c) owns the four cells (y0 + r, x0 + 4 c .. + 3): their sprite masks and status bytes as two dwords, their
-//   burn_amounts as four doubles.  A row of the window is a DPP row of 16 lanes, a wave holds four rows.
-//   per step  the sprite masks of the rows above / below come from a copy of the window's mask plane in LDS (one ds_read2), the
-//             dwords left / right of them by DPP row shifts; expiry -> BURNED (fire.py:116-161), slot recycling, eligible & next
-//             to a live sprite (fire.py:163-234) as SWAR over the lane's four cells; per candidate cell the winner source
-//             (pick_winner8), ONE f64 table entry from memory, burn += R dt - attenuation, burn > pixel_scale -> BURNING
-//             (fire.py:696-710, 550-589); the lane's new mask dword goes to the LDS copy; ONE workgroup barrier; fold.
+// instead keeps the window ON THE CU for as many steps as it stays inside - sprite masks and burn_amounts in LDS, status bytes in
+// registers:
+//   lane (r, c) owns the four cells (y0 + r, x0 + 4 c .. + 3).  A row of the window is a DPP row of 16 lanes, a wave holds four rows.
+//   per step  the lane's mask dword and the ones above / below from the window's mask plane in LDS, the live masks left / right
+//             by DPP row shifts; expiry -> BURNED (fire.py:116-161), slot recycling, eligible & next to a live sprite
+//             (fire.py:163-234) as SWAR over the lane's four cells -> a 4-bit frontier mask per lane;
+//             the WAVE compacts its frontier cells (one DPP prefix sum, a 16-bit entry per cell in its LDS list) and walks them,
+//             one or two cells per lane: 3 x 3 sprite masks from the LDS plane, winner source (pick_winner8), ONE f64 table entry
+//             from memory + burn from LDS, burn += R dt - attenuation, burn > pixel_scale -> the cell's mask byte in LDS
+//             (fire.py:696-710, 550-589; the owner lane sets BURNING when it sees the bit in the next step);
+//             ONE workgroup barrier; fold.
 //   Waves whose rows (and the rows next to them) hold no sprite bit skip the step.  The update is in place like everywhere else:
 //   a step's writers touch the mask slots t and t - md - 2 only, which every reader of that step masks out.
-// No list, no prefix sum, no atomics, no cell-plane traffic: what a step reads from memory is one table entry per candidate cell.
+// No interest sweep, no workgroup-wide list, no atomics, no cell-plane traffic: what a step reads from memory is one table entry per
+// frontier cell.  (First version: every lane walked its own four cells, burn in registers - four passes of winner + update in every
+// wave that held ONE frontier cell; 4.4 k clocks per step against 12 k on the general path.)
 // The window is left (its cells, burn_amounts, the vector bitmaps' rows and the dirty flags of its tiles written back; the general
 // loop of k_run takes over where steps are left) as soon as a sprite sits in the outermost ring of cells on a side that is not
 // the grid's edge - the next update could then ignite a cell outside.  Results never depend on whether, when or where a window
@@ -40,106 +45,203 @@ __device__ __forceinline__ uint32_t dpp_from_right(uint32_t v)     // lane + 1 i
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true);      // row_shl:1
 }
 
+// OR / minimum / maximum over the 64 lanes of a wave on the DPP path (the steps of wave_scan_incl; lanes shifted in from outside read 0)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t row16_or(uint32_t v)           // OR over the first 16 lanes (lane 15 holds it)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+__device__ __forceinline__ uint32_t row16_max(uint32_t v)          // unsigned maximum over the first 16 lanes
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
 struct WinEnv {                    // per-environment bases (wave-uniform)
     uint8_t *cells;                // blocked cell plane (sf_common.h, bl_cell)
     double *burn;
     uint32_t *settled;
     const double *rt;
     uint8_t *tdirty;
+    uint16_t *thist;               // [TY][TX][8] of this environment: cached status histograms of the wave tiles
     unsigned long long *vb_glob;   // this environment's rows of the three vector bitmaps in memory: plane 0; planes 1 / 2 are vb_plane further each
     long long vb_plane;
 };
 
 // Returns the updates made (0: the fire does not fit a window - nothing has been touched).  st is folded like in the general loop;
 // everything the window held is back in memory when this returns (workgroup barrier included).
+// LDS (wl: 8-byte aligned): burn [WR][64] f64 | step masks [8][8] u32 | status-count changes [16][8] i32 | per-wave slots [16][4] u32 |
+// mask plane [WR + 2][18] u32 (a zero dword left / right of every row, a zero row above / below) | "burn changed" bytes [WR][16] |
+// frontier lists [waves][256] u16.
+__host__ __device__ inline size_t win_lds_bytes(int n_waves)
+{
+    const int WR = n_waves * 4;
+    return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)n_waves * 256 * 2;
+}
+
 template <int ATT>
-__device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, EnvState &st, const int n_steps, const bool diag, uint32_t *wmask,
-                                          uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done)
+__device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, EnvState &st, const int n_steps, const bool diag, uint32_t *wl,
+                                          uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done, PhaseClock &lpc, const int e, bool &result_done)
 {
     const Geo &g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int WR = nthr >> 4;                                  // window rows
+    PhaseClock pc;           // (timeline of one step; lpc: timeline of the launch)
+    pc.start();
     if (g.H < WR || g.PV < 4 || g.dense || n_steps <= 0 || !st.running || !a.win) return 0;       // (uniform)
-    // ---- where is the fire?  Rows and vector columns that hold a sprite bit, from the vector bitmap in memory
-    if (tid == 0) { ctl[kWinCtl] = 0x7FFFFFFFu; ctl[kWinCtl + 1] = 0; ctl[kWinCtl + 2] = 0; ctl[kWinCtl + 3] = 0; ctl[kWinCtl + 4] = 0; }
-    __syncthreads();
+    // ---- where is the fire?  Rows and vector columns that hold a sprite bit, from the vector bitmap in memory: thread y looks at row y.
+    // (No LDS atomics: on a uniform address the compiler turns them into a scalar loop over the lanes - 6 k clocks of every launch.)
+    if (g.H > nthr) return 0;
+    uint32_t *const wslot = wl + (size_t)WR * 128 + 64 + 128;                            // [waves][4]: per wave first row, last row + 1 (0: none), column bits
     {
-        unsigned long long cm = 0;
-        int ylo = 0x7FFFFFFF, yhi = 0;
-        for (int y = tid; y < g.H; y += nthr) {
-            const unsigned long long w = ev.vb_glob[y];
-            if (w) { cm |= w; ylo = y < ylo ? y : ylo; yhi = y + 1; }
-        }
-        if (cm) {
-            atomicMin(reinterpret_cast<int *>(ctl + kWinCtl), ylo);
-            atomicMax(reinterpret_cast<int *>(ctl + kWinCtl + 1), yhi);
-            atomicOr(ctl + kWinCtl + 2, (uint32_t)cm);
-            atomicOr(ctl + kWinCtl + 3, (uint32_t)(cm >> 32));
+        const unsigned long long w = tid < g.H ? ev.vb_glob[tid] : 0ull;
+        const unsigned long long nz = __ballot(w != 0ull);
+        const uint32_t c_lo = wave_or((uint32_t)w), c_hi = wave_or((uint32_t)(w >> 32));
+        // are the cached status histograms of this environment's tiles all valid?  Then the result block can be brought up to date
+        // from what this phase changes (below) instead of a sweep over the tiles' flags and histograms (counts_env)
+        bool dirty = false;
+        for (int t = tid; t < g.TY * g.TX; t += nthr) dirty |= ev.tdirty[t] != 0;
+        const bool wave_dirty = __ballot(dirty) != 0ull;
+        if (lane == 0) {
+            uint32_t *sl = wslot + wave * 4;
+            sl[0] = (nz ? (uint32_t)(wave * 64 + __ffsll((long long)nz) - 1) : 0u) | (wave_dirty ? 0x80000000u : 0u);
+            sl[1] = nz ? (uint32_t)(wave * 64 + 64 - __clzll((long long)nz)) : 0u;
+            sl[2] = c_lo; sl[3] = c_hi;
         }
     }
     __syncthreads();
-    const int ymin = __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl]), ymax1 = __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 1]);
-    const uint32_t cm_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 2]), cm_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 3]);
-    const unsigned long long cmask = (unsigned long long)cm_lo | ((unsigned long long)cm_hi << 32);
+    int ymin, ymax1;
+    unsigned long long cmask;
+    bool hist_clean;
+    {
+        const int n_waves = nthr >> 6;
+        const uint4 sl = lane < n_waves ? *reinterpret_cast<const uint4 *>(wslot + lane * 4) : make_uint4(0, 0, 0, 0);
+        // first row: the smallest (first row + 1) among the waves that hold any = maximum of its complement
+        const uint32_t inv = sl.y ? 0xFFFFFFFFu - (sl.x & 0x7FFFFFFFu) : 0u;
+        const uint32_t mi = row16_max(inv), ma = row16_max(sl.y), clo = row16_or(sl.z), chi = row16_or(sl.w);
+        hist_clean = (row16_or(sl.x) & 0x80000000u) == 0u;
+        ymin = mi ? (int)(0xFFFFFFFFu - mi) : 0;
+        ymax1 = (int)ma;
+        cmask = (unsigned long long)clo | ((unsigned long long)chi << 32);
+    }
     if (!cmask) return 0;                                      // no sprite anywhere: the general loop's next update says QUIT
+    lpc.note(31);            // where the fire is
     const int vmin = __ffsll((long long)cmask) - 1, vmax = 63 - __clzll((long long)cmask);
     const int hb = ymax1 - ymin, wv = vmax - vmin + 1;
     if (hb > WR || wv > 4) return 0;
     int wy0 = ymin - ((WR - hb) >> 1), wv0 = vmin - ((4 - wv) >> 1);
     wy0 = wy0 < 0 ? 0 : (wy0 > g.H - WR ? g.H - WR : wy0);
     wv0 = wv0 < 0 ? 0 : (wv0 > g.PV - 4 ? g.PV - 4 : wv0);
+    const int wx0 = wv0 << 4;
+    // the ring: outermost cells of the window on the sides that are not the grid's edge.  A sprite there could ignite a cell outside.
+    const bool open_top = wy0 > 0, open_bot = wy0 + WR < g.H, open_left = wv0 > 0, open_right = (wv0 + 4) * 16 < g.W;
+    // ---- LDS
+    double *const wb = reinterpret_cast<double *>(wl);                                   // burn_amounts of the window
+    uint32_t *const tab = wl + (size_t)WR * 128;                                         // masks of a step by slot of its number
+    int32_t *const dt = reinterpret_cast<int32_t *>(tab + 64);                           // [16 tiles][8]: cells per BurnStatus gained / lost; [15][0..7]: the old result row
+    uint32_t *const wm = tab + 64 + 128 + 64;                                            // sprite masks (behind the per-wave slots of the search above)
+    uint8_t *const wdirty = reinterpret_cast<uint8_t *>(wm + (WR + 2) * 18);             // per lane: burn_amounts of its cells changed
+    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16) + wave * 256; // this wave's frontier cells of the step
     // ---- load: two dwords + four doubles per lane
     const int r = tid >> 4, c = tid & 15;
-    const int y = wy0 + r, x = (wv0 << 4) + 4 * c;
+    const int y = wy0 + r, x = wx0 + 4 * c;
     uint8_t *const cellp = ev.cells + bl_cell(g, y, x);
     const uint32_t idx = (uint32_t)(y * g.P + x);
-    uint32_t ag = *reinterpret_cast<const uint32_t *>(cellp), sv = *reinterpret_cast<const uint32_t *>(cellp + kBlStatus);
-    double bn[4];
+    const uint32_t ag0 = *reinterpret_cast<const uint32_t *>(cellp), sv0 = *reinterpret_cast<const uint32_t *>(cellp + kBlStatus);
     {
         const double2 b01 = *reinterpret_cast<const double2 *>(ev.burn + idx), b23 = *reinterpret_cast<const double2 *>(ev.burn + idx + 2);
-        bn[0] = b01.x; bn[1] = b01.y; bn[2] = b23.x; bn[3] = b23.y;
+        double2 *dst = reinterpret_cast<double2 *>(wb + (r * 16 + c) * 4);
+        dst[0] = b01; dst[1] = b23;
     }
-    // the ring: outermost cells of the window on the sides that are not the grid's edge.  A sprite there could ignite a cell outside.
     uint32_t ring = 0;
-    if ((r == 0 && wy0 > 0) || (r == WR - 1 && wy0 + WR < g.H)) ring = 0xFFFFFFFFu;
-    if (c == 0 && wv0 > 0) ring |= 0x000000FFu;
-    if (c == 15 && (wv0 + 4) * 16 < g.W) ring |= 0xFF000000u;
+    if ((r == 0 && open_top) || (r == WR - 1 && open_bot)) ring = 0xFFFFFFFFu;
+    if (c == 0 && open_left) ring |= 0x000000FFu;
+    if (c == 15 && open_right) ring |= 0xFF000000u;
     const uint32_t in_w = first01(g.W - x);                    // 0 / 1 per byte: the cell exists (pitch padding never takes part)
-    wmask[(r + 1) * 16 + c] = ag;                              // the LDS copy of the mask plane, a zero row above and below
-    if (tid < 16) { wmask[tid] = 0; wmask[(WR + 1) * 16 + tid] = 0; }
-    if (ag & ring) ctl[kWinCtl + 4] = 1;
+    const int own = (r + 1) * 18 + c + 1;                      // this lane's dword in the mask plane
+    wm[own] = ag0;
+    wdirty[r * 16 + c] = 0;
+    // The result block by difference: where every cached tile histogram of the environment is valid, the last result row is too
+    // (whoever validates a histogram writes the row: counts_env), and what this phase changes is known cell by cell.
+    const int ty0 = wy0 >> th_log, tx0 = wv0 >> g.logLC;
+    const int nty = ((wy0 + WR - 1) >> th_log) - ty0 + 1, ntx = ((wv0 + 3) >> g.logLC) - tx0 + 1;
+    const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15;
+    if (tid < 128) dt[tid] = (by_delta && tid >= 120) ? a.res_block[e * 8 + (tid - 120)] : 0;
+    if (tid < 18) { wm[tid] = 0; wm[(WR + 1) * 18 + tid] = 0; }
+    if (tid < WR) { wm[(tid + 1) * 18] = 0; wm[(tid + 1) * 18 + 17] = 0; }
+    if (tid < g.N) {
+        // the masks of a step depend on the slot of its number only (make_masks): one row per slot
+        const Masks m = make_masks(tid, g.md, g.N);
+        const uint32_t L4 = rep4(m.m_live);
+        uint32_t *row = tab + tid * 8;
+        row[0] = L4; row[1] = rep4(m.b_exp); row[2] = rep4(m.b_clr); row[3] = m.b_new;
+        row[4] = diag ? L4 : (L4 & 0xFF00FF00u); row[5] = diag ? L4 : (L4 & 0x00FF00FFu);
+        row[6] = (uint32_t)m.rot | ((uint32_t)(g.N - m.rot) << 8) | ((uint32_t)(__ffs(m.b_exp) - 1) << 16) | ((uint32_t)slot_of(tid - 1, g.N) << 24);
+        row[7] = 0;
+    }
+    if (ag0 & ring) ctl[kWinCtl + 4] = 1;
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 4]) != 0) return 0;      // (uniform) the fire is at the window's edge already
-    const uint32_t ag0 = ag, sv0 = sv;
-    bool burn_dirty = false;
-    const uint32_t HP = (uint32_t)(g.H * g.P);
+    lpc.note(32);            // window loaded
+    uint32_t sv = sv0;
+    const uint32_t HP = (uint32_t)(g.H * g.P), nmask = (1u << g.N) - 1u;
     const int s_cap = a.win > 1 && a.win < n_steps ? a.win : n_steps;      // (SF_TUNE_RUN_WINDOW = k > 1: tests leave the window after k updates)
-    int s = 0;
-    bool leave = false;
-    for (; s < s_cap && st.running && !leave; ++s) {
-        const int k = s % 3, kn = (s + 1) % 3;
+    int s = 0, k = 0;
+    int s0 = slot_of(st.steps + 1, g.N);                       // slot of the coming step's number
+    // The usual step - some sprite is alive, some cell is a candidate, no runtime limit (fire.py:637-652, 717) - folds into three
+    // additions; what the environment state holds is brought up to date when anything else happens, and at the end.
+    const bool plain_fold = !g.has_max_time && st.running == 1 && !st.time_quit;
+    int n_plain = 0;                                           // plain steps not yet in st.steps / st.complete
+    double elapsed = st.elapsed;
+    const double rate = g.update_rate;
+    const bool stats = a.counters != nullptr;
+    uint32_t up = wm[own - 18], mid = wm[own], dn = wm[own + 18];
+    for (;;) {
+        const int kn = k == 2 ? 0 : k + 1;
+#ifdef SF_PHASES
+        pc.tl = (e == g_timeline_env && s == g_timeline_step) ? g_timeline + (tid >> 6) * 64 : nullptr;
+        pc.tl_n = 0;
+#endif
+        pc.note(20);         // window step start
         if (tid == 0) ctl[3 + kn] = 0;                         // predicate bytes of the next step (last read before the barrier that ended step s - 1)
-        const int t = st.steps + 1;
-        const Masks mk = make_masks(t, g.md, g.N);
-        const bool spread = !st.time_quit;                     // fire.py:641-643: prune only, then QUIT
-        const uint32_t L4 = rep4(mk.m_live), EXP4 = rep4(mk.b_exp), CLR4 = rep4(mk.b_clr);
-        const int exp_sh = __ffs(mk.b_exp) - 1;
-        const uint32_t lo_mask = diag ? L4 : (L4 & 0xFF00FF00u), hi_mask = diag ? L4 : (L4 & 0x00FF00FFu);
-        const uint32_t up = wmask[r * 16 + c], dn = wmask[(r + 2) * 16 + c];
-        if (__ballot((ag | up | dn) != 0u) != 0ull) {          // (wave-uniform) nothing in or next to this wave's four rows: nothing to do
-            if (a.counters) n_vec_done += lane == 0 ? 16u : 0u;            // four rows x four vectors swept
-            const uint32_t upl = dpp_from_left(up), upr = dpp_from_right(up), ml = dpp_from_left(ag), mr = dpp_from_right(ag);
-            const uint32_t dl = dpp_from_left(dn), dr = dpp_from_right(dn);
-            const uint32_t midL = ag & L4;
+        if (__ballot((mid | up | dn) != 0u) != 0ull) {         // (wave-uniform) nothing in or next to this wave's four rows: nothing to do
+            const uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
+            const uint32_t L4 = t0.x, CLR4 = t0.z, b_new = t0.w, lo_mask = t1.x, hi_mask = t1.y;
+            const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
+            const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
+            pc.note(21);     // rows arrived
+            if (stats) n_vec_done += lane == 0 ? 16u : 0u;     // four rows x four vectors swept
+            // the cells this window ignited in the step before: BURNING (fire.py:587; not in a window's first step: a bit of that age
+            // may sit under a control line drawn since)
+            {
+                const uint32_t im = spread01((mid >> prev_sh) & (s > 0 ? 0x01010101u : 0u));
+                sv = (sv & ~im) | (0x01010101u & im);
+            }
+            const uint32_t midL = mid & L4;
             if (__ballot(midL != 0u) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;      // FLAG_LIVE (fire.py:637)
             // S1 prune: cells whose sprite reached max_fire_duration become BURNED
-            uint32_t snew = sv;
-            const uint32_t ex = ag & EXP4;
-            if (ex) {
+            {
                 const uint32_t s7 = sv & 0x07070707u;
-                const uint32_t em = spread01((ex >> exp_sh) & 0x01010101u);
-                snew = (s7 & ~em) | (0x02020202u & em);
-                if (ATT) {
+                const uint32_t em = spread01((mid >> exp_sh) & 0x01010101u);
+                sv = (s7 & ~em) | (0x02020202u & em);
+                if (ATT && em) {
                     // a control line drawn on a burning cell ends when that sprite expires (the prune overwrites it with BURNED,
                     // fire.py:140): make up the attenuation the cell is still owed
                     uint32_t sp = pack4(ge3_01(s7) & em & 0x01010101u);
@@ -147,101 +249,181 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                         const int b = __ffs(sp) - 1;
                         sp &= sp - 1;
                         const uint32_t s_pre = (s7 >> (8 * b)) & 7u;
-                        const double v = lazy_sub(b == 0 ? bn[0] : (b == 1 ? bn[1] : (b == 2 ? bn[2] : bn[3])), line_factor(s_pre),
-                                                  (uint32_t)st.complete - ev.settled[idx + b]);
-                        if (b == 0) bn[0] = v; else if (b == 1) bn[1] = v; else if (b == 2) bn[2] = v; else bn[3] = v;
-                        burn_dirty = true;
+                        double *bp = wb + (r * 16 + c) * 4 + b;
+                        *bp = lazy_sub(*bp, line_factor(s_pre), (uint32_t)(st.complete + n_plain) - ev.settled[idx + b]);
+                        wdirty[r * 16 + c] = 1;
                     }
                 }
             }
-            uint32_t agn = ag & ~CLR4;                         // the slot of sprites that were pruned one step ago is recycled
+            if (mid & CLR4) wm[own] = mid & ~CLR4;             // the slot of sprites that were pruned one step ago is recycled
             if (spread) {
                 const uint32_t vsrc = (up | dn) & L4;
                 const uint32_t hsrc = diag ? (midL | vsrc) : midL;
-                const uint32_t hl = (diag ? (ml | upl | dl) : ml) & L4, hr = (diag ? (mr | upr | dr) : mr) & L4;
+                const uint32_t hl = dpp_from_left(hsrc), hr = dpp_from_right(hsrc);
                 // per cell: OR of the live masks of its (4 or 8) neighbours
                 const uint32_t nb = vsrc | (hsrc << 8) | (hl >> 24) | (hsrc >> 8) | (hr << 24);
-                // frontier cells (0 / 1 per byte): eligible (fire.py:192-205) & next to a live sprite
-                const uint32_t p = ELIG(snew) & nz01(nb) & in_w;
-                if (__ballot(p != 0u) != 0ull) {
-                    // first half, all four cells: winner source, the one table entry requested
-                    double rtab[4] = {0.0, 0.0, 0.0, 0.0};
-                    uint32_t owed[4] = {0u, 0u, 0u, 0u};
-                    bool cd[4];
+                // frontier cells: eligible (fire.py:192-205) & next to a live sprite
+                const uint32_t p4 = pack4(ELIG(sv) & nz01(nb) & in_w);
+                const uint32_t cnt = (uint32_t)__popc(p4);
+                pc.note(22); // frontier cells known
+                if (__ballot(cnt != 0u) != 0ull) {
+                    // ---- the wave's frontier cells, compacted: entry = owner lane << 2 | cell | status << 8
+                    const uint32_t incl = wave_scan_incl(cnt, lane);
+                    const uint32_t total = wave_last(incl);
+                    {
+                        uint32_t pos = incl - cnt;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        cd[j] = ((p >> (8 * j)) & 1u) != 0u;
-                        if (__ballot(cd[j]) != 0ull) {
-                            // bytes 0..2 = cells x - 1, x, x + 1 of the rows y - 1, y, y + 1
-                            const uint32_t up3 = j == 0 ? __builtin_amdgcn_alignbyte(up, upl, 3) : (j == 1 ? up : (j == 2 ? up >> 8 : __builtin_amdgcn_alignbyte(upr, up, 2)));
-                            const uint32_t mid3 = j == 0 ? __builtin_amdgcn_alignbyte(ag, ml, 3) : (j == 1 ? ag : (j == 2 ? ag >> 8 : __builtin_amdgcn_alignbyte(mr, ag, 2)));
-                            const uint32_t dn3 = j == 0 ? __builtin_amdgcn_alignbyte(dn, dl, 3) : (j == 1 ? dn : (j == 2 ? dn >> 8 : __builtin_amdgcn_alignbyte(dr, dn, 2)));
-                            const int bestk = pick_winner8(up3, mid3, dn3, mk, lo_mask, hi_mask);
-                            cd[j] = cd[j] && bestk >= 0;
-                            if (cd[j]) {
-                                rtab[j] = ev.rt[(uint32_t)bestk * HP + idx + j];                     // 8 H P < 2^29
-                                if (ATT && ((snew >> (8 * j)) & 7u) >= SF_FIRELINE) owed[j] = (uint32_t)st.complete - ev.settled[idx + j];
+                        for (int j = 0; j < 4; ++j)
+                            if ((p4 >> j) & 1u) wlist[pos++] = (uint16_t)((uint32_t)(lane << 2 | j) | (((sv >> (8 * j)) & 7u) << 8));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    struct WCell { bool cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
+                    // first half of a cell: which, winner source, operands requested
+                    auto front = [&](uint32_t i) {
+                        WCell q;
+                        const bool valid = i < total;
+                        const uint32_t ent = wlist[valid ? i : 0u];
+                        const uint32_t rr = (uint32_t)(wave * 4) + ((ent >> 6) & 3u), cx = ((ent >> 2) & 15u) * 4u + (ent & 3u);      // row / column inside the window
+                        // bytes 0..2 = cells x - 1, x, x + 1 of the rows y - 1, y, y + 1: cell cx sits at byte 4 + cx of a plane row
+                        const uint32_t b0 = cx + 3u, sh = b0 & 3u;
+                        const uint32_t *pr = wm + rr * 18u + (b0 >> 2);
+                        const uint32_t up3 = __builtin_amdgcn_alignbyte(pr[1], pr[0], sh);
+                        const uint32_t mid3 = __builtin_amdgcn_alignbyte(pr[19], pr[18], sh);
+                        const uint32_t dn3 = __builtin_amdgcn_alignbyte(pr[37], pr[36], sh);
+                        int bestk = -1;
+                        {
+                            // pick_winner8 (sf_step_kernels.h) on this step's masks from the table
+                            const uint32_t lo = __builtin_amdgcn_perm(mid3, dn3, 0x06000102u) & lo_mask;
+                            const uint32_t hi = __builtin_amdgcn_perm(mid3, up3, 0x00010204u) & hi_mask;
+                            uint32_t o = lo | hi;
+                            o |= o >> 16;
+                            o = (o | (o >> 8)) & 0xFFu;
+                            if (o) {
+                                const uint32_t rq = ((o << rot) | (o >> nrot)) & nmask;
+                                int slot = (31 - __clz(rq)) - (int)rot;        // bit of the newest sprite in the unrotated masks
+                                if (slot < 0) slot += g.N;
+                                const uint32_t T = __builtin_amdgcn_perm(0u, 1u << slot, 0u);     // that bit in every byte
+                                const uint32_t cl = lo & T, ch = hi & T;
+                                bestk = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
                             }
                         }
-                    }
-                    const unsigned long long cb = __ballot(cd[0] | cd[1] | cd[2] | cd[3]);
-                    if (cb != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;   // FLAG_CAND (fire.py:651)
-                    if (a.counters)
-                        n_active += (uint32_t)(__popcll(__ballot(cd[0])) + __popcll(__ballot(cd[1])) + __popcll(__ballot(cd[2])) + __popcll(__ballot(cd[3])));
+                        q.cand = valid && bestk >= 0;
+                        q.pos = rr * 64u + cx;
+                        q.own_spost = ((mid3 >> 8) & 0xFFu) | (((ent >> 8) & 7u) << 8);
+                        q.owed = 0; q.bn = 0.0; q.r_tab = 0.0;
+                        if (q.cand) {
+                            const uint32_t gi = (uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx);
+                            q.r_tab = ev.rt[(uint32_t)bestk * HP + gi];                              // 8 H P < 2^29
+                            q.bn = wb[q.pos];
+                            if (ATT && (q.own_spost >> 8) >= SF_FIRELINE) q.owed = (uint32_t)(st.complete + n_plain) - ev.settled[gi];
+                        }
+                        return q;
+                    };
                     // second half: accumulate, ignite
-                    uint32_t ign = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (cd[j]) {
-                            const uint32_t s_post = (snew >> (8 * j)) & 7u;
-                            double b = bn[j];
-                            double ros = rtab[j] * g.update_rate;                                    // fire.py:696,705
+                    auto back = [&](const WCell &q) {
+                        bool ignited = false;
+                        if (q.cand) {
+                            const uint32_t rr = q.pos >> 6, cx = q.pos & 63u, s_post = q.own_spost >> 8;
+                            double b = q.bn;
+                            double ros = q.r_tab * g.update_rate;                                    // fire.py:696,705
                             if (s_post >= SF_FIRELINE) {                                             // fire.py:271-282
                                 if (ATT) {
                                     const double f = line_factor(s_post);
-                                    b = lazy_sub(b, f, owed[j]);       // the updates since this cell was last touched (fire.py:278, ros = 0)
+                                    b = lazy_sub(b, f, q.owed);        // the updates since this cell was last touched (fire.py:278, ros = 0)
                                     ros = ros - f;
-                                    ev.settled[idx + j] = (uint32_t)st.complete + 1u;                // this update runs to the end: it has a candidate
+                                    ev.settled[(uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx)] = (uint32_t)(st.complete + n_plain) + 1u;      // this update runs to the end: it has a candidate
                                 } else ros = 0.0;
                             }
                             b = b + ros;                                                             // fire.py:710
-                            bn[j] = b;
-                            burn_dirty = true;
-                            if (b > g.pixel_scale) ign |= 1u << (8 * j);                             // fire.py:568
+                            wb[q.pos] = b;
+                            wdirty[q.pos >> 2] = 1;
+                            if (b > g.pixel_scale) {                                                 // fire.py:568
+                                ignited = true;
+                                reinterpret_cast<uint8_t *>(wm)[(rr + 1u) * 72u + 4u + cx] = (uint8_t)(((q.own_spost & 0xFFu) & ~(CLR4 & 0xFFu)) | b_new);      // fire.py:571-579
+                                const bool on_ring = (rr == 0u && open_top) || (rr == (uint32_t)(WR - 1) && open_bot) || (cx == 0u && open_left) || (cx == 63u && open_right);
+                                if (on_ring) reinterpret_cast<uint8_t *>(ctl + 3 + k)[2] = 1;        // a sprite in the ring: the window is left after this step
+                            }
                         }
+                        if (stats) n_ignite += (uint32_t)__popcll(__ballot(ignited));
+                    };
+                    bool any_cand = false;
+                    for (uint32_t base = 0; base < total; base += 128u) {
+                        const bool two = base + 64u < total;       // (uniform) two cells per lane: one memory round trip for both
+                        WCell c0 = front(base + (uint32_t)lane), c1;
+                        c1.cand = false; c1.pos = 0; c1.own_spost = 0; c1.owed = 0; c1.bn = 0.0; c1.r_tab = 0.0;
+                        if (two) c1 = front(base + 64u + (uint32_t)lane);
+                        const unsigned long long cb = __ballot(c0.cand | c1.cand);
+                        any_cand |= cb != 0ull;
+                        if (stats) n_active += (uint32_t)(__popcll(__ballot(c0.cand)) + __popcll(__ballot(c1.cand)));
+                        pc.note(23);     // winners, operands requested
+#ifdef SF_PHASES
+                        asm volatile("" : "+v"(c0.r_tab), "+v"(c1.r_tab));
+                        pc.note(24);     // table entries arrived
+#endif
+                        back(c0);
+                        if (two) back(c1);
                     }
-                    if (ign) {
-                        agn |= ign * mk.b_new;                                                       // fire.py:571-579
-                        const uint32_t im = spread01(ign);
-                        snew = (snew & ~im) | (0x01010101u & im);                                    // BURNING, fire.py:587
-                    }
-                    if (a.counters) n_ignite += (uint32_t)__popcll(__ballot((ign & 1u) != 0)) + (uint32_t)__popcll(__ballot((ign & 0x100u) != 0)) +
-                                                (uint32_t)__popcll(__ballot((ign & 0x10000u) != 0)) + (uint32_t)__popcll(__ballot((ign & 0x1000000u) != 0));
+                    if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
+                    pc.note(25);         // updates, ignitions
                 }
             }
-            sv = snew;
-            if (agn != ag) { ag = agn; wmask[(r + 1) * 16 + c] = agn; }
-            if (__ballot((ag & ring) != 0u) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[2] = 1;      // a sprite in the ring: leave
         }
+        pc.note(26);         // at the barrier
         __syncthreads();
-        // ---- fold (every thread the same arithmetic on the same values)
-        const uint32_t f = ctl[3 + k];
+        pc.note(27);         // through the barrier
+        // ---- fold (every thread the same arithmetic on the same values); the next step's rows are requested with the predicates
+        const uint32_t fv = ctl[3 + k];
+        up = wm[own - 18]; mid = wm[own]; dn = wm[own + 18];
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fv);
+        ++s;
+        k = kn;
+        s0 = s0 + 1 == g.N ? 0 : s0 + 1;
+        if (plain_fold && (f & 0x00FFFFFFu) == (FLAG_LIVE | FLAG_CAND)) {
+            ++n_plain;
+            elapsed += rate;                                   // fire.py:717
+            pc.note(28);     // folded
+            if (s < s_cap) continue;
+            break;
+        }
+        st.steps += n_plain; st.complete += n_plain; st.elapsed = elapsed;
+        n_plain = 0;
         st = fold_state(st, f, g);
         st.running = __builtin_amdgcn_readfirstlane(st.running);
         st.steps = __builtin_amdgcn_readfirstlane(st.steps);
         st.complete = __builtin_amdgcn_readfirstlane(st.complete);
         st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
-        leave = __builtin_amdgcn_readfirstlane((int)(f & 0x00FF0000u)) != 0;
+        elapsed = st.elapsed;
+        pc.note(28);         // folded
+        if (!(s < s_cap && st.running && (f & 0x00FF0000u) == 0u)) break;
     }
+    st.steps += n_plain; st.complete += n_plain; st.elapsed = elapsed;
+    lpc.note(33);            // updates done
     // ---- back to memory: the cells and burn_amounts that changed, the dirty flags of their tiles, the window's part of the vector bitmaps
+    const uint32_t ag = wm[own];
+    if (s > 0) {                                               // the last step's ignitions: BURNING
+        const uint32_t prev_sh = tab[s0 * 8 + 6] >> 24;
+        const uint32_t im = spread01((ag >> prev_sh) & 0x01010101u);
+        sv = (sv & ~im) | (0x01010101u & im);
+    }
     if (ag != ag0) *reinterpret_cast<uint32_t *>(cellp) = ag;
     if (sv != sv0) {
         *reinterpret_cast<uint32_t *>(cellp + kBlStatus) = sv;
-        ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+        if (by_delta) {
+            int32_t *dtile = dt + (((y >> th_log) - ty0) * ntx + (((x >> 4) >> g.logLC) - tx0)) * 8;
+#pragma unroll
+            for (int q = 1; q < 6; ++q) {
+                const uint32_t kk = (uint32_t)q * 0x01010101u;
+                const int d = __popc(((sv0 ^ kk) + 0x7F7F7F7Fu) & 0x80808080u) - __popc(((sv ^ kk) + 0x7F7F7F7Fu) & 0x80808080u);      // bytes == q: now - before
+                if (d) atomicAdd(dtile + q, d);                // (addresses differ from lane to lane: plain LDS atomics)
+            }
+        } else ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
     }
-    if (burn_dirty) {
-        *reinterpret_cast<double2 *>(ev.burn + idx) = make_double2(bn[0], bn[1]);
-        *reinterpret_cast<double2 *>(ev.burn + idx + 2) = make_double2(bn[2], bn[3]);
+    if (wdirty[r * 16 + c]) {
+        const double2 *src = reinterpret_cast<const double2 *>(wb + (r * 16 + c) * 4);
+        *reinterpret_cast<double2 *>(ev.burn + idx) = src[0];
+        *reinterpret_cast<double2 *>(ev.burn + idx + 2) = src[1];
     }
     {
         // bit v of a row: the 16-cell vector holds a sprite bit / holds one in its first cell / in its last cell.  A vector = four lanes.
@@ -267,6 +449,28 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         }
     }
     __syncthreads();
+    lpc.note(34);            // window written back
+    if (by_delta) {
+        if (tid < nty * ntx * 8) {
+            const int tl = tid >> 3, q = tid & 7, d = dt[tid];
+            if (d) ev.thist[((ty0 + tl / ntx) * g.TX + tx0 + tl % ntx) * 8 + q] += (uint16_t)d;       // (mod 2^16: a negative change wraps to the right count)
+        }
+        if (tid == 0) {
+            int32_t others = 0;
+            for (int q = 1; q < 6; ++q) {
+                int32_t v = dt[120 + 2 + q];
+                for (int tl = 0; tl < nty * ntx; ++tl) v += dt[tl * 8 + q];
+                a.res_block[e * 8 + 2 + q] = v;
+                if (a.res_sink) a.res_sink[e * 8 + 2 + q] = v;
+                others += v;
+            }
+            const int32_t unburned = g.H * g.W - others;       // UNBURNED = H * W - the others (counts_env)
+            a.res_block[e * 8 + 2] = unburned; a.res_block[e * 8] = st.running == 1; a.res_block[e * 8 + 1] = st.steps;
+            a.res_elapsed[e] = st.elapsed;
+            if (a.res_sink) { a.res_sink[e * 8 + 2] = unburned; a.res_sink[e * 8] = st.running == 1; a.res_sink[e * 8 + 1] = st.steps; }
+        }
+        result_done = true;
+    }
     return s;
 }
 
