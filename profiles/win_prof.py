@@ -1,0 +1,29 @@
+"""Development aid: shader clocks per wave and phase of the window loop of k_run (library built with -DSF_WIN_PROF: profiles/win_prof.sh).
+usage: win_prof.py <steps> <warmup> [envs]"""
+import ctypes, sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from simfire_amd import workloads
+from simfire_amd.engine import FireEngine
+steps, warm = int(sys.argv[1]), int(sys.argv[2])
+E = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+w = workloads.c3(1024, E)
+eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
+eng.set_layers(*w.layers())
+for rep in range(2):
+    eng.reset(w.init_xy)
+    if warm:
+        eng.step(warm)
+    ms = eng.step_timed(steps)
+prof = np.zeros((1024, 16, 8), dtype=np.uint64)
+eng._L.sf_debug_win_prof.argtypes = [ctypes.c_void_p]
+eng._L.sf_debug_win_prof(prof.ctypes.data_as(ctypes.c_void_p))
+p = prof[:E].astype(np.float64) / steps
+names = ["phase A", "barrier 1", "walk front", "walk wait", "walk back", "rest of B", "barrier 2", "fold + rows"]
+print(f"{steps} updates after {warm}: {ms*1e3:.1f} us; clocks per update and wave, mean over environments")
+tot = p.sum(axis=2)
+print("   wave  " + "  ".join(f"{n:>11s}" for n in names) + "        total")
+for wv in range(16):
+    print(f"   {wv:4d}  " + "  ".join(f"{p[:, wv, q].mean():11.0f}" for q in range(8)) + f"  {tot[:, wv].mean():11.0f}")
+busy = p[:, :, 0].argmax(axis=1)
+print("   busiest phase-A wave per env: phase A mean %.0f, max over envs %.0f" % (p[np.arange(E), busy, 0].mean(), p[np.arange(E), busy, 0].max()))

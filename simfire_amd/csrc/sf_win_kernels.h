@@ -74,6 +74,29 @@ __device__ __forceinline__ uint32_t row16_max(uint32_t v)          // unsigned m
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
 }
 
+#ifdef SF_WIN_PROF
+// development build only (profiles/win_prof.sh): shader clocks per wave and phase of the window loop, summed over the steps of a launch
+__device__ unsigned long long g_win_prof[1024 * 16 * 8];
+#define WPROF(i) { const unsigned long long n_ = __builtin_readcyclecounter(); wp_acc[i] += n_ - wp_t; wp_t = n_; }
+#else
+#define WPROF(i)
+#endif
+
+// The barriers of the window loop.  Without attenuation the loop makes no store to memory at all, and what the waves hand each other
+// is in LDS: the fences name the LDS only, so that loads still in flight (the touches in front of the next step) cross the barrier -
+// a fence over memory waits for every load of the wave on this hardware (one counter for loads and stores).  With attenuation a
+// walker's store to the `settled` plane is read by the cell's owner in a later step: the full barrier.
+template <int ATT>
+__device__ __forceinline__ void win_barrier()
+{
+    if (ATT) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+}
+
 struct WinEnv {                    // per-environment bases (wave-uniform)
     uint8_t *cells;                // blocked cell plane (sf_common.h, bl_cell)
     double *burn;
@@ -158,7 +181,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     int32_t *const dt = reinterpret_cast<int32_t *>(tab + 64);                           // [16 tiles][8]: cells per BurnStatus gained / lost; [15][0..7]: the old result row
     uint32_t *const wm = tab + 64 + 128 + 64;                                            // sprite masks (behind the per-wave slots of the search above)
     uint8_t *const wdirty = reinterpret_cast<uint8_t *>(wm + (WR + 2) * 18);             // per lane: burn_amounts of its cells changed
-    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16) + wave * 256; // this wave's frontier cells of the step
+    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16);              // the step's frontier cells [WR x 64]
     // ---- load: two dwords + four doubles per lane
     const int r = tid >> 4, c = tid & 15;
     const int y = wy0 + r, x = wx0 + 4 * c;
@@ -213,6 +236,13 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const double rate = g.update_rate;
     const bool stats = a.counters != nullptr;
     uint32_t up = wm[own - 18], mid = wm[own], dn = wm[own + 18];
+    // (Measured and dropped: touching, when a cell ignites, the eight table entries its neighbours will most likely ask for in the next
+    // step - eight loads whose results nobody uses.  The walkers' wait for their operands fell from ~900 to ~100 clocks, and the
+    // step got 25 % LONGER: loads return in order, so the next step's operands queue behind the touches, and sixty more
+    // instructions sit on the walkers' path.)
+#ifdef SF_WIN_PROF
+    unsigned long long wp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wp_t = __builtin_readcyclecounter();
+#endif
     for (;;) {
         const int kn = k == 2 ? 0 : k + 1;
 #ifdef SF_PHASES
@@ -220,11 +250,13 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         pc.tl_n = 0;
 #endif
         pc.note(20);         // window step start
-        if (tid == 0) ctl[3 + kn] = 0;                         // predicate bytes of the next step (last read before the barrier that ended step s - 1)
-        if (__ballot((mid | up | dn) != 0u) != 0ull) {         // (wave-uniform) nothing in or next to this wave's four rows: nothing to do
-            const uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
-            const uint32_t L4 = t0.x, CLR4 = t0.z, b_new = t0.w, lo_mask = t1.x, hi_mask = t1.y;
-            const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
+        if (tid == 0) { ctl[3 + kn] = 0; ctl[kn] = 0; }        // predicate bytes / list length of the next step (last read before the barrier that ended step s - 1)
+        // the masks of this step (every wave: the walkers need them too)
+        const uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
+        const uint32_t L4 = t0.x, CLR4 = t0.z, b_new = t0.w, lo_mask = t1.x, hi_mask = t1.y;
+        const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
+        // ---- phase A, the waves with a sprite bit in or next to their four rows: prune, recycle, frontier cells -> the step's list
+        if (__ballot((mid | up | dn) != 0u) != 0ull) {         // (wave-uniform)
             const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
             pc.note(21);     // rows arrived
             if (stats) n_vec_done += lane == 0 ? 16u : 0u;     // four rows x four vectors swept
@@ -267,111 +299,115 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 const uint32_t cnt = (uint32_t)__popc(p4);
                 pc.note(22); // frontier cells known
                 if (__ballot(cnt != 0u) != 0ull) {
-                    // ---- the wave's frontier cells, compacted: entry = owner lane << 2 | cell | status << 8
+                    // the wave's cells behind those of the waves that came before: entry = row << 6 | column | status << 12
                     const uint32_t incl = wave_scan_incl(cnt, lane);
-                    const uint32_t total = wave_last(incl);
-                    {
-                        uint32_t pos = incl - cnt;
+                    uint32_t base = 0;
+                    if (lane == 63) base = atomicAdd(&ctl[k], incl);
+                    uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + incl - cnt;
+                    const uint32_t ent0 = (uint32_t)(r << 6 | c << 2);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if ((p4 >> j) & 1u) wlist[pos++] = (uint16_t)((uint32_t)(lane << 2 | j) | (((sv >> (8 * j)) & 7u) << 8));
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    struct WCell { bool cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
-                    // first half of a cell: which, winner source, operands requested
-                    auto front = [&](uint32_t i) {
-                        WCell q;
-                        const bool valid = i < total;
-                        const uint32_t ent = wlist[valid ? i : 0u];
-                        const uint32_t rr = (uint32_t)(wave * 4) + ((ent >> 6) & 3u), cx = ((ent >> 2) & 15u) * 4u + (ent & 3u);      // row / column inside the window
-                        // bytes 0..2 = cells x - 1, x, x + 1 of the rows y - 1, y, y + 1: cell cx sits at byte 4 + cx of a plane row
-                        const uint32_t b0 = cx + 3u, sh = b0 & 3u;
-                        const uint32_t *pr = wm + rr * 18u + (b0 >> 2);
-                        const uint32_t up3 = __builtin_amdgcn_alignbyte(pr[1], pr[0], sh);
-                        const uint32_t mid3 = __builtin_amdgcn_alignbyte(pr[19], pr[18], sh);
-                        const uint32_t dn3 = __builtin_amdgcn_alignbyte(pr[37], pr[36], sh);
-                        int bestk = -1;
-                        {
-                            // pick_winner8 (sf_step_kernels.h) on this step's masks from the table
-                            const uint32_t lo = __builtin_amdgcn_perm(mid3, dn3, 0x06000102u) & lo_mask;
-                            const uint32_t hi = __builtin_amdgcn_perm(mid3, up3, 0x00010204u) & hi_mask;
-                            uint32_t o = lo | hi;
-                            o |= o >> 16;
-                            o = (o | (o >> 8)) & 0xFFu;
-                            if (o) {
-                                const uint32_t rq = ((o << rot) | (o >> nrot)) & nmask;
-                                int slot = (31 - __clz(rq)) - (int)rot;        // bit of the newest sprite in the unrotated masks
-                                if (slot < 0) slot += g.N;
-                                const uint32_t T = __builtin_amdgcn_perm(0u, 1u << slot, 0u);     // that bit in every byte
-                                const uint32_t cl = lo & T, ch = hi & T;
-                                bestk = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
-                            }
-                        }
-                        q.cand = valid && bestk >= 0;
-                        q.pos = rr * 64u + cx;
-                        q.own_spost = ((mid3 >> 8) & 0xFFu) | (((ent >> 8) & 7u) << 8);
-                        q.owed = 0; q.bn = 0.0; q.r_tab = 0.0;
-                        if (q.cand) {
-                            const uint32_t gi = (uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx);
-                            q.r_tab = ev.rt[(uint32_t)bestk * HP + gi];                              // 8 H P < 2^29
-                            q.bn = wb[q.pos];
-                            if (ATT && (q.own_spost >> 8) >= SF_FIRELINE) q.owed = (uint32_t)(st.complete + n_plain) - ev.settled[gi];
-                        }
-                        return q;
-                    };
-                    // second half: accumulate, ignite
-                    auto back = [&](const WCell &q) {
-                        bool ignited = false;
-                        if (q.cand) {
-                            const uint32_t rr = q.pos >> 6, cx = q.pos & 63u, s_post = q.own_spost >> 8;
-                            double b = q.bn;
-                            double ros = q.r_tab * g.update_rate;                                    // fire.py:696,705
-                            if (s_post >= SF_FIRELINE) {                                             // fire.py:271-282
-                                if (ATT) {
-                                    const double f = line_factor(s_post);
-                                    b = lazy_sub(b, f, q.owed);        // the updates since this cell was last touched (fire.py:278, ros = 0)
-                                    ros = ros - f;
-                                    ev.settled[(uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx)] = (uint32_t)(st.complete + n_plain) + 1u;      // this update runs to the end: it has a candidate
-                                } else ros = 0.0;
-                            }
-                            b = b + ros;                                                             // fire.py:710
-                            wb[q.pos] = b;
-                            wdirty[q.pos >> 2] = 1;
-                            if (b > g.pixel_scale) {                                                 // fire.py:568
-                                ignited = true;
-                                reinterpret_cast<uint8_t *>(wm)[(rr + 1u) * 72u + 4u + cx] = (uint8_t)(((q.own_spost & 0xFFu) & ~(CLR4 & 0xFFu)) | b_new);      // fire.py:571-579
-                                const bool on_ring = (rr == 0u && open_top) || (rr == (uint32_t)(WR - 1) && open_bot) || (cx == 0u && open_left) || (cx == 63u && open_right);
-                                if (on_ring) reinterpret_cast<uint8_t *>(ctl + 3 + k)[2] = 1;        // a sprite in the ring: the window is left after this step
-                            }
-                        }
-                        if (stats) n_ignite += (uint32_t)__popcll(__ballot(ignited));
-                    };
-                    bool any_cand = false;
-                    for (uint32_t base = 0; base < total; base += 128u) {
-                        const bool two = base + 64u < total;       // (uniform) two cells per lane: one memory round trip for both
-                        WCell c0 = front(base + (uint32_t)lane), c1;
-                        c1.cand = false; c1.pos = 0; c1.own_spost = 0; c1.owed = 0; c1.bn = 0.0; c1.r_tab = 0.0;
-                        if (two) c1 = front(base + 64u + (uint32_t)lane);
-                        const unsigned long long cb = __ballot(c0.cand | c1.cand);
-                        any_cand |= cb != 0ull;
-                        if (stats) n_active += (uint32_t)(__popcll(__ballot(c0.cand)) + __popcll(__ballot(c1.cand)));
-                        pc.note(23);     // winners, operands requested
-#ifdef SF_PHASES
-                        asm volatile("" : "+v"(c0.r_tab), "+v"(c1.r_tab));
-                        pc.note(24);     // table entries arrived
-#endif
-                        back(c0);
-                        if (two) back(c1);
-                    }
-                    if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
-                    pc.note(25);         // updates, ignitions
+                    for (int j = 0; j < 4; ++j)
+                        if ((p4 >> j) & 1u) wlist[pos++] = (uint16_t)(ent0 | (uint32_t)j | (((sv >> (8 * j)) & 7u) << 12));
                 }
             }
         }
+        pc.note(23);         // list written
+        WPROF(0)             // phase A
+        win_barrier<ATT>();
+        WPROF(1)             // barrier behind the list
+        // ---- phase B, as few waves as the list needs: walk the frontier cells, one per lane
+        {
+            const uint32_t total = ctl[k];
+            struct WCell { bool cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
+            // first half of a cell: which, winner source, operands requested
+            auto front = [&](uint32_t i, uint32_t ent) {
+                WCell q;
+                const bool valid = i < total;
+                const uint32_t rr = (ent >> 6) & 63u, cx = ent & 63u;      // row / column inside the window
+                // bytes 0..2 = cells x - 1, x, x + 1 of the rows y - 1, y, y + 1: cell cx sits at byte 4 + cx of a plane row
+                const uint32_t b0 = cx + 3u, sh = b0 & 3u;
+                const uint32_t *pr = wm + rr * 18u + (b0 >> 2);
+                const uint32_t up3 = __builtin_amdgcn_alignbyte(pr[1], pr[0], sh);
+                const uint32_t mid3 = __builtin_amdgcn_alignbyte(pr[19], pr[18], sh);
+                const uint32_t dn3 = __builtin_amdgcn_alignbyte(pr[37], pr[36], sh);
+                int bestk = -1;
+                {
+                    // pick_winner8 (sf_step_kernels.h) on this step's masks from the table
+                    const uint32_t lo = __builtin_amdgcn_perm(mid3, dn3, 0x06000102u) & lo_mask;
+                    const uint32_t hi = __builtin_amdgcn_perm(mid3, up3, 0x00010204u) & hi_mask;
+                    uint32_t o = lo | hi;
+                    o |= o >> 16;
+                    o = (o | (o >> 8)) & 0xFFu;
+                    if (o) {
+                        const uint32_t rq = ((o << rot) | (o >> nrot)) & nmask;
+                        int slot = (31 - __clz(rq)) - (int)rot;        // bit of the newest sprite in the unrotated masks
+                        if (slot < 0) slot += g.N;
+                        const uint32_t T = __builtin_amdgcn_perm(0u, 1u << slot, 0u);     // that bit in every byte
+                        const uint32_t cl = lo & T, ch = hi & T;
+                        bestk = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
+                    }
+                }
+                q.cand = valid && bestk >= 0;
+                q.pos = rr * 64u + cx;
+                q.own_spost = ((mid3 >> 8) & 0xFFu) | (((ent >> 12) & 7u) << 8);
+                q.owed = 0; q.bn = 0.0; q.r_tab = 0.0;
+                if (q.cand) {
+                    const uint32_t gi = (uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx);
+                    q.r_tab = ev.rt[(uint32_t)bestk * HP + gi];                              // 8 H P < 2^29
+                    q.bn = wb[q.pos];
+                    if (ATT && (q.own_spost >> 8) >= SF_FIRELINE) q.owed = (uint32_t)(st.complete + n_plain) - ev.settled[gi];
+                }
+                return q;
+            };
+            // second half: accumulate, ignite
+            auto back = [&](const WCell &q) {
+                bool ignited = false;
+                if (q.cand) {
+                    const uint32_t rr = q.pos >> 6, cx = q.pos & 63u, s_post = q.own_spost >> 8;
+                    double b = q.bn;
+                    double ros = q.r_tab * g.update_rate;                                    // fire.py:696,705
+                    if (s_post >= SF_FIRELINE) {                                             // fire.py:271-282
+                        if (ATT) {
+                            const double f = line_factor(s_post);
+                            b = lazy_sub(b, f, q.owed);        // the updates since this cell was last touched (fire.py:278, ros = 0)
+                            ros = ros - f;
+                            ev.settled[(uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx)] = (uint32_t)(st.complete + n_plain) + 1u;      // this update runs to the end: it has a candidate
+                        } else ros = 0.0;
+                    }
+                    b = b + ros;                                                             // fire.py:710
+                    wb[q.pos] = b;
+                    wdirty[q.pos >> 2] = 1;
+                    if (b > g.pixel_scale) {                                                 // fire.py:568
+                        ignited = true;
+                        reinterpret_cast<uint8_t *>(wm)[(rr + 1u) * 72u + 4u + cx] = (uint8_t)(((q.own_spost & 0xFFu) & ~(CLR4 & 0xFFu)) | b_new);      // fire.py:571-579
+                        const bool on_ring = (rr == 0u && open_top) || (rr == (uint32_t)(WR - 1) && open_bot) || (cx == 0u && open_left) || (cx == 63u && open_right);
+                        if (on_ring) reinterpret_cast<uint8_t *>(ctl + 3 + k)[2] = 1;        // a sprite in the ring: the window is left after this step
+                    }
+                }
+                if (stats) n_ignite += (uint32_t)__popcll(__ballot(ignited));
+            };
+            bool any_cand = false;
+            for (uint32_t i = (uint32_t)tid; i - (uint32_t)lane < total; i += (uint32_t)nthr) {      // (wave-uniform trip count)
+                const uint32_t ent = wlist[i < total ? i : 0u];
+                WCell c0 = front(i, ent);
+                any_cand |= __ballot(c0.cand) != 0ull;
+                if (stats) n_active += (uint32_t)__popcll(__ballot(c0.cand));
+                pc.note(24); // winners, operands requested
+                WPROF(2)     // walk: cells, winners, requests
+#ifdef SF_WIN_PROF
+                asm volatile("" : "+v"(c0.r_tab), "+v"(c0.bn));
+                WPROF(3)     // walk: operands arrived
+#endif
+                back(c0);
+                WPROF(4)     // walk: updates, ignitions
+                pc.note(25); // updates, ignitions
+            }
+            if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
+        }
         pc.note(26);         // at the barrier
-        __syncthreads();
+        WPROF(5)             // rest of phase B
+        win_barrier<ATT>();
+        WPROF(6)             // barrier at the end of the step
         pc.note(27);         // through the barrier
         // ---- fold (every thread the same arithmetic on the same values); the next step's rows are requested with the predicates
         const uint32_t fv = ctl[3 + k];
@@ -383,6 +419,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (plain_fold && (f & 0x00FFFFFFu) == (FLAG_LIVE | FLAG_CAND)) {
             ++n_plain;
             elapsed += rate;                                   // fire.py:717
+            WPROF(7)         // predicates, next rows, fold
             pc.note(28);     // folded
             if (s < s_cap) continue;
             break;
@@ -399,6 +436,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (!(s < s_cap && st.running && (f & 0x00FF0000u) == 0u)) break;
     }
     st.steps += n_plain; st.complete += n_plain; st.elapsed = elapsed;
+#ifdef SF_WIN_PROF
+    if (lane == 0 && e < 1024)
+        for (int q = 0; q < 8; ++q) g_win_prof[((size_t)e * 16 + wave) * 8 + q] = wp_acc[q];
+#endif
+    if (tid < 3) ctl[tid] = 0;                                 // (the general loop's list lengths)
     lpc.note(33);            // updates done
     // ---- back to memory: the cells and burn_amounts that changed, the dirty flags of their tiles, the window's part of the vector bitmaps
     const uint32_t ag = wm[own];

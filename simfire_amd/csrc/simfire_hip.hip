@@ -1615,6 +1615,13 @@ extern "C" int sf_debug_timeline(int32_t env, int32_t step, unsigned long long *
 }
 #endif
 
+#ifdef SF_WIN_PROF
+extern "C" int sf_debug_win_prof(unsigned long long *out /* [1024][16][8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_win_prof), sizeof(unsigned long long) * 1024 * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 #ifdef SF_PHASES
 extern "C" int sf_debug_phases(unsigned long long *out16)
 {
