@@ -235,11 +235,12 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
     achieved = alg_bytes / sec / 1e9
     resident = kind in (2, 4, 5, 6)
     launches = 1 if resident else a.steps * (2 if kind == 0 else 1)
-    traffic = None
+    traffic, replayed = None, {}
     if pmc and pmc.get("steps") == a.steps and pmc.get("warmup") == a.warmup and pmc.get("kernel") == LAUNCH_KINDS.get(kind):
-        traffic = pmc.get("hbm_bytes_per_launch")           # measured on this very window by profiles/collect_pmc.sh
+        traffic = pmc.get("hbm_bytes_per_launch")           # measured on this very window by profiles/collect_pmc.sh ...
+        replayed["traffic"] = pmc.get("_file")              # ... in ANOTHER run (rocprofv3 --pmc): a replay, not a counter of this run
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": LAUNCH_KINDS.get(kind, "?"),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "replayed_from": replayed, "kernel": LAUNCH_KINDS.get(kind, "?"),
             "random_access": random_access_block(traffic, kernel_ms / (1 if resident else a.steps)),
             "bytes_model": model, "launches": launches, "steps_per_launch": a.steps if resident else 1,
             "launch_ms": kernel_ms / (1 if resident else a.steps), "kernel_ms_per_step": kernel_ms / a.steps,
@@ -283,7 +284,7 @@ def issue_block(w, a, rl, cost, n_cu=256):
            "clocks_max_env": float(clocks.max()), "clocks_median_env": float(np.median(clocks)),
            "clock_ghz_measured": float(clocks.max() / sec / 1e9),
            "source": "sf_get_run_cost (s_memtime stamps of the timed launch) / HIP-event duration"}
-    p = os.path.join(ROOT, "profiles", f"r03_sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
+    p = os.path.join(ROOT, "profiles", f"r04_sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
     if os.path.exists(p):
         with open(p) as f:
             sq = json.load(f)
@@ -292,11 +293,15 @@ def issue_block(w, a, rl, cost, n_cu=256):
         slots4 = n_cu * 4 * (sec * blk["clock_ghz_measured"] * 1e9) / 4.0
         blk.update({"valu_issue_util": sq["SQ_INSTS_VALU"] / slots4, "salu_issue_util": sq["SQ_INSTS_SALU"] / slots4,
                     "wave_wait_share": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "sq_source": os.path.relpath(p, ROOT)})
-    p = os.path.join(ROOT, "profiles", f"r03_phase_clocks_k_run_{w.name}_s{a.steps}_w{a.warmup}.json")
+        # (counters of a separate rocprofv3 --pmc run of this window, committed under profiles/: replays, not counters of this run)
+        rl.setdefault("replayed_from", {}).update({k: os.path.relpath(p, ROOT) for k in
+                                                   ("issue.valu_issue_util", "issue.salu_issue_util", "issue.wave_wait_share")})
+    p = os.path.join(ROOT, "profiles", f"r04_phase_clocks_window_{w.name}_s{a.steps}_w{a.warmup}.json")
     if os.path.exists(p):
         with open(p) as f:
             ph = json.load(f)
-        blk.update({"barrier_wait_share": ph.get("barrier_wait_share"), "phase_source": os.path.relpath(p, ROOT)})
+        blk.update({"window_phase_clocks_per_update": ph.get("clocks_per_update"), "phase_source": os.path.relpath(p, ROOT)})
+        rl.setdefault("replayed_from", {})["issue.window_phase_clocks_per_update"] = os.path.relpath(p, ROOT)
     return blk
 
 
@@ -380,6 +385,17 @@ def side_workload(name, a, device, torch, n_check, tile_cells):
         out["roofline"]["issue"] = iss
     eng.close()
     return out
+
+
+def load_pmc(w, steps, warmup):
+    """PMC traffic of a window, if profiles/collect_pmc.sh has been run for it (one file per window: ..._s<K>_w<W>.json)."""
+    path = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{w.name}_s{steps}_w{warmup}.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            pmc = json.load(f)
+        pmc["_file"] = os.path.relpath(path, ROOT)
+        return pmc
+    return None
 
 
 def reference_python_timing():
@@ -533,18 +549,19 @@ def main():
             verified = bool(v.item())
     res = gathered.cpu().numpy()
 
+    # kernel time and work of the timed window, on EVERY rank (a replay of the same deterministic rollout with HIP events around the
+    # launch and the statistics counters on): the north star asks for achieved HBM GB/s at 1, 2, 4 and 8 GPUs
+    geo = eng.geometry()
+    tile_cells = geo["tile_w"] * geo["tile_h"]
+    kms, env_steps_local, cnt, kind = measure(eng, w, a, agent_pts, a.dense)
+    rl_local = roofline_block(w, a, kms, cnt, tile_cells, kind, env_steps_local, load_pmc(w, a.steps, a.warmup) if rank == 0 else None, a.dense)
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([kms, rl_local["algorithmic_bytes_per_launch"] * rl_local["launches"], rl_local["achieved"]], dtype=torch.float64, device=coll_dev)
+        allr = torch.zeros(world * 3, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = allr.cpu().numpy().reshape(world, 3)
     if rank == 0:
-        geo = eng.geometry()
-        tile_cells = geo["tile_w"] * geo["tile_h"]
-        kms, env_steps_local, cnt, kind = measure(eng, w, a, agent_pts, a.dense)
-        pmc = None
-        # PMC traffic of this very window, if profiles/collect_pmc.sh has been run for it (per window: ..._s<K>_w<W>.json)
-        for pmc_path in (os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}_s{a.steps}_w{a.warmup}.json"),
-                         os.path.join(ROOT, "profiles", f"pmc_traffic_{w.name}.json")):
-            if os.path.exists(pmc_path):
-                with open(pmc_path) as f:
-                    pmc = json.load(f)
-                break
         out = {
             "metric": "cell-updates/sec (grid x envs x steps)",
             # every update() call really made (environments that reached QUIT stop counting,
@@ -569,8 +586,15 @@ def main():
                        "env_steps_executed": env_steps, "env_steps_requested": w.n_envs * world * a.steps,
                        "envs_running_at_end": int(res[:, 0].sum()),
                        "burned_cells_total": int(res[:, 4].sum())},
-            "roofline": roofline_block(w, a, kms, cnt, tile_cells, kind, env_steps_local, pmc, a.dense),
+            "roofline": rl_local,
         }
+        if per_rank is not None:
+            # every rank's own launch: kernel ms (HIP events), algorithmic bytes, achieved GB/s (rank 0's block above is rank 0's)
+            out["roofline"]["per_rank_kernel_ms"] = [float(v) for v in per_rank[:, 0]]
+            out["roofline"]["per_rank_algorithmic_bytes"] = [float(v) for v in per_rank[:, 1]]
+            out["roofline"]["per_rank_gbs"] = [float(v) for v in per_rank[:, 2]]
+            out["roofline"]["per_rank_frac"] = [float(v) / HBM_PEAK_GBS for v in per_rank[:, 2]]
+            out["roofline"]["aggregate_gbs"] = float(per_rank[:, 2].sum())
         iss = issue_block(w, a, out["roofline"], measure.last_cost)
         if iss:
             out["roofline"]["issue"] = iss
@@ -591,6 +615,57 @@ def main():
             out["cpu_baseline"] = cpu_base
         if world == 1 and not a.no_extra and a.workload == "c3":
             also = {}
+            # the same batch on fresh ignitions, no dress rehearsal: nothing of the timed rollout's cells, burn_amounts or table lines
+            # has been touched before (the headline's rollout is rehearsed on the identical episodes: `rehearsal`)
+            cold = make_workload("c3", a.size, w.n_envs, 100000)
+            eng.reset(cold.init_xy)
+            if a.warmup:
+                run_steps(eng, a.warmup, 0, None)
+            eng.copy_status_to(result.data_ptr())
+            c0 = result[:, 1].sum().item()
+            fence()
+            t0c = time.perf_counter()
+            rollout(a.steps, a.warmup)
+            fence()
+            dtc = time.perf_counter() - t0c
+            esc = result[:, 1].sum().item() - c0
+            also["cold"] = {"value": H * W * esc / dtc, "unit": "cell-updates/s", "ms_per_step": dtc * 1e3 / a.steps, "rehearsal": False,
+                            "ignition_seeds": "1234 + 100000 + e (the headline: 1234 + e)", "env_steps_executed": esc,
+                            "note": "first and only run of these episodes in this process: caches cold for their cells"}
+            if a.steps != 1000:
+                # the long window (the builder's default line: 1000 updates after 20): large fires, CU balance; checked on 16 environments
+                al = argparse.Namespace(**vars(a))
+                al.steps, al.warmup = 1000, 20
+                eng.reset(w.init_xy)
+                run_steps(eng, al.warmup, 0, None)
+                eng.copy_status_to(result.data_ptr())
+                l0 = result[:, 1].sum().item()
+                fence()
+                t0l = time.perf_counter()
+                rollout(al.steps, al.warmup)
+                fence()
+                dtl = time.perf_counter() - t0l
+                esl_ = result[:, 1].sum().item() - l0
+                blk_l = result.cpu().numpy()
+                ver_l = None
+                if not a.no_cpu_baseline:
+                    nchk = min(16, w.n_envs)
+                    smp = sorted(set([0, nchk // 2, nchk - 1]))
+                    maps_l = {e: eng.fire_map(e) for e in smp}
+                    o, ost, _, _ = oracle_rollout(w, eng.get_rtable(), al.steps, al.warmup, a.cpu_threads or max(1, min(os.cpu_count() or 1, 32)), None, nchk)
+                    ver_l = bool((blk_l[:nchk] == ost).all()) and all(bool((maps_l[e] == o.fire_map(e)).all()) for e in smp)
+                    del o
+                kl, esl2, cl, kindl = measure(eng, w, al, None, False)
+                rll = roofline_block(w, al, kl, cl, tile_cells, kindl, esl2, load_pmc(w, al.steps, al.warmup), False)
+                issl = issue_block(w, al, rll, measure.last_cost)
+                if issl:
+                    rll["issue"] = issl
+                also["c3_long"] = {"steps": al.steps, "warmup": al.warmup, "value": H * W * esl_ / dtl, "unit": "cell-updates/s",
+                                   "ms_per_step": dtl * 1e3 / al.steps, "verified": ver_l, "envs_checked": 0 if ver_l is None else min(16, w.n_envs),
+                                   "env_steps_executed": esl_, "envs_running_at_end": int(blk_l[:, 0].sum()),
+                                   "roofline": {k: rll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "replayed_from", "kernel", "launches",
+                                                                    "launch_ms", "kernel_ms_per_step", "cells_swept_per_step", "active_cell_updates_per_step",
+                                                                    "algorithmic_bytes_per_launch", "issue") if k in rll}}
             # the throughput regime: same workload, 4 x the batch (256 environments do not fill the chip)
             eng.close()
             big = make_workload("c3", a.size, 4 * w.n_envs, 0)

@@ -77,6 +77,8 @@ typedef struct sf_params {
 
 typedef struct sf_sim sf_sim; /* opaque */
 
+/* (Launch-geometry knobs, launch-structure forcing, statistics counters, timing and cost introspection - what bench.py, the
+ * tests and the scripts under profiles/ use and a SimFire maintainer never binds - are declared in simfire_hip_lab.h; same library.) */
 const char *sf_last_error(void);
 const char *sf_version(void);
 
@@ -150,9 +152,6 @@ int sf_load_fire_map(sf_sim *sim, int32_t env, const uint8_t *fire_map);
 /* n_steps calls of RothermelFireManager.update (fire.py:616-719) on every environment that
  * is still RUNNING - the loop of FireSimulation.run (simulation.py:533-544). */
 int sf_step(sf_sim *sim, int32_t n_steps);
-/* same; also reports the GPU time of the n_steps step kernels (HIP events on the handle's
- * stream) so that callers can form bytes / launch-duration. */
-int sf_step_timed(sf_sim *sim, int32_t n_steps, float *ms_out);
 
 /* Outputs.  fire_map: uint8 [H*W] BurnStatus values; burn: RothermelFireManager.burn_amounts
  * float64 [H*W]. */
@@ -212,22 +211,7 @@ int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const floa
                    const float *new_loc_y, const float *w_0, const float *delta, const float *M_x,
                    const float *sigma, const float *h, const float *S_T, const float *S_e,
                    const float *p_p, const float *M_f, const float *U, const float *U_dir,
-                   const float *slope_mag, const float *slope_dir, double *R_out, int32_t device);
-
-/* Introspection for benchmarks: out[0] = active cell-updates (cells whose burn_amounts were
- * read+written: candidates and attenuated line cells), out[1] = ignitions, out[2] = cells handed
- * to the frontier phase, out[3] = wavefronts that survived the quick reject, out[4] = frontier
- * walks (row iterations with a non-empty work list), out[5..7] = 0; summed over all steps since the
- * last reset of the counters. */
-int sf_get_counters(sf_sim *sim, int64_t *out /* [8] */, int32_t reset);
-/* The statistics cost a few atomics per active wavefront, so they are off by default. */
-int sf_enable_counters(sf_sim *sim, int32_t on);
-/* launch geometry: out[0..7] = wave-tile width and height in cells, tiles per environment in x and
- * y, rows per lane band, row pitch, LDS bytes per wave, dense flag */
-int sf_get_geometry(sf_sim *sim, int32_t *out /* [8] */);
-/* bytes of device memory held */
-int sf_memory_bytes(sf_sim *sim, int64_t *bytes);
-int sf_set_rows_per_band(sf_sim *sim, int32_t rows); /* tuning knob of the step kernel */
+                   const float *slope_mag, const float *slope_dir, double *R_out, int32_t device); /* tuning knob of the step kernel */
 /* Overwrite the ignition threshold only (the reference's tests assign manager.pixel_scale after
  * construction, test_fire.py:334; slopes keep the constructor value, fire.py:377). */
 int sf_set_threshold(sf_sim *sim, double pixel_scale);
@@ -242,76 +226,6 @@ int sf_sync(sf_sim *sim);
  * adj_locs order (x+1,y) (x+1,y+1) (x,y+1) (x-1,y+1) (x-1,y) (x-1,y-1) (x,y-1) (x+1,y-1). */
 int sf_enable_spread_graph(sf_sim *sim, int32_t on);
 int sf_get_spread_parents(sf_sim *sim, int32_t env, uint8_t *parents_out);
-/* 1 = step with the generic one-thread-per-cell kernel (the product path for max_fire_duration > 5,
- * and an independent on-device cross-check of the tiled kernels otherwise), 0 = default. */
-int sf_set_generic(sf_sim *sim, int32_t on);
-/* Step launch structure.  -1 = automatic (default): sf_step(n >= 2) on a grid up to 1024 cells wide is ONE
- * environment-resident launch (k_run: a workgroup owns an environment for all n steps; environments are
- * independent FireSimulation objects, simulation.py:202-214, so nothing is synchronised between them);
- * otherwise one fused launch per step up to 12288 wave tiles, k_select + k_step above.
- * 0 = always two launches per step, 1 = always one fused launch per step, 2 = always the resident launch
- * (falls back to the per-step launches while the spread graph / history by-products are on or
- * max_fire_duration > 5), 3 = the tile flavour of the resident launch (k_run_tiles; development / cross-check),
- * 4 = one frontier-resident launch per call (k_front: per environment the burning sprites and their ignition candidates
- * are kept as lists in LDS for all n steps; falls back to 2 in attenuation mode, in the visit-everything mode and when
- * control lines are applied inside the launch). */
-int sf_set_fused(sf_sim *sim, int32_t mode);
-/* (modes 3 and 4 are measured alternatives that were never the automatic choice; they are compiled only into the
- * cross-check build, -DSF_EXPERIMENTAL -> libsimfire_hip_exp.so; the product library answers SF_ENOTSUP.) */
-
-/* Launch-geometry knobs of a handle.  RESULTS NEVER DEPEND ON THEM (the tests force several values of each against the
- * oracle); the defaults are the measured choices of DESIGN.md section 5.  This is the only way to change them: the
- * library does not read the environment - except that, for the measurement scripts under profiles/, a process started
- * with SF_DEBUG_KNOBS=1 takes the initial values of new handles from variables named like the enumerators
- * (SF_TUNE_RUN_WAVES=8 ...).  No reference counterpart (the reference has no launch geometry). */
-enum sf_tuning_knob {
-    SF_TUNE_WAVES_PER_CU = 0,   /* persistent waves per CU of k_step (default 24) */
-    SF_TUNE_RUN_WAVES = 1,      /* waves per workgroup of the resident launch k_run, 1..16 (default 16; 8 when there are more environments than CUs) */
-    SF_TUNE_RUN_MIN_ENVS = 2,   /* automatic mode picks k_run from this many environments (default 1) */
-    SF_TUNE_RUN_VCAP = 3,       /* entries of k_run's vector list in LDS (default 4096; longer lists are taken in chunks) */
-    SF_TUNE_RUN_COMPACT = 4,    /* 1 = 8-wave workgroups, two per CU, when there are more environments than CUs (default 1) */
-    SF_TUNE_RUN_BATCH = 5,      /* vectors per batch of k_run, 8..64 (default 64) */
-    SF_TUNE_RUN_RESULT = 6,     /* 1 = k_run writes the result block itself when its steps are done (default 1) */
-    SF_TUNE_RUN_SEGMENT = 7,    /* steps per k_run launch when there are more environments than workgroup slots (default 64; 0 = one launch) */
-    SF_TUNE_FRONT_MIN_STEPS = 8,/* cross-check build only: k_front knobs */
-    SF_TUNE_FRONT_AUTO = 9,
-    SF_TUNE_FRONT_WAVES = 10,
-    SF_TUNE_FRONT_RC = 11,
-    SF_TUNE_FRONT_IC = 12,
-    SF_TUNE_FRONT_TAB = 13,
-    SF_TUNE_FRONT_DEBUG = 14,
-    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in the resident launch (k_run<TEAM>: bands of rows, one boundary row exchanged per step):
-                                 * 0 = automatic (default): teams on grids of more than 1024 columns, where one workgroup cannot hold an
-                                 * environment's bitmaps (one member with a window of rows while a call ends with every fire surely young -
-                                 * the library keeps an upper bound on the fires' extent since the last reset -, two and more after that),
-                                 * and - sized by cost, in long calls - where two to a quarter as many environments as CUs leave most of the
-                                 * chip idle; one workgroup per environment otherwise (measured faster);
-                                 * 1 = never; 2 / 3 / 4 = every environment split into exactly that many (tests);
-                                 * -1 = teams of 1..4 sized from what the environments cost in the launch before, on any grid */
-    SF_TUNE_TEAM_PLACEMENT = 16,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
-                                 * 1 = consecutive slots (spread over the XCDs), 2 = as 0 but the hand-off written through as if they were apart (tests) */
-    SF_TUNE_TEAM_RECUT = 17,    /* teams of a fixed size (forced; or all the chip's workgroup slots taken at the smallest size: C4's share): 1 (default) =
-                                 * the whole rollout is ONE launch whose teams cut their bands anew every 2 x SF_TUNE_RUN_SEGMENT steps inside it,
-                                 * 0 = one launch per segment (the bands are cut by each launch's prologue) */
-    SF_TUNE_RUN_WINDOW = 18,    /* the window phase of the resident launch (a young fire's cells held in registers while the fire fits 64 x 64 cells): 1 (default) = on,
-                                 * 0 = off, k > 1 = on, but the window is left after k updates (tests: forces the hand-over to the general loop anywhere) */
-    SF_TUNE_COUNT = 19
-};
-int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
-/* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:
- * uint32 [n_envs].  The next launch orders / sizes its workgroups by it; bench.py turns it into the CU balance
- * sum(cost) / (max(cost) x min(n_envs, CUs)) and, with the launch's duration, into the shader clock the launch ran at.
- * Zeros before the first resident launch.  No reference counterpart. */
-int sf_get_run_cost(sf_sim *sim, uint32_t *cost_out);
-/* Workgroups every environment had in the last environment-resident launch if that was a team launch (k_run<TEAM>: the
- * environment's rows are cut into bands, one workgroup each; the members exchange one boundary row per step): uint32 [n_envs],
- * zeros if the last launch gave every environment one workgroup.  No reference counterpart. */
-int sf_get_team_sizes(sf_sim *sim, uint32_t *sizes_out);
-/* How many environment-resident launches (k_run) the last sf_step / sf_step_mitigated / sf_rollout call was made of (0: it ran
- * on the per-step kernels).  bench.py divides a rollout's algorithmic bytes and duration by it, so that its per-launch figures
- * are those of the rocprofv3 kernel statistics.  No reference counterpart. */
-int sf_get_last_launches(sf_sim *sim, int32_t *n_out);
-int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* RothermelFireManager.update called again after it returned QUIT on the runtime check still prunes and ages the
  * sprites (fire.py:631-643 run before the check at 641): 1 = sf_step does the same for such environments (they stay
  * QUIT in the result block, spread stays off); 0 (default) = a QUIT environment is frozen, as FireSimulation.run
@@ -339,13 +253,6 @@ int sf_loop_start(sf_sim *sim, int32_t k);
 int sf_loop_step(sf_sim *sim, const int32_t *points, int32_t *status_out, double *elapsed_out);
 int sf_loop_stop(sf_sim *sim);
 int sf_loop_restarts(sf_sim *sim, int32_t *count_out);
-/* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
- * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = k_run_tiles, 5 = one
- * frontier-resident launch (k_front), 6 = k_front, and k_run for the steps of environments that outgrew k_front's
- * record capacity, -1 = none yet. */
-int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);
-/* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
-int sf_set_dense(sf_sim *sim, int32_t dense);
 
 #ifdef __cplusplus
 }

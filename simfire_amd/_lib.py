@@ -107,7 +107,7 @@ def variant_path(variant):
 
 TUNE = {name: i for i, name in enumerate((
     "waves_per_cu", "run_waves", "run_min_envs", "run_vcap", "run_compact", "run_batch", "run_result", "run_segment",
-    "front_min_steps", "front_auto", "front_waves", "front_rc", "front_ic", "front_tab", "front_debug", "run_team", "team_placement", "team_recut", "run_window"))}
+    "front_min_steps", "front_auto", "front_waves", "front_rc", "front_ic", "front_tab", "front_debug", "run_team", "team_placement", "team_recut", "run_window", "team_timeout_ms"))}
 
 _libs = {}
 

@@ -15,13 +15,32 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
-def needs_build(out=OUT):
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+def source_hash():
+    """sha256 over every source the library is built from + the flags (what a `.srchash` file beside a built library records)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "simfire_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    lab = os.path.join(os.path.dirname(_HERE), "include", "simfire_hip_lab.h")
+    if os.path.exists(lab):
+        deps.append(lab)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def needs_build(out=OUT):
+    """True unless `out` exists and was built from exactly these sources (a hash stored beside it, not modification times)."""
+    if os.environ.get("SF_FORCE_BUILD") == "1" or not os.path.exists(out):
+        return True
+    try:
+        with open(out + ".srchash") as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def _compile_cmds(out, extra=()):
@@ -40,8 +59,18 @@ def variant_out(v):
     return os.path.join(CSRC, _lib.VARIANTS[v])
 
 
-def build(force=False, verbose=False, variants=()):
-    """Product library + the named test-only variants (all compiles run side by side, then the links)."""
+def hipcc_version():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+        return next((ln.strip() for ln in out.splitlines() if "HIP version" in ln), out.splitlines()[0].strip() if out else "?")
+    except OSError:
+        return "hipcc not found"
+
+
+def build(force=False, verbose=False, variants=(), jobs=None):
+    """Product library + the named test-only variants: at most `jobs` compiles side by side (default: the CPUs), then the links.
+    Every compile is waited for even if one fails, and the object files are removed whatever happens."""
     targets = []
     if force or needs_build(OUT):
         targets.append((OUT, ()))
@@ -49,21 +78,38 @@ def build(force=False, verbose=False, variants=()):
         if force or needs_build(variant_out(v)):
             targets.append((variant_out(v), VARIANT_FLAGS[v]))
     plans = [_compile_cmds(out, extra) for out, extra in targets]
-    procs = []
-    for compiles, _, _ in plans:
-        for cmd in compiles:
+    jobs = jobs or max(1, min(os.cpu_count() or 1, 8))
+    pending = [cmd for compiles, _, _ in plans for cmd in compiles]
+    running, failed = [], None
+    try:
+        while pending or running:
+            while pending and len(running) < jobs and failed is None:
+                cmd = pending.pop(0)
+                if verbose:
+                    print(" ".join(cmd))
+                running.append((cmd, subprocess.Popen(cmd)))
+            if not running:
+                break
+            cmd, p = running.pop(0)
+            if p.wait() != 0 and failed is None:
+                failed = (p.returncode, cmd)
+        if failed is not None:
+            raise subprocess.CalledProcessError(*failed)
+        h = source_hash()
+        for (out, _), (_, link, _) in zip(targets, plans):
             if verbose:
-                print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    for _, link, objs in plans:
-        if verbose:
-            print(" ".join(link))
-        subprocess.check_call(link)
-        for o in objs:
-            os.remove(o)
+                print(" ".join(link))
+            subprocess.check_call(link)
+            with open(out + ".srchash", "w") as f:
+                f.write(h + "\n")
+    finally:
+        for _, p in running:
+            p.kill()
+            p.wait()
+        for _, _, objs in plans:
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
     return OUT
 
 

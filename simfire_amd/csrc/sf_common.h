@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "../../include/simfire_hip.h"
+#include "../../include/simfire_hip_lab.h"
 
 namespace {
 
@@ -122,6 +123,9 @@ struct StepArgs {
     uint32_t *xerr;              // != 0: a wait for a team member timed out (the launch's results are void)
     int xrow;                    // bytes per published row: 64 (bitmap words) + PV * 16, rounded up to 128
     int team_rcap;               // bitmap rows a member keeps in LDS (+ 2 halo rows); 0 = the whole grid
+    unsigned long long team_timeout;   // ticks of the 100 MHz wall clock (s_memrealtime) a member waits for the others before it gives up (xerr): the members
+                                 // of a team are not guaranteed to be resident together - another stream's kernels, a CU mask or a preempted queue can
+                                 // keep one out - so the bound is generous (SF_TUNE_TEAM_TIMEOUT_MS, 2 s by default) and in wall time, not shader clocks
     int team_recut;              // > 0: the members of a team cut their bands anew every team_recut steps INSIDE the launch (teams of a fixed size: the whole
                                  // rollout is one launch; cut into launches it lasts the sum of the launches' slowest environments - 12 % more on C4's share)
     // k_run in LOOP mode (sf_loop_start / sf_loop_step): the launch stays resident and is driven step by step by the host

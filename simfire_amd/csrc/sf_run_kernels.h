@@ -416,12 +416,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u;      // HW_REG_XCC_ID
         if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, (1ull << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u64 x = 1ull << 32 | xcc;
-        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
             if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((uint32_t)(x >> 32) == 1u)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_readcyclecounter() - t0 > (1ull << 29)) break;        // (the first step boundary reports a member that never shows up)
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) break;        // (the first step boundary reports a member that never shows up)
         }
         one_l2 = __all((uint32_t)(x >> 32) == 1u && ((uint32_t)x & 15u) == xcc) && !a.team_far;
     }
@@ -1141,12 +1141,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 // every member's granule of this step (a member can be one step ahead at most: two granules by parity)
                 u64 x = (u64)epoch << 32;
                 {
-                    const unsigned long long t0 = __builtin_readcyclecounter();
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     for (;;) {
                         if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (skips the L1)
                         if (__all((uint32_t)(x >> 32) == epoch)) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if (gave_up || __builtin_readcyclecounter() - t0 > (1ull << 29)) {       // (bounded, ~0.25 s: a lost member must not hang the GPU)
+                        if (gave_up || __builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) {       // (bounded - wall clock, SF_TUNE_TEAM_TIMEOUT_MS, 2 s by default: a lost member must not hang the GPU)
                             if (lane == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
                             gave_up = true;
                             break;
@@ -1209,12 +1209,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 const uint32_t tag = 2u + (uint32_t)((s + 1) / a.team_recut);
                 if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, (u64)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 u64 x = (u64)tag << 32;
-                const unsigned long long t0 = __builtin_readcyclecounter();
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
                     if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__all((uint32_t)(x >> 32) >= tag)) break;
                     __builtin_amdgcn_s_sleep(2);
-                    if (gave_up || __builtin_readcyclecounter() - t0 > (1ull << 29)) {       // (bounded like every wait for a member)
+                    if (gave_up || __builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) {       // (bounded like every wait for a member)
                         if (lane == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
                         gave_up = true;
                         break;

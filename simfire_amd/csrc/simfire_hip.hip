@@ -108,11 +108,11 @@ struct Tuning {
 static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
     /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
-    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1};
+    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1, /* TEAM_TIMEOUT_MS */ 2000};
 static const char *const kTuneName[SF_TUNE_COUNT] = {
     "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
     "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
-    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW"};
+    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW", "SF_TUNE_TEAM_TIMEOUT_MS"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -233,6 +233,16 @@ hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block,
 static int ensure_rm(sf_sim *s);
 static int alloc_bl(sf_sim *s);
 static bool prefers_bl(const sf_sim *s);
+
+// Behind every wait for the handle's stream: has a workgroup of a team launch (k_run<TEAM>) given up waiting for a team member?
+// Then what the launch left behind is void - say so wherever data is handed back, not only in sf_sync / a synchronous sf_step.
+// (A reset of every environment rewrites all the state a team launch touches and clears the word: the handle recovers.)
+static int check_team_error(const sf_sim *s, const char *where)
+{
+    if (s->xerr_pinned && *s->xerr_pinned)
+        return fail(SF_EHIP, "%s: a workgroup of a team launch (k_run<TEAM>) gave up waiting for a team member; the state of this handle is void until every environment is reset", where);
+    return SF_OK;
+}
 
 static int ensure_stage(sf_sim *s, size_t bytes)
 {
@@ -900,6 +910,7 @@ extern "C" int sf_reset(sf_sim *s, const int32_t *init_xy)
     if (!s || !init_xy) return fail(SF_EINVAL, "sf_reset: null argument");
     int rc = reset_range(s, 0, s->g.E, init_xy);
     if (rc == SF_OK) { s->was_reset = true; s->vbits_valid = true; s->vbits_fl_valid = true; s->tiles_valid = !s->bl_cur; s->fire_rows = 1; }     // every environment freshly written
+    if (rc == SF_OK && s->xerr_pinned) *s->xerr_pinned = 0;      // (cells, bitmaps, states of every environment are new: what a failed team launch left is gone)
     return rc;
 }
 
@@ -1210,6 +1221,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     StepArgs a;
     a.loop_db = nullptr;      // (not the closed loop of sf_loop_start)
     a.team_recut = 0;
+    a.team_timeout = 100000ull * (unsigned long long)(s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] < 1 ? 1 : s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS]);
     s->last_launches = 0;
     const int n_requested = n_steps;
     if (n_steps != 1 || mit_dev || s->last_was_step1) s->step1_polls = 0;       // (another kind of call, or nobody looked at the last update's result)
@@ -1881,7 +1893,7 @@ static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    return SF_OK;
+    return check_team_error(s, "sf_get_fire_map(s)");
 }
 
 extern "C" int sf_get_fire_map(sf_sim *s, int32_t env, uint8_t *out)
@@ -1922,7 +1934,7 @@ extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    return SF_OK;
+    return check_team_error(s, "sf_get_burn");
 }
 
 extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
@@ -2007,7 +2019,7 @@ extern "C" int sf_get_status(sf_sim *s, int32_t *status, double *elapsed)
     HIPCHK(hipStreamSynchronize(s->stream));
     memcpy(status, pin, nb_st);
     if (elapsed) memcpy(elapsed, pin + nb_st, nb_el);
-    return SF_OK;
+    return check_team_error(s, "sf_get_status");
 }
 
 extern "C" int sf_enable_counters(sf_sim *s, int32_t on)
@@ -2037,7 +2049,7 @@ extern "C" int sf_copy_status_to(sf_sim *s, void *device_dst)
     int rc = update_status_async(s, static_cast<int32_t *>(device_dst));       // (the counting kernel writes the copy too)
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));       // (one wait for steps still in flight and the count)
-    return SF_OK;
+    return check_team_error(s, "sf_copy_status_to");
 }
 
 extern "C" int sf_rollout(sf_sim *s, int32_t n_steps, void *device_dst)
@@ -2075,9 +2087,11 @@ RcclApi g_rccl;
 int rccl_load()
 {
     if (g_rccl.lib) return SF_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // (SIMFIRE_RCCL_LIB: another library with the same five entry points - the tests' single-process stand-in, tests/fake_rccl.cpp,
+    // which lets 8 handles on ONE GPU play the 8 ranks of a node; never set in production)
+    const char *names[] = {getenv("SIMFIRE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
-    for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    for (const char *n : names) if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!lib) return fail(SF_ERCCL, "librccl.so could not be loaded: %s", dlerror());
     RcclApi a;
     a.lib = lib;
@@ -2143,7 +2157,7 @@ extern "C" int sf_allgather_status(sf_sim *s, void *device_out)
     // on the handle's stream: behind the steps in flight and the refresh, no host wait in between
     RCCLCHK(g_rccl.AllGather(s->status_block, device_out, (size_t)8 * s->g.E, ncclInt32, s->comm, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    return SF_OK;
+    return check_team_error(s, "sf_allgather_status");
 }
 
 extern "C" int sf_status_device(sf_sim *s, void **ptr)

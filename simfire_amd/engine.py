@@ -240,6 +240,8 @@ class FireEngine:
     def loop_step(self, pts=None):
         """``update_mitigation(pts); run(1)`` for every environment; ``pts`` int32 [n_envs, k, 3] = (column, row, type) or None.
         Returns (status int32 [n_envs, 8], elapsed_time float64 [n_envs]) - views that the next call overwrites."""
+        if getattr(self, "_loop_k", None) is None:
+            raise _lib.SimfireHipError("loop_step: call loop_start first")
         if pts is not None:
             pts = np.ascontiguousarray(np.asarray(pts, dtype=np.int32))
             if pts.shape != (self.n_envs, self._loop_k, 3):

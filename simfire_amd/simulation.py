@@ -82,7 +82,12 @@ def _fingerprint(a) -> int:
         return 0
     a = np.asarray(a)
     if a.dtype != object:
-        return zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        # shape, dtype and a strided sample of ~64 K elements (crc32 of a full 1024^2 f64 plane is ~5 ms, five planes per reset -
+        # the device-side sf_reset it guards takes microseconds): catches wholesale edits such as ``wind.speed[...] = x``; after
+        # editing single elements in place call ``invalidate_layers()``
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 65536)
+        return zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8).reshape(-1)) ^ hash((a.shape, str(a.dtype)))
     flat = a.reshape(-1)
     step = max(1, flat.size // 4096)
     return hash(tuple((f.w_0, f.delta, f.M_x, f.sigma) for f in flat[::step]))
@@ -104,10 +109,10 @@ class FireSimulation:
         cfg = self.config
         # The device handle (layers in HBM, R table) is rebuilt only if something it was built from changed:
         # an RL harness that calls reset() per episode with a new ignition pays one sf_reset, not k_rtable again.
-        # "Changed" = another object OR other contents: numeric planes are fingerprinted in full (crc32, a few ms at 1024^2), so an
-        # in-place edit such as ``config.wind.speed[...] = x`` rebuilds the handle like the reference's reset() rebuilds its
-        # terrain and fire manager (simulation.py:202-214); an object array of ``Fuel`` by a strided sample of its elements -
-        # after editing single elements of such an array in place call ``invalidate_layers()``.
+        # "Changed" = another object OR other contents: every layer is fingerprinted by its shape, dtype and a strided sample of
+        # its elements (~0.3 ms per reset at 1024^2), so a wholesale in-place edit such as ``config.wind.speed[...] = x`` rebuilds
+        # the handle like the reference's reset() rebuilds its terrain and fire manager (simulation.py:202-214); after editing
+        # single elements in place call ``invalidate_layers()``.
         key_objs = (cfg.terrain.fuel_layer.data, cfg.terrain.topography_layer.data, cfg.wind.speed, cfg.wind.direction,
                     getattr(cfg, "fuel_codes", None))
         key_vals = tuple(getattr(getattr(cfg, a), b) for a, b in _SHARED_FIELDS) + tuple(_fingerprint(o) for o in key_objs)
@@ -452,19 +457,26 @@ class BatchedFireSimulation:
         equals the ``update_mitigation`` + ``run(1)`` loop for every input.  A CUDA tensor is not read on the host: its
         entries outside [0, W) x [0, H) are dropped by the kernel, like padding."""
         if isinstance(points, np.ndarray) or not hasattr(points, "data_ptr"):
-            q = np.array(points, dtype=np.int64)
-            if q.ndim == 4 and q.shape[-1] == 3 and q.size:
-                H, W = self.config.area.screen_size
-                real = (q[..., 2] >= int(BurnStatus.FIRELINE)) & (q[..., 2] <= int(BurnStatus.WETLINE))
-                bad = real & ((q[..., 0] < -W) | (q[..., 0] >= W) | (q[..., 1] < -H) | (q[..., 1] >= H))
-                if bad.any():
-                    raise IndexError(f"mitigation point out of bounds for a {H}x{W} fire_map")
-                q[..., 0] = np.where(real, q[..., 0] % W, q[..., 0])
-                q[..., 1] = np.where(real, q[..., 1] % H, q[..., 1])
-                points = q.astype(np.int32)
+            points = self._normalise_points(points, 4)
         self._engine.step_mitigated(points)
         st, _ = self._engine.status()
         return (self._engine.fire_maps() if return_maps else None), st[:, 0].astype(bool)
+
+    def _normalise_points(self, points, ndim):
+        """Control-line points as ``update_mitigation`` takes them (mitigation.py:75-78 indexes the fire map with them): negative
+        columns / rows count from the end, anything further out raises IndexError; entries whose type is no control line are
+        padding and pass through.  ``points``: integer array [..., 3] = (column, row, type) with ``ndim`` axes."""
+        q = np.array(points, dtype=np.int64)
+        if q.ndim == ndim and q.shape[-1] == 3 and q.size:
+            H, W = self.config.area.screen_size
+            real = (q[..., 2] >= int(BurnStatus.FIRELINE)) & (q[..., 2] <= int(BurnStatus.WETLINE))
+            bad = real & ((q[..., 0] < -W) | (q[..., 0] >= W) | (q[..., 1] < -H) | (q[..., 1] >= H))
+            if bad.any():
+                raise IndexError(f"mitigation point out of bounds for a {H}x{W} fire_map")
+            q[..., 0] = np.where(real, q[..., 0] % W, q[..., 0])
+            q[..., 1] = np.where(real, q[..., 1] % H, q[..., 1])
+            return q.astype(np.int32)
+        return points
 
     # ---- closed loop: actions that depend on the last observation, one update per call, no launch per call (sf_loop_*)
     def loop_start(self, points_per_env: int) -> None:
@@ -474,7 +486,10 @@ class BatchedFireSimulation:
     def loop_step(self, points=None):
         """``update_mitigation(points); run(1)`` for every environment (simulation.py:449-478, 501-553); ``points`` int32
         [n_envs, k, 3] = (column, row, type), type outside FIRELINE..WETLINE = padding, or None.  Returns (result block int32
-        [n_envs, 8] = running, elapsed_steps, cells per BurnStatus; elapsed_time float64 [n_envs])."""
+        [n_envs, 8] = running, elapsed_steps, cells per BurnStatus; elapsed_time float64 [n_envs]).  Points are normalised like
+        ``rollout``'s: negative coordinates count from the end, out-of-range ones raise IndexError."""
+        if points is not None:
+            points = self._normalise_points(points, 3)
         return self._engine.loop_step(points)
 
     def loop_stop(self) -> None:

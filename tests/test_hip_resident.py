@@ -774,6 +774,13 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(workload):
                "--no-extra", "--cpu-threads", 2)
     assert j["n_gpus"] == 8 and j["config"]["envs_total"] == 24 and j["ranks_seen_by_collective"] == 8
     assert j["verified"] is True and j["scaling"] == "weak" and j["config"]["collective_backend"] == "gloo"
+    # every rank's own launch in the line (kernel time by HIP events, algorithmic bytes, achieved GB/s): the north star's "HBM GB/s at
+    # 1, 2, 4 and 8 GPUs" needs no rank-0 extrapolation
+    rl = j["roofline"]
+    assert len(rl["per_rank_gbs"]) == 8 and len(rl["per_rank_kernel_ms"]) == 8 and len(rl["per_rank_algorithmic_bytes"]) == 8
+    assert all(v > 0 for v in rl["per_rank_kernel_ms"]) and all(v > 0 for v in rl["per_rank_gbs"])
+    assert abs(rl["per_rank_gbs"][0] - rl["achieved"]) <= 1e-6 * rl["achieved"]
+    assert abs(sum(rl["per_rank_gbs"]) - rl["aggregate_gbs"]) <= 1e-6 * rl["aggregate_gbs"]
 
 
 # ------------------------------------------------------------------ closed loop: one step per call on a resident launch
@@ -1255,3 +1262,67 @@ def test_window_phase_random_worlds(seed, win):
         assert cnt["window_updates"] == 0
     else:
         assert cnt["window_updates"] > 0, "the window phase never ran"
+
+
+def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path):
+    """Everything around the one RCCL call of the C ABI for a world of EIGHT ranks, on one GPU: tests/fake_rccl.cpp (test
+    infrastructure, loaded instead of librccl through SIMFIRE_RCCL_LIB) lets eight handles of one process play the ranks.  Checked:
+    the unique id made by rank 0 and handed to every rank, bad ranks / worlds / ids (SF_EINVAL before RCCL is asked, SF_ERCCL from
+    it), a gather before the communicator exists (SF_ESTATE), the gathered block int32 [8 x n_envs][8] in rank-major order in EVERY
+    rank's buffer after resident rollouts of different lengths, and a second gather after more updates on a re-created world.
+    Runs in a process of its own: the library loads its RCCL once."""
+    import subprocess, sys, os, textwrap
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", str(so), os.path.join(os.path.dirname(__file__), "fake_rccl.cpp")])
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from simfire_amd import _lib
+        from simfire_amd.engine import FireEngine
+        from oracle import fire_dense
+        rng = np.random.default_rng(11)
+        H, W, E, WORLD = 72, 96, 3, 8
+        kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=False)
+        R8 = rng.choice([0.0, 7.5, 30.0, 400.0], size=(8, H, W))
+        engs, orcs = [], []
+        for r in range(WORLD):
+            inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+            e = FireEngine(**kw); o = fire_dense.DenseOracle(**kw)
+            for x in (e, o):
+                x.set_rtable(R8); x.reset(inits)
+            engs.append(e); orcs.append(o)
+        outs = [torch.full((WORLD * E, 8), -1, dtype=torch.int32, device="cuda:0") for _ in range(WORLD)]
+        def raises(f):
+            try:
+                f()
+            except (ValueError, RuntimeError) as ex:         # SF_EINVAL -> ValueError; SF_ESTATE / SF_ERCCL -> RuntimeError (simfire_amd/_lib.py)
+                return type(ex).__name__
+            return None
+        assert raises(lambda: engs[0].allgather_status(outs[0].data_ptr())) is not None          # no communicator yet
+        for round_ in range(2):
+            uid = engs[0].comm_unique_id()                                                      # made by rank 0 ...
+            assert len(uid) == 128
+            assert raises(lambda: engs[1].comm_init(WORLD, WORLD, uid)) == "ValueError"          # rank out of range: SF_EINVAL
+            assert raises(lambda: engs[1].comm_init(-1, WORLD, uid)) == "ValueError"
+            assert raises(lambda: engs[1].comm_init(0, 0, uid)) == "ValueError"
+            assert raises(lambda: engs[1].comm_init(1, WORLD, bytes(128))) is not None           # not an id: refused by the collective library
+            for r in range(WORLD):
+                engs[r].comm_init(r, WORLD, uid)                                                # ... handed to every rank
+            assert raises(lambda: FireEngine(**kw).comm_init(3, WORLD, uid)) is not None         # a rank taken twice
+            for r in range(WORLD):
+                n = 4 + 3 * r + round_
+                engs[r].set_async(True); engs[r].step(n); engs[r].set_async(False)
+                orcs[r].step(n)
+            for r in range(WORLD):
+                engs[r].allgather_status(outs[r].data_ptr())
+            want = np.concatenate([orcs[r].status()[0] for r in range(WORLD)], axis=0)           # rank-major
+            assert want.shape == (WORLD * E, 8)
+            for r in range(WORLD):
+                assert (outs[r].cpu().numpy() == want).all(), (round_, r)
+            for r in range(WORLD):
+                engs[r].comm_destroy()
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIMFIRE_RCCL_LIB=str(so))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]

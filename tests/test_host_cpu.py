@@ -87,11 +87,18 @@ def test_shard_envs():
 
 
 def test_c_abi_exports_every_declared_symbol():
-    """The shared library loads (no GPU needed for that) and exports every function that
-    include/simfire_hip.h declares; the ctypes table binds exactly that set."""
+    """The shared library loads (no GPU needed for that) and exports every function that include/simfire_hip.h (the boundary a
+    SimFire maintainer binds) and include/simfire_hip_lab.h (knobs, counters, introspection: bench / tests / profiles) declare;
+    the ctypes table binds exactly that set; the boundary header holds no laboratory entry."""
     from simfire_amd import _lib
     header = open(os.path.join(ROOT, "include", "simfire_hip.h")).read()
-    declared = set(re.findall(r"\b(sf_[a-z_0-9]+)\s*\(", header))
+    lab = open(os.path.join(ROOT, "include", "simfire_hip_lab.h")).read()
+    strip = lambda h: re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    boundary = set(re.findall(r"\b(sf_[a-z_0-9]+)\s*\(", strip(header)))
+    laboratory = set(re.findall(r"\b(sf_[a-z_0-9]+)\s*\(", strip(lab)))
+    assert not (boundary & laboratory)
+    assert "No reference counterpart" not in header and "sf_set_tuning" not in boundary and "sf_get_run_cost" not in boundary
+    declared = boundary | laboratory
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
