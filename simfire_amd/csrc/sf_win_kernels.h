@@ -236,10 +236,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const double rate = g.update_rate;
     const bool stats = a.counters != nullptr;
     uint32_t up = wm[own - 18], mid = wm[own], dn = wm[own + 18];
-    // (Measured and dropped: touching, when a cell ignites, the eight table entries its neighbours will most likely ask for in the next
-    // step - eight loads whose results nobody uses.  The walkers' wait for their operands fell from ~900 to ~100 clocks, and the
-    // step got 25 % LONGER: loads return in order, so the next step's operands queue behind the touches, and sixty more
-    // instructions sit on the walkers' path.)
+    // (Measured and dropped, twice: touching the eight table entries the neighbours of a new ignition will most likely ask for in the next
+    // step - loads whose results nobody uses.  By the walkers themselves, when a cell ignites: their wait for operands fell from ~900
+    // to ~100 clocks and the step got 25 % LONGER (loads return in order per wave: the next operands queue behind the touches).  By an
+    // otherwise idle wave at the start of the next step: 35 % longer.  The walkers' wait is not latency, it is the CU's rate of
+    // scattered line fetches - ~130 lines per step at the 0.10 - 0.25 lines per clock and CU that profiles/scatter_probe.hip measures
+    // when every CU does it - and 250 touches per step take their share of exactly that.)
 #ifdef SF_WIN_PROF
     unsigned long long wp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wp_t = __builtin_readcyclecounter();
 #endif
