@@ -19,6 +19,18 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc -o write
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc -o calib_fetch -- /tmp/sf_mb > $O/calib.txt 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $O/pmc -o sq -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES -d $O/pmc -o sq2 -- $B > /dev/null 2>&1
+# the per-dispatch rows of the resident launch (k_run) out of the kernel trace: the timed launch's duration can be read off a tracked file
+python - <<PY2
+import csv, glob
+for f in glob.glob("$O/stats/default_kernel_trace.csv"):
+    rows = [r for r in csv.DictReader(open(f)) if "k_run" in r["Kernel_Name"] and "rebuild" not in r["Kernel_Name"]]
+    with open("$O/kernel_trace_k_run.csv", "w") as o:
+        o.write("dispatch,kernel,start_ns,end_ns,duration_us,grid,workgroup,lds_bytes,vgpr,sgpr\n")
+        for i, r in enumerate(rows):
+            o.write("%d,%s,%s,%s,%.2f,%s,%s,%s,%s,%s\n" % (i, r["Kernel_Name"].split("(")[0][-40:], r["Start_Timestamp"], r["End_Timestamp"],
+                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
+                    r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""), r.get("SGPR_Count", "")))
+PY2
 rm -f $O/stats/*_kernel_trace.csv
 R=$R STEPS=$STEPS WARM=$WARM python - <<'PY'
 import csv, glob, collections, json, os

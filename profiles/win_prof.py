@@ -25,5 +25,12 @@ tot = p.sum(axis=2)
 print("   wave  " + "  ".join(f"{n:>11s}" for n in names) + "        total")
 for wv in range(16):
     print(f"   {wv:4d}  " + "  ".join(f"{p[:, wv, q].mean():11.0f}" for q in range(8)) + f"  {tot[:, wv].mean():11.0f}")
+import json
 busy = p[:, :, 0].argmax(axis=1)
+if len(sys.argv) > 4:
+    walk = p[:, 0, :]
+    json.dump({"steps": steps, "warmup": warm, "envs": E, "kernel_us": ms * 1e3, "build": "-DSF_WIN_PROF (s_memtime stamps in the window loop: ~10 % slower than the product)",
+               "clocks_per_update": {"phase_A_busiest_wave_mean": float(p[np.arange(E), busy, 0].mean()), "phase_A_busiest_wave_max": float(p[np.arange(E), busy, 0].max()),
+                                     "walker_wave0": {n: float(walk[:, q].mean()) for q, n in enumerate(names)}, "total_per_update": float(tot[:, 0].mean())}},
+              open(sys.argv[4], "w"), indent=1)
 print("   busiest phase-A wave per env: phase A mean %.0f, max over envs %.0f" % (p[np.arange(E), busy, 0].mean(), p[np.arange(E), busy, 0].max()))

@@ -316,11 +316,14 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_vec_done = 0;
     // ---- a young fire: as many updates as it stays inside a window of cells held in registers (sf_win_kernels.h); the loop below
     // takes over where updates are left.  (The instantiations of sf_step on one-word rows: no teams, no control lines inside the launch.)
-    constexpr bool kWin = TEAM == 0 && MAXD == 1 && MIT == 0;
+    // (also: two bitmap words per thread - 8-wave workgroups on 1024 rows, the many-environments regime; 2048-wide grids in a team of ONE,
+    // C4's young fires - through the window code's general path)
+    constexpr bool kWin = MIT == 0 && MAXD <= 2;
+    constexpr int kWinGen = (MAXD == 1 && TEAM == 0) ? 0 : 1;
     int s_begin = 0;
     bool win_result = false;  // the window phase has written this environment's row of the result block
     PhaseClock wpc;          // (timeline of the launch as a whole: sf_debug_timeline(env, -1))
-    if (kWin) {
+    if (kWin && (!TEAM || tn == 1)) {
         WinEnv we;
         we.cells = a.cells + (long long)e * g.cells_env;
         we.burn = a.burn + (long long)e * g.plane_env;
@@ -335,11 +338,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
 #endif
         wpc.note(30);        // launch: state read
-        s_begin = run_window<ATT>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result);
+        s_begin = run_window<ATT, kWinGen>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result);
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 6 of the plain kernel: updates made inside a window)
             atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * 8 + 6, (unsigned long long)s_begin);
     }
-    const bool general = !kWin || (s_begin < n_steps && st.running);       // (uniform) the bitmaps in LDS, the loop over the vector list
+    const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && st.running);       // (uniform) the bitmaps in LDS, the loop over the vector list
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         __syncthreads();
         return fits;
     };
-    if (TEAM && (tn > 1 || a.team_rcap)) {
+    if (TEAM && (tn > 1 || a.team_rcap) && general) {
         const bool fits = cut_bands(tn > 1 && a.team_recut > 0 && a.team_recut < n_steps ? a.team_recut : n_steps);
         if (a.todo_out && tm == 0 && tid == 0) a.todo_out[e] = fits ? 0 : n_steps;
         if (!fits && !a.todo_out && tid == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;      // (the host promised a fit and made no catch-up launch: fail loudly)
@@ -1246,7 +1249,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         }
     }
     if (TEAM) {
-        store_band();
+        if (general) store_band();
     } else if (general) {              // (a launch that never left the window phase has kept the bitmaps in memory)
         for (int i = tid; i < n_words; i += nthr) vb_glob[i] = vb[i];
         if (fine)

@@ -56,6 +56,17 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v)          // unsigned maximum over the 64 lanes
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t row16_or(uint32_t v)           // OR over the first 16 lanes (lane 15 holds it)
 {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
@@ -119,7 +130,9 @@ __host__ __device__ inline size_t win_lds_bytes(int n_waves)
     return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)n_waves * 256 * 2;
 }
 
-template <int ATT>
+// GEN = 0: rows of one bitmap word, a thread per grid row (k_run<1, ...>: the code the headline runs); GEN = 1: rows of g.VW words,
+// any number of rows per thread (k_run<2, ...>: many environments in 8-wave workgroups, 2048-wide grids in teams of one).
+template <int ATT, int GEN>
 __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, EnvState &st, const int n_steps, const bool diag, uint32_t *wl,
                                           uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done, PhaseClock &lpc, const int e, bool &result_done)
 {
@@ -131,8 +144,38 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (g.H < WR || g.PV < 4 || g.dense || n_steps <= 0 || !st.running || !a.win) return 0;       // (uniform)
     // ---- where is the fire?  Rows and vector columns that hold a sprite bit, from the vector bitmap in memory: thread y looks at row y.
     // (No LDS atomics: on a uniform address the compiler turns them into a scalar loop over the lanes - 6 k clocks of every launch.)
-    if (g.H > nthr) return 0;
+    const int VW = GEN ? g.VW : 1;
+    if (!GEN && g.H > nthr) return 0;
     uint32_t *const wslot = wl + (size_t)WR * 128 + 64 + 128;                            // [waves][4]: per wave first row, last row + 1 (0: none), column bits
+    int ymin, ymax1, vmin, vmax;
+    bool hist_clean;
+    if (GEN) {
+        // any rows per thread, any words per row: complements for the minima, maxima over the wave, then over the waves
+        uint32_t iy = 0, y1 = 0, iv = 0, v1 = 0;               // ~first row, last row + 1, ~first vector, last vector + 1 (0: none)
+        for (int y = tid; y < g.H; y += nthr)
+            for (int w = 0; w < VW; ++w) {
+                const unsigned long long word = ev.vb_glob[y * VW + w];
+                if (word) {
+                    const uint32_t a_ = 0xFFFFFFFFu - (uint32_t)y, b_ = 0xFFFFFFFFu - (uint32_t)(w * 64 + __ffsll((long long)word) - 1), c_ = (uint32_t)(w * 64 + 64 - __clzll((long long)word));
+                    iy = iy > a_ ? iy : a_; y1 = (uint32_t)y + 1u; iv = iv > b_ ? iv : b_; v1 = v1 > c_ ? v1 : c_;
+                }
+            }
+        bool dirty = false;
+        for (int t = tid; t < g.TY * g.TX; t += nthr) dirty |= ev.tdirty[t] != 0;
+        const bool wave_dirty = __ballot(dirty) != 0ull;
+        const uint32_t miy = wave_umax(iy), may = wave_umax(y1), miv = wave_umax(iv), mav = wave_umax(v1);
+        if (lane == 0) {
+            uint32_t *sl = wslot + wave * 4;
+            sl[0] = miy; sl[1] = may | (wave_dirty ? 0x80000000u : 0u); sl[2] = miv; sl[3] = mav;
+        }
+        __syncthreads();
+        const int n_waves = nthr >> 6;
+        const uint4 sl = lane < n_waves ? *reinterpret_cast<const uint4 *>(wslot + lane * 4) : make_uint4(0, 0, 0, 0);
+        const uint32_t a_ = row16_max(sl.x), b_ = row16_max(sl.y & 0x7FFFFFFFu), c_ = row16_max(sl.z), d_ = row16_max(sl.w);
+        hist_clean = (row16_or(sl.y) & 0x80000000u) == 0u;
+        if (!b_) return 0;                                     // no sprite anywhere: the general loop's next update says QUIT
+        ymin = (int)(0xFFFFFFFFu - a_); ymax1 = (int)b_; vmin = (int)(0xFFFFFFFFu - c_); vmax = (int)d_ - 1;
+    } else {
     {
         const unsigned long long w = tid < g.H ? ev.vb_glob[tid] : 0ull;
         const unsigned long long nz = __ballot(w != 0ull);
@@ -150,9 +193,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         }
     }
     __syncthreads();
-    int ymin, ymax1;
     unsigned long long cmask;
-    bool hist_clean;
     {
         const int n_waves = nthr >> 6;
         const uint4 sl = lane < n_waves ? *reinterpret_cast<const uint4 *>(wslot + lane * 4) : make_uint4(0, 0, 0, 0);
@@ -165,8 +206,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         cmask = (unsigned long long)clo | ((unsigned long long)chi << 32);
     }
     if (!cmask) return 0;                                      // no sprite anywhere: the general loop's next update says QUIT
+    vmin = __ffsll((long long)cmask) - 1; vmax = 63 - __clzll((long long)cmask);
+    }
     lpc.note(31);            // where the fire is
-    const int vmin = __ffsll((long long)cmask) - 1, vmax = 63 - __clzll((long long)cmask);
     const int hb = ymax1 - ymin, wv = vmax - vmin + 1;
     if (hb > WR || wv > 4) return 0;
     int wy0 = ymin - ((WR - hb) >> 1), wv0 = vmin - ((4 - wv) >> 1);
@@ -482,6 +524,21 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 nf4 |= ((f16 >> (4 * j)) & 1u) << j;
                 nl4 |= ((l16 >> (4 * j + 3)) & 1u) << j;
             }
+            if (GEN) {
+                // (the window's four vectors may sit in two words of the row)
+                for (int ww = wv0 >> 6; ww <= (wv0 + 3) >> 6; ++ww) {
+                    const int j0 = ww * 64 - wv0 > 0 ? ww * 64 - wv0 : 0, j1 = ww * 64 + 64 - wv0 < 4 ? ww * 64 + 64 - wv0 : 4;      // its vectors [j0, j1) of the window
+                    const int sh = wv0 + j0 - ww * 64;
+                    const unsigned long long m = (1ull << (j1 - j0)) - 1ull, keep = ~(m << sh);
+                    unsigned long long *w0 = ev.vb_glob + y * VW + ww, *w1 = w0 + ev.vb_plane, *w2 = w1 + ev.vb_plane;
+                    const unsigned long long o0 = *w0, o1 = *w1, o2 = *w2;
+                    const unsigned long long v0 = (o0 & keep) | ((((unsigned long long)nb4 >> j0) & m) << sh), v1 = (o1 & keep) | ((((unsigned long long)nf4 >> j0) & m) << sh),
+                                             v2 = (o2 & keep) | ((((unsigned long long)nl4 >> j0) & m) << sh);
+                    if (v0 != o0) *w0 = v0;
+                    if (v1 != o1) *w1 = v1;
+                    if (v2 != o2) *w2 = v2;
+                }
+            } else {
             const unsigned long long keep = ~(0xFull << wv0);
             unsigned long long *w0 = ev.vb_glob + y, *w1 = w0 + ev.vb_plane, *w2 = w1 + ev.vb_plane;
             const unsigned long long o0 = *w0, o1 = *w1, o2 = *w2;
@@ -490,6 +547,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             if (v0 != o0) *w0 = v0;
             if (v1 != o1) *w1 = v1;
             if (v2 != o2) *w2 = v2;
+            }
         }
     }
     __syncthreads();

@@ -1107,7 +1107,7 @@ static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, in
     const int ia = s->g.att ? 1 : 0, id = s->g.diag ? 1 : 0;
     if (which > 0) {
         // two / four words per thread: instantiated in the library's third translation unit (simfire_hip_run3.hip)
-        size_t &attr3 = s->attr_run[which == 2 ? 20 + ia : (which * 2 + ia) * 2 + id];
+        size_t &attr3 = s->attr_run[which == 2 ? 20 + ia : ((id && !a.mit) ? 16 + ia : (which * 2 + ia) * 2 + id)];      // (16 / 17: the instantiations without control lines inside the launch)
         const bool set_lds = lds > 64 * 1024 && lds > attr3;
         HIPCHK(sf_run3_launch_plain(which, ia, id, (unsigned)s->g.E, (unsigned)waves * 64, lds, set_lds, s->stream, &a, sizeof a, n_steps, vcap, bsz));
         if (set_lds) attr3 = lds;

@@ -28,7 +28,9 @@ hipError_t sf_run3_launch_plain(int which, int att, int diag, unsigned grid, uns
     if (args_bytes != sizeof(StepArgs) || which < 1 || which > 2) return hipErrorInvalidValue;
     StepArgs a;
     memcpy(&a, args, sizeof a);
-    const run_fn kern = table[which - 1][att ? 1 : 0][diag ? 1 : 0];
+    // two words per thread, diagonal spread known to be on, no control lines inside the launch: the instantiations with the window phase
+    static const run_fn table_nomit[2] = {k_run<2, 0, 1, 0>, k_run<2, 1, 1, 0>};
+    const run_fn kern = (which == 1 && diag && !a.mit) ? table_nomit[att ? 1 : 0] : table[which - 1][att ? 1 : 0][diag ? 1 : 0];
     if (set_lds) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

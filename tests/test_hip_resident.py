@@ -1326,3 +1326,60 @@ def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path
     env = dict(os.environ, SIMFIRE_RCCL_LIB=str(so))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("case", ["wide", "wide_att", "eight_waves", "eight_waves_att", "many_envs"])
+@pytest.mark.parametrize("seed", range(4))
+def test_window_phase_two_words_per_thread(seed, case):
+    """The window phase on its general path: rows of two bitmap words (grids of 1025 ... 2048 columns, stepped by teams of one
+    workgroup while the fires are young; a window may straddle the two words of a row) and two rows per thread (8-wave
+    workgroups: SF_TUNE_RUN_WAVES = 8 on ~1000 rows, and the automatic choice with more environments than the chip holds
+    workgroups).  Random worlds as above, ignitions also next to column 1024 and at the grid's edges; equal to the oracle after
+    every call, and the window phase must have run."""
+    rng = np.random.default_rng(52000 + 31 * seed + len(case))
+    att = case.endswith("_att")
+    if case.startswith("wide"):
+        H, W, E = int(rng.integers(200, 700)), int(rng.integers(1025, 2049)), int(rng.integers(1, 4))
+    elif case == "many_envs":
+        H, W, E = int(rng.integers(64, 100)), int(rng.integers(64, 130)), 600
+    else:
+        H, W, E = int(rng.integers(600, 1025)), int(rng.integers(64, 300)), int(rng.integers(1, 5))
+    kw, R8 = _window_world(rng, H, W, E, att=att)
+    if case == "many_envs":
+        kw["max_time"] = None
+    inits = []
+    for _ in range(E):
+        q = rng.random()
+        if case.startswith("wide") and q < 0.4:
+            inits.append((int(rng.integers(1010, min(W, 1040))), int(rng.integers(H))))        # around the word boundary of a row
+        elif q < 0.55:
+            inits.append((int(rng.choice([0, 1, W - 2, W - 1])), int(rng.choice([0, 1, H - 2, H - 1]))))
+        else:
+            inits.append((int(rng.integers(W)), int(rng.integers(H))))
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    if case.startswith("eight"):
+        eng.set_tuning(run_waves=8)
+    win = [1, 3, 1, 6][seed]
+    eng.set_tuning(run_window=win)
+    eng.enable_counters(True)
+    done = 0
+    while done < (40 if case == "many_envs" else 70):
+        n = int(rng.integers(2, 26))
+        if rng.random() < 0.4 and case != "many_envs":
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(int(rng.integers(1, 30)))]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        eng.step(n)
+        o.step(n)
+        done += n
+        if case == "many_envs":
+            st, el = eng.status()
+            so, eo = o.status()
+            assert (st == so).all() and (el == eo).all(), (seed, case, done)
+            for e in (0, 1, E // 2, E - 1):
+                assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all(), (seed, case, done, e)
+        else:
+            _same(eng, o, E, tag=(seed, case, done))
+    assert eng.counters()["window_updates"] > 0, "the window phase never ran"
