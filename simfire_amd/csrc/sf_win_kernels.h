@@ -248,7 +248,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const int ty0 = wy0 >> th_log, tx0 = wv0 >> g.logLC;
     const int nty = ((wy0 + WR - 1) >> th_log) - ty0 + 1, ntx = ((wv0 + 3) >> g.logLC) - tx0 + 1;
     const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15;
-    if (tid < 128) dt[tid] = (by_delta && tid >= 120) ? a.res_block[e * 8 + (tid - 120)] : 0;
+    for (int i = tid; i < 128; i += nthr) dt[i] = (by_delta && i >= 120) ? a.res_block[e * 8 + (i - 120)] : 0;      // (workgroups of one wave exist: small grids)
     if (tid < 18) { wm[tid] = 0; wm[(WR + 1) * 18 + tid] = 0; }
     if (tid < WR) { wm[(tid + 1) * 18] = 0; wm[(tid + 1) * 18 + 17] = 0; }
     if (tid < g.N) {
@@ -553,8 +553,8 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     __syncthreads();
     lpc.note(34);            // window written back
     if (by_delta) {
-        if (tid < nty * ntx * 8) {
-            const int tl = tid >> 3, q = tid & 7, d = dt[tid];
+        for (int i = tid; i < nty * ntx * 8; i += nthr) {
+            const int tl = i >> 3, q = i & 7, d = dt[i];
             if (d) ev.thist[((ty0 + tl / ntx) * g.TX + tx0 + tl % ntx) * 8 + q] += (uint16_t)d;       // (mod 2^16: a negative change wraps to the right count)
         }
         if (tid == 0) {

@@ -35,6 +35,8 @@ def world(seed):
     eng.set_tuning(run_team=int(rng.choice([0, 0, 1, -1, 2, 3, 4])), team_placement=int(rng.integers(3)))
     # teams of a fixed size: new bands inside the launch every 2 .. 10 steps (or the default 128), or one launch per segment
     eng.set_tuning(run_segment=int(rng.choice([64, 64, 1, 2, 5])), team_recut=int(rng.random() < 0.8))
+    # the window phase of the resident launch (young fires): on, off, left after 2 .. 7 updates for the general loop
+    eng.set_tuning(run_window=int(rng.choice([1, 1, 1, 0, 2, 3, 7])), run_waves=int(rng.choice([16, 16, 8, 4])))
     if os.environ.get("SOAK_DEBUG"):
         print("world", seed, "H W E", H, W, E, "md", md, "att diag", att, diag, "fused", eng.get_tuning("run_team"), {k: eng.get_tuning(k) for k in ("run_team", "team_placement", "run_segment", "team_recut")}, flush=True)
     eng.set_dense(bool(rng.random() < 0.2))

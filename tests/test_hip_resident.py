@@ -1328,18 +1328,21 @@ def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
 
 
-@pytest.mark.parametrize("case", ["wide", "wide_att", "eight_waves", "eight_waves_att", "many_envs"])
+@pytest.mark.parametrize("case", ["wide", "wide_att", "eight_waves", "eight_waves_att", "many_envs", "one_wave", "one_wave_att"])
 @pytest.mark.parametrize("seed", range(4))
 def test_window_phase_two_words_per_thread(seed, case):
     """The window phase on its general path: rows of two bitmap words (grids of 1025 ... 2048 columns, stepped by teams of one
     workgroup while the fires are young; a window may straddle the two words of a row) and two rows per thread (8-wave
     workgroups: SF_TUNE_RUN_WAVES = 8 on ~1000 rows, and the automatic choice with more environments than the chip holds
     workgroups).  Random worlds as above, ignitions also next to column 1024 and at the grid's edges; equal to the oracle after
-    every call, and the window phase must have run."""
+    every call, and the window phase must have run.  one_wave: grids of up to 64 rows are stepped by a workgroup of one wave (the
+    result block by difference was once initialised by "the first 128 threads": the soak found it)."""
     rng = np.random.default_rng(52000 + 31 * seed + len(case))
     att = case.endswith("_att")
     if case.startswith("wide"):
         H, W, E = int(rng.integers(200, 700)), int(rng.integers(1025, 2049)), int(rng.integers(1, 4))
+    elif case.startswith("one_wave"):
+        H, W, E = int(rng.integers(8, 65)), int(rng.integers(49, 200)), int(rng.integers(1, 5))      # a workgroup of ONE wave: a window of 4 rows
     elif case == "many_envs":
         H, W, E = int(rng.integers(64, 100)), int(rng.integers(64, 130)), 600
     else:
