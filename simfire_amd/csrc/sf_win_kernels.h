@@ -346,7 +346,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                     // the wave's cells behind those of the waves that came before: entry = row << 6 | column | status << 12
                     const uint32_t incl = wave_scan_incl(cnt, lane);
                     uint32_t base = 0;
-                    if (lane == 63) base = atomicAdd(&ctl[k], incl);
+                    // (ds_add_rtn by hand: the compiler wraps an atomicAdd of one lane into its scalar loop over the active lanes + a
+                    // second election, ~30 instructions in every wave that holds a frontier cell)
+                    if (lane == 63) {
+                        const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(ctl + k);
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(lds_addr), "v"(incl) : "memory");
+                    }
                     uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + incl - cnt;
                     const uint32_t ent0 = (uint32_t)(r << 6 | c << 2);
 #pragma unroll
@@ -377,6 +382,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 int bestk = -1;
                 {
                     // pick_winner8 (sf_step_kernels.h) on this step's masks from the table
+                    // (a form without branches - both halves computed, selects - was measured: + 3 us on the driver's window)
                     const uint32_t lo = __builtin_amdgcn_perm(mid3, dn3, 0x06000102u) & lo_mask;
                     const uint32_t hi = __builtin_amdgcn_perm(mid3, up3, 0x00010204u) & hi_mask;
                     uint32_t o = lo | hi;
