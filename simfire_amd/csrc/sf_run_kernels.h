@@ -318,12 +318,20 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // takes over where updates are left.  (The instantiations of sf_step on one-word rows: no teams, no control lines inside the launch.)
     // (also: two bitmap words per thread - 8-wave workgroups on 1024 rows, the many-environments regime; 2048-wide grids in a team of ONE,
     // C4's young fires - through the window code's general path)
-    constexpr bool kWin = MIT == 0 && MAXD <= 2;
+    // (and, on one-word rows without teams, with control lines inside the launch - sf_step_mitigated, up to 64 points per step: C5)
+    constexpr bool kWin = (MIT == 0 && MAXD <= 2) || (MIT == -1 && MAXD == 1 && TEAM == 0 && DIAG == 1);
     constexpr int kWinGen = (MAXD == 1 && TEAM == 0) ? 0 : 1;
+    constexpr int kWinMit = MIT == -1 ? 1 : 0;
+    int32_t px = 0, py = 0, pty = 0;       // control lines inside the launch: lane i of the LAST wave holds point i of the coming step
     int s_begin = 0;
     bool win_result = false;  // the window phase has written this environment's row of the result block
     PhaseClock wpc;          // (timeline of the launch as a whole: sf_debug_timeline(env, -1))
-    if (kWin && (!TEAM || tn == 1)) {
+    const bool win_mit_ok = !kWinMit || !mit || a.mit_k <= 64;       // (more points per step go through the whole workgroup: the loop below)
+    if (kWinMit && mit && a.mit_k <= 64 && n_steps > 0 && wave == n_waves - 1 && lane < a.mit_k) {
+        const int32_t *p0 = mit + ((long long)e * a.mit_k + lane) * 3;      // the points of the launch's first step
+        px = p0[0]; py = p0[1]; pty = p0[2];
+    }
+    if (kWin && (!TEAM || tn == 1) && win_mit_ok) {
         WinEnv we;
         we.cells = a.cells + (long long)e * g.cells_env;
         we.burn = a.burn + (long long)e * g.plane_env;
@@ -338,11 +346,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
 #endif
         wpc.note(30);        // launch: state read
-        s_begin = run_window<ATT, kWinGen>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result);
+        s_begin = run_window<ATT, kWinGen, kWinMit>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result,
+                                                    kWinMit ? mit : nullptr, n_steps, &px, &py, &pty, vlist, vcap >= 1024 ? 15 : 11);      // (the duplicate filter's bits in the list's LDS: 4 KB, or 256 bytes on small grids)
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 6 of the plain kernel: updates made inside a window)
             atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * 8 + 6, (unsigned long long)s_begin);
     }
-    const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && st.running);       // (uniform) the bitmaps in LDS, the loop over the vector list
+    const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && (st.running || mit));       // (uniform) the bitmaps in LDS, the loop over the vector list
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;
@@ -490,7 +499,6 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // step (a young fire's one batch is dealt to wave 0: the control lines' plane work runs beside it, not in front of it)
     const bool mit_one_wave = mit && a.mit_k <= 64;
     const int mit_wave = n_waves - 1;
-    int32_t px = 0, py = 0, pty = 0;
     constexpr bool loop = MIT == -2;       // LOOP mode: steps on the host's doorbell (see below); its own instantiation, so that the others do not carry it
     const int loop_slot_ints = (g.E * a.mit_k * 3 * 4 + 15) / 16 * 4;          // LOOP mode: a slot of the points ring, padded to 16 bytes
     auto load_pt = [&](int s) {
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             } else { px = p[0]; py = p[1]; pty = p[2]; }
         }
     };
-    if (mit_one_wave && n_steps > 0 && !loop) load_pt(0);
+    if (mit_one_wave && n_steps > 0 && !loop && !kWinMit) load_pt(0);      // (kWinMit: the wave holds the points of step s_begin already - asked for in front of the window phase, kept up by it)
     // LOOP mode (sf_loop_start): the closed loop of an RL harness - update_mitigation(actions that depend on the last observation),
     // run(1), look at the result (simulation.py:449-478, 501-553) - without a launch per step.  The launch stays resident.  Host
     // memory is touched by ONE workgroup per step in each direction (hundreds of workgroups polling or reading it dword by dword

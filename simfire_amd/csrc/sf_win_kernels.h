@@ -123,18 +123,24 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
 // everything the window held is back in memory when this returns (workgroup barrier included).
 // LDS (wl: 8-byte aligned): burn [WR][64] f64 | step masks [8][8] u32 | status-count changes [16][8] i32 | per-wave slots [16][4] u32 |
 // mask plane [WR + 2][18] u32 (a zero dword left / right of every row, a zero row above / below) | "burn changed" bytes [WR][16] |
-// frontier lists [waves][256] u16.
+// the step's frontier list [WR x 64] u16 | control-line patches [2][WR][64] bytes.
 __host__ __device__ inline size_t win_lds_bytes(int n_waves)
 {
     const int WR = n_waves * 4;
-    return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)n_waves * 256 * 2;
+    return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)n_waves * 256 * 2 + (size_t)2 * WR * 64;
 }
 
 // GEN = 0: rows of one bitmap word, a thread per grid row (k_run<1, ...>: the code the headline runs); GEN = 1: rows of g.VW words,
 // any number of rows per thread (k_run<2, ...>: many environments in 8-wave workgroups, 2048-wide grids in teams of one).
-template <int ATT, int GEN>
+// MITW = 1: control lines inside the launch (sf_step_mitigated; up to 64 points per environment and step, held by the LAST wave, a point per
+// lane - the arrangement of k_run's loop): a point that falls inside the window goes to a byte-per-cell PATCH plane in LDS, a step ahead,
+// and is taken by the cell's owner lane in its phase A (the owner has the old type in its status register: the make-up of the attenuation
+// where the TYPE changes is the owner's); the others - 99.6 % on a 1024 x 1024 grid - go to the planes in memory as in k_run's loop, by
+// the last wave alone, off everybody else's path: cells outside the window hold no sprite and are read by nobody in this phase.
+template <int ATT, int GEN, int MITW>
 __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, EnvState &st, const int n_steps, const bool diag, uint32_t *wl,
-                                          uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done, PhaseClock &lpc, const int e, bool &result_done)
+                                          uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done, PhaseClock &lpc, const int e, bool &result_done,
+                                          const int32_t *mit = nullptr, const int n_total = 0, int32_t *ppx = nullptr, int32_t *ppy = nullptr, int32_t *ppty = nullptr, uint32_t *duptab = nullptr, const int dup_log2 = 11)
 {
     const Geo &g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -142,6 +148,15 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     PhaseClock pc;           // (timeline of one step; lpc: timeline of the launch)
     pc.start();
     if (g.H < WR || g.PV < 4 || g.dense || n_steps <= 0 || !st.running || !a.win) return 0;       // (uniform)
+    // ---- LDS
+    double *const wb = reinterpret_cast<double *>(wl);                                   // burn_amounts of the window
+    uint32_t *const tab = wl + (size_t)WR * 128;                                         // masks of a step by slot of its number
+    int32_t *const dt = reinterpret_cast<int32_t *>(tab + 64);                           // [16 tiles][8]: cells per BurnStatus gained / lost; [15][0..7]: the old result row
+    uint32_t *const wm = tab + 64 + 128 + 64;                                            // sprite masks (behind the per-wave slots of the search above)
+    uint8_t *const wdirty = reinterpret_cast<uint8_t *>(wm + (WR + 2) * 18);             // per lane: burn_amounts of its cells changed
+    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16);              // the step's frontier cells [WR x 64]
+    uint32_t *const wpatch = reinterpret_cast<uint32_t *>(wlist + WR * 64);              // MITW: [2][WR][16] control-line types drawn inside the window, by parity of the step (a byte per cell, 0 = none)
+    if (MITW) { wpatch[tid] = 0; wpatch[nthr + tid] = 0; }   // (both patch planes: [2][WR x 16] dwords = two per thread; in front of the barrier below)
     // ---- where is the fire?  Rows and vector columns that hold a sprite bit, from the vector bitmap in memory: thread y looks at row y.
     // (No LDS atomics: on a uniform address the compiler turns them into a scalar loop over the lanes - 6 k clocks of every launch.)
     const int VW = GEN ? g.VW : 1;
@@ -217,13 +232,6 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const int wx0 = wv0 << 4;
     // the ring: outermost cells of the window on the sides that are not the grid's edge.  A sprite there could ignite a cell outside.
     const bool open_top = wy0 > 0, open_bot = wy0 + WR < g.H, open_left = wv0 > 0, open_right = (wv0 + 4) * 16 < g.W;
-    // ---- LDS
-    double *const wb = reinterpret_cast<double *>(wl);                                   // burn_amounts of the window
-    uint32_t *const tab = wl + (size_t)WR * 128;                                         // masks of a step by slot of its number
-    int32_t *const dt = reinterpret_cast<int32_t *>(tab + 64);                           // [16 tiles][8]: cells per BurnStatus gained / lost; [15][0..7]: the old result row
-    uint32_t *const wm = tab + 64 + 128 + 64;                                            // sprite masks (behind the per-wave slots of the search above)
-    uint8_t *const wdirty = reinterpret_cast<uint8_t *>(wm + (WR + 2) * 18);             // per lane: burn_amounts of its cells changed
-    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16);              // the step's frontier cells [WR x 64]
     // ---- load: two dwords + four doubles per lane
     const int r = tid >> 4, c = tid & 15;
     const int y = wy0 + r, x = wx0 + 4 * c;
@@ -247,7 +255,45 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // (whoever validates a histogram writes the row: counts_env), and what this phase changes is known cell by cell.
     const int ty0 = wy0 >> th_log, tx0 = wv0 >> g.logLC;
     const int nty = ((wy0 + WR - 1) >> th_log) - ty0 + 1, ntx = ((wv0 + 3) >> g.logLC) - tx0 + 1;
-    const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15;
+    const bool mitw = MITW && mit != nullptr;
+    const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15 && !mitw;      // (control lines change cells outside the window too: counts_env)
+    const int mit_wave = (nthr >> 6) - 1;
+    // the control-line wave's view of ONE step's points (made a step ahead): valid, column, row, the type that stands on its cell, inside the window
+    bool m_ok = false, m_in = false;
+    int m_x = 0, m_y = 0, m_fin = 0;
+    auto mit_classify = [&](int sp) {
+        // points of launch step sp are in the wave's registers (*ppx, *ppy, *ppty): which are real, which type stands where two share a
+        // cell (the reference writes FIRELINE, then SCRATCHLINE, then WETLINE: the highest), which fall inside the window -> its patch plane
+        const int ty = *ppty, qx = *ppx, qy = *ppy;
+        m_ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && qx >= 0 && qx < g.W && qy >= 0 && qy < g.H;
+        m_x = m_ok ? qx : 0; m_y = m_ok ? qy : 0;
+        int fin = ty;
+        const unsigned long long above = __ballot(m_ok && ty > SF_FIRELINE);
+        if (above && (__ballot(m_ok && ty != SF_WETLINE) != 0ull)) {            // (all of one type: nothing to settle)
+            const uint32_t o = (uint32_t)(m_y * g.P + m_x);
+            const uint32_t h = (o * 2654435761u) >> (32 - dup_log2), bit = 1u << (h & 31);      // (a bit per hashed cell: 2^dup_log2 bits of LDS; a false hit only costs the exact answer below)
+            if (m_ok) duptab[h >> 5] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t clash = m_ok ? (atomicOr(&duptab[h >> 5], bit) & bit) : 0u;
+            if (__ballot(clash != 0) != 0ull) {
+                const uint32_t key = m_ok ? o : 0xFFFFFFFFu;
+                for (unsigned long long hi = above; hi; hi &= hi - 1) {
+                    const int j = __ffsll((long long)hi) - 1;
+                    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+                    const int tj = __builtin_amdgcn_readlane(ty, j);
+                    if (key == kj && tj > fin) fin = tj;
+                }
+            }
+        }
+        m_fin = fin;
+        m_in = m_ok && m_y >= wy0 && m_y < wy0 + WR && m_x >= wx0 && m_x < wx0 + kWinCols;
+        if (m_in) reinterpret_cast<uint8_t *>(wpatch + (sp & 1) * WR * 16)[(m_y - wy0) * 64 + (m_x - wx0)] = (uint8_t)fin;      // (duplicates store the same type)
+        const bool any_in = __ballot(m_in) != 0ull;
+        if (lane == 0) ctl[kWinCtl + 5 + (sp & 1)] = any_in ? 1u : 0u;
+    };
+    if (MITW && mitw && tid >> 6 == mit_wave) mit_classify(0);    // (the first step's points were asked for before this phase)
     for (int i = tid; i < 128; i += nthr) dt[i] = (by_delta && i >= 120) ? a.res_block[e * 8 + (i - 120)] : 0;      // (workgroups of one wave exist: small grids)
     if (tid < 18) { wm[tid] = 0; wm[(WR + 1) * 18 + tid] = 0; }
     if (tid < WR) { wm[(tid + 1) * 18] = 0; wm[(tid + 1) * 18 + 17] = 0; }
@@ -278,6 +324,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const double rate = g.update_rate;
     const bool stats = a.counters != nullptr;
     uint32_t up = wm[own - 18], mid = wm[own], dn = wm[own + 18];
+    bool pflag = MITW ? __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 5]) != 0 : false;      // control lines inside the window in front of the coming update
     // (Measured and dropped, twice: touching the eight table entries the neighbours of a new ignition will most likely ask for in the next
     // step - loads whose results nobody uses.  By the walkers themselves, when a cell ignites: their wait for operands fell from ~900
     // to ~100 clocks and the step got 25 % LONGER (loads return in order per wave: the next operands queue behind the touches).  By an
@@ -295,12 +342,36 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
 #endif
         pc.note(20);         // window step start
         if (tid == 0) { ctl[3 + kn] = 0; ctl[kn] = 0; }        // predicate bytes / list length of the next step (last read before the barrier that ended step s - 1)
+        if (MITW && mitw && wave == mit_wave) {
+            // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80), the points OUTSIDE the window:
+            // k_run's one-wave scheme on the planes in memory.  The coming step's points are asked for first.
+            const bool ok = m_ok && !m_in;
+            const int fin = m_fin;
+            const uint32_t o = (uint32_t)(m_y * g.P + m_x);
+            uint8_t *cell = ev.cells + bl_cell(g, m_y, m_x & ~3) + kBlStatus + (m_x & 3);
+            if (s + 1 < n_total && lane < a.mit_k) {
+                const int32_t *pp = mit + (((long long)(s + 1) * g.E + e) * a.mit_k + lane) * 3;
+                *ppx = pp[0]; *ppy = pp[1]; *ppty = pp[2];
+            }
+            uint32_t was = 0, owed_since = 0;
+            double bn = 0.0;
+            if (ATT && ok) { was = *cell & 7u; bn = ev.burn[o]; owed_since = ev.settled[o]; }
+            if (ATT && ok && was != (uint32_t)fin) {
+                if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)(st.complete + n_plain) - owed_since);
+                ev.settled[o] = (uint32_t)(st.complete + n_plain);
+            }
+            if (ok) *cell = (uint8_t)fin;
+            if (ok) ev.tdirty[(m_y >> th_log) * g.TX + ((m_x >> 4) >> g.logLC)] = 1;
+        }
+        // (control lines drawn inside the window in front of this update, if any: the owner lanes take them in phase A)
+        uint32_t pw = 0;
+        if (MITW && pflag) pw = wpatch[(s & 1) * WR * 16 + r * 16 + c];
         // the masks of this step (every wave: the walkers need them too)
         const uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
         const uint32_t L4 = t0.x, CLR4 = t0.z, b_new = t0.w, lo_mask = t1.x, hi_mask = t1.y;
         const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
         // ---- phase A, the waves with a sprite bit in or next to their four rows: prune, recycle, frontier cells -> the step's list
-        if (__ballot((mid | up | dn) != 0u) != 0ull) {         // (wave-uniform)
+        if (__ballot((mid | up | dn | pw) != 0u) != 0ull) {    // (wave-uniform)
             const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
             pc.note(21);     // rows arrived
             if (stats) n_vec_done += lane == 0 ? 16u : 0u;     // four rows x four vectors swept
@@ -309,6 +380,29 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             {
                 const uint32_t im = spread01((mid >> prev_sh) & (s > 0 ? 0x01010101u : 0u));
                 sv = (sv & ~im) | (0x01010101u & im);
+            }
+            if (MITW && pw) {
+                // update_mitigation ASSIGNS the type (mitigation.py:60-80) - also on a burning cell, whose sprite lives on under the line.
+                // With attenuation a cell whose TYPE changes is paid up under its old type first (lazy_sub, sf_common.h).
+                if (ATT) {
+                    uint32_t pb = pack4(nz01(pw));
+                    while (pb) {
+                        const int b = __ffs(pb) - 1;
+                        pb &= pb - 1;
+                        const uint32_t was = (sv >> (8 * b)) & 7u, fin = (pw >> (8 * b)) & 7u;
+                        if (was != fin) {
+                            if (was >= SF_FIRELINE) {
+                                double *bp = wb + (r * 16 + c) * 4 + b;
+                                *bp = lazy_sub(*bp, line_factor(was), (uint32_t)(st.complete + n_plain) - ev.settled[idx + b]);
+                                wdirty[r * 16 + c] = 1;
+                            }
+                            ev.settled[idx + b] = (uint32_t)(st.complete + n_plain);
+                        }
+                    }
+                }
+                const uint32_t pm = spread01(nz01(pw));
+                sv = (sv & ~pm) | pw;
+                wpatch[(s & 1) * WR * 16 + r * 16 + c] = 0;
             }
             const uint32_t midL = mid & L4;
             if (__ballot(midL != 0u) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;      // FLAG_LIVE (fire.py:637)
@@ -454,6 +548,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             }
             if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
         }
+        if (MITW && mitw && wave == mit_wave && s + 1 < n_total) mit_classify(s + 1);      // (its points have arrived by now; patches for the next step)
         pc.note(26);         // at the barrier
         WPROF(5)             // rest of phase B
         win_barrier<ATT>();
@@ -462,6 +557,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         // ---- fold (every thread the same arithmetic on the same values); the next step's rows are requested with the predicates
         const uint32_t fv = ctl[3 + k];
         up = wm[own - 18]; mid = wm[own]; dn = wm[own + 18];
+        if (MITW) pflag = __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 5 + ((s + 1) & 1)]) != 0;
         const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fv);
         ++s;
         k = kn;

@@ -1386,3 +1386,50 @@ def test_window_phase_two_words_per_thread(seed, case):
         else:
             _same(eng, o, E, tag=(seed, case, done))
     assert eng.counters()["window_updates"] > 0, "the window phase never ran"
+
+
+@pytest.mark.parametrize("att", [False, True])
+@pytest.mark.parametrize("seed", range(8))
+def test_window_phase_with_control_lines_inside_the_launch(seed, att):
+    """sf_step_mitigated on young fires: the window phase takes the control lines of every step itself - points inside the window
+    through a patch plane in LDS (the cell's owner lane assigns the type and, with attenuation, pays the cell up under its old
+    type), points outside through the planes in memory.  Points are drawn AROUND the fires (most fall inside the 64 x 64 window:
+    on unburned cells, on burning cells, on lines of the steps before), anywhere on the grid, off the grid and as padding; two and
+    three points of a step on one cell with different types; 1 ... 64 points per step; calls of random length, SF_TUNE_RUN_WINDOW
+    = k leaves the window after k updates (the general loop then finds the coming step's points in the wave's registers).
+    Equal to the oracle after every call."""
+    rng = np.random.default_rng(63000 + 2 * seed + int(att))
+    H, W = int(rng.integers(64, 300)), int(rng.integers(64, 300))
+    E = int(rng.integers(1, 5))
+    kw, R8 = _window_world(rng, H, W, E, att=att)
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.set_tuning(run_window=int([1, 1, 3, 7, 1, 2, 1, 5][seed]))
+    eng.enable_counters(True)
+    K = int([1, 3, 12, 64, 64, 20, 7, 64][seed])
+    done = 0
+    while done < 60:
+        n = int(rng.integers(2, 20))
+        blk = np.zeros((n, E, K, 3), dtype=np.int32)
+        blk[..., 2] = rng.integers(2, 7, (n, E, K))                       # 2 and 6 are no control lines: padding
+        for e in range(E):
+            burning = np.argwhere(o.fire_map(e) == 1)
+            cx, cy = (int(burning[0][1]), int(burning[0][0])) if len(burning) else inits[e]
+            near = rng.random((n, K)) < 0.7
+            blk[:, e, :, 0] = np.where(near, cx + rng.integers(-12, 13, (n, K)), rng.integers(-1, W + 1, (n, K)))
+            blk[:, e, :, 1] = np.where(near, cy + rng.integers(-12, 13, (n, K)), rng.integers(-1, H + 1, (n, K)))
+        if K >= 3:
+            blk[:, :, 1, :2] = blk[:, :, 0, :2]                           # the same cell twice / three times in a step, other types
+            blk[:, :, 2, :2] = blk[:, :, 0, :2]
+            blk[1:, :, 0, :2] = blk[:-1, :, 2, :2]                        # ... and again in the step after
+        eng.step_mitigated(blk)
+        for s_ in range(n):
+            rows = [(e, int(blk[s_, e, i, 0]), int(blk[s_, e, i, 1]), int(blk[s_, e, i, 2])) for e in range(E) for i in range(K)
+                    if 3 <= blk[s_, e, i, 2] <= 5 and 0 <= blk[s_, e, i, 0] < W and 0 <= blk[s_, e, i, 1] < H]
+            if rows:
+                o.apply_mitigation(rows)
+            o.step(1)
+        done += n
+        _same(eng, o, E, tag=(seed, att, done))
+    assert eng.counters()["window_updates"] > 0, "the window phase never ran"
