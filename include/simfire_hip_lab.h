@@ -84,7 +84,11 @@ enum sf_tuning_knob {
                                  * 0 = off, k > 1 = on, but the window is left after k updates (tests: forces the hand-over to the general loop anywhere) */
     SF_TUNE_TEAM_TIMEOUT_MS = 19,/* how long a member of a team waits for the others (wall clock, ms; default 2000) before the launch is declared void
                                  * (SF_EHIP at the next call that hands data back; sf_reset of every environment recovers the handle) */
-    SF_TUNE_COUNT = 20
+    SF_TUNE_RUN_JOIN = 20,      /* teams that GROW inside the resident launch (k_run<TEAM = 2>: grids up to 1024 cells wide, at most one environment per CU, no control
+                                 * lines inside the launch): a workgroup whose environment is done joins the running environment that would finish last, at that
+                                 * team's next cut.  1 (default) = in calls of 192 updates or more, 0 = never, k > 1 = in calls of k updates or more,
+                                 * -k = the same but every free workgroup joins whatever runs, whether the cost model says it pays or not (tests) */
+    SF_TUNE_COUNT = 21
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
 /* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:
@@ -96,6 +100,10 @@ int sf_get_run_cost(sf_sim *sim, uint32_t *cost_out);
  * environment's rows are cut into bands, one workgroup each; the members exchange one boundary row per step): uint32 [n_envs],
  * zeros if the last launch gave every environment one workgroup.  No reference counterpart. */
 int sf_get_team_sizes(sf_sim *sim, uint32_t *sizes_out);
+/* What happened to the teams of the last resident launch whose teams grow inside it (SF_TUNE_RUN_JOIN): uint32 triples, at most `cap` of them,
+ * *n_out = how many - (environment, first update of the enlarged team counted from the start of the call, team size from then on) for every
+ * growth, and (environment, the device's 100 MHz wall clock, 255) when an environment's updates were done.  No reference counterpart. */
+int sf_get_join_log(sf_sim *sim, uint32_t *triples_out, int32_t cap, int32_t *n_out);
 /* How many environment-resident launches (k_run) the last sf_step / sf_step_mitigated / sf_rollout call was made of (0: it ran
  * on the per-step kernels).  bench.py divides a rollout's algorithmic bytes and duration by it, so that its per-launch figures
  * are those of the rocprofv3 kernel statistics.  No reference counterpart. */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "sf_loop_stop": [_VP],
     "sf_loop_restarts": [_VP, C.POINTER(_I32)],
     "sf_get_team_sizes": [_VP, _VP],
+    "sf_get_join_log": [_VP, _VP, C.c_int32, _VP],
     "sf_get_last_launches": [_VP, _VP],
     "sf_last_step_launch": [_VP, C.POINTER(_I32)],
     "sf_set_prune_after_quit": [_VP, _I32],
@@ -107,7 +108,7 @@ def variant_path(variant):
 
 TUNE = {name: i for i, name in enumerate((
     "waves_per_cu", "run_waves", "run_min_envs", "run_vcap", "run_compact", "run_batch", "run_result", "run_segment",
-    "front_min_steps", "front_auto", "front_waves", "front_rc", "front_ic", "front_tab", "front_debug", "run_team", "team_placement", "team_recut", "run_window", "team_timeout_ms"))}
+    "front_min_steps", "front_auto", "front_waves", "front_rc", "front_ic", "front_tab", "front_debug", "run_team", "team_placement", "team_recut", "run_window", "team_timeout_ms", "run_join"))}
 
 _libs = {}
 

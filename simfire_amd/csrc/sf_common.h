@@ -74,6 +74,8 @@ __host__ __device__ inline int bl_cell(const Geo &g, int y, int x)     // sprite
 constexpr int kBlStatus = 32;      // status row = mask row + 32 inside a sector
 
 constexpr uint32_t kLoopStop = 0x80000000u;     // doorbell bit: the host ends the loop
+constexpr uint32_t kJoinClosed = 0x80000000u;  // k_run<TEAM = 2>: bit of xj[e] - the environment takes no more members
+constexpr int kJoinLog = 4096;                  // entries of the join log (more are dropped)
 constexpr int kTeamMax = 4;                      // workgroups per environment in the resident launch (k_run<TEAM>)
 constexpr uint32_t kTeamUnused = 0xFFFFFFFFu;
 __host__ __device__ inline int team_xrow(const Geo &g) { return (64 + g.PV * 16 + 127) / 128 * 128; }
@@ -128,6 +130,19 @@ struct StepArgs {
                                  // keep one out - so the bound is generous (SF_TUNE_TEAM_TIMEOUT_MS, 2 s by default) and in wall time, not shader clocks
     int team_recut;              // > 0: the members of a team cut their bands anew every team_recut steps INSIDE the launch (teams of a fixed size: the whole
                                  // rollout is one launch; cut into launches it lasts the sum of the launches' slowest environments - 12 % more on C4's share)
+    // k_run<TEAM = 2> only: teams that GROW inside the launch - a workgroup whose environment is done JOINS the team of a running one at that
+    // team's next cut (sf_run_kernels.h).  All of it touched with agent-scope accesses only; cleared by k_team_plan.
+    uint32_t *xj;                // [E] members + workgroups waiting to become members (the next member number) | kJoinClosed: the environment is done
+                                 // [E .. 2E) the board: what the environment costs per update (all members, clocks / 16) << 14 | updates left (0: not worth joining)
+                                 // [2E] environments that are done, [2E + 1] joins made (statistics), [2E + 2 .. 3E + 2) the XCC id of the environment's member 0
+    unsigned long long *xcut;    // [E] the last growth of the team: {team size from then on << 24 | first update of the new team} (0: none yet; ~0: the environment is done)
+    uint32_t *tsize;             // [E] team sizes as the launch leaves them (sf_get_team_sizes)
+    uint32_t *jlog;              // [1 + 3 x kJoinLog] what happened to the teams (sf_get_join_log): [0] entries; (environment, first update of the enlarged team, new
+                                 // size) per growth, (environment, wall clock 100 MHz, 0xFF) when an environment is done
+    int join_local;              // 1: a workgroup joins only environments whose members sit on its own XCD (hardware XCC id) - their step boundaries and cuts then stay in
+                                 // that XCD's L2 (no write-back / invalidation of the L2 at a cut: waiting for the stores and dropping the CU's L1 is all it takes);
+                                 // 2: the same choice, but every hand-off done as if the members were apart (tests); 0: any environment
+    int join_floor, join_ovh;    // the cost model of k_team_plan in shader clocks: a member's update never costs less than join_floor, belonging to a team costs join_ovh per update
     // k_run in LOOP mode (sf_loop_start / sf_loop_step): the launch stays resident and is driven step by step by the host
     const uint32_t *loop_db;     // HOST-mapped doorbell: sequence number of the newest step the host has posted | kLoopStop = leave
     const int32_t *loop_pts_host;// HOST-mapped [2][E][k][3]: the points of the two newest steps (slot = sequence number & 1)

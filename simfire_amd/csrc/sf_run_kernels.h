@@ -253,6 +253,91 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
     return acc;
 }
 
+// k_run<TEAM = 2>: a workgroup that has nothing (more) to do looks for a running environment to JOIN.  The board (a.xj, written by member 0
+// of every team at the team's cuts) says what an environment's update costs all its members together and how many updates it has left;
+// a.xj[e] says how many members it has or is about to get.  Under k_team_plan's cost model (a member's update costs max(floor, all / members)
+// + ovh in a team, `all` alone) the workgroup picks the environment that would finish LAST as things stand among those that gain at least an
+// eighth from one more member, puts its name down (atomic increment = its member number) and waits for the team's next cut: member 0
+// announces the new size and the first update of the enlarged team in a.xcut[e], with the environment's state in commit[] and every
+// member's rows in memory, released.  An environment that ends first sends the waiting workgroup on (~0 in a.xcut[e]).  false: every
+// environment is done (or nothing worth joining turned up for the length of the team timeout) - the workgroup leaves the launch (x = ~0).
+// Independent environments (simulation.py:202-214): which workgroup computes which rows never shows in the results.
+// (What it needs of the argument block comes by value.  Measured: not inlined it costs k_run 97 spilled VGPRs instead of 35 - the call saves what it may clobber.)
+struct JoinArgs { uint32_t *xj; unsigned long long *xcut; uint32_t *xerr; int E, t_cap, team_recut, join_floor, join_ovh, join_local; unsigned long long team_timeout; };
+__device__ __forceinline__ uint4 find_team(const JoinArgs a, uint32_t *sc)
+{
+    typedef unsigned long long u64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
+    const int E = a.E;
+    const uint4 none = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    const uint32_t my_xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u;      // HW_REG_XCC_ID
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();          // (the LDS of the pass before is free)
+    for (;;) {
+        uint32_t best = 0, best_e = 0;
+        for (int i = tid; i < E; i += nthr) {
+            const uint32_t cnt = __hip_atomic_load(a.xj + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t b = __hip_atomic_load(a.xj + E + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long c = cnt & 0xFFFFu;
+            if ((cnt & kJoinClosed) || !b || c >= a.t_cap || c == 0) continue;
+            if (a.join_local && __hip_atomic_load(a.xj + 2 * E + 2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc) continue;      // (another XCD's)
+            const long long per = (long long)(b >> 14) << 4, left = b & 0x3FFFu;
+            if (left <= 2 * a.team_recut) continue;                 // (it is taken in at the next cut only)
+            const long long share_now = per / c, share_join = per / (c + 1);
+            const long long now_t = c == 1 ? per : (share_now > a.join_floor ? share_now : a.join_floor) + a.join_ovh;
+            const long long join_t = (share_join > a.join_floor ? share_join : a.join_floor) + a.join_ovh;
+            if (join_t * 8 >= now_t * 7) continue;
+            const long long fin = (now_t * left) >> 8;              // when it would be done as things stand, in 256-clock units
+            const uint32_t score = fin > 0xFFFFFFFFll ? 0xFFFFFFFFu : (fin < 1 ? 1u : (uint32_t)fin);
+            if (score > best) { best = score; best_e = (uint32_t)i; }
+        }
+        const uint32_t wm = wave_umax(best);
+        const int src = __ffsll((long long)__ballot(best == wm)) - 1;
+        const uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)best_e, src);
+        if (lane == 0) { sc[wave * 2] = wm; sc[wave * 2 + 1] = we; }
+        __syncthreads();
+        uint32_t bs = 0, be = 0;
+        for (int w = 0; w < n_waves; ++w) { const uint32_t v = sc[2 * w]; if (v > bs) { bs = v; be = sc[2 * w + 1]; } }
+        if (tid == 0 && bs == 0) sc[40] = __hip_atomic_load(a.xj + 2 * E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (bs == 0) {            // (uniform) nothing to join as things stand
+            const uint32_t closed = sc[40];
+            __syncthreads();
+            if (closed >= (uint32_t)E) return none;
+            if (__builtin_amdgcn_s_memrealtime() - t_start > a.team_timeout) return none;      // (nobody waits for this workgroup: it may simply leave)
+            for (int q = 0; q < 8; ++q) __builtin_amdgcn_s_sleep(127);                            // (~25 us: the teams cut every few hundred)
+            continue;
+        }
+        if (tid == 0) {
+            uint32_t res = 0xFFFFFFFFu;
+            const uint32_t old = atomicAdd(a.xj + be, 1u);
+            if (!(old & kJoinClosed) && (old & 0xFFFFu) < (uint32_t)a.t_cap) {
+                const uint32_t idx = old & 0xFFFFu;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    const u64 x = __hip_atomic_load(a.xcut + be, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (x == ~0ull) break;                           // the environment was done first
+                    if ((uint32_t)((x >> 24) & 0xFFu) > idx) { res = idx; sc[42] = (uint32_t)((x >> 24) & 0xFFu); sc[43] = (uint32_t)(x & 0xFFFFFFu); break; }
+                    __builtin_amdgcn_s_sleep(16);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) {      // (a team that may count on this member must not find it gone: fail loudly)
+                        *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
+                        res = 0xFFFFFFFEu;
+                        break;
+                    }
+                }
+            }
+            sc[41] = res;
+        }
+        __syncthreads();
+        const uint32_t res = sc[41], tn = sc[42], s0 = sc[43];
+        __syncthreads();
+        if (res == 0xFFFFFFFEu) return none;
+        if (res == 0xFFFFFFFFu) continue;         // (the place was taken or the environment is done: look again)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return make_uint4(be, res, tn, s0);         // environment, member number, team size, first update
+    }
+}
+
 // Template parameters: MAXD = bitmap words a thread owns; ATT = attenuate_line_ros (fire.py:236-284) known at compile time;
 // DIAG = 1: diagonal_spread known to be on, -1: read from the geometry (the 4-connected case is rare); MIT = 0: no control lines
 // inside the launch (sf_step), -1: look at the argument (sf_step_mitigated), -2: the closed loop of sf_loop_start (points per step from
@@ -277,18 +362,35 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
 // behind the wait for everybody's, cuts the bands from the global bitmap as the prologue does, loads its new band and halo rows, and
 // lines up once more before anyone writes again (cut_bands / load_band / store_band below).
 template <int MAXD, int ATT, int DIAG, int MIT, int TEAM = 0>
-__global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap, int bsz)
+__global__ __launch_bounds__(1024) void k_run(StepArgs a, const int n_steps_launch, int vcap, int bsz)
 {
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     int e_ = 0, tm_ = 0, tn_ = 1;
+    bool no_work = false;
     if (TEAM) {
         const uint32_t tt = a.team_tab[blockIdx.x];
-        if (tt == kTeamUnused) return;
-        e_ = (int)(tt & 0xFFFFu); tm_ = (int)((tt >> 16) & 0xFFu); tn_ = (int)(tt >> 24);
+        if (tt == kTeamUnused) { if (TEAM != 2) return; no_work = true; }      // (TEAM = 2: a slot without an environment looks for a team to join)
+        else { e_ = (int)(tt & 0xFFFFu); tm_ = (int)((tt >> 16) & 0xFFu); tn_ = (int)(tt >> 24); }
     } else e_ = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
-    const int e = e_, tm = tm_, tn = tn_;        // environment, member of its team, team size
+    int j_s0 = -1;            // TEAM = 2: >= 0 - this workgroup JOINS environment e_ as member tm_ of a team of tn_ in front of update j_s0
+    // TEAM = 2: a workgroup serves one environment after the other (find_team below); everything else: one pass
+    for (bool first_pass = true;; first_pass = false) {
+    if (TEAM == 2 && (!first_pass || no_work)) {
+        if (a.team_recut >= n_steps_launch) return;                 // (no cut inside this launch: nobody is taken in anywhere)
+        uint32_t *sc = reinterpret_cast<uint32_t *>(s_dyn);        // (scratch: the LDS of a pass that is over)
+        JoinArgs ja;
+        ja.xj = a.xj; ja.xcut = a.xcut; ja.xerr = a.xerr; ja.E = g.E; ja.team_recut = a.team_recut; ja.join_floor = a.join_floor; ja.join_ovh = a.join_ovh;
+        ja.team_timeout = a.team_timeout; ja.join_local = a.join_local; ja.t_cap = kTeamMax < g.TY ? kTeamMax : g.TY;
+        const uint4 t = find_team(ja, sc);
+        if (t.x == 0xFFFFFFFFu) return;
+        e_ = (int)t.x; tm_ = (int)t.y; tn_ = (int)t.z; j_s0 = (int)t.w;
+    }
+    {
+    int n_steps = n_steps_launch;
+    const int e = e_, tm = tm_;                  // environment, member of its team
+    int tn = tn_;                                // team size (TEAM = 2: grows at the team's cuts)
     const unsigned long long clk0 = __builtin_readcyclecounter();
     const bool fine = TEAM ? true : (MAXD == 1 ? true : g.VW == 1);                // refined interest rule (see below)
     const int VW = MAXD == 1 ? 1 : g.VW;                                           // 64-bit words per bitmap row
@@ -319,7 +421,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     // (also: two bitmap words per thread - 8-wave workgroups on 1024 rows, the many-environments regime; 2048-wide grids in a team of ONE,
     // C4's young fires - through the window code's general path)
     // (and, on one-word rows without teams, with control lines inside the launch - sf_step_mitigated, up to 64 points per step: C5)
-    constexpr bool kWin = (MIT == 0 && MAXD <= 2) || (MIT == -1 && MAXD == 1 && TEAM == 0 && DIAG == 1);
+    // (not where teams grow inside the launch, TEAM = 2: calls of hundreds of updates, of which a window saves the first 25 some 3 us each - and
+    // the window code and the team code in one body spill 450 SGPRs and 68 VGPRs)
+    constexpr bool kWin = ((MIT == 0 && MAXD <= 2) || (MIT == -1 && MAXD == 1 && TEAM == 0 && DIAG == 1)) && TEAM != 2;
     constexpr int kWinGen = (MAXD == 1 && TEAM == 0) ? 0 : 1;
     constexpr int kWinMit = MIT == -1 ? 1 : 0;
     int32_t px = 0, py = 0, pty = 0;       // control lines inside the launch: lane i of the LAST wave holds point i of the coming step
@@ -331,7 +435,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         const int32_t *p0 = mit + ((long long)e * a.mit_k + lane) * 3;      // the points of the launch's first step
         px = p0[0]; py = p0[1]; pty = p0[2];
     }
-    if (kWin && (!TEAM || tn == 1) && win_mit_ok) {
+    if (kWin && (!TEAM || tn == 1) && win_mit_ok && j_s0 < 0) {
         WinEnv we;
         we.cells = a.cells + (long long)e * g.cells_env;
         we.burn = a.burn + (long long)e * g.plane_env;
@@ -351,6 +455,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 6 of the plain kernel: updates made inside a window)
             atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * 8 + 6, (unsigned long long)s_begin);
     }
+    if (TEAM == 2 && j_s0 >= 0) s_begin = j_s0;          // a workgroup that joins: the team's next update (st: what member 0 left in commit[] at the cut)
     const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && (st.running || mit));       // (uniform) the bitmaps in LDS, the loop over the vector list
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
@@ -417,26 +522,46 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         if (!fits && !a.todo_out && tid == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;      // (the host promised a fit and made no catch-up launch: fail loudly)
         if (!fits) return;          // (uniform over the team: every member sees the same bitmap) nothing has been touched
     }
-    const bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;           // a neighbour above / below the band
+    bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;                 // a neighbour above / below the band
     // Do all members of the team sit on one XCD (one L2)?  Then the per-step hand-off can stay in that L2: plain stores (the L1 is
     // write-through), loads that skip the L1 - ~1 us instead of the ~4 - 5 us of a written-through hand-off between busy CUs.  This is
     // found out at run time from the hardware's XCC id, never assumed from the slot number: either path is correct wherever the
     // members sit.  (Third granule of every member: {1, XCC id}; also the team's start line.)
+    if (TEAM == 2 && tm == 0 && j_s0 < 0 && tid == 0)           // (the board: where this environment's members sit)
+        __hip_atomic_store(a.xj + 2 * g.E + 2 + e, (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // What a team's members hand each other through memory at a cut: released / acquired at agent scope (write-back and invalidation of the
+    // XCD's L2) - unless they are known to sit on ONE XCD (TEAM = 2, join_local = 1): the L1 is write-through, so a store that has been
+    // acknowledged is in the L2 they share - no write-back of the L2 - and only the reader's L1 can be stale.
+    auto team_release = [&]() {
+        if (TEAM == 2 && a.join_local == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    };
+    auto team_acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); };      // (drops the CU's L1; this device's memory is never stale in an L2)
     bool one_l2 = false;
-    if (TEAM && tn > 1 && wave == 0) {
+    bool gave_up = false;        // TEAM: a wait for the other members timed out (the handle is void; never wait again)
+    // The team's LINE: granule [2] of every member = {tag << 32 | XCC id}; nobody goes on before every member has reached the line with this
+    // tag (wave 0; tags only grow: 1 = the start of the launch, 2 + n = behind the n-th cut inside it).  A wait that times out is reported
+    // (xerr) unless this is the start line (the first step boundary reports a member that never shows up).
+    auto line_up = [&](const uint32_t tag, const bool report) {
         typedef unsigned long long u64;
         const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u;      // HW_REG_XCC_ID
-        if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, (1ull << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u64 x = 1ull << 32 | xcc;
+        if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, ((u64)tag << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 x = ((u64)tag << 32) | xcc;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
             if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((uint32_t)(x >> 32) == 1u)) break;
+            if (__all((uint32_t)(x >> 32) >= tag)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) break;        // (the first step boundary reports a member that never shows up)
+            if (gave_up || __builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) {       // (bounded like every wait for a member)
+                if (report) {
+                    if (lane == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
+                    gave_up = true;
+                }
+                break;
+            }
         }
-        one_l2 = __all((uint32_t)(x >> 32) == 1u && ((uint32_t)x & 15u) == xcc) && !a.team_far;
-    }
+        one_l2 = __all((uint32_t)(x >> 32) >= tag && ((uint32_t)x & 15u) == xcc) && !a.team_far;
+    };
     // The bitmaps are indexed by the grid row: with a window of rows in LDS the base pointers are shifted so that row y sits where it is.
     unsigned long long *vb = vb0, *vf = nullptr, *vl = nullptr, *ve = nullptr;
     auto load_band = [&]() {
@@ -475,6 +600,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
     pc.start();
 #endif
     __syncthreads();
+    if (TEAM && tn > 1) {
+        // the team's start line (nobody writes before everybody has loaded its band and halo rows); a workgroup that has JOINED lines up with
+        // the team behind its cut
+        if (wave == 0) line_up(TEAM == 2 && j_s0 >= 0 ? 2u + (uint32_t)(j_s0 / a.team_recut) : 1u, TEAM == 2 && j_s0 >= 0);
+        if (TEAM == 2) __syncthreads();
+    }
 
     RunEnv ev;
     ev.cells = a.cells + (long long)e * g.cells_env;
@@ -530,7 +661,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         lseq = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[18]);
         n_steps = 0x7FFFFFFF;
     }
-    bool gave_up = false;        // TEAM: a wait for the other members timed out (the handle is void; never wait again)
+    unsigned long long join_clk = __builtin_readcyclecounter();      // TEAM = 2, member 0: when the last cut was (what an update costs: the board)
     unsigned long long x_clocks = 0, x_steps = 0;      // TEAM statistics: clocks wave 0 spent at the team's step boundaries (publish + wait + read), boundaries
     for (int s = s_begin; s < n_steps && (st.running || mit); ++s) {
         const int k = s % 3, kn = (s + 1) % 3;
@@ -1081,7 +1212,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 pc.mark(10);
                 if (!kEarly && j_next < n_chunk) fetch(j_next, nxt);
             };
-            if (TEAM == 0 && MAXD == 1) {
+            if ((TEAM == 0 || TEAM == 2) && MAXD == 1) {
                 for (uint32_t ja = j_first; ja < n_chunk;) {
                     uint32_t jb;
                     batch(vin_a, ja, vin_b, jb);
@@ -1109,12 +1240,34 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         // member's granule it ACQUIRES, cuts the bands from the global bitmap like the prologue - every member the same cut from
         // the same data -, loads its new band and lines up once more (a member that started the next step early would be writing
         // rows whose old contents a slower one is still loading as its halo).
-        const bool recut_now = TEAM && tn > 1 && a.team_recut > 0 && (s + 1) % a.team_recut == 0 && s + 1 < n_steps;      // (uniform over the team)
+        const bool cut_step = TEAM && a.team_recut > 0 && (s + 1) % a.team_recut == 0 && s + 1 < n_steps;      // (uniform over the team)
+        const bool recut_now = cut_step && tn > 1;
+        // TEAM = 2, teams that GROW: workgroups whose environment is done have put their names down for this one (xj[e], find_team); at a cut
+        // member 0 looks how many there are and what its own updates have cost since the last cut (the board the others choose from), and
+        // tells the team with its granule of this update; a team of ONE asks at the same updates and becomes a team when somebody waits.
+        int tn_new = tn;
+        if (TEAM == 2 && cut_step) {
+            if (tm == 0 && tid == 0) {
+                const uint32_t c = __hip_atomic_load(a.xj + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFu;
+                const uint32_t t_cap = (uint32_t)(kTeamMax < g.TY ? kTeamMax : g.TY);          // (every member owns a tile row at least)
+                ctl[20] = c > t_cap ? t_cap : (c < (uint32_t)tn ? (uint32_t)tn : c);
+                const unsigned long long now = __builtin_readcyclecounter();
+                long long per = (long long)((now - join_clk) / (unsigned long long)a.team_recut);     // what an update costs this member
+                join_clk = now;
+                if (tn > 1) per = (per - a.join_ovh) * tn;                // ... and the team as a whole
+                if (per < a.join_floor) per = a.join_floor;
+                const long long left = n_steps - (s + 1);
+                const uint32_t b = (uint32_t)((per >> 4) > 0x3FFFF ? 0x3FFFF : (per >> 4)) << 14 | (uint32_t)(left > 0x3FFF ? 0x3FFF : left);
+                __hip_atomic_store(a.xj + g.E + e, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!recut_now) __syncthreads();
+        }
         if (recut_now) {
             store_band();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            team_release();
             __syncthreads();
         }
+        if (TEAM == 2 && cut_step && tm == 0) tn_new = __builtin_amdgcn_readfirstlane((int)ctl[20]);
         if (TEAM && tn > 1) {
             // ---- the team's step boundary: publish this member's boundary rows and predicates, wait for every member's, take the
             // neighbours' rows into the LDS halo (wave 0; the other waves wait at the barrier below)
@@ -1145,7 +1298,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are acknowledged (by the L2 / written through) ...
                 if (lane == 0) {                                        // ... before the one tagged word that says so
-                    const u64 gv = ((u64)epoch << 32) | (u64)(ctl[3 + k] & 0xFFFFu);
+                    const u64 gv = ((u64)epoch << 32) | (u64)(ctl[3 + k] & 0xFFFFu) | (TEAM == 2 ? (u64)tn_new << 16 : 0ull);       // (member 0's: the team's size from the next update on)
                     if (one_l2) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + par, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + par, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1166,6 +1319,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
                 }
                 const bool live_any = __ballot(lane < tn && (x & 0xFFull)) != 0ull, cand_any = __ballot(lane < tn && (x & 0xFF00ull)) != 0ull;
                 if (lane == 0) ctl[3 + k] = (live_any ? FLAG_LIVE : 0u) | (cand_any ? FLAG_CAND : 0u);     // fire.py:637, 651: over the whole environment
+                if (TEAM == 2 && cut_step && lane == 0) ctl[20] = (uint32_t)(x >> 16) & 0xFFu;             // (lane 0 holds member 0's granule)
                 for (int side = 0; side < 2; ++side) {
                     if (!(side ? has_dn : has_up)) continue;
                     const int nj = side ? tm + 1 : tm - 1, yh = side ? R1 : R0 - 1;
@@ -1205,8 +1359,27 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         st.complete = __builtin_amdgcn_readfirstlane(st.complete);
         st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
         if (loop) loop_finish();
-        if (recut_now && (st.running || mit)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (TEAM == 2 && cut_step && tn > 1) tn_new = __builtin_amdgcn_readfirstlane((int)ctl[20]);      // (behind the barrier of the step boundary)
+        if (TEAM == 2 && gave_up) tn_new = tn;
+        if ((recut_now || tn_new > tn) && (st.running || mit)) {
+            if (TEAM == 2 && tn == 1) {
+                // a team of one takes members: what a team does in front of its step boundary - the bitmaps back to memory, everything released
+                store_band();
+                team_release();
+                __syncthreads();
+            }
+            if (TEAM == 2 && tn_new > tn && tm == 0 && tid == 0) {
+                // every member's rows are in memory and released (their granules of this update came behind that): the newcomers may read.
+                // The state they start from, then the word they wait for.
+                a.commit[e] = st;
+                team_release();
+                __hip_atomic_store(a.xcut + e, ((unsigned long long)tn_new << 24) | (unsigned long long)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(a.xj + 2 * g.E + 1, (uint32_t)(tn_new - tn));
+                const uint32_t li = atomicAdd(a.jlog, 1u);
+                if (li < (uint32_t)kJoinLog) { a.jlog[1 + 3 * li] = (uint32_t)e; a.jlog[2 + 3 * li] = (uint32_t)(s + 1); a.jlog[3 + 3 * li] = (uint32_t)tn_new; }
+            }
+            team_acquire();
+            if (TEAM == 2) { tn = tn_new; has_up = tm > 0; has_dn = tm + 1 < tn; }
             const int left = n_steps - (s + 1);
             cut_bands(a.team_recut < left ? a.team_recut : left);        // (fits: the host offers this only where t_min members hold the whole grid)
             load_band();
@@ -1214,26 +1387,19 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             rpt = (R1 - R0 + nthr - 1) / nthr;
             row0 = R0;
             __syncthreads();
-            if (wave == 0) {
-                // the second line-up: granule [2] (the start line's), tagged with the number of the cut
-                typedef unsigned long long u64;
-                const uint32_t tag = 2u + (uint32_t)((s + 1) / a.team_recut);
-                if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, (u64)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u64 x = (u64)tag << 32;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    if (lane < tn) x = __hip_atomic_load(a.xg + ((size_t)e * kTeamMax + lane) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((uint32_t)(x >> 32) >= tag)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (gave_up || __builtin_amdgcn_s_memrealtime() - t0 > a.team_timeout) {       // (bounded like every wait for a member)
-                        if (lane == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
-                        gave_up = true;
-                        break;
-                    }
-                }
-            }
+            if (wave == 0) line_up(2u + (uint32_t)((s + 1) / a.team_recut), true);      // the second line-up: nobody writes before everybody has loaded
             __syncthreads();
         }
+    }
+    if (TEAM == 2 && tm == 0 && tid == 0) {
+        // this environment takes no more members: whoever waits for a place is sent on, whoever looks for one does not look here
+        atomicOr(a.xj + e, kJoinClosed);
+        __hip_atomic_store(a.xcut + e, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.xj + g.E + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(a.xj + 2 * g.E, 1u);
+        a.tsize[e] = (uint32_t)tn;
+        const uint32_t li = atomicAdd(a.jlog, 1u);
+        if (li < (uint32_t)kJoinLog) { a.jlog[1 + 3 * li] = (uint32_t)e; a.jlog[2 + 3 * li] = (uint32_t)__builtin_amdgcn_s_memrealtime(); a.jlog[3 + 3 * li] = 0xFFu; }
     }
 #ifdef SF_PHASES
     pc.mark(12);
@@ -1293,7 +1459,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
             ctl[0] = last ? 1u : 0u;
         }
         __syncthreads();
-        if (!ctl[0]) return;       // (uniform)
+        if (!ctl[0]) {             // (uniform)
+            if (TEAM == 2) continue;       // (on to the next environment that can use a workgroup)
+            return;
+        }
     }
     if (a.res_block && !(win_result && !general)) {
         __syncthreads();
@@ -1301,6 +1470,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, int n_steps, int vcap,
         counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
                    reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
         wpc.note(37);        // result block written
+    }
+    }
+    if (TEAM != 2) return;
     }
 }
 
@@ -1353,7 +1525,7 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
 // however few rows a member has (measured: ~12 k clocks), and belonging to a team costs `ovh` per step (~6.5 k clocks: publish, wait
 // for the slowest member, read).  An environment is split only where that beats its cost in one workgroup.
 __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, uint32_t floor_c, int scatter, uint32_t *cost, uint32_t *tab, uint32_t *tsize,
-                                                    unsigned long long *xg, uint32_t *xdone, int keep_cost)
+                                                    unsigned long long *xg, uint32_t *xdone, int keep_cost, uint32_t *xj, unsigned long long *xcut)
 {
     __shared__ uint32_t s_T[1024], s_sum, s_cls[8], s_over;
     const int t = threadIdx.x;
@@ -1361,6 +1533,10 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
     const uint32_t c = t < E ? cost[t] : 0u;
     for (int i = t; i < E * kTeamMax * 3; i += 1024) xg[i] = 0ull;
     if (t < E) { xdone[t] = 0u; if (!keep_cost) cost[t] = 0u; }
+    if (xj) {           // k_run<TEAM = 2>: every environment starts with one member (t_min = t_max = 1), nobody waits, the board is empty
+        if (t < E) { xj[t] = 1u; xj[E + t] = 0u; xcut[t] = 0ull; }
+        if (t < 2) xj[2 * E + t] = 0u;
+    }
     auto member = [&](int T) -> uint32_t { const uint32_t share = c / (uint32_t)T; return T <= 1 ? c : (share > floor_c ? share : floor_c) + ovh; };
     auto need = [&](uint32_t tgt) -> uint32_t {
         if (t >= E) return 0u;

@@ -108,11 +108,13 @@ struct Tuning {
 static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
     /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
-    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1, /* TEAM_TIMEOUT_MS */ 2000};
+    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1, /* TEAM_TIMEOUT_MS */ 2000,
+    /* RUN_JOIN */ 1};
 static const char *const kTuneName[SF_TUNE_COUNT] = {
     "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
     "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
-    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW", "SF_TUNE_TEAM_TIMEOUT_MS"};
+    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW", "SF_TUNE_TEAM_TIMEOUT_MS",
+    "SF_TUNE_RUN_JOIN"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -169,6 +171,10 @@ struct sf_sim {
     int comm_world = 0;
     // k_run<TEAM>: an environment served by several workgroups (sf_run_kernels.h); allocated at the first team launch
     uint32_t *team_tab = nullptr, *team_size = nullptr, *xdone = nullptr;
+    uint32_t *xj = nullptr;            // k_run<TEAM = 2> (teams that grow inside the launch): names put down / the board / counters (StepArgs::xj)
+    unsigned long long *xcut = nullptr;
+    uint32_t *jlog = nullptr;          // what happened to the teams in the last such launch (sf_get_join_log)
+    bool jlog_valid = false;
     unsigned long long *xg = nullptr;
     uint8_t *xbuf = nullptr;
     uint32_t *xerr_pinned = nullptr, *xerr_mapped = nullptr;
@@ -191,7 +197,7 @@ struct sf_sim {
     uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
     int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
     int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_join[2] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -226,6 +232,8 @@ hipError_t sf_run4_launch_team2(int att, int diag, unsigned grid, unsigned block
                                 const void *args, size_t args_bytes, int n_steps, int vcap);
 hipError_t sf_run3_launch_plain(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                 const void *args, size_t args_bytes, int n_steps, int vcap, int bsz);
+hipError_t sf_run2_launch_join(int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                               const void *args, size_t args_bytes, int n_steps, int vcap);
 hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int vcap);
 // every entry point except sf_loop_step ends the closed loop (sf_loop_start) first: the handle's stream is busy with the resident launch
@@ -409,7 +417,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
     for (void *hp : {(void *)s->loop_db, (void *)s->loop_res, (void *)s->loop_pts}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)s->loop_mem, (void *)s->loop_pts_mem}) if (dp) (void)hipFree(dp);
-    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
+    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
@@ -594,6 +602,21 @@ extern "C" int sf_get_team_sizes(sf_sim *s, uint32_t *out)
     HIPCHK(hipStreamSynchronize(s->stream));
     if (!s->last_team_max || !s->team_size) { for (int e = 0; e < s->g.E; ++e) out[e] = 0; return SF_OK; }
     HIPCHK(hipMemcpy(out, s->team_size, (size_t)s->g.E * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SF_OK;
+}
+extern "C" int sf_get_join_log(sf_sim *s, uint32_t *out, int32_t cap, int32_t *n_out)
+{
+    if (!s || !n_out || cap < 0 || (cap > 0 && !out)) return fail(SF_EINVAL, "sf_get_join_log: bad argument");
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *n_out = 0;
+    if (!s->jlog || !s->jlog_valid) return SF_OK;
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, s->jlog, sizeof n, hipMemcpyDeviceToHost));
+    if (n > (uint32_t)kJoinLog) n = kJoinLog;
+    if (n > (uint32_t)cap) n = (uint32_t)cap;
+    if (n) HIPCHK(hipMemcpy(out, s->jlog + 1, (size_t)n * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_out = (int32_t)n;
     return SF_OK;
 }
 extern "C" int sf_get_last_launches(sf_sim *s, int32_t *out)
@@ -1160,8 +1183,61 @@ static TeamGeo team_geometry(const sf_sim *s)
     return t;
 }
 
-// keep_cost: the launch neither reads nor records what the environments cost (the catch-up launch behind a windowed one)
-static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo &t, int t_min, int t_max, int steps_before, bool keep_cost = false)
+static int team_buffers(sf_sim *s, const TeamGeo &t);
+
+// Teams that GROW inside the launch (k_run<TEAM = 2>, sf_run_kernels.h): one-word rows, one 16-wave workgroup per CU, every environment starts
+// with ONE member; a workgroup whose environment is done (or that had none) joins the team of the running environment that would finish
+// last, at that team's next cut (every `recut` updates).  Results never depend on who joined whom when.
+static TeamGeo join_geometry(const sf_sim *s)
+{
+    const Geo &g = s->g;
+    TeamGeo t = {};
+    if (g.ab != 1 || g.VW != 1 || g.TY > 64 || g.H > 16 * 64 || g.E > 1024 || g.E > s->n_cu || g.dense || !g.diag) return t;
+    t.waves = 16; t.vcap = 4096; t.rcap = 0; t.t_min = 1;
+    const long long all_vec = (long long)g.H * g.PV;
+    if (t.vcap > all_vec) t.vcap = (int)((all_vec + 63) / 64 * 64);
+    t.lds = run_lds_bytes(g, t.waves, t.vcap, 1, 0);
+    if (t.lds > 160 * 1024 || g.TY < 2) return t;
+    t.slots = s->n_cu;
+    t.ok = true;
+    return t;
+}
+static int launch_k_run_join(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo &t, int recut, bool eager)
+{
+    const Geo &g = s->g;
+    { int rc = team_buffers(s, t); if (rc) return rc; }
+    if (!s->xj) {
+        int rc = dev_alloc(s, &s->xj, (size_t)3 * g.E + 2); if (rc) return rc;
+        rc = dev_alloc(s, &s->xcut, (size_t)g.E); if (rc) return rc;
+        rc = dev_alloc(s, &s->jlog, (size_t)1 + 3 * kJoinLog); if (rc) return rc;
+    }
+    HIPCHK(hipMemsetAsync(s->jlog, 0, sizeof(uint32_t), s->stream));
+    s->jlog_valid = true;
+    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, 1, 1, 0u, 0u, 1, s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, 0,
+                       s->xj, s->xcut);
+    a.cost = s->run_cost;
+    a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
+    a.xrow = team_xrow(g); a.team_rcap = 0;
+    a.team_far = s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 2;
+    a.order = nullptr; a.todo = nullptr; a.todo_out = nullptr;
+    a.team_recut = recut;
+    a.xj = s->xj; a.xcut = s->xcut; a.tsize = s->team_size; a.jlog = s->jlog;
+    // (k_team_plan's model of a team: the chain no member's update gets shorter than, what belonging to a team costs per update; eager - tests -:
+    // every workgroup that is free joins whatever runs)
+    // Where the newcomers come from: the environment's own XCD (default: the team's step boundaries and cuts stay in one L2 - measured on C3, 1000 updates:
+    // teams spread over the XCDs pay ~12 k clocks per update for belonging, and every cut writes back and invalidates a whole L2 under 31 other
+    // environments; 10.9 -> 12.7 us per update); SF_TUNE_TEAM_PLACEMENT 1 = from anywhere, 2 = the own XCD but every hand-off as if they were apart
+    const int place = s->tune.v[SF_TUNE_TEAM_PLACEMENT];
+    a.join_local = place == 1 ? 0 : (place == 2 ? 2 : 1);
+    a.join_floor = eager ? 0 : 12000; a.join_ovh = eager ? 0 : (a.join_local == 1 ? 3000 : 12000);
+    const int ia = g.att ? 1 : 0;
+    const bool set_lds = t.lds > 64 * 1024 && t.lds > s->attr_join[ia];
+    HIPCHK(sf_run2_launch_join(ia, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
+    if (set_lds) s->attr_join[ia] = t.lds;
+    return SF_OK;
+}
+
+static int team_buffers(sf_sim *s, const TeamGeo &t)
 {
     const Geo &g = s->g;
     if (!s->team_tab || s->team_slots < t.slots) {
@@ -1179,13 +1255,21 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
         *s->xerr_pinned = 0;
         HIPCHK(hipMemsetAsync(s->xbuf, 0, (size_t)g.E * kTeamMax * 4 * team_xrow(g), s->stream));
     }
+    return SF_OK;
+}
+
+// keep_cost: the launch neither reads nor records what the environments cost (the catch-up launch behind a windowed one)
+static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo &t, int t_min, int t_max, int steps_before, bool keep_cost = false)
+{
+    const Geo &g = s->g;
+    { int rc = team_buffers(s, t); if (rc) return rc; }
     // what a member pays per step for belonging to a team (publish, wait for the slowest member, read: ~6.5 k clocks measured) and the
     // latency chain no member's step gets shorter than (~12 k clocks), in the unit of the cost array
     const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 6500 / 16);
     const uint32_t floor_c = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 12000 / 16);
     // (the plan also clears the granules, the "left" counters and the cost array it has read: the members add their clocks)
     hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, floor_c, s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0,
-                       s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, keep_cost ? 1 : 0);
+                       s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, keep_cost ? 1 : 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     a.cost = keep_cost ? nullptr : s->run_cost;
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
     a.xrow = team_xrow(g); a.team_rcap = t.rcap;
@@ -1265,7 +1349,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
 #endif
     int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
     size_t fr_lds = 0;
-    TeamGeo tgeo = {};
+    TeamGeo tgeo = {}, jgeo = {};
     bool team_forced = false, team_wide = false, team_auto = false;
     int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
     size_t fit_lds = 0;
@@ -1296,6 +1380,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // ... which the team launch (k_run<TEAM>: several workgroups per environment, each with the bitmaps of its own band of rows) takes away:
         // grids of two-word rows run there in the automatic mode too
         tgeo = team_geometry(s);
+        jgeo = join_geometry(s);
         const int team_knob = tn.v[SF_TUNE_RUN_TEAM];
         team_forced = tgeo.ok && team_knob >= 2 && team_knob <= kTeamMax && team_knob <= g.TY && team_knob >= tgeo.t_min && (long long)g.E * team_knob <= tgeo.slots;
         // (control lines inside the launch: every row needs an owner, so the members' windows of rows have to hold the whole grid between them)
@@ -1477,14 +1562,28 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                 // (C4's share, calls of 60 / 100 / 150 / 250 / 350 updates after 20: one member 7.8 / 8.3 / 9.6 / 11.9 / 15.8 us per step, two 9.1 / 9.3 / 10.8 / 12.1 / 14.1)
                 if (done == 0 && fit >= n_steps && s->fire_rows + 2LL * n_steps <= 480) { young = true; seg = n_steps - done; a.team_recut = 0; }
             }
-            const bool use_team = team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
+            // Teams that grow inside the launch (k_run<TEAM = 2>): long calls on one-word rows with at most one environment per CU - the CUs of
+            // fires that go out (C3: three quarters of them over 1000 updates) join the fires that are left.  SF_TUNE_RUN_JOIN.
+            const int join_knob = tn.v[SF_TUNE_RUN_JOIN];
+            const int join_min = join_knob > 1 ? join_knob : (join_knob < -1 ? -join_knob : 192);
+            // (few environments - at most a quarter as many as CUs -: the teams sized by cost between segments stay the automatic choice; the knob set by hand wins)
+            const bool use_join = join_knob != 0 && !team_forced && !team_wide && (!team_auto || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
+                                  n_steps >= join_min && !tn.set[SF_TUNE_RUN_WAVES] && !tn.set[SF_TUNE_RUN_VCAP] && jgeo.ok;
+            if (use_join) { seg = n_steps; a.team_recut = 0; }
+            const bool use_team = !use_join && team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
                 hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
                 a.order = s->run_order;
             }
             a.mit = mit_dev ? mit_dev + (size_t)done * s->g.E * mit_k * 3 : nullptr;
             if (res_knob && done + seg == n_steps) { a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink; }
-            if (use_team) {
+            if (use_join) {
+                const int recut = seg_knob >= 4 ? seg_knob / 2 : 2;
+                int rc0 = launch_k_run_join(s, a, seg, jgeo, recut, join_knob < 0);
+                if (rc0) return rc0;
+                a.team_recut = 0;
+                s->last_team_max = kTeamMax;
+            } else if (use_team) {
                 const int tk = tn.v[SF_TUNE_RUN_TEAM];
                 const int t_max = team_forced ? tk : (kTeamMax < s->g.TY ? kTeamMax : s->g.TY);
                 // Windows of rows (two-word rows): a fire that is small enough runs in ONE workgroup with the window around it, the largest ones

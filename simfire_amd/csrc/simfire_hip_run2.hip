@@ -38,6 +38,23 @@ hipError_t sf_run2_launch_team(int att, int diag, unsigned grid, unsigned block,
     return hipSuccess;
 }
 
+// Teams that grow inside the launch (k_run<TEAM = 2>): one-word rows, diagonal spread, no control lines inside the launch.
+hipError_t sf_run2_launch_join(int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                               const void *args, size_t args_bytes, int n_steps, int vcap)
+{
+    static const run_fn table[2] = {k_run<1, 0, 1, 0, 2>, k_run<1, 1, 1, 0, 2>};
+    if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
+    StepArgs a;
+    memcpy(&a, args, sizeof a);
+    const run_fn kern = table[att ? 1 : 0];
+    if (set_lds) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, n_steps, vcap, 64);
+    return hipSuccess;
+}
+
 // the closed loop of sf_loop_start: one workgroup per environment, steps until the host's stop
 hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int vcap)

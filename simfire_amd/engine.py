@@ -269,6 +269,14 @@ class FireEngine:
         self._chk(self._L.sf_get_team_sizes(self._h, _ptr(out)))
         return out
 
+    def join_log(self):
+        """Growths of the teams in the last resident launch whose teams grow inside it: array [n, 3] of (environment, first update of the
+        enlarged team, new size); rows with size 255: (environment, the device's 100 MHz wall clock when its updates were done, 255)."""
+        out = np.zeros((4096, 3), dtype=np.uint32)
+        n = C.c_int32()
+        self._chk(self._L.sf_get_join_log(self._h, _ptr(out), 4096, C.byref(n)))
+        return out[:n.value]
+
     def last_launches(self):
         """Environment-resident launches the last step / step_mitigated / rollout call was made of (0: per-step kernels)."""
         v = C.c_int32()

@@ -36,8 +36,13 @@ def world(seed):
     # teams of a fixed size: new bands inside the launch every 2 .. 10 steps (or the default 128), or one launch per segment
     eng.set_tuning(run_segment=int(rng.choice([64, 64, 1, 2, 5])), team_recut=int(rng.random() < 0.8))
     # the window phase of the resident launch (young fires): on, off, left after 2 .. 7 updates for the general loop
-    eng.set_tuning(run_window=int(rng.choice([1, 1, 1, 0, 2, 3, 7])), run_waves=int(rng.choice([16, 16, 8, 4])))
+    eng.set_tuning(run_window=int(rng.choice([1, 1, 1, 0, 2, 3, 7])))
+    if rng.random() < 0.5:
+        eng.set_tuning(run_waves=int(rng.choice([16, 8, 4])))
+    # teams that grow inside the launch (k_run<TEAM = 2>): by the cost model (never, on worlds this small), every free workgroup at once
+    eng.set_tuning(run_join=int(rng.choice([1, 0, 2, -2, -2, -5])))
     if os.environ.get("SOAK_DEBUG"):
+        print("tuning", {k: eng.get_tuning(k) for k in ("run_join", "run_window", "run_waves", "run_segment", "team_placement", "run_team")}, flush=True)
         print("world", seed, "H W E", H, W, E, "md", md, "att diag", att, diag, "fused", eng.get_tuning("run_team"), {k: eng.get_tuning(k) for k in ("run_team", "team_placement", "run_segment", "team_recut")}, flush=True)
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
@@ -85,6 +90,8 @@ def world(seed):
             assert (b == o.burn(e)).all(), (seed, t, e, "burn before round trip")
             eng.set_burn(e, b)
         n = int(rng.choice([1, 1, 1, 2, 5, 17]))
+        if os.environ.get("SOAK_DEBUG"):
+            print("t", t, "n", n, "r %.3f" % r, flush=True)
         if rng.random() < 0.06 and md <= 5:
             # the closed loop (sf_loop_*): n calls of update_mitigation(points) + run(1) on a launch that stays resident
             K = int(rng.choice([0, 2, 9, 64]))

@@ -1433,3 +1433,54 @@ def test_window_phase_with_control_lines_inside_the_launch(seed, att):
         done += n
         _same(eng, o, E, tag=(seed, att, done))
     assert eng.counters()["window_updates"] > 0, "the window phase never ran"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_teams_that_grow_inside_the_launch(seed):
+    """k_run<TEAM = 2> (SF_TUNE_RUN_JOIN): every environment starts with ONE workgroup; a workgroup whose environment is done - or a
+    slot of the chip that had none - puts its name down for a running environment and is taken into that environment's team at the
+    team's next cut inside the launch (here every 2 .. 6 updates; `-k` = every free workgroup joins whatever runs, whether the cost
+    model says it pays or not).  Covered: joins in front of any update, several newcomers at one cut, teams growing from one to four,
+    a workgroup that serves several environments one after the other, environments whose fire goes out / whose max_time runs out while
+    newcomers are inside or still waiting for their place, calls that end before a cut, attenuation on / off - fire maps,
+    burn_amounts, states against the oracle after every call; and that joins did happen."""
+    rng = np.random.default_rng(7100 + seed)
+    H, W = int(rng.integers(100, 400)), int(rng.integers(64, 400))
+    E = int(rng.choice([1, 2, 5, 9]))
+    att = bool(seed % 2)
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=int(rng.integers(2, 6)), pixel_scale=float(rng.choice([5.0, 20.0])),
+              update_rate=1.0, max_time=(None if seed % 3 else float(rng.integers(25, 60))),
+              attenuate_line_ros=att, diagonal_spread=True)
+    R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1200.0], size=(8, H, W))
+    R8[:, rng.random((H, W)) < 0.08] = 0.0
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    if E > 2:
+        # some fires go out early: an island of fuel around the ignition point
+        for e in range(0, E, 2):
+            x, y = inits[e]
+            m = np.ones((H, W), dtype=np.int8)
+            m[max(0, y - 6):y + 7, max(0, x - 6):x + 7] = 0
+            fm = o.fire_map(e).copy()
+            fm[(m == 1) & (fm == 0)] = 2                              # BURNED everywhere else: nothing to ignite
+            eng.load_fire_map(e, fm)
+            o.load_fire_map(e, fm)
+    eng.set_fused(2)
+    eng.set_tuning(run_join=-2, run_segment=int(rng.choice([1, 4, 8, 12])), team_placement=seed % 3)
+    grown, done = 0, 0
+    while done < 150:
+        n = int(rng.integers(2, 60))
+        if rng.random() < 0.4:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(12)]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        eng.step(n)
+        o.step(n)
+        done += n
+        assert eng.last_launch_kind() == 2 and eng.last_launches() == 1
+        sizes = eng.team_sizes()
+        assert sizes.min() >= 1 and sizes.max() <= 4, sizes
+        grown += int((sizes > 1).sum())
+        _same(eng, o, E, tag=(seed, done))
+    assert grown > 0                                                  # (free workgroups from the first update on: 256 CUs, at most 9 environments)
