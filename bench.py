@@ -275,8 +275,20 @@ def issue_block(w, a, rl, cost, n_cu=256):
         rl["launch_ms"] = rl["kernel_ms_per_step"] * a.steps / launches
         rl["steps_per_launch"] = a.steps / launches
         rl["algorithmic_bytes_per_launch"] = rl["algorithmic_bytes_per_launch"] / launches
-        return {"team_launch": True, "workgroups_per_environment": {int(k): int(v) for k, v in zip(*np.unique(teams, return_counts=True))},
-                "note": "k_run<TEAM>: bands of rows, one workgroup each; teams of a fixed size: one launch, new bands every 128 steps inside it; sized by cost: launches of 128 steps (profiles/r03_team/README.md)"}
+        blk = {"team_launch": True, "workgroups_per_environment": {int(k): int(v) for k, v in zip(*np.unique(teams, return_counts=True))},
+               "note": "k_run<TEAM>: bands of rows, one workgroup each; teams of a fixed size: one launch, new bands every 128 steps inside it; sized by cost: launches of 128 steps (profiles/r03_team/README.md)"}
+        if launches == 1 and w.name.startswith("c3"):
+            # teams that grow inside the launch (k_run<TEAM = 2>): workgroups whose environment is done join the running ones.  An environment's
+            # cost is the sum over everybody who worked on it, their waits for each other at the step boundaries included; the launch's length in
+            # clocks is not known from inside (no single workgroup spans it), so the share is quoted against the nominal 2.4 GHz.
+            clocks = cost.astype(np.float64) * 16.0
+            slots = min(len(cost), n_cu)
+            blk.update({"cu_busy_share": float(clocks.sum() / (slots * rl["launch_ms"] * 1e-3 * 2.4e9)), "workgroup_slots": slots,
+                        "cu_busy_share_note": "sum over environments and members of the clocks spent on them / (slots x launch time x 2.4 GHz): lower bound (the real "
+                                              "clock is lower); includes the members' waits for each other; without teams the same figure is cu_balance",
+                        "note": "k_run<TEAM = 2>: every environment starts with one workgroup; workgroups whose environment is done join a running "
+                                "environment of their own XCD at that team's next cut inside the launch (DESIGN.md 5.8)"})
+        return blk
     clocks = cost.astype(np.float64) * 16.0
     slots = min(len(cost), n_cu)
     sec = rl["launch_ms"] * 1e-3
@@ -636,6 +648,12 @@ def main():
                 # the long window (the builder's default line: 1000 updates after 20): large fires, CU balance; checked on 16 environments
                 al = argparse.Namespace(**vars(a))
                 al.steps, al.warmup = 1000, 20
+                if not a.no_rehearsal:
+                    # (rehearsed like the headline: the launch of 1000 updates may be another kernel than the headline's - teams that grow inside
+                    # the launch -, and a kernel's first launch in a process costs ~2 ms once: code object, scratch)
+                    eng.reset(w.init_xy)
+                    run_steps(eng, al.warmup, 0, None)
+                    rollout(al.steps, al.warmup)
                 eng.reset(w.init_xy)
                 run_steps(eng, al.warmup, 0, None)
                 eng.copy_status_to(result.data_ptr())
@@ -661,7 +679,7 @@ def main():
                 if issl:
                     rll["issue"] = issl
                 also["c3_long"] = {"steps": al.steps, "warmup": al.warmup, "value": H * W * esl_ / dtl, "unit": "cell-updates/s",
-                                   "ms_per_step": dtl * 1e3 / al.steps, "verified": ver_l, "envs_checked": 0 if ver_l is None else min(16, w.n_envs),
+                                   "ms_per_step": dtl * 1e3 / al.steps, "rehearsal": not a.no_rehearsal, "verified": ver_l, "envs_checked": 0 if ver_l is None else min(16, w.n_envs),
                                    "env_steps_executed": esl_, "envs_running_at_end": int(blk_l[:, 0].sum()),
                                    "roofline": {k: rll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "replayed_from", "kernel", "launches",
                                                                     "launch_ms", "kernel_ms_per_step", "cells_swept_per_step", "active_cell_updates_per_step",

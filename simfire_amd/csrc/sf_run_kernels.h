@@ -362,8 +362,18 @@ __device__ __forceinline__ uint4 find_team(const JoinArgs a, uint32_t *sc)
 // behind the wait for everybody's, cuts the bands from the global bitmap as the prologue does, loads its new band and halo rows, and
 // lines up once more before anyone writes again (cut_bands / load_band / store_band below).
 template <int MAXD, int ATT, int DIAG, int MIT, int TEAM = 0>
-__global__ __launch_bounds__(1024) void k_run(StepArgs a, const int n_steps_launch, int vcap, int bsz)
+__global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_steps_launch, int vcap, int bsz)
 {
+    // The argument block is read where it is used, through the kernel-argument segment (constant address space: scalar loads), instead of
+    // being taken by value - by value the compiler loads all of it in the entry block and spills most of it at once (239 of the join kernel's
+    // 345 spilled SGPRs were written there).  Measured per instantiation (profiles/r04_resource_usage.txt): the plain and the team kernels spill
+    // 25 - 40 % fewer SGPRs this way; the closed loop and the kernel whose teams grow get worse (VGPR spills), so they keep the copy.
+#ifdef SF_ARGS_BY_VALUE
+    constexpr bool kArgsByValue = true;          // (profiles/: the A / B build)
+#else
+    constexpr bool kArgsByValue = TEAM == 2 || MIT == -2;
+#endif
+    const StepArgs &a = kArgsByValue ? a_by_value : *(const StepArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ uint4 s_dyn[];
     const Geo &g = a.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, nthr = blockDim.x;
@@ -1212,7 +1222,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a, const int n_steps_laun
                 pc.mark(10);
                 if (!kEarly && j_next < n_chunk) fetch(j_next, nxt);
             };
-            if ((TEAM == 0 || TEAM == 2) && MAXD == 1) {
+            if (TEAM == 0 && MAXD == 1) {
                 for (uint32_t ja = j_first; ja < n_chunk;) {
                     uint32_t jb;
                     batch(vin_a, ja, vin_b, jb);

@@ -1230,6 +1230,13 @@ static int launch_k_run_join(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int place = s->tune.v[SF_TUNE_TEAM_PLACEMENT];
     a.join_local = place == 1 ? 0 : (place == 2 ? 2 : 1);
     a.join_floor = eager ? 0 : 12000; a.join_ovh = eager ? 0 : (a.join_local == 1 ? 3000 : 12000);
+    {   // (measurement scripts only, like the knobs: SF_DEBUG_KNOBS=1 SF_JOIN_FLOOR=.. SF_JOIN_OVH=..)
+        const char *dk = getenv("SF_DEBUG_KNOBS");
+        if (dk && atoi(dk) != 0 && !eager) {
+            if (const char *v = getenv("SF_JOIN_FLOOR")) a.join_floor = atoi(v);
+            if (const char *v = getenv("SF_JOIN_OVH")) a.join_ovh = atoi(v);
+        }
+    }
     const int ia = g.att ? 1 : 0;
     const bool set_lds = t.lds > 64 * 1024 && t.lds > s->attr_join[ia];
     HIPCHK(sf_run2_launch_join(ia, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
