@@ -367,11 +367,14 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     // The argument block is read where it is used, through the kernel-argument segment (constant address space: scalar loads), instead of
     // being taken by value - by value the compiler loads all of it in the entry block and spills most of it at once (239 of the join kernel's
     // 345 spilled SGPRs were written there).  Measured per instantiation (profiles/r04_resource_usage.txt): the plain and the team kernels spill
-    // 25 - 40 % fewer SGPRs this way; the closed loop and the kernel whose teams grow get worse (VGPR spills), so they keep the copy.
+    // 25 - 40 % fewer SGPRs this way and need no scratch; the closed loop and the kernel whose teams grow get worse (VGPR spills), so they keep
+    // the copy - and so do the kernels that were measured SLOWER reading the segment (scalar loads inside the step loop): sf_step's on one-word
+    // rows (the general loop on young fires 5.5 -> 5.7 us per update; the window phase the same either way) and the two-word team kernels
+    // (C4's share over 300 updates 13.1 -> 13.5).  sf_step_mitigated's kernels and the one-word team kernels: the same speed either way.
 #ifdef SF_ARGS_BY_VALUE
     constexpr bool kArgsByValue = true;          // (profiles/: the A / B build)
 #else
-    constexpr bool kArgsByValue = TEAM == 2 || MIT == -2;
+    constexpr bool kArgsByValue = TEAM == 2 || MIT == -2 || (MIT == 0 && TEAM == 0) || (TEAM == 1 && MAXD == 2);
 #endif
     const StepArgs &a = kArgsByValue ? a_by_value : *(const StepArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ uint4 s_dyn[];
