@@ -1484,3 +1484,36 @@ def test_teams_that_grow_inside_the_launch(seed):
         grown += int((sizes > 1).sum())
         _same(eng, o, E, tag=(seed, done))
     assert grown > 0                                                  # (free workgroups from the first update on: 256 CUs, at most 9 environments)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("place", [0, 1])
+def test_teams_that_grow_on_the_c3_grid_by_the_cost_model(place):
+    """C3's full grid, 40 environments x 700 updates in ONE launch with SF_TUNE_RUN_JOIN at its default (the cost model decides who is
+    worth joining; 216 workgroup slots have no environment and look for one from the first cut on): every environment's state and
+    eight environments' fire maps + burn_amounts against the oracle, and the join log is consistent (sizes grow 1 -> ... <= 4, every
+    environment is reported done once).  place 1: newcomers from any XCD (every hand-off written through, agent-scope fences at the cuts)."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    w = workloads.c3(1024, 40)
+    kw = w.engine_kwargs()
+    eng = FireEngine(M_f=w.M_f, **kw)
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy)
+    o.reset(w.init_xy)
+    eng.set_tuning(run_join=1, team_placement=place)       # (set by hand: wins over the teams sized by cost between segments, which 40 environments would get)
+    eng.step(700)
+    o.step(700, 8)
+    assert eng.last_launch_kind() == 2 and eng.last_launches() == 1
+    sizes, log = eng.team_sizes(), eng.join_log()
+    assert sizes.min() >= 1 and sizes.max() <= 4 and (sizes > 1).any(), sizes
+    done = log[log[:, 2] == 255]
+    assert sorted(done[:, 0].tolist()) == list(range(40))
+    for e in range(40):
+        g = log[(log[:, 0] == e) & (log[:, 2] != 255)]
+        g = g[np.argsort(g[:, 1])]
+        assert (np.diff(g[:, 2].astype(int)) > 0).all() and (len(g) == 0 or (g[0, 2] >= 2 and g[-1, 2] == sizes[e])), (e, g)
+        assert len(g) > 0 or sizes[e] == 1
+    _same(eng, o, 40, burn_envs=range(0, 40, 5), tag=("join c3", place))
