@@ -27,7 +27,7 @@ for f in glob.glob("$O/stats/default_kernel_trace.csv"):
     with open("$O/kernel_trace_k_run.csv", "w") as o:
         o.write("dispatch,kernel,start_ns,end_ns,duration_us,grid,workgroup,lds_bytes,vgpr,sgpr\n")
         for i, r in enumerate(rows):
-            o.write("%d,%s,%s,%s,%.2f,%s,%s,%s,%s,%s\n" % (i, r["Kernel_Name"].split("(")[0][-40:], r["Start_Timestamp"], r["End_Timestamp"],
+            o.write("%d,%s,%s,%s,%.2f,%s,%s,%s,%s,%s\n" % (i, r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace(", ", " ")[-40:], r["Start_Timestamp"], r["End_Timestamp"],
                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
                     r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""), r.get("SGPR_Count", "")))
 PY2
