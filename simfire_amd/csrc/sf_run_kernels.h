@@ -398,7 +398,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         ja.team_timeout = a.team_timeout; ja.join_local = a.join_local; ja.t_cap = kTeamMax < g.TY ? kTeamMax : g.TY;
         const uint4 t = find_team(ja, sc);
         if (t.x == 0xFFFFFFFFu) return;
-        e_ = (int)t.x; tm_ = (int)t.y; tn_ = (int)t.z; j_s0 = (int)t.w;
+        // (uniform values that came through LDS: said so, or every base pointer derived from the environment's number lives in a VGPR pair)
+        e_ = __builtin_amdgcn_readfirstlane((int)t.x); tm_ = __builtin_amdgcn_readfirstlane((int)t.y);
+        tn_ = __builtin_amdgcn_readfirstlane((int)t.z); j_s0 = __builtin_amdgcn_readfirstlane((int)t.w);
     }
     {
     int n_steps = n_steps_launch;
