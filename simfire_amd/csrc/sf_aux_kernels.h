@@ -11,6 +11,7 @@ namespace {
 // ------------------------------------------------------------------ layers -> R table
 // np.gradient(elevations, pixel_scale) (fire.py:446): centred 2nd-order differences inside,
 // one-sided 1st-order at the borders; slope_mag / slope_dir (fire.py:447-448) in float64.
+#ifndef SF_RUN_UNIT
 __global__ void k_slopes(int H, int W, const double *el, double ps, double *mag, double *dir)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -28,10 +29,12 @@ __global__ void k_slopes(int H, int W, const double *el, double ps, double *mag,
     mag[i] = sqrt(gx * gx + gy * gy);
     dir[i] = atan2(gy, gx + 0.000001);
 }
+#endif
 
 struct Thetas { float v[8]; };
 
 // One thread per cell: direction-independent terms once, then the 8 travel directions.
+#ifndef SF_RUN_UNIT
 __global__ void k_rtable(int H, int W, int P, const double *w0, const double *delta, const double *Mx,
                          const double *sigma, const double *U, const double *Udir, const double *mag,
                          const double *dir, float h, float S_T, float S_e, float p_p, float M_f,
@@ -51,7 +54,9 @@ __global__ void k_rtable(int H, int W, int P, const double *w0, const double *de
                                                  (float)mag[i], (float)dir[i]);
     for (int k = 0; k < 8; ++k) rt[k * plane + o] = sfdev::ros_dir(t, th.v[k]);
 }
+#endif
 
+#ifndef SF_RUN_UNIT
 __global__ void k_compute_ros(long long n, const float *lx, const float *ly, const float *nx, const float *ny,
                               const float *w0, const float *delta, const float *Mx, const float *sigma,
                               const float *h, const float *S_T, const float *S_e, const float *p_p,
@@ -65,6 +70,7 @@ __global__ void k_compute_ros(long long n, const float *lx, const float *ly, con
                                                  M_f[i], U[i], Udir[i], mag[i], dir[i]);
     out[i] = sfdev::ros_dir(t, theta);
 }
+#endif
 
 // pitched <-> dense plane copies
 // FBFM13 code -> Fuel (w_0, delta, M_x, sigma); the table travels as a kernel argument
@@ -74,6 +80,7 @@ struct FuelLut {
     int32_t code[kMaxFuelLut];
     double fuel[kMaxFuelLut][4];
 };
+#ifndef SF_RUN_UNIT
 __global__ void k_fuel_lut(long long n, const int32_t *codes, FuelLut lut, double *w0, double *delta, double *mx,
                            double *sigma, int32_t *bad)
 {
@@ -85,8 +92,10 @@ __global__ void k_fuel_lut(long long n, const int32_t *codes, FuelLut lut, doubl
     if (hit < 0) { *bad = c; return; }      // any offending code will do for the message
     w0[i] = lut.fuel[hit][0]; delta[i] = lut.fuel[hit][1]; mx[i] = lut.fuel[hit][2]; sigma[i] = lut.fuel[hit][3];
 }
+#endif
 
 // observation planes in the dtypes of get_attribute_data (simulation.py:395-399)
+#ifndef SF_RUN_UNIT
 __global__ void k_attribute_planes(long long n, const double *w0, const double *delta, const double *mx, const double *sigma,
                                    float *o_w0, uint32_t *o_sigma, float *o_delta, float *o_mx)
 {
@@ -94,8 +103,10 @@ __global__ void k_attribute_planes(long long n, const double *w0, const double *
     if (i >= n) return;
     o_w0[i] = (float)w0[i]; o_sigma[i] = (uint32_t)sigma[i]; o_delta[i] = (float)delta[i]; o_mx[i] = (float)mx[i];
 }
+#endif
 
 // fire map after the update this launch executed, for the environments that executed one
+#ifndef SF_RUN_UNIT
 __global__ void k_record(Geo g, const uint8_t *status, const EnvState *st, int8_t *hist, int cap)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
@@ -105,20 +116,26 @@ __global__ void k_record(Geo g, const uint8_t *status, const EnvState *st, int8_
     hist[(((long long)e * cap + s.steps % cap) * g.H + y) * g.W + x] =
         (int8_t)(status[(long long)e * g.plane_env + (long long)y * g.P + x] & 7u);
 }
+#endif
 
+#ifndef SF_RUN_UNIT
 __global__ void k_pack_rt(int H, int W, int P, const double *dense, double *pitched)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
     if (x >= P) return;
     pitched[((long long)k * H + y) * P + x] = x < W ? dense[((long long)k * H + y) * W + x] : 0.0;
 }
+#endif
+#ifndef SF_RUN_UNIT
 __global__ void k_unpack_f64(int H, int W, int P, const double *pitched, double *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
     if (x >= W) return;
     dense[((long long)k * H + y) * W + x] = pitched[((long long)k * H + y) * P + x];
 }
+#endif
 // (cells: the blocked cell plane when it is the current one - sf_common.h, bl_vec - else null)
+#ifndef SF_RUN_UNIT
 __global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cells, int env0, uint8_t *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, i = blockIdx.z;
@@ -127,9 +144,11 @@ __global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cel
                              : status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x];
     dense[((long long)i * g.H + y) * g.W + x] = st & 7u;
 }
+#endif
 
 // burn_amounts as the reference would hold them now: the attenuation a control-line cell is still owed
 // (see lazy_sub) is resolved on the fly
+#ifndef SF_RUN_UNIT
 __global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint32_t *settled, const double *burn,
                               const EnvState *commit, int e, double *dense)
 {
@@ -141,9 +160,11 @@ __global__ void k_unpack_burn(Geo g, const uint8_t *status, const uint32_t *sett
     if (g.att && st >= SF_FIRELINE) b = lazy_sub(b, line_factor(st), (uint32_t)commit[e].complete - settled[o]);
     dense[(long long)y * g.W + x] = b;
 }
+#endif
 
 // Make the owed attenuation of one environment real (apply) and mark every line cell as up to date.
 // Used before fire_map / burn are overwritten wholesale (load_mitigation, set_burn).
+#ifndef SF_RUN_UNIT
 __global__ void k_settle_env(Geo g, const uint8_t *status, uint32_t *settled, double *burn, const EnvState *commit,
                              int e, int apply)
 {
@@ -156,7 +177,9 @@ __global__ void k_settle_env(Geo g, const uint8_t *status, uint32_t *settled, do
     if (apply) burn[o] = lazy_sub(burn[o], line_factor(st), now - settled[o]);
     settled[o] = now;
 }
+#endif
 
+#ifndef SF_RUN_UNIT
 __global__ void k_pack_status(Geo g, uint8_t *status, uint32_t *settled, const EnvState *commit, int e, const uint8_t *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -167,12 +190,15 @@ __global__ void k_pack_status(Geo g, uint8_t *status, uint32_t *settled, const E
     // a freshly loaded line cell owes nothing for the updates that ran before it existed
     if (g.att && v >= SF_FIRELINE) settled[o] = (uint32_t)commit[e].complete;
 }
+#endif
+#ifndef SF_RUN_UNIT
 __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= g.W) return;
     burn[(long long)e * g.plane_env + (long long)y * g.P + x] = dense[(long long)y * g.W + x];
 }
+#endif
 
 // ------------------------------------------------------------------------- mitigation
 // FireSimulation.update_mitigation (simulation.py:449-478) as two tiny launches, one thread per
@@ -185,6 +211,7 @@ __global__ void k_pack_burn(Geo g, double *burn, int e, const double *dense)
 //                     order for duplicates (simulation.py:476-478); each write is unconditional
 //                     w.r.t. the old status (mitigation.py:75-78) because pass 1 cleared it.  The
 //                     new line cell owes attenuation from the next update on.
+#ifndef SF_RUN_UNIT
 __global__ void k_mitigate_clear(Geo g, uint8_t *status, uint8_t *cells, const uint32_t *settled, double *burn, const EnvState *commit,
                                  const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
                                  const int32_t *pts, int n)
@@ -203,7 +230,9 @@ __global__ void k_mitigate_clear(Geo g, uint8_t *status, uint8_t *cells, const u
         burn[o] = lazy_sub(burn[o], line_factor(old), now - settled[o]);
     }
 }
+#endif
 
+#ifndef SF_RUN_UNIT
 __global__ void k_mitigate_write(Geo g, uint8_t *status, uint8_t *cells, uint32_t *settled, uint8_t *tdirty, const EnvState *commit,
                                  const EnvState *tmp, const uint32_t *flags, int launch, int from_commit,
                                  const int32_t *pts, int n)
@@ -227,10 +256,12 @@ __global__ void k_mitigate_write(Geo g, uint8_t *status, uint8_t *cells, uint32_
         settled[o] = (uint32_t)entering_state(commit, tmp, flags, launch, from_commit, e, g).complete;
     tdirty[((long long)e * g.TY + y / (g.LR * g.RB)) * g.TX + (x / 16) / g.LC] = 1;
 }
+#endif
 
 // ------------------------------------------------------------- per-environment results
 // 16 cells per load, byte-parallel compares; the pitch padding (x >= W) always holds UNBURNED, so the
 // UNBURNED count is derived from the others.
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, const EnvState *commit,
                                                 int32_t *out)
 {
@@ -273,6 +304,7 @@ __global__ __launch_bounds__(256) void k_counts(Geo g, const uint8_t *status, co
         atomicAdd(&out[e * 8 + 2], g.H * g.W);
     }
 }
+#endif
 
 // The same counts from per-tile histograms: only tiles whose status bytes changed since the last query
 // (marked by the step kernels and the mitigation scatter) are recounted, the others come from the
@@ -380,6 +412,7 @@ __device__ __forceinline__ void counts_env(const Geo &g, int e, const uint8_t *s
     }
 }
 
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *status, const uint8_t *cells, uint8_t *tdirty, uint16_t *thist,
                                                        const EnvState *commit, int32_t *out, double *elapsed, int32_t *out2)
 {
@@ -388,11 +421,14 @@ __global__ __launch_bounds__(1024) void k_counts_tiles(Geo g, const uint8_t *sta
     counts_env(g, e, status, cells, tdirty, thist, commit[e].running, commit[e].steps, commit[e].elapsed, out, elapsed, out2,
                reinterpret_cast<int32_t (*)[6]>(s_mem));
 }
+#endif
 
+#ifndef SF_RUN_UNIT
 __global__ void k_elapsed(int E, const EnvState *commit, double *out)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) out[e] = commit[e].elapsed;
 }
+#endif
 
 }  // namespace

@@ -1494,6 +1494,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
 // Launch order of the environments for the resident launch when there are more of them than the chip holds workgroups: the
 // most expensive first (cost = clocks of the environment's workgroup in the launch before; 1024 linear buckets, counting sort),
 // so that the launch does not end with a large fire that started late.  One workgroup.  Results never depend on the order.
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uint32_t *order)
 {
     __shared__ uint32_t s_max, s_hist[1024], s_wave[16];
@@ -1526,6 +1527,7 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
     __syncthreads();
     for (int e = tid; e < E; e += 1024) order[atomicAdd(&s_hist[bucket(cost[e])], 1u)] = (uint32_t)e;
 }
+#endif
 
 // Team sizes and workgroup slots of a k_run<TEAM> launch (one workgroup, E <= 1024 environments, G slots = what the chip holds
 // at once).  cost[e] = shader clocks / 16 the environment's workgroups spent in the launch before (ovh = what a member pays per
@@ -1539,6 +1541,7 @@ __global__ __launch_bounds__(1024) void k_order(int E, const uint32_t *cost, uin
 // What a member of a team of T costs: max(floor, cost / T) + ovh - a step is a latency chain that does not get shorter than `floor`
 // however few rows a member has (measured: ~12 k clocks), and belonging to a team costs `ovh` per step (~6.5 k clocks: publish, wait
 // for the slowest member, read).  An environment is split only where that beats its cost in one workgroup.
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int t_max, uint32_t ovh, uint32_t floor_c, int scatter, uint32_t *cost, uint32_t *tab, uint32_t *tsize,
                                                     unsigned long long *xg, uint32_t *xdone, int keep_cost, uint32_t *xj, unsigned long long *xcut)
 {
@@ -1608,9 +1611,11 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
         }
     }
 }
+#endif
 
 // The vector bitmap of environments [env0, env0 + n) from their sprite-mask planes (after steps of the per-step
 // kernels, which do not maintain it).  One wave per (row, 64-vector word).
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(64) void k_rebuild_vbits(Geo g, const uint8_t *age, unsigned long long *vbits, int env0)
 {
     const int w = blockIdx.x, y = blockIdx.y, e = env0 + blockIdx.z, lane = threadIdx.x;
@@ -1623,9 +1628,11 @@ __global__ __launch_bounds__(64) void k_rebuild_vbits(Geo g, const uint8_t *age,
         vbits[o] = b; vbits[plane + o] = f; vbits[2 * plane + o] = l;      // any sprite bit / in the first cell / in the last cell
     }
 }
+#endif
 
 // Row-major planes <-> blocked cell plane, one thread per 16-cell vector (the host switches when the resident launch and the
 // per-step kernels / getters alternate: ensure_bl / ensure_rm).
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(64) void k_rm_to_bl(Geo g, const uint8_t *status, const uint8_t *age, uint8_t *cells)
 {
     const int v = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
@@ -1636,6 +1643,8 @@ __global__ __launch_bounds__(64) void k_rm_to_bl(Geo g, const uint8_t *status, c
     *reinterpret_cast<uint4 *>(row) = m;
     *reinterpret_cast<uint4 *>(row + kBlStatus) = st;
 }
+#endif
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(64) void k_bl_to_rm(Geo g, const uint8_t *cells, uint8_t *status, uint8_t *age)
 {
     const int v = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, e = blockIdx.z;
@@ -1644,5 +1653,6 @@ __global__ __launch_bounds__(64) void k_bl_to_rm(Geo g, const uint8_t *cells, ui
     if (age) *reinterpret_cast<uint4 *>(age + (long long)e * g.age_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row);      // (null: a snapshot of the fire maps only)
     *reinterpret_cast<uint4 *>(status + (long long)e * g.plane_env + (long long)y * g.P + v * 16) = *reinterpret_cast<const uint4 *>(row + kBlStatus);
 }
+#endif
 
 }  // namespace

@@ -26,6 +26,7 @@ namespace {
 // [LR * RB][LC * 16].  5.5 KB per wave at LC = 4, RB = 2.
 // ------------------------------------------------------------------------------------------
 constexpr int kSelectThreads = 1024;     // few, large workgroups: one list-slot atomic each, and they all hit one address
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
 {
     __shared__ uint32_t s_base, s_wsum[kSelectThreads / 64];
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kSelectThreads) void k_select(StepArgs a)
         }
     }
 }
+#endif
 
 // Development aid (build with -DSF_PHASES, see profiles/phase_profile.sh): lane 0 of every wave sums
 // the shader clocks it spends in each phase of step_tile into the statistics counters.
@@ -1006,6 +1008,7 @@ __device__ __forceinline__ void graph_cell(const StepArgs &a, const Masks &mk, i
 }
 
 // every cell (fused / per-cell step kernels: no tile list)
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(256) void k_graph_pass(StepArgs a)
 {
     const Geo &g = a.g;
@@ -1015,9 +1018,11 @@ __global__ __launch_bounds__(256) void k_graph_pass(StepArgs a)
     if (!st.running) return;
     graph_cell(a, make_masks(st.steps + 1, g.md, g.N), e, x, y);
 }
+#endif
 
 // only the tiles k_step has just visited (an ignition can only have happened there): grid-stride over
 // the tile list of this step, one workgroup per tile
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(256) void k_graph_pass_tiles(StepArgs a)
 {
     const Geo &g = a.g;
@@ -1036,6 +1041,7 @@ __global__ __launch_bounds__(256) void k_graph_pass_tiles(StepArgs a)
         }
     }
 }
+#endif
 
 typedef void (*StepKernel)(StepArgs);
 static StepKernel pick_step_kernel(int rb, bool fused)
@@ -1049,6 +1055,7 @@ static StepKernel pick_step_kernel(int rb, bool fused)
 }
 
 // Fold the flags of the last launch of a sf_step call into the committed state, zero the ring.
+#ifndef SF_RUN_UNIT
 __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t *flags, int last_launch, uint32_t *n_active)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1057,7 +1064,9 @@ __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t 
     commit[e] = fold_state(tmp[(last_launch & 1) * g.E + e], flags[(last_launch % 3) * g.E + e], g);
     flags[e] = 0; flags[g.E + e] = 0; flags[2 * g.E + e] = 0;
 }
+#endif
 
+#ifndef SF_RUN_UNIT
 __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, uint8_t *cells, EnvState *commit, uint8_t *tflags, int ring,
                            unsigned long long *vbits, const int32_t *xy, int env0, int n, uint8_t *tdirty)
 {
@@ -1089,9 +1098,11 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, uint8_t *cells,
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
     commit[e] = s;
 }
+#endif
 
 // Recompute the seam planes of environments [env0, env0 + n) from the sprite-mask plane (after a reset,
 // or when the per-cell kernel, which does not maintain them, hands over to the tiled kernels).
+#ifndef SF_RUN_UNIT
 __global__ void k_rebuild_seams(Geo g, const uint8_t *age, uint8_t *seam, int env0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index in the seam column
@@ -1104,9 +1115,11 @@ __global__ void k_rebuild_seams(Geo g, const uint8_t *age, uint8_t *seam, int en
         v = age[(long long)e * g.age_env + (long long)y * g.P + x];
     seam[(long long)e * g.seam_env + (long long)bs * g.Hs + i] = v;
 }
+#endif
 
 // Recompute the tile activity map of environments [env0, env0 + n) from the cell planes (after a
 // geometry change or a wholesale fire_map replacement).  One 64-lane workgroup per tile.
+#ifndef SF_RUN_UNIT
 __global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *status, const uint8_t *age,
                                                        uint8_t *tflags, int ring, int env0)
 {
@@ -1125,5 +1138,6 @@ __global__ __launch_bounds__(64) void k_rebuild_tflags(Geo g, const uint8_t *sta
             tflags[((long long)k * g.E + e) * plane + o] = (k == ring && a_any) ? (uint8_t)(1 | 4 | 8 | 16 | 32) : (uint8_t)0;
     }
 }
+#endif
 
 }  // namespace

@@ -5,6 +5,8 @@
 // comes from the same headers (all in anonymous namespaces: each unit has its own copy of the device helpers); the launch arguments
 // cross the boundary as bytes.
 // Replaces (like sf_run_kernels.h): n calls of RothermelFireManager.update per environment, simfire/game/managers/fire.py:616-719.
+// (only the k_run instantiations below are compiled here: the kernels every handle launches live in simfire_hip.hip alone)
+#define SF_RUN_UNIT 1
 #include <hip/hip_runtime.h>
 
 #include <cstring>

@@ -1518,3 +1518,62 @@ def test_teams_that_grow_on_the_c3_grid_by_the_cost_model(place, knob):
         assert (np.diff(g[:, 2].astype(int)) > 0).all() and (len(g) == 0 or (g[0, 2] >= 2 and g[-1, 2] == sizes[e])), (e, g)
         assert len(g) > 0 or sizes[e] == 1
     _same(eng, o, 40, burn_envs=range(0, 40, 5), tag=("join c3", place))
+
+
+@pytest.mark.gpu
+def test_a_team_whose_members_cannot_all_be_resident_fails_loudly_and_the_handle_recovers():
+    """The members of a team wait for each other inside the launch, so all of them have to be resident at once - which another
+    stream's kernels can prevent.  Here: handle A keeps half the chip busy (128 environments, one 16-wave workgroup each, a long
+    call, not waited for) while handle B launches 128 teams of two (256 workgroups) with a wait bound of 3 ms
+    (SF_TUNE_TEAM_TIMEOUT_MS): members whose partner is not resident give up, the launch ends, the next call that hands data back
+    says so (SF_EHIP, never wrong data, never a hang), and a reset of every environment makes the handle whole again - checked
+    against the oracle.  (Should the scheduler fit everything in after all, the call simply succeeds and has to be right.)"""
+    from simfire_amd import workloads
+    from simfire_amd._lib import SimfireHipError
+    from simfire_amd.engine import FireEngine
+    wa, wb = workloads.c3(1024, 128), workloads.c3(1024, 128)
+    ea = FireEngine(M_f=wa.M_f, **wa.engine_kwargs())
+    ea.set_layers(*wa.layers())
+    ea.reset(wa.init_xy)
+    ea.set_tuning(run_join=0, run_team=0)
+    ea.step(300)                                        # (fires of some size: the long call below lasts tens of ms)
+    kw = wb.engine_kwargs()
+    eb = FireEngine(M_f=wb.M_f, **kw)
+    eb.set_layers(*wb.layers())
+    o = fire_dense.DenseOracle(**kw)
+    o.set_rtable(eb.get_rtable())
+    eb.reset(wb.init_xy)
+    eb.set_fused(2)
+    eb.set_tuning(run_team=2, team_timeout_ms=3)
+    eb.step(4)                                          # (first launch of the team kernel: not while the chip is contended)
+    eb.status()
+    eb.reset(wb.init_xy)
+    ea.set_async(True)
+    eb.set_async(True)
+    ea.step(2500)
+    failed = False
+    try:
+        eb.step(40)
+        eb.sync()
+        eb.status()
+    except SimfireHipError as ex:
+        failed = True
+        assert "gave up waiting for a team member" in str(ex)
+    ea.sync()
+    ea.set_async(False)
+    eb.set_async(False)
+    if failed:
+        with pytest.raises(SimfireHipError):            # the handle stays void until every environment is reset
+            eb.fire_map(0)
+        eb.reset(wb.init_xy)
+        eb.set_tuning(team_timeout_ms=2000)
+    o.reset(wb.init_xy)
+    if failed:
+        eb.step(40)
+    o.step(40, 8)
+    st, el = eb.status()
+    so, eo = o.status()
+    assert (st == so).all() and (el == eo).all()
+    for e in (0, 63, 127):
+        assert (eb.fire_map(e) == o.fire_map(e)).all(), e
+    print("team launch under contention:", "gave up and recovered" if failed else "fitted in")
