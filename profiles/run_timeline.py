@@ -21,10 +21,13 @@ def main():
     steps, warm = int(sys.argv[1]), int(sys.argv[2])
     env = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     envs = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-    c5 = len(sys.argv) > 5 and sys.argv[5] == "c5"      # C5: 64 agents per environment, control lines inside the launch
-    w = workloads.c5(1024, envs) if c5 else workloads.c3(1024, envs)
+    c5 = len(sys.argv) > 5 and sys.argv[5] in ("c5", "c3mit")      # C5: 64 agents per environment, control lines inside the launch
+    c3mit = len(sys.argv) > 5 and sys.argv[5] == "c3mit"             # C3's fires through sf_step_mitigated with points that draw nothing (type 0)
+    w = workloads.c5(1024, envs) if c5 and not c3mit else workloads.c3(1024, envs)
     pts = None
-    if c5:
+    if c3mit:
+        pts = np.zeros((steps + warm, w.n_envs, 64, 3), dtype=np.int32)
+    elif c5:
         H, W = w.shape
         pts = np.ascontiguousarray(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, steps + warm).reshape(
             steps + warm, w.n_envs, w.agents_per_env, 4)[..., 1:])

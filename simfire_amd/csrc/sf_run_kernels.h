@@ -912,7 +912,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 const int i = MAXD == 1 ? 0 : d / VW, w = MAXD == 1 ? 0 : d - i * VW;
                 const int y = row0 + tid * rpt + i;
                 if (i < rpt && y < R1) {
-                    const int o = y * VW + w;
+                    int o = y * VW + w;
+                    // (opaque to the optimiser: the dozen LDS addresses derived from it are loop invariants, and kept in VGPRs across the whole step they
+                    // were what got spilled - two scratch reloads with a full wait each in this pass of sf_step_mitigated's kernel, ~1.5 k clocks per update)
+                    asm volatile("" : "+v"(o));
                     const int up_o = y > 0 ? -VW : 0, dn_o = y + 1 < g.H ? VW : 0;
                     const unsigned long long b1 = vb[o], l1 = vl[o], f1 = vf[o], e1 = ve[o];
                     unsigned long long b02 = 0, l02 = 0, f02 = 0;
