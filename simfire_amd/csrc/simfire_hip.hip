@@ -1573,10 +1573,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             // fires that go out (C3: three quarters of them over 1000 updates) join the fires that are left.  SF_TUNE_RUN_JOIN.
             const int join_knob = tn.v[SF_TUNE_RUN_JOIN];
             const int join_min = join_knob > 1 ? join_knob : (join_knob < -1 ? -join_knob : 192);
-            // (Few environments - at most a quarter as many as CUs -: not automatic.  From two on the teams sized by cost between segments stay the choice;
+            // (Measured on C3 over 1000 updates with 256 / 192 / 128 / 96 / 64 environments: 10.8 -> 10.0, 10.5 -> 9.4, 9.8 -> 8.8, 9.6 -> 8.7, 9.5 -> 8.6 us per update -
+            // the last against the teams sized by cost between segments, which stay the choice for fewer environments than a quarter of the CUs;
             // ONE environment - FireSimulation.run(), C2 - keeps the plain kernel: its fire is young for hundreds of updates, and this kernel has no window
             // phase - measured on C2, 300 updates after 20: 5.1 against 6.0 us per update.  The knob set by hand wins.)
-            const bool use_join = join_knob != 0 && !team_forced && !team_wide && ((!team_auto && s->g.E * 4 > s->n_cu) || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
+            const bool use_join = join_knob != 0 && !team_forced && !team_wide && (s->g.E * 4 >= s->n_cu || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
                                   n_steps >= join_min && !tn.set[SF_TUNE_RUN_WAVES] && !tn.set[SF_TUNE_RUN_VCAP] && jgeo.ok;
             if (use_join) { seg = n_steps; a.team_recut = 0; }
             const bool use_team = !use_join && team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
