@@ -477,6 +477,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     int R0 = 0, R1 = g.H;
     // (steps_ahead: the updates until the bands are cut again - the fire advances one row per update at most)
     auto cut_bands = [&](int steps_ahead) -> bool {
+        int tid = threadIdx.x;                   // (their own values: what is derived from them must not live in VGPRs across the step loop)
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
         const int th = g.LR * g.RB, ntr = (g.H + th - 1) / th;        // (the host offers teams only for <= 64 tile rows)
         if (tid < 64) tcnt[tid] = 0;
         __syncthreads();
@@ -559,6 +562,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     // (xerr) unless this is the start line (the first step boundary reports a member that never shows up).
     auto line_up = [&](const uint32_t tag, const bool report) {
         typedef unsigned long long u64;
+        int lane = threadIdx.x & 63;             // (its own value: see the step boundary)
+        asm volatile("" : "+v"(lane));
         const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u;      // HW_REG_XCC_ID
         if (lane == 0) __hip_atomic_store(a.xg + ((size_t)e * kTeamMax + tm) * 3 + 2, ((u64)tag << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u64 x = ((u64)tag << 32) | xcc;
@@ -580,6 +585,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     // The bitmaps are indexed by the grid row: with a window of rows in LDS the base pointers are shifted so that row y sits where it is.
     unsigned long long *vb = vb0, *vf = nullptr, *vl = nullptr, *ve = nullptr;
     auto load_band = [&]() {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         const int yoff = TEAM && a.team_rcap ? R0 - 1 : 0;
         vb = vb0 - (long long)yoff * VW;
         vf = fine ? vb + (size_t)lds_rows * VW : nullptr; vl = fine ? vb + (size_t)2 * lds_rows * VW : nullptr;
@@ -633,6 +640,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     int row0 = TEAM ? R0 : 0;                                         // first row of this workgroup's rows
     // this member's rows of the bitmaps -> the global array (the others' rows in its LDS are not maintained)
     auto store_band = [&]() {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         for (int i = R0 * VW + tid; i < R1 * VW; i += nthr) {
             vb_glob[i] = vb[i];
             vb_glob[(long long)g.E * g.vb_env + i] = vf[i];
@@ -851,6 +860,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     pc.mark(14); // control lines: the wave's plane work issued
                 }
             } else {
+                int tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
                 const int32_t *pts = mit + ((long long)s * g.E + e) * a.mit_k * 3;
                 for (int i = tid; i < a.mit_k; i += nthr) {
                     const int x = pts[3 * i], y = pts[3 * i + 1], ty = pts[3 * i + 2];
@@ -1291,6 +1302,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
             // neighbours' rows into the LDS halo (wave 0; the other waves wait at the barrier below)
             if (wave == 0) {
                 typedef unsigned long long u64;
+                // (the lane number as this block's own value: the addresses derived from it - granules, rows of the hand-off buffer - are loop
+                // invariants otherwise, and the compiler keeps them in VGPRs across the whole step loop, where they are what gets spilled)
+                int lane = threadIdx.x & 63;
+                asm volatile("" : "+v"(lane));
                 const unsigned long long xt0 = a.counters ? __builtin_readcyclecounter() : 0ull;
                 const uint32_t epoch = (uint32_t)s + 1u, par = (uint32_t)s & 1u;
                 uint8_t *xb_me = a.xbuf + ((size_t)(e * kTeamMax + tm) * 4) * (size_t)a.xrow;      // [side][parity][xrow]
