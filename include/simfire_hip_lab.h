@@ -86,7 +86,7 @@ enum sf_tuning_knob {
                                  * (SF_EHIP at the next call that hands data back; sf_reset of every environment recovers the handle) */
     SF_TUNE_RUN_JOIN = 20,      /* teams that GROW inside the resident launch (k_run<TEAM = 2>: grids up to 1024 cells wide, at most one environment per CU, no control
                                  * lines inside the launch): a workgroup whose environment is done joins the running environment that would finish last, at that
-                                 * team's next cut.  1 (default) = in calls of 192 updates or more with at least a quarter as many environments as CUs (set by hand: with any number), 0 = never, k > 1 = in calls of k updates or more,
+                                 * team's next cut.  1 (default) = in calls of 192 updates or more on two or more environments (set by hand: also on one), 0 = never, k > 1 = in calls of k updates or more,
                                  * -k = the same but every free workgroup joins whatever runs, whether the cost model says it pays or not (tests) */
     SF_TUNE_COUNT = 21
 };

@@ -1574,10 +1574,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             const int join_knob = tn.v[SF_TUNE_RUN_JOIN];
             const int join_min = join_knob > 1 ? join_knob : (join_knob < -1 ? -join_knob : 192);
             // (Measured on C3 over 1000 updates with 256 / 192 / 128 / 96 / 64 environments: 10.8 -> 10.0, 10.5 -> 9.4, 9.8 -> 8.8, 9.6 -> 8.7, 9.5 -> 8.6 us per update -
-            // the last against the teams sized by cost between segments, which stay the choice for fewer environments than a quarter of the CUs;
+            // 32 / 16 / 8 / 2 environments: 8.6 -> 8.1, 8.2 -> 7.6, 7.8 -> 7.2, 7.3 -> 7.1 - from 64 down against the teams sized by cost between segments, which
+            // this replaces wherever it applies (they remain for calls with control lines inside the launch: C5);
             // ONE environment - FireSimulation.run(), C2 - keeps the plain kernel: its fire is young for hundreds of updates, and this kernel has no window
             // phase - measured on C2, 300 updates after 20: 5.1 against 6.0 us per update.  The knob set by hand wins.)
-            const bool use_join = join_knob != 0 && !team_forced && !team_wide && (s->g.E * 4 >= s->n_cu || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
+            const bool use_join = join_knob != 0 && !team_forced && !team_wide && (s->g.E >= 2 || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
                                   n_steps >= join_min && !tn.set[SF_TUNE_RUN_WAVES] && !tn.set[SF_TUNE_RUN_VCAP] && jgeo.ok;
             if (use_join) { seg = n_steps; a.team_recut = 0; }
             const bool use_team = !use_join && team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
