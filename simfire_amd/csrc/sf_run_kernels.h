@@ -534,11 +534,18 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         __syncthreads();
         return fits;
     };
-    if (TEAM && (tn > 1 || a.team_rcap) && general) {
-        const bool fits = cut_bands(tn > 1 && a.team_recut > 0 && a.team_recut < n_steps ? a.team_recut : n_steps);
-        if (a.todo_out && tm == 0 && tid == 0) a.todo_out[e] = fits ? 0 : n_steps;
-        if (!fits && !a.todo_out && tid == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;      // (the host promised a fit and made no catch-up launch: fail loudly)
-        if (!fits) return;          // (uniform over the team: every member sees the same bitmap) nothing has been touched
+    {
+        bool fits = true;
+        if (TEAM && (tn > 1 || a.team_rcap) && general) fits = cut_bands(tn > 1 && a.team_recut > 0 && a.team_recut < n_steps ? a.team_recut : n_steps - s_begin);
+        // What is left for the host's catch-up launch: nothing where the bands fit - ALSO where the window phase has made every update of the call
+        // (found by the soak, world 5007397: the entry was only written on the way into the loop, so a call the window phase finished left a stale
+        // one behind, and the catch-up launch made the update a second time) -, else the updates the window phase has not made.
+        if (TEAM && a.todo_out && tm == 0 && tid == 0) a.todo_out[e] = fits ? 0 : n_steps - s_begin;
+        if (TEAM && !fits) {        // (uniform over the team: every member sees the same bitmap)
+            if (!a.todo_out && tid == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;      // (the host promised a fit and made no catch-up launch: fail loudly)
+            if (s_begin > 0 && tm == 0 && tid == 0) a.commit[e] = st;      // (what the window phase did is in memory: its state with it; the loop has touched nothing)
+            return;
+        }
     }
     bool has_up = TEAM && tm > 0, has_dn = TEAM && tm + 1 < tn;                 // a neighbour above / below the band
     // Do all members of the team sit on one XCD (one L2)?  Then the per-step hand-off can stay in that L2: plain stores (the L1 is

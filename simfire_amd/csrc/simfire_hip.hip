@@ -1578,7 +1578,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             // this replaces wherever it applies (they remain for calls with control lines inside the launch: C5);
             // ONE environment - FireSimulation.run(), C2 - keeps the plain kernel: its fire is young for hundreds of updates, and this kernel has no window
             // phase - measured on C2, 300 updates after 20: 5.1 against 6.0 us per update.  The knob set by hand wins.)
-            const bool use_join = join_knob != 0 && !team_forced && !team_wide && (s->g.E >= 2 || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
+            const bool use_join = join_knob != 0 && !team_forced && !team_wide && ((s->g.E >= 2 && !tn.set[SF_TUNE_RUN_TEAM]) || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
                                   n_steps >= join_min && !tn.set[SF_TUNE_RUN_WAVES] && !tn.set[SF_TUNE_RUN_VCAP] && jgeo.ok;
             if (use_join) { seg = n_steps; a.team_recut = 0; }
             const bool use_team = !use_join && team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));

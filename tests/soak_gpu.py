@@ -40,7 +40,12 @@ def world(seed):
     if rng.random() < 0.5:
         eng.set_tuning(run_waves=int(rng.choice([16, 8, 4])))
     # teams that grow inside the launch (k_run<TEAM = 2>): by the cost model (never, on worlds this small), every free workgroup at once
-    eng.set_tuning(run_join=int(rng.choice([1, 0, 2, -2, -2, -5])))
+    _rj = int(rng.choice([1, 0, 2, -2, -2, -5]))
+    try:
+        eng.set_tuning(run_join=_rj)
+    except Exception:                                  # (an older build of the library without the knob: bisecting)
+        if not os.environ.get("SOAK_OLD"):
+            raise
     if os.environ.get("SOAK_DEBUG"):
         print("tuning", {k: eng.get_tuning(k) for k in ("run_join", "run_window", "run_waves", "run_segment", "team_placement", "run_team")}, flush=True)
         print("world", seed, "H W E", H, W, E, "md", md, "att diag", att, diag, "fused", eng.get_tuning("run_team"), {k: eng.get_tuning(k) for k in ("run_team", "team_placement", "run_segment", "team_recut")}, flush=True)
@@ -90,6 +95,10 @@ def world(seed):
             assert (b == o.burn(e)).all(), (seed, t, e, "burn before round trip")
             eng.set_burn(e, b)
         n = int(rng.choice([1, 1, 1, 2, 5, 17]))
+        if os.environ.get("SOAK_CHECK_ALL"):
+            _prev = [o.burn(e).copy() for e in range(E)]
+        if os.environ.get("SOAK_AT", "").startswith(f"{t}:"):      # (debugging aid: "8:run_window=0,run_team=1" - tuning applied in front of call t)
+            eng.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["SOAK_AT"].split(":", 1)[1].split(","))})
         if os.environ.get("SOAK_DEBUG"):
             print("t", t, "n", n, "r %.3f" % r, flush=True)
         if rng.random() < 0.06 and md <= 5:
@@ -139,6 +148,29 @@ def world(seed):
         else:
             eng.step(n)
             o.step(n)
+        if os.environ.get("SOAK_DEBUG"):
+            print("   launch kind", eng.last_launch_kind(), "launches", eng.last_launches(), "teams", eng.team_sizes().tolist(), flush=True)
+            if os.environ.get("SOAK_CHECK_ALL"):
+                print("   steps hip", eng.status()[0][:, 1].tolist(), "oracle", o.status()[0][:, 1].tolist(), flush=True)
+        if os.environ.get("SOAK_CHECK_ALL"):           # (debugging aid: compare everything after every call; changes the random stream's use below? no - checks draw nothing)
+            for e in range(E):
+                fm_ok = (eng.fire_map(e) == o.fire_map(e)).all()
+                b_ok = (eng.burn(e) == o.burn(e)).all()
+                if not (fm_ok and b_ok):
+                    d = np.argwhere(eng.burn(e) != o.burn(e))
+                    print("   MISMATCH after t", t, "env", e, "fire_map ok", fm_ok, "burn ok", b_ok, "first burn diffs (y, x)", d[:6].tolist(),
+                          "hip", [float(eng.burn(e)[tuple(q)]) for q in d[:3]], "oracle", [float(o.burn(e)[tuple(q)]) for q in d[:3]], flush=True)
+                    for q in d[:6]:
+                        yy, xx = int(q[0]), int(q[1])
+                        print("     cell", (yy, xx), "hip delta", float(eng.burn(e)[yy, xx] - _prev[e][yy, xx]), "oracle delta", float(o.burn(e)[yy, xx] - _prev[e][yy, xx]),
+                              "R8 x rate (k = 0..7)", (R8[:, yy, xx] * kw["update_rate"]).tolist())
+                    fm = o.fire_map(e)
+                    y0, y1, x0, x1 = max(d[:, 0].min() - 3, 0), d[:, 0].max() + 4, max(d[:, 1].min() - 6, 0), d[:, 1].max() + 7
+                    print("   oracle fire_map rows", y0, "..", y1 - 1, "cols", x0, "..", x1 - 1)
+                    for yy in range(y0, min(y1, H)):
+                        print("     ", yy, "".join(str(int(v)) for v in fm[yy, x0:x1]), "  diff", "".join("X" if eng.burn(e)[yy, xx] != o.burn(e)[yy, xx] else "." for xx in range(x0, min(x1, W))))
+                    bb = np.argwhere(fm == 1)
+                    print("   burning cells: rows", bb[:, 0].min(), "..", bb[:, 0].max(), "cols", bb[:, 1].min(), "..", bb[:, 1].max(), "count", len(bb))
         if rng.random() < 0.6 or t == steps - 1:      # otherwise the states stay in the device rings
             st, el = eng.status()
             so, eo = o.status()

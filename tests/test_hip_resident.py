@@ -1577,3 +1577,15 @@ def test_a_team_whose_members_cannot_all_be_resident_fails_loudly_and_the_handle
     for e in (0, 63, 127):
         assert (eb.fire_map(e) == o.fire_map(e)).all(), e
     print("team launch under contention:", "gave up and recovered" if failed else "fitted in")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [900540, 2000064, 2000357, 2000495, 5007397])
+def test_worlds_the_soak_found(seed):
+    """Random worlds of tests/soak_gpu.py that once failed, replayed: 900540 - the window phase in a workgroup of one wave (result block by
+    difference initialised by 'the first 128 threads'); 2000064 / 2000357 / 2000495 - teams that grow inside the launch on grids with fewer
+    tile rows than members; 5007397 - two-word rows with teams sized by cost: the per-environment entry for the host's catch-up launch was
+    only written on the way into the loop, so a call whose updates the window phase made left a stale one behind (here: k_front's
+    left-overs in the cross-check build) and the catch-up launch made the update a second time."""
+    import soak_gpu
+    assert soak_gpu.world(seed) > 0
