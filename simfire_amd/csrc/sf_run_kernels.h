@@ -361,6 +361,14 @@ __device__ __forceinline__ uint4 find_team(const JoinArgs a, uint32_t *sc)
 // steps the members cut their bands anew - each writes its bitmap rows back and releases (agent scope) before that step's granule, acquires
 // behind the wait for everybody's, cuts the bands from the global bitmap as the prologue does, loads its new band and halo rows, and
 // lines up once more before anyone writes again (cut_bands / load_band / store_band below).
+//
+// TEAM = 2: teams that GROW inside the launch (one-word rows, no control lines inside the launch, no window phase).  Every
+// environment starts with one workgroup; the kernel's body is a loop over ASSIGNMENTS: a workgroup whose environment is done (or whose slot
+// had none) looks for a running environment of its own XCD to join (find_team above), is taken in at that team's next cut - the cuts of
+// TEAM = 1, every team_recut updates, at which member 0 also looks who has put a name down and tells the team its new size with its granule -
+// and serves it to the end; then the next one.  The simulations are independent (simulation.py:202-214) and the in-place update does not care
+// who computes which rows: results do not depend on who joined whom when (tests: every free workgroup joins at once; by the cost model; from
+// the own XCD / from anywhere).
 template <int MAXD, int ATT, int DIAG, int MIT, int TEAM = 0>
 __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_steps_launch, int vcap, int bsz)
 {
