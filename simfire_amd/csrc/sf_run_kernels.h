@@ -1276,6 +1276,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
             __syncthreads();                               // everybody is done with this chunk's list
             if (tid == 0) ctl[6 + k] = 0;
         }
+        // (TEAM, members on one XCD: the neighbours read this member's boundary rows straight from the cell plane in the L2 they share, as soon as
+        // its granule says the step is done - every wave's stores have to be acknowledged by then; the L1 is write-through)
+        if (TEAM && tn > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         pc.mark(0);          // waiting for the slowest wave of the step
         // ---- TEAM: new bands every team_recut steps, inside the launch (teams of a fixed size).  What a launch boundary does for the
@@ -1324,7 +1327,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 const unsigned long long xt0 = a.counters ? __builtin_readcyclecounter() : 0ull;
                 const uint32_t epoch = (uint32_t)s + 1u, par = (uint32_t)s & 1u;
                 uint8_t *xb_me = a.xbuf + ((size_t)(e * kTeamMax + tm) * 4) * (size_t)a.xrow;      // [side][parity][xrow]
-                for (int side = 0; side < 2; ++side) {
+                // Members on ONE XCD (one_l2): nothing is copied.  A member's boundary rows ARE in the L2 the team shares once its waves' stores are
+                // acknowledged (above), and the neighbour reads them there (below) - two L2 round trips (granules, rows) instead of four (own rows,
+                // the copy acknowledged, granules, the copy).  What it may see beyond the step's state - the owner is at most one step ahead - are bits
+                // that are not alive in the coming step (new ignitions, recycled slots): the invariant that makes the update in place legal at all.
+                for (int side = 0; side < 2 && !one_l2; ++side) {
                     if (!(side ? has_dn : has_up)) continue;           // (uniform)
                     const int yb = side ? R1 - 1 : R0;                 // my last row is the row above the band below, my first row the row below the band above
                     u64 *dst = reinterpret_cast<u64 *>(xb_me + (size_t)(side * 2 + par) * a.xrow);
@@ -1368,7 +1375,24 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 const bool live_any = __ballot(lane < tn && (x & 0xFFull)) != 0ull, cand_any = __ballot(lane < tn && (x & 0xFF00ull)) != 0ull;
                 if (lane == 0) ctl[3 + k] = (live_any ? FLAG_LIVE : 0u) | (cand_any ? FLAG_CAND : 0u);     // fire.py:637, 651: over the whole environment
                 if (TEAM == 2 && cut_step && lane == 0) ctl[20] = (uint32_t)(x >> 16) & 0xFFu;             // (lane 0 holds member 0's granule)
-                for (int side = 0; side < 2; ++side) {
+                for (int side = 0; side < 2 && one_l2; ++side) {
+                    if (!(side ? has_dn : has_up)) continue;
+                    const int yh = side ? R1 : R0 - 1;
+                    for (int v0 = 0; v0 < g.PV; v0 += 64) {
+                        const int v = v0 + lane;
+                        u64 lo = 0, hi = 0;
+                        if (v < g.PV) {      // (loads that skip this CU's L1: its copy of the neighbour's line may be a step old)
+                            const u64 *src = reinterpret_cast<const u64 *>(ev.cells + bl_vec(g, yh, v) + (yh & 1) * 16);
+                            lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (v < g.PV) halo[side * g.PV + v] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                        // the row's bitmap words from the masks themselves (k_rebuild_vbits): any sprite bit / in the first cell / in the last cell
+                        const u64 bw = __ballot((lo | hi) != 0ull), fw = __ballot((lo & 0xFFull) != 0ull), lw = __ballot((hi >> 56) != 0ull);
+                        if (lane == 0) { vb[yh * VW + (v0 >> 6)] = bw; vf[yh * VW + (v0 >> 6)] = fw; vl[yh * VW + (v0 >> 6)] = lw; }
+                    }
+                }
+                for (int side = 0; side < 2 && !one_l2; ++side) {
                     if (!(side ? has_dn : has_up)) continue;
                     const int nj = side ? tm + 1 : tm - 1, yh = side ? R1 : R0 - 1;
                     const u64 *src = reinterpret_cast<const u64 *>(a.xbuf + ((size_t)(e * kTeamMax + nj) * 4 + (size_t)((side ^ 1) * 2 + par)) * a.xrow);
