@@ -18,8 +18,9 @@ done
 bash profiles/win_prof.sh 20 5 256 $O/phase_clocks_window_c3_s20.json 2>/dev/null | grep -v amdgpu.ids > $O/phase_clocks_window_c3_s20.txt
 bash profiles/run_timeline.sh 20 5 -1 256 2>/dev/null | grep -v amdgpu.ids > $O/timeline_window_step25.txt
 bash profiles/run_timeline.sh 20 5 -1 256 c3 launch 2>/dev/null | grep -v amdgpu.ids > $O/timeline_window_launch.txt
-bash profiles/run_timeline.sh 300 20 -1 2>/dev/null | grep -v amdgpu.ids > $O/timeline_step320.txt
-bash profiles/run_phase_profile.sh 1000 256 2 20 > $O/phase_clocks_k_run_c3_s1000.json 2>/dev/null
+# (the general loop of the plain kernel: the clock stamps are not recorded by the kernel whose teams grow, which long calls get by default)
+SF_DEBUG_KNOBS=1 SF_TUNE_RUN_JOIN=0 bash profiles/run_timeline.sh 300 20 -1 2>/dev/null | grep -v amdgpu.ids > $O/timeline_step320.txt
+SF_DEBUG_KNOBS=1 SF_TUNE_RUN_JOIN=0 bash profiles/run_phase_profile.sh 1000 256 2 20 > $O/phase_clocks_k_run_c3_s1000.json 2>/dev/null
 # what a launch of n updates costs, window phase on and off; SQ counters per window update
 python profiles/window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/window_probe.txt
 bash profiles/win_sq.sh 2>/dev/null | grep -v amdgpu.ids > $O/window_sq_counters.txt
