@@ -42,7 +42,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4", "c5"],
+                    help="default c3 (BASELINE config C3); without it a --gpus N run also reports its ranks' shares of C4 and C5 (`also`)")
+    ap.add_argument("--also-envs", type=int, default=None, help="environments per GPU of the C4 / C5 companions (default: BASELINE's shares, 128 / 64)")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="reset + warm-up + timed K-step rollout repetitions; `value` / `ms_per_step` are the MEDIAN, the spread is config.repeat_spread")
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--rows-per-band", type=int, default=0)
@@ -62,7 +66,11 @@ def parse(argv=None):
     ap.add_argument("--no-rehearsal", action="store_true", help="skip the untimed dress rehearsal of the timed region")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / all-gather plumbing without touching a GPU (CPU test of --gpus N)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    a.workload_given = a.workload is not None
+    a.workload = a.workload or "c3"
+    a.repeats = max(1, a.repeats)
+    return a
 
 
 # ----------------------------------------------------------------------------------- launch
@@ -142,6 +150,15 @@ def run_steps(eng, steps, first_step, agent_pts):
             eng.step_mitigated(agent_pts.block[first_step:first_step + steps])
     finally:
         eng.set_async(False)
+
+
+def profile_file(stem):
+    """The newest committed round's copy of a replayed measurement under profiles/ (r05_<stem>, else r04_<stem>); None if absent."""
+    for rnd in ("r05", "r04"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
+        if os.path.exists(p):
+            return p
+    return None
 
 
 def cpu_model():
@@ -296,8 +313,8 @@ def issue_block(w, a, rl, cost, n_cu=256):
            "clocks_max_env": float(clocks.max()), "clocks_median_env": float(np.median(clocks)),
            "clock_ghz_measured": float(clocks.max() / sec / 1e9),
            "source": "sf_get_run_cost (s_memtime stamps of the timed launch) / HIP-event duration"}
-    p = os.path.join(ROOT, "profiles", f"r04_sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
-    if os.path.exists(p):
+    p = profile_file(f"sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
+    if p:
         with open(p) as f:
             sq = json.load(f)
         # one VALU / SALU issue slot per SIMD every 4 clocks (a SIMD is visited once per 4-clock round); SQ_WAVE_CYCLES and
@@ -308,8 +325,8 @@ def issue_block(w, a, rl, cost, n_cu=256):
         # (counters of a separate rocprofv3 --pmc run of this window, committed under profiles/: replays, not counters of this run)
         rl.setdefault("replayed_from", {}).update({k: os.path.relpath(p, ROOT) for k in
                                                    ("issue.valu_issue_util", "issue.salu_issue_util", "issue.wave_wait_share")})
-    p = os.path.join(ROOT, "profiles", f"r04_phase_clocks_window_{w.name}_s{a.steps}_w{a.warmup}.json")
-    if os.path.exists(p):
+    p = profile_file(f"phase_clocks_window_{w.name}_s{a.steps}_w{a.warmup}.json")
+    if p:
         with open(p) as f:
             ph = json.load(f)
         blk.update({"window_phase_clocks_per_update": ph.get("clocks_per_update"), "phase_source": os.path.relpath(p, ROOT)})
@@ -342,16 +359,17 @@ def random_access_block(traffic, kernel_ms, n_cu=256, clock_ghz=2.4):
             "source": "profiles/r02_scatter_probe.txt (profiles/scatter_probe.hip), profiles/pmc_traffic_*.json"}
 
 
-def side_workload(name, a, device, torch, n_check, tile_cells):
+def side_workload(name, a, device, torch, n_check, tile_cells, env_offset=0, world=1):
     """One GPU's share of another BASELINE config (C4: 128 x 2048^2 with the simplex wind field; C5: 64 x 1024^2 with 64
     agents per environment drawing control lines before every update), measured like the main line - wall time of the
     rollout + result block, kernel time, roofline block - and checked against the oracle on the first n_check environments."""
     from simfire_amd import workloads
-    w = make_workload(name, a.size, None, 0)
+    n_envs = a.also_envs or {"c4": 128, "c5": 64}[name]
+    w = make_workload(name, a.size, n_envs, env_offset * n_envs)
     H, W = w.shape
     agent_pts = None
     if name == "c5":
-        agent_pts = AgentPoints(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup), w.n_envs,
+        agent_pts = AgentPoints(workloads.agent_walk(w.n_envs, w.agents_per_env, H, W, a.steps + a.warmup, env_offset=env_offset * n_envs), w.n_envs,
                                 w.agents_per_env, device)
     eng = make_engine(w, device, a.rows_per_band)
     eng.set_fused(a.fused)
@@ -379,7 +397,7 @@ def side_workload(name, a, device, torch, n_check, tile_cells):
         n_check = min(n_check, w.n_envs)
         sample = sorted(set([0, n_check // 2, n_check - 1]))
         maps = {e: eng.fire_map(e) for e in sample}
-        threads = a.cpu_threads or max(1, min(os.cpu_count() or 1, 32))
+        threads = a.cpu_threads or max(1, min(os.cpu_count() or 1, 32) // world)
         o, ost, _, _ = oracle_rollout(w, eng.get_rtable(), a.steps, a.warmup, threads, agent_pts, n_check)
         verified = bool((block[:n_check] == ost).all()) and all(bool((maps[e] == o.fire_map(e)).all()) for e in sample)
         del o
@@ -401,8 +419,8 @@ def side_workload(name, a, device, torch, n_check, tile_cells):
 
 def load_pmc(w, steps, warmup):
     """PMC traffic of a window, if profiles/collect_pmc.sh has been run for it (one file per window: ..._s<K>_w<W>.json)."""
-    path = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{w.name}_s{steps}_w{warmup}.json")
-    if os.path.exists(path):
+    path = profile_file(f"pmc_traffic_{w.name}_s{steps}_w{warmup}.json")
+    if path:
         with open(path) as f:
             pmc = json.load(f)
         pmc["_file"] = os.path.relpath(path, ROOT)
@@ -507,23 +525,33 @@ def main():
         rollout(a.steps, a.warmup)
         fence()
         eng.reset(w.init_xy)
-    if a.warmup:
-        run_steps(eng, a.warmup, 0, agent_pts)
-    eng.copy_status_to(result.data_ptr())
-    steps_before = result[:, 1].sum().item()
     if dist is not None:
         # untimed warm-up of the one collective of the rollout (communicator set-up, first-use kernel load)
         dist.all_gather_into_tensor(gathered, result.to(coll_dev))
 
-    # ------------------------------------------------------------------ timed region
-    fence()
-    t0 = time.perf_counter()
-    rollout(a.steps, a.warmup)
-    fence()
-    dt = time.perf_counter() - t0
+    # ------------------------------------------------------------------ timed region, `repeats` times from scratch:
+    # reset -> W untimed warm-up updates -> fence -> EXACTLY K updates + the result block (+ the all-gather) -> fence.
+    # `value` / `ms_per_step` come from the MEDIAN repetition (max over ranks per repetition first); every repetition's
+    # result block must be the same block (the episodes are deterministic) - the one the oracle is checked against below.
+    dts, blocks, esteps = [], [], []
+    for _ in range(a.repeats):
+        eng.reset(w.init_xy)
+        if a.warmup:
+            run_steps(eng, a.warmup, 0, agent_pts)
+        eng.copy_status_to(result.data_ptr())
+        steps_before = result[:, 1].sum().item()
+        fence()
+        t0 = time.perf_counter()
+        rollout(a.steps, a.warmup)
+        fence()
+        dts.append(time.perf_counter() - t0)
+        esteps.append(result[:, 1].sum().item() - steps_before)      # update() calls really made
+        blocks.append(result.cpu().numpy())
     # ---------------------------------------------------------------------------------
-    env_steps = result[:, 1].sum().item() - steps_before      # update() calls really made
-    local_block = result.cpu().numpy()
+    repeats_identical = all((b == blocks[0]).all() for b in blocks) and len(set(esteps)) == 1
+    env_steps = esteps[-1]
+    local_block = blocks[-1]
+    dts = np.asarray(dts, dtype=np.float64)
 
     # ---- outside the timed region: check the rollout that was just timed against the oracle.  A one-GPU run
     # checks every environment (and times the oracle: cpu_baseline); in a multi-rank run every rank checks the
@@ -548,17 +576,20 @@ def main():
                 cpu_base["reference_python"] = ref
         del o
 
+    if verified is not None:
+        verified = verified and repeats_identical
     if dist is not None:
-        red = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device=coll_dev)
-        tmax = red[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = red[1:].clone()
+        tmax = torch.tensor(dts, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)             # per repetition: the slowest rank
+        tot = torch.tensor([float(env_steps)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt, env_steps = float(tmax.item()), float(tot.item())
+        dts, env_steps = tmax.cpu().numpy(), float(tot.item())
+        v = torch.tensor([1 if verified else 0, 1 if repeats_identical else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        repeats_identical = bool(v[1].item())
         if verified is not None:
-            v = torch.tensor([1 if verified else 0], dtype=torch.int32, device=coll_dev)
-            dist.all_reduce(v, op=dist.ReduceOp.MIN)
-            verified = bool(v.item())
+            verified = bool(v[0].item())
+    dt = float(np.median(dts))
     res = gathered.cpu().numpy()
 
     # kernel time and work of the timed window, on EVERY rank (a replay of the same deterministic rollout with HIP events around the
@@ -573,6 +604,28 @@ def main():
         allr = torch.zeros(world * 3, dtype=torch.float64, device=coll_dev)
         dist.all_gather_into_tensor(allr, mine)
         per_rank = allr.cpu().numpy().reshape(world, 3)
+    side = {}
+    if world > 1 and not a.no_extra and not a.workload_given:
+        # `--gpus N` without --workload: every rank also runs its share of BASELINE configs C4 (128 environments of 2048^2 per GPU, simplex
+        # wind) and C5 (64 environments with 64 agents each per GPU), each rank on its own ignition seeds / walks, checked against the oracle on
+        # a sample; the per-rank figures are gathered like the main line's (no data-path collective: the shards are independent)
+        eng.close()
+        saved = (measure.last_cost, measure.last_teams, measure.last_launches)      # (the main line's launch: issue_block below reads them)
+        for name in ("c4", "c5"):
+            mine = side_workload(name, a, device, torch, 8, tile_cells, env_offset=rank, world=world)
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            Hs, Ws = every[0]["grid"]
+            slowest = max(r["ms_per_step"] for r in every)
+            side[name if name == "c5" else "c4"] = {
+                "workload": every[0]["workload"], "grid": every[0]["grid"], "envs_per_gpu": every[0]["envs_per_gpu"], "envs_total": every[0]["envs_per_gpu"] * world,
+                "agents_per_env": every[0]["agents_per_env"], "n_gpus": world, "scaling": "weak",
+                "value": Hs * Ws * sum(r["env_steps_executed"] for r in every) / (slowest * 1e-3 * a.steps), "unit": "cell-updates/s",
+                "ms_per_step": slowest, "verified": (None if any(r["verified"] is None for r in every) else all(r["verified"] for r in every)),
+                "per_rank_ms_per_step": [r["ms_per_step"] for r in every], "per_rank_kernel_ms_per_step": [r["kernel_ms_per_step"] for r in every],
+                "per_rank_gbs": [r["roofline"]["achieved"] for r in every], "per_rank_frac": [r["roofline"]["frac"] for r in every],
+                "aggregate_gbs": float(sum(r["roofline"]["achieved"] for r in every)), "roofline_rank0": every[0]["roofline"]}
+        measure.last_cost, measure.last_teams, measure.last_launches = saved
     if rank == 0:
         out = {
             "metric": "cell-updates/sec (grid x envs x steps)",
@@ -584,7 +637,7 @@ def main():
             "ms_per_step": dt * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 status + u8 sprite masks + f64 burn_amounts", "data": "synthetic",
-            "verified": verified, "rehearsal": not a.no_rehearsal,
+            "verified": verified, "rehearsal": not a.no_rehearsal, "repeats": a.repeats,
             "verification": (None if verified is None else
                              f"result block (running, steps, cells per BurnStatus) of {n_check} environments per rank + fire "
                              "maps of 3 of them after the timed rollout == oracle/fire_dense.c on the same inputs, bit for bit"),
@@ -597,7 +650,13 @@ def main():
                        "collective_backend": (None if world == 1 else a.backend),
                        "env_steps_executed": env_steps, "env_steps_requested": w.n_envs * world * a.steps,
                        "envs_running_at_end": int(res[:, 0].sum()),
-                       "burned_cells_total": int(res[:, 4].sum())},
+                       "burned_cells_total": int(res[:, 4].sum()),
+                       # the timed region was run `repeats` times from a reset; `value` / `ms_per_step` are the median repetition
+                       "repeat_spread": {"n": a.repeats, "statistic": "median", "ms_per_step_min": float(dts.min()) * 1e3 / a.steps,
+                                         "ms_per_step_max": float(dts.max()) * 1e3 / a.steps,
+                                         "rel_min": float(dts.min() / dt - 1.0), "rel_max": float(dts.max() / dt - 1.0),
+                                         "ms_per_step_all": [float(x) * 1e3 / a.steps for x in dts],
+                                         "result_blocks_identical": repeats_identical}},
             "roofline": rl_local,
         }
         if per_rank is not None:
@@ -644,6 +703,10 @@ def main():
             also["cold"] = {"value": H * W * esc / dtc, "unit": "cell-updates/s", "ms_per_step": dtc * 1e3 / a.steps, "rehearsal": False,
                             "ignition_seeds": "1234 + 100000 + e (the headline: 1234 + e)", "env_steps_executed": esc,
                             "note": "first and only run of these episodes in this process: caches cold for their cells"}
+            # (the honest companion of the rehearsed headline: also where the driver's record keeps it)
+            out["config"]["cold_value"] = also["cold"]["value"]
+            out["config"]["cold_ms_per_step"] = also["cold"]["ms_per_step"]
+            out["config"]["cold_note"] = "same batch, fresh ignition seeds (1234 + 100000 + e), nothing rehearsed, one run: " + also["cold"]["note"]
             if a.steps != 1000:
                 # the long window (the builder's default line: 1000 updates after 20): large fires, CU balance; checked on 16 environments
                 al = argparse.Namespace(**vars(a))
@@ -654,16 +717,19 @@ def main():
                     eng.reset(w.init_xy)
                     run_steps(eng, al.warmup, 0, None)
                     rollout(al.steps, al.warmup)
-                eng.reset(w.init_xy)
-                run_steps(eng, al.warmup, 0, None)
-                eng.copy_status_to(result.data_ptr())
-                l0 = result[:, 1].sum().item()
-                fence()
-                t0l = time.perf_counter()
-                rollout(al.steps, al.warmup)
-                fence()
-                dtl = time.perf_counter() - t0l
-                esl_ = result[:, 1].sum().item() - l0
+                dtls = []
+                for _ in range(3):
+                    eng.reset(w.init_xy)
+                    run_steps(eng, al.warmup, 0, None)
+                    eng.copy_status_to(result.data_ptr())
+                    l0 = result[:, 1].sum().item()
+                    fence()
+                    t0l = time.perf_counter()
+                    rollout(al.steps, al.warmup)
+                    fence()
+                    dtls.append(time.perf_counter() - t0l)
+                    esl_ = result[:, 1].sum().item() - l0
+                dtl = float(np.median(dtls))
                 blk_l = result.cpu().numpy()
                 ver_l = None
                 if not a.no_cpu_baseline:
@@ -684,6 +750,14 @@ def main():
                                    "roofline": {k: rll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "replayed_from", "kernel", "launches",
                                                                     "launch_ms", "kernel_ms_per_step", "cells_swept_per_step", "active_cell_updates_per_step",
                                                                     "algorithmic_bytes_per_launch", "issue") if k in rll}}
+                tr = rll.get("traffic")
+                out["roofline"]["long_window"] = {
+                    "steps": al.steps, "warmup": al.warmup, "value": also["c3_long"]["value"], "ms_per_step": also["c3_long"]["ms_per_step"],
+                    "repeats": 3, "ms_per_step_all": [float(x) * 1e3 / al.steps for x in dtls], "kernel_ms_per_step": rll["kernel_ms_per_step"],
+                    "frac": rll["frac"], "achieved": rll["achieved"], "kernel": rll["kernel"], "verified": ver_l,
+                    "traffic": tr, "traffic_over_algorithmic": (tr / (rll["algorithmic_bytes_per_launch"] * rll["launches"]) if tr else None),
+                    "replayed_from": rll.get("replayed_from"),
+                    "note": "1000 updates after 20 on the same batch: fires of hundreds of cells, the general loop + teams that grow inside the launch"}
             # the throughput regime: same workload, 4 x the batch (256 environments do not fill the chip)
             eng.close()
             big = make_workload("c3", a.size, 4 * w.n_envs, 0)
@@ -715,6 +789,8 @@ def main():
             also["c4_share"] = side_workload("c4", a, device, torch, 16, tile_cells)
             also["c5"] = side_workload("c5", a, device, torch, 32, tile_cells)
             out["also"] = also
+        if side:
+            out["also"] = side
         if world > 1:
             # the all-gathered block really holds every rank's rows (rank r's environments report their own ignition seeds' fires)
             out["ranks_seen_by_collective"] = int(sum(1 for r in range(world) if res[r * w.n_envs:(r + 1) * w.n_envs, 1].max() > 0))

@@ -211,7 +211,7 @@ int sf_compute_ros(int64_t n, const float *loc_x, const float *loc_y, const floa
                    const float *new_loc_y, const float *w_0, const float *delta, const float *M_x,
                    const float *sigma, const float *h, const float *S_T, const float *S_e,
                    const float *p_p, const float *M_f, const float *U, const float *U_dir,
-                   const float *slope_mag, const float *slope_dir, double *R_out, int32_t device); /* tuning knob of the step kernel */
+                   const float *slope_mag, const float *slope_dir, double *R_out, int32_t device);
 /* Overwrite the ignition threshold only (the reference's tests assign manager.pixel_scale after
  * construction, test_fire.py:334; slopes keep the constructor value, fire.py:377). */
 int sf_set_threshold(sf_sim *sim, double pixel_scale);

@@ -18,9 +18,10 @@ int sf_step_timed(sf_sim *sim, int32_t n_steps, float *ms_out);
 /* Introspection for benchmarks: out[0] = active cell-updates (cells whose burn_amounts were
  * read+written: candidates and attenuated line cells), out[1] = ignitions, out[2] = cells handed
  * to the frontier phase, out[3] = wavefronts that survived the quick reject, out[4] = frontier
- * walks (row iterations with a non-empty work list), out[5..7] = 0; summed over all steps since the
- * last reset of the counters. */
-int sf_get_counters(sf_sim *sim, int64_t *out /* [8] */, int32_t reset);
+ * walks (row iterations with a non-empty work list), out[5] = 16-cell vectors visited, out[6] / out[7] = k_front's records / sprite
+ * events or the team kernels' step boundaries (| those through one L2 << 32) / their clocks, out[8] = updates made in the window
+ * phase, out[9..15] = 0; summed over all steps since the last reset of the counters. */
+int sf_get_counters(sf_sim *sim, int64_t *out /* [16] */, int32_t reset);
 /* The statistics cost a few atomics per active wavefront, so they are off by default. */
 int sf_enable_counters(sf_sim *sim, int32_t on);
 /* launch geometry: out[0..7] = wave-tile width and height in cells, tiles per environment in x and

@@ -22,6 +22,9 @@ class _Params(C.Structure):
 
 
 def build(force=False):
+    # SF_ORACLE_LIB: another build of the same source (tests/run_asan.sh: the -fsanitize=address,undefined one, `make -C oracle asan`)
+    if os.environ.get("SF_ORACLE_LIB"):
+        return os.environ["SF_ORACLE_LIB"]
     so = os.path.join(_HERE, "libfire_oracle.so")
     src = os.path.join(_HERE, "fire_dense.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

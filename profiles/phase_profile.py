@@ -28,7 +28,7 @@ def main():
     eng.reset(w.init_xy)
     eng.step(100)
     eng.enable_counters(True)
-    out = np.zeros(8, dtype=np.int64)
+    out = np.zeros(16, dtype=np.int64)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
     ms = eng.step_timed(steps)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))

@@ -38,7 +38,7 @@ def main():
     else:
         eng.step(warm)
     eng.enable_counters(True)
-    out = np.zeros(8, dtype=np.int64)
+    out = np.zeros(16, dtype=np.int64)
     _lib.check(eng._L.sf_get_counters(eng._h, out.ctypes.data_as(_lib.C.c_void_p), 1))
     fn = eng._L.sf_debug_wave_log
     fn.argtypes = [ctypes.c_int32, ctypes.c_void_p]

@@ -15,8 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
-def source_hash():
-    """sha256 over every source the library is built from + the flags (what a `.srchash` file beside a built library records)."""
+def source_hash(extra=()):
+    """sha256 over every source the library is built from, the flags of THIS target (base + the variant's extra ones) and the
+    compiler's version (what a `.srchash` file beside a built library records)."""
     import hashlib
     h = hashlib.sha256()
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
@@ -28,17 +29,19 @@ def source_hash():
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(list(FLAGS) + list(extra)).encode())
+    h.update(hipcc_version().encode())
     return h.hexdigest()
 
 
-def needs_build(out=OUT):
-    """True unless `out` exists and was built from exactly these sources (a hash stored beside it, not modification times)."""
+def needs_build(out=OUT, extra=()):
+    """True unless `out` exists and was built from exactly these sources with exactly these flags by this compiler (a hash stored
+    beside it, not modification times)."""
     if os.environ.get("SF_FORCE_BUILD") == "1" or not os.path.exists(out):
         return True
     try:
         with open(out + ".srchash") as f:
-            return f.read().strip() != source_hash()
+            return f.read().strip() != source_hash(extra)
     except OSError:
         return True
 
@@ -75,7 +78,7 @@ def build(force=False, verbose=False, variants=(), jobs=None):
     if force or needs_build(OUT):
         targets.append((OUT, ()))
     for v in variants:
-        if force or needs_build(variant_out(v)):
+        if force or needs_build(variant_out(v), VARIANT_FLAGS[v]):
             targets.append((variant_out(v), VARIANT_FLAGS[v]))
     plans = [_compile_cmds(out, extra) for out, extra in targets]
     jobs = jobs or max(1, min(os.cpu_count() or 1, 8))
@@ -95,13 +98,14 @@ def build(force=False, verbose=False, variants=(), jobs=None):
                 failed = (p.returncode, cmd)
         if failed is not None:
             raise subprocess.CalledProcessError(*failed)
-        h = source_hash()
-        for (out, _), (_, link, _) in zip(targets, plans):
+        for (out, extra), (_, link, _) in zip(targets, plans):
             if verbose:
                 print(" ".join(link))
+            if os.path.exists(out + ".srchash"):
+                os.remove(out + ".srchash")                     # (a failed link must not leave the old library looking current)
             subprocess.check_call(link)
             with open(out + ".srchash", "w") as f:
-                f.write(h + "\n")
+                f.write(source_hash(extra) + "\n")
     finally:
         for _, p in running:
             p.kill()
@@ -110,6 +114,9 @@ def build(force=False, verbose=False, variants=(), jobs=None):
             for o in objs:
                 if os.path.exists(o):
                     os.remove(o)
+        for f in os.listdir(CSRC):                              # hipcc's temporaries of an interrupted compile
+            if f.startswith(".lib") and f.endswith(".tmp"):
+                os.remove(os.path.join(CSRC, f))
     return OUT
 
 

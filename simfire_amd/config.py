@@ -309,9 +309,24 @@ class Config:
             direction = y["simple"]["direction"]
             return WindConfig(np.full((H, W), speed).astype(np.float64),
                               np.full((H, W), direction).astype(np.float64))
-        if name in ("perlin", "cfd"):
-            raise ConfigError(f"`{name}` wind needs the third-party `noise` package / a CFD pre-computation; pass the "
-                              "wind fields through Config.from_arrays instead")
+        if name == "perlin":
+            # config.py:892-929 (WindController.init_wind_speed_generator / init_wind_direction_generator, perlin_wind.py:83-98): the speed
+            # range is converted to ft/min BEFORE the map is made, the maps are float32 and widened afterwards (config.py:943-944).
+            # The reference draws the noise with the third-party `noise` wheel (snoise2), which is not available offline and whose
+            # output the reference pins nowhere for wind: the fields come from this build's own 2-D simplex generator
+            # (workloads.simplex_field) with the same parameters - generator parity UNPINNED, the field is an input.
+            from .workloads import simplex_field
+            ps, pd = dict(y["perlin"]["speed"]), dict(y["perlin"]["direction"])
+            try:
+                sp = simplex_field(H, W, ps["seed"], ps["scale"], ps["octaves"], ps["persistence"], ps["lacunarity"],
+                                   mph_to_ftpm(ps["range_min"]), mph_to_ftpm(ps["range_max"]))
+                dr = simplex_field(H, W, pd["seed"], pd["scale"], pd["octaves"], pd["persistence"], pd["lacunarity"],
+                                   pd["range_min"], pd["range_max"])
+            except KeyError as err:
+                raise ConfigError(f"wind.perlin is missing the parameter {err}") from None
+            return WindConfig(sp.astype(np.float64), dr.astype(np.float64), FunctionalConfig("perlin", ps), FunctionalConfig("perlin", pd))
+        if name == "cfd":
+            raise ConfigError("`cfd` wind needs a CFD pre-computation; pass the wind fields through Config.from_arrays instead")
         raise ConfigError(f"Wind type {name} is not supported")
 
     # ---------------------------------------------------------------------- re-seeding
@@ -336,6 +351,9 @@ class Config:
 
     def reset_wind(self, speed_seed: Optional[int] = None, direction_seed: Optional[int] = None) -> None:
         """config.py:1048-1086 (only generated wind functions have seeds; `simple` has none)."""
+        for seed, fn, key in ((speed_seed, self.wind.speed_function, "speed"), (direction_seed, self.wind.direction_function, "direction")):
+            if seed is not None and fn is not None and "seed" in (self.yaml_data["wind"].get(fn.name, {}).get(key) or {}):
+                self.yaml_data["wind"][fn.name][key]["seed"] = seed
         self.wind = self._load_wind()
 
     def reset_fire(self, seed: Optional[int] = None, pos: Optional[Tuple[int, int]] = None) -> None:

@@ -22,6 +22,7 @@ constexpr int kWaves = SF_WAVES_PER_GROUP;   // waves per k_step workgroup (each
 constexpr int kListCap = 384;        // frontier cells per walk window (u16 entries in LDS); larger frontiers take several windows
 constexpr int kSeamPad = 8;          // row y of a seam column sits at index y + kSeamPad (zero guard, keeps 8-byte loads aligned)
 constexpr int kCounterShards = 256; // statistics are sharded over cache lines (atomics serialise per address)
+constexpr int kCounterRow = 16;     // slots per shard: 0..7 as sf_get_counters documents them, 8 = updates made in the window phase, 9.. free
 constexpr uint32_t FLAG_LIVE = 1u; // some sprite survives the prune            (fire.py:637)
 constexpr uint32_t FLAG_CAND = 0x100u; // (own byte of the flag word, so the tiled kernels can set it with a plain byte store)
 // some sprite has a cell to spread into     (fire.py:651)
@@ -90,7 +91,7 @@ struct StepArgs {
     EnvState *commit;    // [E]   state between API calls
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)
     uint32_t *flags;     // [3][E] ring
-    unsigned long long *counters;   // [kCounterShards][8]: active cell-updates, ignitions, frontier items; null = off
+    unsigned long long *counters;   // [kCounterShards][kCounterRow]: active cell-updates, ignitions, frontier items; null = off
     uint8_t *tflags;     // [2][E][TYp][TXp] tile activity maps: bit0 = tile holds sprites, bits 2-5 = on its top / bottom / left / right edge
     int ring;            // map read by this step (0/1); the other one is rebuilt for the next step
     uint32_t *tile_list; // [E * TY * TX] wave tiles to visit in this step (written by k_select)

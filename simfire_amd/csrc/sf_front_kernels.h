@@ -786,7 +786,7 @@ __global__ __launch_bounds__(1024) void k_front(StepArgs a, int n_steps, int RC,
         if (left > 0) atomicOr(reinterpret_cast<uint32_t *>(ovf_host), 0x100u | ctl[FC_OVF] | (ctl[FC_MULTI] ? 0x20u : 0u));       // (host memory: system-scope atomic)
     }
     if (a.counters && lane == 0) {
-        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
+        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
         if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
         if (n_rec) atomicAdd(&cs[6], (unsigned long long)n_rec);         // frontier records visited

@@ -475,8 +475,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         wpc.note(30);        // launch: state read
         s_begin = run_window<ATT, kWinGen, kWinMit>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result,
                                                     kWinMit ? mit : nullptr, n_steps, &px, &py, &pty, vlist, vcap >= 1024 ? 15 : 11);      // (the duplicate filter's bits in the list's LDS: 4 KB, or 256 bytes on small grids)
-        if (a.counters && tid == 0 && s_begin)           // (statistics slot 6 of the plain kernel: updates made inside a window)
-            atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * 8 + 6, (unsigned long long)s_begin);
+        if (a.counters && tid == 0 && s_begin)           // (statistics slot 8: updates made inside a window - a slot of its own, whatever the instantiation)
+            atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * kCounterRow + 8, (unsigned long long)s_begin);
     }
     if (TEAM == 2 && j_s0 >= 0) s_begin = j_s0;          // a workgroup that joins: the team's next update (st: what member 0 left in commit[] at the cut)
     const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && (st.running || mit));       // (uniform) the bitmaps in LDS, the loop over the vector list
@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
             }
     }
     if (a.counters && lane == 0) {
-        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
+        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
         if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
         if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);

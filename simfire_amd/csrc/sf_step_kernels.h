@@ -687,7 +687,7 @@ __global__ __launch_bounds__(kWaves * 64, (RB <= 2 ? SF_WAVES_SMALL_TILES : SF_W
     // optional statistics for the roofline accounting (active cell-updates = phi * cells)
     if (a.counters && n_tiles_done) {
         if (lane == 0) {
-            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * kCounterRow;
 #ifndef SF_PHASES
             if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
             if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(kWaves * 64, SF_WAVES_PER_SIMD) void k_step_fused(S
                   n_active, n_ignite, n_items_acc, n_phase2, pc);
     if (a.counters) {
         if (lane == 0) {
-            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * 8;
+            unsigned long long *cs = a.counters + (size_t)(blockIdx.x & (kCounterShards - 1)) * kCounterRow;
             if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
             if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
             if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run_tiles(StepArgs a
         f_glob[o] = fcur[o];
     }
     if (a.counters && n_tiles_done && lane == 0) {
-        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * 8;
+        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
 #ifndef SF_PHASES
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
         if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256) void k_step_cells(StepArgs a)
             bn = bn + ros;                                                          // fire.py:710
             if (bn > g.pixel_scale) { st_new = SF_BURNING; age_new |= mk.b_new; }   // fire.py:568-587
             a.burn[cell] = bn;
-            if (a.counters) atomicAdd(&a.counters[(size_t)(blockIdx.x & (kCounterShards - 1)) * 8], 1ull);
+            if (a.counters) atomicAdd(&a.counters[(size_t)(blockIdx.x & (kCounterShards - 1)) * kCounterRow], 1ull);
         }
         if (st_new != sraw) a.status[cell] = (uint8_t)st_new;
         if (age_new != own) age_e[o] = (AgeT)age_new;

@@ -359,7 +359,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->commit, (size_t)g.E));
     TRY(dev_alloc(s, &s->tmp, (size_t)2 * g.E));
     TRY(dev_alloc(s, &s->flags, (size_t)3 * g.E));
-    TRY(dev_alloc(s, &s->counters, (size_t)kCounterShards * 8));
+    TRY(dev_alloc(s, &s->counters, (size_t)kCounterShards * kCounterRow));
     s->tflags_bytes = (size_t)2 * g.E * ((size_t)(g.H + g.LR - 1) / g.LR + 2) * (g.chunks_x + 2) + 64;
     TRY(dev_alloc(s, &s->tflags, s->tflags_bytes));
     // + 64: every wave of k_step requests its first list entry before it knows the list length
@@ -395,7 +395,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRYHIP(hipMemsetAsync(s->seam, 0, (size_t)g.E * g.seam_env, s->stream));
     TRYHIP(hipMemsetAsync(s->vbits, 0, (size_t)3 * g.E * g.vb_env * sizeof(unsigned long long), s->stream));
     if (s->settled) TRYHIP(hipMemsetAsync(s->settled, 0, cells * sizeof(uint32_t), s->stream));
-    TRYHIP(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * 8, s->stream));
+    TRYHIP(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * kCounterShards * kCounterRow, s->stream));
     TRYHIP(hipMemsetAsync(s->commit, 0, sizeof(EnvState) * g.E, s->stream));
     TRYHIP(hipMemsetAsync(s->age_alloc, 0, ((size_t)g.E * g.age_env + 2 * (size_t)g.P) * g.ab, s->stream));
     TRYHIP(hipMemsetAsync(s->status, 0, cells, s->stream));
@@ -2144,11 +2144,11 @@ extern "C" int sf_get_counters(sf_sim *s, int64_t *out, int32_t reset)
     if (!s || !out) return fail(SF_EINVAL, "sf_get_counters: null argument");
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     HIPCHK(hipStreamSynchronize(s->stream));
-    std::vector<unsigned long long> h((size_t)kCounterShards * 8);
+    std::vector<unsigned long long> h((size_t)kCounterShards * kCounterRow);
     HIPCHK(hipMemcpy(h.data(), s->counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int k = 0; k < kCounterRow; ++k) out[k] = 0;
     for (int i = 0; i < kCounterShards; ++i)
-        for (int k = 0; k < 8; ++k) out[k] += (int64_t)h[(size_t)i * 8 + k];
+        for (int k = 0; k < kCounterRow; ++k) out[k] += (int64_t)h[(size_t)i * kCounterRow + k];
     if (reset) HIPCHK(hipMemset(s->counters, 0, h.size() * sizeof(unsigned long long)));
     return SF_OK;
 }

@@ -469,12 +469,12 @@ class FireEngine:
 
     def counters(self, reset=False):
         """dict(active_cell_updates, ignitions, frontier_items) summed since the last reset."""
-        out = np.zeros(8, dtype=np.int64)
+        out = np.zeros(16, dtype=np.int64)
         self._chk(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
         return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
                     active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]),
                     records=int(out[6]), sprite_events=int(out[7]),
-                    window_updates=int(out[6]))      # (slot 6 of the plain k_run: updates made in the window phase)
+                    window_updates=int(out[8]))
 
     def update_status_device(self):
         self._chk(self._L.sf_update_status_device(self._h))

@@ -75,22 +75,27 @@ _SHARED_FIELDS = (("area", "screen_size"), ("area", "pixel_scale"), ("fire", "ma
                   ("mitigation", "ros_attenuation"), ("environment", "moisture"))
 
 
+def _hash_bytes(buf) -> int:
+    """64-bit content hash of a contiguous buffer: xxh3 where the wheel is importable (~10 GB/s), zlib.crc32 otherwise."""
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(buf)
+    except ImportError:                                                           # pragma: no cover
+        import zlib
+        return zlib.crc32(buf)
+
+
 def _fingerprint(a) -> int:
-    """Content fingerprint of a layer for ``FireSimulation.reset``'s "did anything change" test."""
-    import zlib
+    """Content fingerprint of a layer for ``FireSimulation.reset``'s "did anything change" test: EVERY element takes part
+    (the reference's reset() rebuilds terrain and fire manager unconditionally, simulation.py:202-214, so an in-place edit
+    of a single cell must rebuild the device handle here)."""
     if a is None:
         return 0
     a = np.asarray(a)
     if a.dtype != object:
-        # shape, dtype and a strided sample of ~64 K elements (crc32 of a full 1024^2 f64 plane is ~5 ms, five planes per reset -
-        # the device-side sf_reset it guards takes microseconds): catches wholesale edits such as ``wind.speed[...] = x``; after
-        # editing single elements in place call ``invalidate_layers()``
-        flat = a.reshape(-1)
-        step = max(1, flat.size // 65536)
-        return zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8).reshape(-1)) ^ hash((a.shape, str(a.dtype)))
-    flat = a.reshape(-1)
-    step = max(1, flat.size // 4096)
-    return hash(tuple((f.w_0, f.delta, f.M_x, f.sigma) for f in flat[::step]))
+        flat = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+        return _hash_bytes(flat) ^ hash((a.shape, str(a.dtype)))
+    return hash(tuple((f.w_0, f.delta, f.M_x, f.sigma) for f in a.reshape(-1)))
 
 
 class FireSimulation:
@@ -109,13 +114,15 @@ class FireSimulation:
         cfg = self.config
         # The device handle (layers in HBM, R table) is rebuilt only if something it was built from changed:
         # an RL harness that calls reset() per episode with a new ignition pays one sf_reset, not k_rtable again.
-        # "Changed" = another object OR other contents: every layer is fingerprinted by its shape, dtype and a strided sample of
-        # its elements (~0.3 ms per reset at 1024^2), so a wholesale in-place edit such as ``config.wind.speed[...] = x`` rebuilds
-        # the handle like the reference's reset() rebuilds its terrain and fire manager (simulation.py:202-214); after editing
-        # single elements in place call ``invalidate_layers()``.
+        # "Changed" = another object OR other contents: every layer is fingerprinted over ALL of its elements (a few ms per
+        # reset at 1024^2), so any in-place edit - one cell of ``config.wind.speed`` included - rebuilds the handle like the
+        # reference's reset() rebuilds its terrain and fire manager (simulation.py:202-214).  A harness that never edits its
+        # layers in place can set ``sim.assume_layers_immutable = True``: then only object identity and the scalars are compared.
         key_objs = (cfg.terrain.fuel_layer.data, cfg.terrain.topography_layer.data, cfg.wind.speed, cfg.wind.direction,
                     getattr(cfg, "fuel_codes", None))
-        key_vals = tuple(getattr(getattr(cfg, a), b) for a, b in _SHARED_FIELDS) + tuple(_fingerprint(o) for o in key_objs)
+        key_vals = tuple(getattr(getattr(cfg, a), b) for a, b in _SHARED_FIELDS)
+        if not getattr(self, "assume_layers_immutable", False):
+            key_vals += tuple(_fingerprint(o) for o in key_objs)
         prev = getattr(self, "_engine_key", None)
         if (prev is None or len(prev[0]) != len(key_objs) or any(a is not b for a, b in zip(prev[0], key_objs))
                 or prev[1] != key_vals):

@@ -783,6 +783,36 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(workload):
     assert abs(sum(rl["per_rank_gbs"]) - rl["aggregate_gbs"]) <= 1e-6 * rl["aggregate_gbs"]
 
 
+def test_bench_eight_ranks_without_workload_also_report_their_shares_of_c4_and_c5():
+    """`--gpus 8` without --workload (what the driver's SCALE run issues): beside the C3 line every rank runs its share of C4 and C5 - own
+    ignition seeds / agent walks per rank, checked against the oracle -, and the line carries them under `also` with every rank's
+    roofline (VERDICT r4 #9).  Tiny grids / batches here: --size 128, --also-envs 3."""
+    j = _bench("--gpus", 8, "--backend", "gloo", "--size", 128, "--envs", 3, "--also-envs", 3, "--steps", 14, "--warmup", 3, "--cpu-threads", 2,
+               "--repeats", 3)
+    assert j["n_gpus"] == 8 and j["verified"] is True and j["config"]["workload"].startswith("c3")
+    for name, prefix in (("c4", "c4_"), ("c5", "c5_")):
+        blk = j["also"][name]
+        assert blk["workload"].startswith(prefix) and blk["n_gpus"] == 8 and blk["envs_total"] == 24 and blk["verified"] is True
+        assert len(blk["per_rank_gbs"]) == 8 and all(v > 0 for v in blk["per_rank_gbs"]) and blk["value"] > 0
+        assert abs(sum(blk["per_rank_gbs"]) - blk["aggregate_gbs"]) <= 1e-6 * blk["aggregate_gbs"]
+    assert j["also"]["c5"]["agents_per_env"] == 64
+
+
+def test_bench_line_is_the_median_of_repeated_resets_and_rollouts():
+    """The timed region is run `repeats` times from a reset; `value` / `ms_per_step` are the median repetition, the spread and the
+    honest companions (fresh ignitions without rehearsal; the 1000-update window) sit in `config` / `roofline`, where the driver's record
+    keeps them (VERDICT r4 #4)."""
+    j = _bench("--size", 256, "--envs", 16, "--steps", 20, "--warmup", 5, "--repeats", 5, "--cpu-threads", 8)
+    sp = j["config"]["repeat_spread"]
+    assert j["repeats"] == 5 and sp["n"] == 5 and len(sp["ms_per_step_all"]) == 5 and sp["result_blocks_identical"] is True
+    assert sp["ms_per_step_min"] <= j["ms_per_step"] <= sp["ms_per_step_max"]
+    assert sorted(sp["ms_per_step_all"])[2] == pytest.approx(j["ms_per_step"], rel=1e-12)
+    assert j["verified"] is True
+    assert j["config"]["cold_value"] > 0 and j["config"]["cold_ms_per_step"] > 0
+    lw = j["roofline"]["long_window"]
+    assert lw["steps"] == 1000 and lw["value"] > 0 and 0 < lw["frac"] < 1 and lw["verified"] is True
+
+
 # ------------------------------------------------------------------ closed loop: one step per call on a resident launch
 @pytest.mark.parametrize("att", [False, True])
 def test_closed_loop_steps_equal_update_mitigation_run_pairs(att):

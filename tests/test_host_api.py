@@ -426,6 +426,18 @@ def test_reset_reuses_the_handle_only_while_nothing_changed(extra, tmp_path):
     a, _ = sim.run(15)
     b, _ = ref2.run(15)
     assert (a == b).all() and not (a == m1).all()
+    # ... of ONE cell (a strided sample of the plane missed it)
+    eng2 = sim._engine
+    sim.config.wind.speed[5, 3] += 1.0
+    sim.reset()
+    assert sim._engine is not eng2
+    # opt-out for harnesses that never edit their layers in place: identity + scalars only
+    sim.assume_layers_immutable = True
+    sim.reset()
+    eng3 = sim._engine
+    sim.config.wind.speed[5, 3] += 1.0
+    sim.reset()
+    assert sim._engine is eng3
 
 
 def test_save_data_bad_type_raises_before_anything_is_stepped(tmp_path):

@@ -41,9 +41,23 @@ def test_config_flat_simple():
 def test_config_gaussian_and_errors():
     from simfire_amd.config import Config, ConfigError
     import yaml
-    with pytest.raises(ConfigError):           # this fixture asks for perlin wind (needs `noise`)
-        Config(os.path.join(CFG, "test_config_gaussian.yml"))
+    # this fixture asks for perlin wind: the fields come from the build's own simplex generator with the fixture's parameters
+    # (config.py:892-929; generator parity unpinned - the `noise` wheel is absent and the reference pins no wind value)
+    cp = Config(os.path.join(CFG, "test_config_gaussian.yml"))
     g = yaml.safe_load(open(os.path.join(CFG, "test_config_gaussian.yml")))
+    ps, pd = g["wind"]["perlin"]["speed"], g["wind"]["perlin"]["direction"]
+    assert cp.wind.speed.dtype == np.float64 and cp.wind.speed.shape == cp.area.screen_size == cp.wind.direction.shape
+    assert cp.wind.speed.min() >= ps["range_min"] * 88.0 - 1e-3 and cp.wind.speed.max() <= ps["range_max"] * 88.0 + 1e-3 and cp.wind.speed.std() > 0
+    assert cp.wind.direction.min() >= pd["range_min"] and cp.wind.direction.max() <= pd["range_max"]      # the reference's own test is this range check (test_wind.py:27-37)
+    assert cp.wind.speed_function.name == "perlin" and cp.wind.speed_function.kwargs["seed"] == ps["seed"]
+    before = cp.wind.speed.copy()
+    cp.reset_wind(speed_seed=ps["seed"] + 1)                   # config.py:1048-1086
+    assert cp.yaml_data["wind"]["perlin"]["speed"]["seed"] == ps["seed"] + 1 and not (cp.wind.speed == before).all()
+    cp.reset_wind(speed_seed=ps["seed"])
+    assert (cp.wind.speed == before).all()                     # deterministic in the seed
+    g["wind"]["function"] = "cfd"
+    with pytest.raises(ConfigError):
+        Config(config_dict=g)
     g["wind"]["function"] = "simple"
     c = Config(config_dict=g)
     H, W = c.area.screen_size
@@ -267,3 +281,19 @@ def test_savedata_writer_against_the_reference_run(tmp_path, data_type):
             assert (np.array(json.load(open(tmp_path / f"{n}.json"))["data"]) == static[n]).all()
     with pytest.raises(ValueError):
         write_history(tmp_path, "csv", hist[:1], 12, static, meta)
+
+
+def test_layer_fingerprint_sees_every_element():
+    """the change test of FireSimulation.reset must see an edit of ANY element - the reference's reset() rebuilds terrain
+    and fire manager every time (simulation.py:202-214).  A strided sample (stride 16 at 1024^2) missed columns 1..15."""
+    from simfire_amd.simulation import _fingerprint
+    a = np.zeros((1024, 1024))
+    f0 = _fingerprint(a)
+    a[:, 1:15] = 3.0
+    f1 = _fingerprint(a)
+    a[777, 9] = 4.0
+    f2 = _fingerprint(a)
+    assert len({f0, f1, f2}) == 3
+    b = np.zeros((1024, 1024), dtype=np.float32)
+    assert _fingerprint(b) != f0                               # dtype takes part
+    assert _fingerprint(a.copy()) == f2                        # contents, not identity
