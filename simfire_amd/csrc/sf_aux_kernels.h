@@ -119,6 +119,25 @@ __global__ void k_record(Geo g, const uint8_t *status, const EnvState *st, int8_
 #endif
 
 #ifndef SF_RUN_UNIT
+// The R table once more, CELL-MAJOR: [H][P][8] - the eight travel directions of a cell in one 64-byte line.  The window phase of the
+// resident launch (sf_win_kernels.h) reads this copy: which line a frontier cell needs does not depend on its winner source, so the line can
+// be asked for as soon as the cell is known to join the frontier (a step ahead), and it stays the cell's line for its whole frontier life.
+// Same values as the direction-major table (fire.py:482-497: everything but the travel angle depends on the destination cell only).
+__global__ void k_rt_cellmajor(int H, int P, const double *rt, double *rtc)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= P) return;
+    const long long o = (long long)y * P + x, plane = (long long)H * P;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = rt[k * plane + o];
+    double2 *dst = reinterpret_cast<double2 *>(rtc + o * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = make_double2(v[2 * k], v[2 * k + 1]);
+}
+#endif
+
+#ifndef SF_RUN_UNIT
 __global__ void k_pack_rt(int H, int W, int P, const double *dense, double *pitched)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;

@@ -60,13 +60,32 @@ constexpr int kRunMaxD = 4;        // interest words a thread keeps in registers
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (the nontemporal builtins take native vectors, not HIP's uint4 struct)
 
+// LDS of the window phase (sf_win_kernels.h; wl: 8-byte aligned), which lives where the general loop keeps its strip buffers:
+// burn [WR][64] f64 | step masks [8][8] u32 | status-count changes [16][8] i32 | per-wave slots [16][4] u32 |
+// mask plane [WR + 2][18] u32 (a zero dword left / right of every row, a zero row above / below) | "burn changed" bytes [WR][16] |
+// the frontier lists of this step and the next [2][WR x 64] u16 | control-line patches [2][WR][64] bytes |
+// status plane [WR][64] bytes | "on the frontier list" bits [WR x 64].
+__host__ __device__ inline size_t win_lds_bytes(int n_waves)
+{
+    const int WR = n_waves * 4;
+    return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)2 * WR * 64 * 2 + (size_t)2 * WR * 64 +
+           (size_t)WR * 64 + (size_t)WR * 8;
+}
+// dwords of the strip-buffer region of k_run: the general loop's strip buffers (+ the walk's owner markers) or the window phase's planes,
+// whichever is larger (16 waves: the strips, 79 872 bytes against 68 752; one wave - small grids -: the window)
+__host__ __device__ inline size_t run_strip_dwords(int n_waves)
+{
+    const size_t strips = (size_t)n_waves * (64 * kStripDw + kMarkDw), win = (win_lds_bytes(n_waves) + 15) / 16 * 4;      // (what follows holds uint4s)
+    return strips > win ? strips : win;
+}
+
 // team: 0 = k_run<TEAM = 0> (a workgroup holds the bitmaps of the whole grid); 1 = k_run<TEAM = 1>: all four bitmaps whatever the
 // row width, for team_rcap + 2 rows (team_rcap = 0: the whole grid), + the two halo rows of sprite masks.
 __host__ __device__ inline size_t run_lds_bytes(const Geo &g, int n_waves, int vcap, int team = 0, int team_rcap = 0)
 {
     const int maps = (team || g.VW == 1) ? 4 : 1;          // one-word rows: + first-cell / last-cell / eligible bitmaps
     const int rows = team && team_rcap ? team_rcap + 2 : g.H;
-    size_t b = (size_t)maps * rows * g.VW * 8 + (size_t)vcap * 4 + (size_t)n_waves * ((64 * kStripDw + kMarkDw) * 4) + kRunCtl * 4;
+    size_t b = (size_t)maps * rows * g.VW * 8 + (size_t)vcap * 4 + run_strip_dwords(n_waves) * 4 + kRunCtl * 4;
     if (team) b += (size_t)2 * g.PV * 16 + 64 * 4;         // halo rows of sprite masks [2][PV] uint4, tile-row counts of the split
     // (LDS comes in granules of 1 280 bytes on gfx950, requests are rounded up - profiles/lds_granule_probe.hip; words behind the
     // request are only there by that luck: out-of-range LDS stores are dropped and loads give 0, silently)
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     unsigned long long *vb0 = reinterpret_cast<unsigned long long *>(s_dyn);       // [lds_rows][VW] x 4 (fine) or x 1
     uint32_t *vlist = reinterpret_cast<uint32_t *>(vb0 + (size_t)(fine ? 4 : 1) * lds_rows * VW);       // [vcap]
     uint32_t *strips = vlist + vcap + wave * (64 * kStripDw + kMarkDw);           // [64][kStripDw] per wave (+ the walk's owner markers)
-    uint32_t *ctl = vlist + vcap + n_waves * (64 * kStripDw + kMarkDw);
+    uint32_t *ctl = vlist + vcap + run_strip_dwords(n_waves);
 #ifdef SF_PHASES
     uint4 *halo = reinterpret_cast<uint4 *>(ctl + kRunCtl + 16 * 16);              // (behind the phase clocks)
 #else
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         we.cells = a.cells + (long long)e * g.cells_env;
         we.burn = a.burn + (long long)e * g.plane_env;
         we.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
-        we.rt = a.rt + (long long)e * g.rt_env;
+        we.rtc = a.rtc ? a.rtc + (long long)e * g.rt_env : nullptr;
         we.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
         we.thist = a.thist + (long long)e * g.TY * g.TX * 8;
         we.vb_glob = vb_glob;

@@ -112,7 +112,7 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
     uint8_t *cells;                // blocked cell plane (sf_common.h, bl_cell)
     double *burn;
     uint32_t *settled;
-    const double *rt;
+    const double *rtc;             // the R table cell-major: [H][P][8] (k_rt_cellmajor)
     uint8_t *tdirty;
     uint16_t *thist;               // [TY][TX][8] of this environment: cached status histograms of the wave tiles
     unsigned long long *vb_glob;   // this environment's rows of the three vector bitmaps in memory: plane 0; planes 1 / 2 are vb_plane further each
@@ -121,15 +121,21 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
 
 // Returns the updates made (0: the fire does not fit a window - nothing has been touched).  st is folded like in the general loop;
 // everything the window held is back in memory when this returns (workgroup barrier included).
-// LDS (wl: 8-byte aligned): burn [WR][64] f64 | step masks [8][8] u32 | status-count changes [16][8] i32 | per-wave slots [16][4] u32 |
-// mask plane [WR + 2][18] u32 (a zero dword left / right of every row, a zero row above / below) | "burn changed" bytes [WR][16] |
-// the step's frontier list [WR x 64] u16 | control-line patches [2][WR][64] bytes.
-__host__ __device__ inline size_t win_lds_bytes(int n_waves)
-{
-    const int WR = n_waves * 4;
-    return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)n_waves * 256 * 2 + (size_t)2 * WR * 64;
-}
-
+// LDS: win_lds_bytes (sf_run_kernels.h).
+//
+// The FRONTIER LIST is kept from step to step (round 5; until then every wave that held fire recomputed "eligible & next to a live sprite"
+// for its 256 cells in every step and the list was made anew - ~150 instructions in 8 - 10 waves, two or three to a SIMD: 1.4 k clocks in front
+// of the walk).
+// F(t + 1) = the cells of F(t) that are still candidates and did not ignite (the walkers put them there)
+//            + the eligible neighbours of the cells that ignited in step t (a sprite is a source from the step after its ignition, fire.py:571-579)
+//            + the cells a control line made eligible again (mitigation.py:60-80 on a burning / burned cell).
+// Proof that nothing is missed: a candidate of step t + 1 is eligible and has a neighbour n that is live in t + 1; n either ignited in t
+// (second term) or earlier - then n was live in t as well, and the cell was a candidate of t (first term) unless it only became eligible since
+// (third term).  What a list entry still is, is decided by the walker from the cell's status byte and 3 x 3 sprite masks, so stale entries
+// only cost a look.  The second and third terms are the OWNERS': a wave next to whose rows a cell ignited in the step before (a bit per wave,
+// set by the walkers) or that takes a control line computes its frontier cells with the SWAR pass of old and appends the ones that are not on
+// the list yet (a bit per cell, "on the list": set by the owners, cleared by the walkers); every other owner wave only keeps the books of its
+// own cells (BURNING / BURNED / slot recycling).  The window's first step finds every wave marked.
 // GEN = 0: rows of one bitmap word, a thread per grid row (k_run<1, ...>: the code the headline runs); GEN = 1: rows of g.VW words,
 // any number of rows per thread (k_run<2, ...>: many environments in 8-wave workgroups, 2048-wide grids in teams of one).
 // MITW = 1: control lines inside the launch (sf_step_mitigated; up to 64 points per environment and step, held by the LAST wave, a point per
@@ -147,16 +153,20 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const int WR = nthr >> 4;                                  // window rows
     PhaseClock pc;           // (timeline of one step; lpc: timeline of the launch)
     pc.start();
-    if (g.H < WR || g.PV < 4 || g.dense || n_steps <= 0 || !st.running || !a.win) return 0;       // (uniform)
+    if (g.H < WR || g.PV < 4 || g.dense || n_steps <= 0 || !st.running || !a.win || !ev.rtc) return 0;       // (uniform)
     // ---- LDS
     double *const wb = reinterpret_cast<double *>(wl);                                   // burn_amounts of the window
     uint32_t *const tab = wl + (size_t)WR * 128;                                         // masks of a step by slot of its number
     int32_t *const dt = reinterpret_cast<int32_t *>(tab + 64);                           // [16 tiles][8]: cells per BurnStatus gained / lost; [15][0..7]: the old result row
     uint32_t *const wm = tab + 64 + 128 + 64;                                            // sprite masks (behind the per-wave slots of the search above)
     uint8_t *const wdirty = reinterpret_cast<uint8_t *>(wm + (WR + 2) * 18);             // per lane: burn_amounts of its cells changed
-    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16);              // the step's frontier cells [WR x 64]
-    uint32_t *const wpatch = reinterpret_cast<uint32_t *>(wlist + WR * 64);              // MITW: [2][WR][16] control-line types drawn inside the window, by parity of the step (a byte per cell, 0 = none)
+    const int capF = WR * 64;                                                            // (entries are unique: never more than the window has cells)
+    uint16_t *const wlist = reinterpret_cast<uint16_t *>(wdirty + WR * 16);              // the frontier lists [2][WR x 64], by parity of the step: row << 6 | column
+    uint32_t *const wpatch = reinterpret_cast<uint32_t *>(wlist + 2 * capF);             // MITW: [2][WR][16] control-line types drawn inside the window, by parity of the step (a byte per cell, 0 = none)
+    uint32_t *const wstat = wpatch + 2 * WR * 16;                                        // status bytes of the window [WR][16] (the owners' registers, for the walkers)
+    uint32_t *const wflag = wstat + WR * 16;                                             // a bit per cell: it is on the frontier list [WR x 2]
     if (MITW) { wpatch[tid] = 0; wpatch[nthr + tid] = 0; }   // (both patch planes: [2][WR x 16] dwords = two per thread; in front of the barrier below)
+    if (tid < WR * 2) wflag[tid] = 0;
     // ---- where is the fire?  Rows and vector columns that hold a sprite bit, from the vector bitmap in memory: thread y looks at row y.
     // (No LDS atomics: on a uniform address the compiler turns them into a scalar loop over the lanes - 6 k clocks of every launch.)
     const int VW = GEN ? g.VW : 1;
@@ -250,6 +260,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const uint32_t in_w = first01(g.W - x);                    // 0 / 1 per byte: the cell exists (pitch padding never takes part)
     const int own = (r + 1) * 18 + c + 1;                      // this lane's dword in the mask plane
     wm[own] = ag0;
+    wstat[r * 16 + c] = sv0;
     wdirty[r * 16 + c] = 0;
     // The result block by difference: where every cached tile histogram of the environment is valid, the last result row is too
     // (whoever validates a histogram writes the row: counts_env), and what this phase changes is known cell by cell.
@@ -312,7 +323,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (__builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 4]) != 0) return 0;      // (uniform) the fire is at the window's edge already
     lpc.note(32);            // window loaded
     uint32_t sv = sv0;
-    const uint32_t HP = (uint32_t)(g.H * g.P), nmask = (1u << g.N) - 1u;
+    const uint32_t nmask = (1u << g.N) - 1u;
     const int s_cap = a.win > 1 && a.win < n_steps ? a.win : n_steps;      // (SF_TUNE_RUN_WINDOW = k > 1: tests leave the window after k updates)
     int s = 0, k = 0;
     int s0 = slot_of(st.steps + 1, g.N);                       // slot of the coming step's number
@@ -324,13 +335,30 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const double rate = g.update_rate;
     const bool stats = a.counters != nullptr;
     uint32_t up = wm[own - 18], mid = wm[own], dn = wm[own + 18];
+    // the masks of a step (every wave: the walkers need them too) come with the rows, a step ahead
+    uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
     bool pflag = MITW ? __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 5]) != 0 : false;      // control lines inside the window in front of the coming update
-    // (Measured and dropped, twice: touching the eight table entries the neighbours of a new ignition will most likely ask for in the next
-    // step - loads whose results nobody uses.  By the walkers themselves, when a cell ignites: their wait for operands fell from ~900
-    // to ~100 clocks and the step got 25 % LONGER (loads return in order per wave: the next operands queue behind the touches).  By an
-    // otherwise idle wave at the start of the next step: 35 % longer.  The walkers' wait is not latency, it is the CU's rate of
-    // scattered line fetches - ~130 lines per step at the 0.10 - 0.25 lines per clock and CU that profiles/scatter_probe.hip measures
-    // when every CU does it - and 250 touches per step take their share of exactly that.)
+    uint32_t marked = 0xFFFFFFFFu;                             // bit w: a cell ignited in or next to wave w's rows in the step before (first step: everywhere)
+    uint32_t onlist = 0;                                       // this lane's four "on the list" bits as the step before left them
+    const int flag_w = r * 2 + (c >> 3), flag_sh = (4 * c) & 31;      // where they sit in the plane of bits
+    // An owner that puts a cell on the list asks for the cell's table line at once - a load whose result nobody uses: the walker's own
+    // request, a barrier and a look at the neighbourhood later, finds the line on its way or in the CU's L1 instead of waiting ~900 clocks for
+    // memory.  One line per NEW frontier cell, nothing speculative: the table is cell-major here (k_rt_cellmajor), so the line does not depend
+    // on the winner source.  (Rounds 3 / 4 measured speculative touches of the direction-major table - eight per ignition, by the walkers or
+    // by an idle wave: 25 - 35 % slower, a CU has only so many misses in flight.)  The load is written in assembly so that the compiler does
+    // not wait for it; its register is `touch`, which nothing reads and which is only released (a wait) behind the loop.
+    uint32_t touch = 0;
+    // one lane reserves n places behind a list's counter (ds_add_rtn by hand: the compiler wraps an atomicAdd of one lane into its scalar
+    // loop over the active lanes + a second election, ~30 instructions)
+    auto reserve = [&](uint32_t *ctr, uint32_t n) -> uint32_t {
+        uint32_t base = 0;
+        if (lane == 0) {
+            const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ctr;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(lds_addr), "v"(n) : "memory");
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+    };
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 #ifdef SF_WIN_PROF
     unsigned long long wp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wp_t = __builtin_readcyclecounter();
 #endif
@@ -341,7 +369,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         pc.tl_n = 0;
 #endif
         pc.note(20);         // window step start
-        if (tid == 0) { ctl[3 + kn] = 0; ctl[kn] = 0; }        // predicate bytes / list length of the next step (last read before the barrier that ended step s - 1)
+        if (tid == 0) { ctl[3 + kn] = 0; ctl[kn] = 0; ctl[6 + kn] = 0; }     // predicate bytes / list length / marked waves of the next step (last read before the barrier that ended step s - 1)
+        uint16_t *const Fcur = wlist + (s & 1) * capF, *const Fnext = wlist + ((s + 1) & 1) * capF;
+        const bool spread = !st.time_quit;                     // fire.py:641-643: prune only, then QUIT (the list is not walked)
+        const uint32_t L4 = t0.x, CLR4 = t0.z, b_new = t0.w, lo_mask = t1.x, hi_mask = t1.y;
+        const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
         if (MITW && mitw && wave == mit_wave) {
             // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80), the points OUTSIDE the window:
             // k_run's one-wave scheme on the planes in memory.  The coming step's points are asked for first.
@@ -366,15 +398,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         // (control lines drawn inside the window in front of this update, if any: the owner lanes take them in phase A)
         uint32_t pw = 0;
         if (MITW && pflag) pw = wpatch[(s & 1) * WR * 16 + r * 16 + c];
-        // the masks of this step (every wave: the walkers need them too)
-        const uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
-        const uint32_t L4 = t0.x, CLR4 = t0.z, b_new = t0.w, lo_mask = t1.x, hi_mask = t1.y;
-        const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
-        // ---- phase A, the waves with a sprite bit in or next to their four rows: prune, recycle, frontier cells -> the step's list
+        // ---- phase A, the waves with a sprite bit in or next to their four rows: the bookkeeping of their own cells (BURNING, control lines,
+        // prune, slot recycling), and - next to last step's ignitions or under a new control line - the cells that join the frontier list
         if (__ballot((mid | up | dn | pw) != 0u) != 0ull) {    // (wave-uniform)
-            const bool spread = !st.time_quit;                 // fire.py:641-643: prune only, then QUIT
             pc.note(21);     // rows arrived
             if (stats) n_vec_done += lane == 0 ? 16u : 0u;     // four rows x four vectors swept
+            const uint32_t sv_in = sv;
             // the cells this window ignited in the step before: BURNING (fire.py:587; not in a window's first step: a bit of that age
             // may sit under a control line drawn since)
             {
@@ -425,32 +454,36 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                     }
                 }
             }
+            if (sv != sv_in) wstat[r * 16 + c] = sv;           // (the walkers' view of this lane's cells)
             if (mid & CLR4) wm[own] = mid & ~CLR4;             // the slot of sprites that were pruned one step ago is recycled
-            if (spread) {
+            // new frontier cells can only be next to a cell that ignited in the step before, or under a control line drawn since (see the
+            // head of this function): the waves marked by the walkers, and the wave of a patch
+            const bool look = spread && (((marked >> wave) & 1u) != 0u || (MITW && __ballot(pw != 0u) != 0ull));       // (wave-uniform)
+            if (look) {
+                // eligible (fire.py:192-205) & next to a live sprite (fire.py:163-234) & not on the list yet
                 const uint32_t vsrc = (up | dn) & L4;
                 const uint32_t hsrc = diag ? (midL | vsrc) : midL;
                 const uint32_t hl = dpp_from_left(hsrc), hr = dpp_from_right(hsrc);
                 // per cell: OR of the live masks of its (4 or 8) neighbours
                 const uint32_t nb = vsrc | (hsrc << 8) | (hl >> 24) | (hsrc >> 8) | (hr << 24);
-                // frontier cells: eligible (fire.py:192-205) & next to a live sprite
-                const uint32_t p4 = pack4(ELIG(sv) & nz01(nb) & in_w);
+                const uint32_t p4 = pack4(ELIG(sv) & nz01(nb) & in_w) & ~onlist;
                 const uint32_t cnt = (uint32_t)__popc(p4);
                 pc.note(22); // frontier cells known
                 if (__ballot(cnt != 0u) != 0ull) {
-                    // the wave's cells behind those of the waves that came before: entry = row << 6 | column | status << 12
                     const uint32_t incl = wave_scan_incl(cnt, lane);
-                    uint32_t base = 0;
-                    // (ds_add_rtn by hand: the compiler wraps an atomicAdd of one lane into its scalar loop over the active lanes + a
-                    // second election, ~30 instructions in every wave that holds a frontier cell)
-                    if (lane == 63) {
-                        const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(ctl + k);
-                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(lds_addr), "v"(incl) : "memory");
-                    }
-                    uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + incl - cnt;
-                    const uint32_t ent0 = (uint32_t)(r << 6 | c << 2);
+                    const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t pos = reserve(ctl + k, wave_total) + incl - cnt;
+                    if (p4) {
+                        atomicOr(&wflag[flag_w], p4 << flag_sh);           // (eight lanes share a word)
+                        const uint32_t ent0 = (uint32_t)(r << 6 | c << 2);
+                        const double *line = ev.rtc + (size_t)idx * 8;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if ((p4 >> j) & 1u) wlist[pos++] = (uint16_t)(ent0 | (uint32_t)j | (((sv >> (8 * j)) & 7u) << 12));
+                        for (int j = 0; j < 4; ++j)
+                            if ((p4 >> j) & 1u) {
+                                Fcur[pos++] = (uint16_t)(ent0 | (uint32_t)j);
+                                asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(line + j * 8) : "memory");
+                            }
+                    }
                 }
             }
         }
@@ -458,14 +491,17 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         WPROF(0)             // phase A
         win_barrier<ATT>();
         WPROF(1)             // barrier behind the list
-        // ---- phase B, as few waves as the list needs: walk the frontier cells, one per lane
+        // ---- phase B, as few waves as the list needs: walk the list, one cell per lane
         {
-            const uint32_t total = ctl[k];
-            struct WCell { bool cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
-            // first half of a cell: which, winner source, operands requested
+            // (the list's length and the lane's first entry are asked for together: one LDS round trip, not two - capF >= threads, an
+            // entry beyond the length is garbage that `valid` refuses)
+            const uint32_t total_raw = ctl[k], ent_first = Fcur[tid];
+            const uint32_t total = spread ? total_raw : 0u;
+            struct WCell { bool valid, cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
+            // first half of a cell: is it (still) a candidate, winner source, operands requested
             auto front = [&](uint32_t i, uint32_t ent) {
                 WCell q;
-                const bool valid = i < total;
+                q.valid = i < total;
                 const uint32_t rr = (ent >> 6) & 63u, cx = ent & 63u;      // row / column inside the window
                 // bytes 0..2 = cells x - 1, x, x + 1 of the rows y - 1, y, y + 1: cell cx sits at byte 4 + cx of a plane row
                 const uint32_t b0 = cx + 3u, sh = b0 & 3u;
@@ -473,6 +509,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 const uint32_t up3 = __builtin_amdgcn_alignbyte(pr[1], pr[0], sh);
                 const uint32_t mid3 = __builtin_amdgcn_alignbyte(pr[19], pr[18], sh);
                 const uint32_t dn3 = __builtin_amdgcn_alignbyte(pr[37], pr[36], sh);
+                const uint32_t stb = reinterpret_cast<const uint8_t *>(wstat)[rr * 64u + cx];
                 int bestk = -1;
                 {
                     // pick_winner8 (sf_step_kernels.h) on this step's masks from the table
@@ -491,20 +528,21 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                         bestk = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
                     }
                 }
-                q.cand = valid && bestk >= 0;
+                // a candidate: eligible (fire.py:192-205: UNBURNED or a control line) and next to a live sprite (fire.py:163-234)
+                q.cand = q.valid && ((0x39u >> stb) & 1u) && bestk >= 0;
                 q.pos = rr * 64u + cx;
-                q.own_spost = ((mid3 >> 8) & 0xFFu) | (((ent >> 12) & 7u) << 8);
+                q.own_spost = ((mid3 >> 8) & 0xFFu) | (stb << 8);
                 q.owed = 0; q.bn = 0.0; q.r_tab = 0.0;
                 if (q.cand) {
                     const uint32_t gi = (uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx);
-                    q.r_tab = ev.rt[(uint32_t)bestk * HP + gi];                              // 8 H P < 2^29
+                    q.r_tab = ev.rtc[(size_t)gi * 8 + (uint32_t)bestk];
                     q.bn = wb[q.pos];
-                    if (ATT && (q.own_spost >> 8) >= SF_FIRELINE) q.owed = (uint32_t)(st.complete + n_plain) - ev.settled[gi];
+                    if (ATT && stb >= SF_FIRELINE) q.owed = (uint32_t)(st.complete + n_plain) - ev.settled[gi];
                 }
                 return q;
             };
             // second half: accumulate, ignite
-            auto back = [&](const WCell &q) {
+            auto back = [&](const WCell &q) -> bool {
                 bool ignited = false;
                 if (q.cand) {
                     const uint32_t rr = q.pos >> 6, cx = q.pos & 63u, s_post = q.own_spost >> 8;
@@ -528,11 +566,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                         if (on_ring) reinterpret_cast<uint8_t *>(ctl + 3 + k)[2] = 1;        // a sprite in the ring: the window is left after this step
                     }
                 }
-                if (stats) n_ignite += (uint32_t)__popcll(__ballot(ignited));
+                return ignited;
             };
             bool any_cand = false;
             for (uint32_t i = (uint32_t)tid; i - (uint32_t)lane < total; i += (uint32_t)nthr) {      // (wave-uniform trip count)
-                const uint32_t ent = wlist[i < total ? i : 0u];
+                const uint32_t ent = i == (uint32_t)tid ? ent_first : (uint32_t)Fcur[i < total ? i : 0u];
                 WCell c0 = front(i, ent);
                 any_cand |= __ballot(c0.cand) != 0ull;
                 if (stats) n_active += (uint32_t)__popcll(__ballot(c0.cand));
@@ -542,8 +580,32 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 asm volatile("" : "+v"(c0.r_tab), "+v"(c0.bn));
                 WPROF(3)     // walk: operands arrived
 #endif
-                back(c0);
+                const bool ignited = back(c0);
                 WPROF(4)     // walk: updates, ignitions
+                // the cell's place from here on: the next step's list (still a candidate) or nowhere (its bit is cleared; the owners put it back
+                // if it becomes a candidate again).  An ignition marks the waves that own the rows next to it: their cells may join the list.
+                const bool stay = c0.cand && !ignited;
+                const unsigned long long sb = __ballot(stay), ib = __ballot(ignited);
+                uint32_t sbase = 0;
+                if (sb != 0ull && lane == 0) {             // (the places are asked for here and taken below: the other LDS work of the tail in between)
+                    const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(ctl + kn);
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(sbase) : "v"(lds_addr), "v"((uint32_t)__popcll(sb)) : "memory");
+                }
+                if (c0.valid && !stay) atomicAnd(&wflag[c0.pos >> 5], ~(1u << (c0.pos & 31u)));          // (addresses differ from lane to lane: a plain LDS atomic)
+                if (ib != 0ull) {
+                    if (stats) n_ignite += (uint32_t)__popcll(ib);
+                    const uint32_t rr = c0.pos >> 6;
+                    const uint32_t wm_all = wave_or(ignited ? (1u << ((rr ? rr - 1u : 0u) >> 2)) | (1u << ((rr + 1u) >> 2)) : 0u);
+                    if (lane == 0) {
+                        const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(ctl + 6 + k);
+                        asm volatile("ds_or_b32 %0, %1" :: "v"(lds_addr), "v"(wm_all) : "memory");
+                    }
+                }
+                if (sb != 0ull) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sbase) :: "memory");
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)sbase, 0);
+                    if (stay) Fnext[base + (uint32_t)__popcll(sb & lanes_below)] = (uint16_t)c0.pos;
+                }
                 pc.note(25); // updates, ignitions
             }
             if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
@@ -551,17 +613,21 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (MITW && mitw && wave == mit_wave && s + 1 < n_total) mit_classify(s + 1);      // (its points have arrived by now; patches for the next step)
         pc.note(26);         // at the barrier
         WPROF(5)             // rest of phase B
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the marks above were made behind the compiler's back)
         win_barrier<ATT>();
         WPROF(6)             // barrier at the end of the step
         pc.note(27);         // through the barrier
-        // ---- fold (every thread the same arithmetic on the same values); the next step's rows are requested with the predicates
-        const uint32_t fv = ctl[3 + k];
+        // ---- fold (every thread the same arithmetic on the same values); the next step's rows, masks, list bits and marks are requested with the predicates
+        const uint32_t fv = ctl[3 + k], mk = ctl[6 + k];
         up = wm[own - 18]; mid = wm[own]; dn = wm[own + 18];
-        if (MITW) pflag = __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 5 + ((s + 1) & 1)]) != 0;
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fv);
+        onlist = (wflag[flag_w] >> flag_sh) & 0xFu;
         ++s;
         k = kn;
         s0 = s0 + 1 == g.N ? 0 : s0 + 1;
+        t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8); t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
+        if (MITW) pflag = __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 5 + (s & 1)]) != 0;
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fv);
+        marked = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk);
         if (plain_fold && (f & 0x00FFFFFFu) == (FLAG_LIVE | FLAG_CAND)) {
             ++n_plain;
             elapsed += rate;                                   // fire.py:717
@@ -581,12 +647,13 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         pc.note(28);         // folded
         if (!(s < s_cap && st.running && (f & 0x00FF0000u) == 0u)) break;
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) :: "memory");      // (the last requests are out of flight: their register is free)
     st.steps += n_plain; st.complete += n_plain; st.elapsed = elapsed;
 #ifdef SF_WIN_PROF
     if (lane == 0 && e < 1024)
         for (int q = 0; q < 8; ++q) g_win_prof[((size_t)e * 16 + wave) * 8 + q] = wp_acc[q];
 #endif
-    if (tid < 3) ctl[tid] = 0;                                 // (the general loop's list lengths)
+    if (tid < 9) ctl[tid] = 0;                                 // (the general loop's list lengths, predicate bytes and batch cursors: rings of three)
     lpc.note(33);            // updates done
     // ---- back to memory: the cells and burn_amounts that changed, the dirty flags of their tiles, the window's part of the vector bitmaps
     const uint32_t ag = wm[own];
@@ -659,19 +726,23 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             const int tl = i >> 3, q = i & 7, d = dt[i];
             if (d) ev.thist[((ty0 + tl / ntx) * g.TX + tx0 + tl % ntx) * 8 + q] += (uint16_t)d;       // (mod 2^16: a negative change wraps to the right count)
         }
-        if (tid == 0) {
-            int32_t others = 0;
-            for (int q = 1; q < 6; ++q) {
-                int32_t v = dt[120 + 2 + q];
-                for (int tl = 0; tl < nty * ntx; ++tl) v += dt[tl * 8 + q];
-                a.res_block[e * 8 + 2 + q] = v;
-                if (a.res_sink) a.res_sink[e * 8 + 2 + q] = v;
-                others += v;
+        if (tid < 8) {
+            // lanes 3 .. 7 of wave 0: the cells per BurnStatus 1 .. 5 = the old row + what every tile of the window gained or lost (a lane per
+            // status: the sums of up to fifteen LDS words side by side, not one after the other); lane 2: UNBURNED = H * W - the others
+            // (counts_env); lanes 0 / 1: running, update() calls made
+            int32_t v = 0;
+            if (tid >= 3) {
+                v = dt[120 + tid];
+                for (int tl = 0; tl < nty * ntx; ++tl) v += dt[tl * 8 + tid - 2];
             }
-            const int32_t unburned = g.H * g.W - others;       // UNBURNED = H * W - the others (counts_env)
-            a.res_block[e * 8 + 2] = unburned; a.res_block[e * 8] = st.running == 1; a.res_block[e * 8 + 1] = st.steps;
-            a.res_elapsed[e] = st.elapsed;
-            if (a.res_sink) { a.res_sink[e * 8 + 2] = unburned; a.res_sink[e * 8] = st.running == 1; a.res_sink[e * 8 + 1] = st.steps; }
+            int32_t others = v;                            // (lanes 0 .. 2 hold 0)
+            others += __shfl_xor(others, 1, 8); others += __shfl_xor(others, 2, 8); others += __shfl_xor(others, 4, 8);
+            if (tid == 2) v = g.H * g.W - others;
+            if (tid == 1) v = st.steps;
+            if (tid == 0) v = st.running == 1;
+            a.res_block[e * 8 + tid] = v;
+            if (a.res_sink) a.res_sink[e * 8 + tid] = v;
+            if (tid == 0) a.res_elapsed[e] = st.elapsed;
         }
         result_done = true;
     }

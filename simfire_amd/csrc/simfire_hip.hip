@@ -126,6 +126,8 @@ struct sf_sim {
     uint8_t *cells_alloc = nullptr, *cells = nullptr;      // blocked cell plane of the resident launch (allocated at its first use)
     bool bl_cur = false;               // the blocked plane holds the sprite masks / status bytes; the row-major planes are stale
     double *burn = nullptr, *rt = nullptr;
+    double *rtc = nullptr;             // the R table(s) cell-major (k_rt_cellmajor): built when the resident launch first needs it, stale after every change of rt
+    bool rtc_valid = false;
     double *lay_all = nullptr;         // [tables][7][H*W] dense: w0 delta Mx sigma elev U Udir (kept for the observation planes)
     double *layer(int table, int i) const { return lay_all + ((size_t)table * 7 + i) * (size_t)g.H * g.W; }
     int8_t *history = nullptr;         // sf_enable_history: [E][history_cap][H][W] fire maps after each update
@@ -417,7 +419,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
     for (void *hp : {(void *)s->loop_db, (void *)s->loop_res, (void *)s->loop_pts}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)s->loop_mem, (void *)s->loop_pts_mem}) if (dp) (void)hipFree(dp);
-    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
+    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
@@ -656,6 +658,7 @@ static int table_range(sf_sim *s, int env, const char *who, int *lo, int *hi)
 static void mark_tables(sf_sim *s, int lo, int hi)
 {
     for (int i = lo; i < hi; ++i) s->rt_set[i] = 1;
+    s->rtc_valid = false;
     s->have_rt = true;
     for (char c : s->rt_set) if (!c) s->have_rt = false;
 }
@@ -1074,6 +1077,20 @@ static bool prefers_bl(const sf_sim *s)
     return g.ab == 1 && !s->generic && (g.VW == 1 || (g.VW == 2 && s->tune.v[SF_TUNE_RUN_TEAM] != 1)) && !s->graph_on && !s->history &&
            (s->fused_mode < 0 || s->fused_mode == 2);
 }
+// the cell-major copy of the R table(s) the window phase of k_run reads (one sweep after every change of the table)
+static int ensure_rtc(sf_sim *s)
+{
+    if (s->rtc_valid) return SF_OK;
+    const Geo &g = s->g;
+    const size_t n_tab = s->rt_set.size(), tab = (size_t)8 * g.plane_env;
+    if (!s->rtc) { int rc = dev_alloc(s, &s->rtc, tab * n_tab); if (rc) return rc; }
+    for (size_t i = 0; i < n_tab; ++i)
+        hipLaunchKernelGGL(k_rt_cellmajor, dim3((g.P + 255) / 256, g.H), dim3(256), 0, s->stream, g.H, g.P, (const double *)(s->rt + i * tab), s->rtc + i * tab);
+    HIPCHK(hipGetLastError());
+    s->rtc_valid = true;
+    return SF_OK;
+}
+
 static int ensure_bl(sf_sim *s)
 {
     if (s->bl_cur) return SF_OK;
@@ -1319,7 +1336,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     const bool polled = n_steps == 1 && !mit_dev && s->step1_polls >= 2;
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.order = nullptr; a.cost = nullptr;
-    a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt;
+    a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt; a.rtc = nullptr;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     a.parents = s->graph_on ? s->parents : nullptr;
     const dim3 block(kWaves * 64);
@@ -1446,6 +1463,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         if (rc0) return rc0;
         rc0 = (run_waves && !fr_waves && !runt_waves) ? ensure_bl(s) : ensure_rm(s);
         if (rc0) return rc0;
+        if (run_waves && a.win) {              // the window phase reads the cell-major copy of the R table
+            rc0 = ensure_rtc(s);
+            if (rc0) return rc0;
+            a.rtc = s->rtc;
+        }
     } else if (!generic) {
         int rc0 = ensure_tiles(s);
         if (rc0) return rc0;
@@ -1834,7 +1856,7 @@ static int loop_launch(sf_sim *s)
     const Geo &g = s->g;
     StepArgs a;
     memset(&a, 0, sizeof a);
-    a.g = g; a.status = s->status; a.age = s->age; a.cells = s->cells; a.burn = s->burn; a.rt = s->rt;
+    a.g = g; a.status = s->status; a.age = s->age; a.cells = s->cells; a.burn = s->burn; a.rt = s->rt; a.rtc = nullptr;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = nullptr; a.tflags = s->tflags; a.tile_list = s->tile_list;
     a.n_active = s->n_active; a.seam = s->seam; a.settled = s->settled; a.tdirty = s->tdirty; a.thist = s->thist; a.vbits = s->vbits;
     a.launch = 0; a.from_commit = 1; a.ring = s->ring;

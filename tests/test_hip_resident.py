@@ -793,7 +793,8 @@ def test_bench_eight_ranks_without_workload_also_report_their_shares_of_c4_and_c
     for name, prefix in (("c4", "c4_"), ("c5", "c5_")):
         blk = j["also"][name]
         assert blk["workload"].startswith(prefix) and blk["n_gpus"] == 8 and blk["envs_total"] == 24 and blk["verified"] is True
-        assert len(blk["per_rank_gbs"]) == 8 and all(v > 0 for v in blk["per_rank_gbs"]) and blk["value"] > 0
+        # (three environments of 128 x 128 per rank: a rank whose ignitions all fall on barren ground sweeps nothing - 0 GB/s is a legal share)
+        assert len(blk["per_rank_gbs"]) == 8 and all(v >= 0 for v in blk["per_rank_gbs"]) and sum(blk["per_rank_gbs"]) > 0 and blk["value"] > 0
         assert abs(sum(blk["per_rank_gbs"]) - blk["aggregate_gbs"]) <= 1e-6 * blk["aggregate_gbs"]
     assert j["also"]["c5"]["agents_per_env"] == 64
 
