@@ -507,7 +507,11 @@ def main():
 
     def rollout(k, first):
         if agent_pts is None:
-            eng.rollout(k, result.data_ptr())            # the steps (not waited for) + the per-env result block (episode returns): one call, one wait
+            # the steps + the per-env result block (episode returns) into the registered tensor: ONE call that only enqueues (asynchronous mode) -
+            # the one host wait of a rollout is the caller's: the fence below (a harness whose policy is a kernel waits for nothing)
+            eng.set_async(dist is None)                  # (N > 1: the collective below runs on torch's stream, so the block is waited for first)
+            eng.rollout(k, result.data_ptr())
+            eng.set_async(False)
         else:
             run_steps(eng, k, first, agent_pts)
             eng.copy_status_to(result.data_ptr())
@@ -548,6 +552,7 @@ def main():
         esteps.append(result[:, 1].sum().item() - steps_before)      # update() calls really made
         blocks.append(result.cpu().numpy())
     # ---------------------------------------------------------------------------------
+    eng.sync()               # (surfaces anything a launch of the timed region reported)
     repeats_identical = all((b == blocks[0]).all() for b in blocks) and len(set(esteps)) == 1
     env_steps = esteps[-1]
     local_block = blocks[-1]

@@ -181,7 +181,9 @@ int sf_update_status_device(sf_sim *sim);
 int sf_copy_status_to(sf_sim *sim, void *device_dst /* int32 [n_envs][8] */);
 /* A rollout in one call: sf_step(sim, n_steps) without a host wait of its own, then sf_copy_status_to(sim, device_dst) - n calls of
  * FireSimulation.run(1) per environment (simulation.py:501-553) and the attributes a harness reads afterwards (541-553), one
- * launch and one wait on grids the resident launch covers.  The handle's asynchronous mode is left as it was. */
+ * launch and one wait on grids the resident launch covers.  The handle's asynchronous mode is left as it was; a handle IN asynchronous
+ * mode (sf_set_async) only enqueues - the block is in device_dst when the handle's stream has got there: sf_sync, or the caller's own
+ * device-wide synchronisation (a harness whose next consumer is a kernel waits for nothing on the host). */
 int sf_rollout(sf_sim *sim, int32_t n_steps, void *device_dst /* int32 [n_envs][8] */);
 /* Register caller-owned device memory (int32 [n_envs][8]; NULL unregisters) as a second home of the
  * result block: every refresh of the block also writes it there.  In particular the resident launch

@@ -83,8 +83,11 @@ enum sf_tuning_knob {
                                  * 0 = one launch per segment (the bands are cut by each launch's prologue) */
     SF_TUNE_RUN_WINDOW = 18,    /* the window phase of the resident launch (a young fire's cells held in registers while the fire fits 64 x 64 cells): 1 (default) = on,
                                  * 0 = off, k > 1 = on, but the window is left after k updates (tests: forces the hand-over to the general loop anywhere) */
-    SF_TUNE_TEAM_TIMEOUT_MS = 19,/* how long a member of a team waits for the others (wall clock, ms; default 2000) before the launch is declared void
-                                 * (SF_EHIP at the next call that hands data back; sf_reset of every environment recovers the handle) */
+    SF_TUNE_TEAM_TIMEOUT_MS = 19,/* how long a member of a team waits for the others (wall clock, ms; default 2000).  At a team's START (teams of a fixed size) a
+                                 * member that has waited this long says ABORT and the environment is stepped by member 0 alone - same results, no error
+                                 * (sf_get_team_fallbacks counts them; 0 = at once unless the team is complete in that instant: tests).  A wait that runs out LATER in
+                                 * the launch - members that were resident together do not go away - declares the launch void (SF_EHIP at the next call that
+                                 * hands data back; sf_reset of every environment recovers the handle) */
     SF_TUNE_RUN_JOIN = 20,      /* teams that GROW inside the resident launch (k_run<TEAM = 2>: grids up to 1024 cells wide, at most one environment per CU, no control
                                  * lines inside the launch): a workgroup whose environment is done joins the running environment that would finish last, at that
                                  * team's next cut.  1 (default) = in calls of 192 updates or more on two or more environments (set by hand: also on one), 0 = never, k > 1 = in calls of k updates or more,
@@ -109,6 +112,10 @@ int sf_get_join_log(sf_sim *sim, uint32_t *triples_out, int32_t cap, int32_t *n_
  * on the per-step kernels).  bench.py divides a rollout's algorithmic bytes and duration by it, so that its per-launch figures
  * are those of the rocprofv3 kernel statistics.  No reference counterpart. */
 int sf_get_last_launches(sf_sim *sim, int32_t *n_out);
+/* How many teams of a fixed size (k_run<TEAM = 1>) have, since the handle was created, found at their start that not all of their members
+ * were resident within SF_TUNE_TEAM_TIMEOUT_MS and had their environment's updates made by member 0 alone instead (sf_run_kernels.h: the
+ * start of a team) - the results are the same, the call is slower.  Waits for the handle's stream.  No reference counterpart. */
+int sf_get_team_fallbacks(sf_sim *sim, int32_t *n_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
  * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = k_run_tiles, 5 = one

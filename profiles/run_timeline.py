@@ -23,7 +23,8 @@ def main():
     envs = int(sys.argv[4]) if len(sys.argv) > 4 else 256
     c5 = len(sys.argv) > 5 and sys.argv[5] in ("c5", "c3mit")      # C5: 64 agents per environment, control lines inside the launch
     c3mit = len(sys.argv) > 5 and sys.argv[5] == "c3mit"             # C3's fires through sf_step_mitigated with points that draw nothing (type 0)
-    w = workloads.c5(1024, envs) if c5 and not c3mit else workloads.c3(1024, envs)
+    c4 = len(sys.argv) > 5 and sys.argv[5] == "c4"                   # C4's share: 2048 x 2048, simplex wind (teams of one while the fires are young)
+    w = workloads.c5(1024, envs) if c5 and not c3mit else (workloads.c4(2048, envs) if c4 else workloads.c3(1024, envs))
     pts = None
     if c3mit:
         pts = np.zeros((steps + warm, w.n_envs, 64, 3), dtype=np.int32)

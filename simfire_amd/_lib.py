@@ -88,6 +88,7 @@ SIGNATURES = {
     "sf_get_team_sizes": [_VP, _VP],
     "sf_get_join_log": [_VP, _VP, C.c_int32, _VP],
     "sf_get_last_launches": [_VP, _VP],
+    "sf_get_team_fallbacks": [_VP, _VP],
     "sf_last_step_launch": [_VP, C.POINTER(_I32)],
     "sf_set_prune_after_quit": [_VP, _I32],
     "sf_set_async": [_VP, _I32],

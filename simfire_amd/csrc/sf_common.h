@@ -123,13 +123,15 @@ struct StepArgs {
     int32_t *todo_out;           // [E] or null: an environment whose rows do not fit the windows of the team it was given is left untouched and
                                  // its steps are noted here (0 for the others): the host's next launch (two members, half the grid each) does them
     uint8_t *xbuf;               // [E][kTeamMax][2 sides][2 parities][xrow] the member's first / last row as its neighbours need it (sc1 stores / loads only)
-    uint32_t *xdone;             // [E] members that have left the launch (the last one counts the environment)
+    uint32_t *xdone;             // [E] members that have left the launch (the last one counts the environment) | [E .. 2E) the start words of the teams of a fixed
+                                 // size (members counted in | GO / ABORT: sf_run_kernels.h, the start of a team) | [2E] teams that started as one (statistics)
     uint32_t *xerr;              // != 0: a wait for a team member timed out (the launch's results are void)
     int xrow;                    // bytes per published row: 64 (bitmap words) + PV * 16, rounded up to 128
     int team_rcap;               // bitmap rows a member keeps in LDS (+ 2 halo rows); 0 = the whole grid
     unsigned long long team_timeout;   // ticks of the 100 MHz wall clock (s_memrealtime) a member waits for the others before it gives up (xerr): the members
                                  // of a team are not guaranteed to be resident together - another stream's kernels, a CU mask or a preempted queue can
                                  // keep one out - so the bound is generous (SF_TUNE_TEAM_TIMEOUT_MS, 2 s by default) and in wall time, not shader clocks
+    unsigned long long team_start_timeout;   // the same bound for the decision at a team's START (0: a team that is not complete in that instant starts as one - tests)
     int team_recut;              // > 0: the members of a team cut their bands anew every team_recut steps INSIDE the launch (teams of a fixed size: the whole
                                  // rollout is one launch; cut into launches it lasts the sum of the launches' slowest environments - 12 % more on C4's share)
     // k_run<TEAM = 2> only: teams that GROW inside the launch - a workgroup whose environment is done JOINS the team of a running one at that

@@ -656,6 +656,57 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     pc.start();
 #endif
     __syncthreads();
+    if (TEAM == 1 && tn > 1) {
+        // THE START of a team whose size is fixed for the launch: are all its members resident?  Nothing has been written yet.  The members
+        // wait for each other inside the launch, and nothing guarantees that they are on the chip together (another stream's kernels, a CU mask,
+        // a grid larger than the chip holds): so they decide TOGETHER, on one word of the environment, before anyone writes - every member
+        // counts itself in; the one that completes the team says GO; one that has waited for team_timeout says ABORT; whichever comes first
+        // stands (compare-and-swap) and everybody acts on it, those that only become resident later included.  ABORT: member 0 - now or
+        // whenever it gets onto the chip - makes the call's updates ALONE, as a team of one (the same kernel: the team code with one member),
+        // the others leave at once and free their CUs.  No environment is lost, no reset is needed (round 4: the launch gave up at the first
+        // step boundary and the handle was void).  Independent environments (simulation.py:202-214): who computes which rows never shows.
+        if (tid == 0) {
+            uint32_t *w = a.xdone + g.E + e;
+            constexpr uint32_t kGo = 0x40000000u, kAbort = 0x80000000u, kDecided = 0xC0000000u;
+            auto decide = [&](uint32_t bit) -> uint32_t {
+                for (;;) {
+                    uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur & kDecided) return cur & kDecided;
+                    if (__hip_atomic_compare_exchange_strong(w, &cur, cur | bit, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return bit;
+                }
+            };
+            const uint32_t mine = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            uint32_t d = mine & kDecided;
+            if (!d && (mine & 0xFFFFu) == (uint32_t)tn) d = decide(kGo);
+            if (!d && a.team_start_timeout == 0ull) d = decide(kAbort);      // (tests: whoever is not the last to arrive does not wait at all)
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (!d) {
+                d = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kDecided;
+                if (d) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (__builtin_amdgcn_s_memrealtime() - t0 >= a.team_start_timeout) d = decide(kAbort);
+            }
+            ctl[16] = d == kGo ? 1u : 2u;
+            if (d != kGo && tm == 0) __hip_atomic_fetch_add(a.xdone + 2 * g.E, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (statistics: teams that started as one, sf_get_team_fallbacks)
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane((int)ctl[16]) != 1) {       // (uniform) ABORT
+            if (tm != 0) return;
+            tn = 1;
+            has_up = false; has_dn = false;
+            bool fits = true;
+            if (a.team_rcap) fits = cut_bands(n_steps - s_begin);
+            else { R0 = 0; R1 = g.H; }
+            if (a.todo_out && tid == 0) a.todo_out[e] = fits ? 0 : n_steps - s_begin;
+            if (!fits) {             // (a window of rows that does not hold this fire: the host's catch-up launch where there is one, else loudly)
+                if (!a.todo_out && tid == 0) *reinterpret_cast<volatile uint32_t *>(a.xerr) = 1u;
+                return;
+            }
+            __syncthreads();
+            load_band();
+            __syncthreads();
+        }
+    }
     if (TEAM && tn > 1) {
         // the team's start line (nobody writes before everybody has loaded its band and halo rows); a workgroup that has JOINED lines up with
         // the team behind its cut
@@ -1626,7 +1677,7 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
     for (int i = t; i < G; i += 1024) tab[i] = kTeamUnused;
     const uint32_t c = t < E ? cost[t] : 0u;
     for (int i = t; i < E * kTeamMax * 3; i += 1024) xg[i] = 0ull;
-    if (t < E) { xdone[t] = 0u; if (!keep_cost) cost[t] = 0u; }
+    if (t < E) { xdone[t] = 0u; xdone[E + t] = 0u; if (!keep_cost) cost[t] = 0u; }      // (members that have left / the teams' start words; [2 E]: teams that started as one, kept)
     if (xj) {           // k_run<TEAM = 2>: every environment starts with one member (t_min = t_max = 1), nobody waits, the board is empty
         if (t < E) { xj[t] = 1u; xj[E + t] = 0u; xcut[t] = 0ull; }
         if (t < 2) xj[2 * E + t] = 0u;

@@ -345,9 +345,16 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // request, a barrier and a look at the neighbourhood later, finds the line on its way or in the CU's L1 instead of waiting ~900 clocks for
     // memory.  One line per NEW frontier cell, nothing speculative: the table is cell-major here (k_rt_cellmajor), so the line does not depend
     // on the winner source.  (Rounds 3 / 4 measured speculative touches of the direction-major table - eight per ignition, by the walkers or
-    // by an idle wave: 25 - 35 % slower, a CU has only so many misses in flight.)  The load is written in assembly so that the compiler does
-    // not wait for it; its register is `touch`, which nothing reads and which is only released (a wait) behind the loop.
-    uint32_t touch = 0;
+    // by an idle wave: 25 - 35 % slower, a CU has only so many misses in flight.)  The load is the LDS-DMA form (global_load_lds_dword: lane
+    // i's dword goes to LDS[M0 + 4 i], no register is written - profiles/lds_dma_probe.hip) into 256 bytes nobody reads (the per-wave slots of
+    // the fire search above, free by now), written in assembly so that the compiler does not wait for it; it is out of flight behind the
+    // loop (a wait).
+    const uint32_t touch_dump = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)wslot);
+    auto touch_line = [&](const double *line) {
+        uint32_t m0_was;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_was) : "s"(touch_dump), "v"(line) : "memory");
+    };
     // one lane reserves n places behind a list's counter (ds_add_rtn by hand: the compiler wraps an atomicAdd of one lane into its scalar
     // loop over the active lanes + a second election, ~30 instructions)
     auto reserve = [&](uint32_t *ctr, uint32_t n) -> uint32_t {
@@ -395,6 +402,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             if (ok) *cell = (uint8_t)fin;
             if (ok) ev.tdirty[(m_y >> th_log) * g.TX + ((m_x >> 4) >> g.logLC)] = 1;
         }
+        uint32_t touch_later = 0;                               // ATT: the lane's new frontier cells of this step (their table lines are asked for behind the barrier)
         // (control lines drawn inside the window in front of this update, if any: the owner lanes take them in phase A)
         uint32_t pw = 0;
         if (MITW && pflag) pw = wpatch[(s & 1) * WR * 16 + r * 16 + c];
@@ -481,8 +489,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                         for (int j = 0; j < 4; ++j)
                             if ((p4 >> j) & 1u) {
                                 Fcur[pos++] = (uint16_t)(ent0 | (uint32_t)j);
-                                asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(line + j * 8) : "memory");
+                                if (!ATT) touch_line(line + j * 8);
                             }
+                        touch_later = p4;
                     }
                 }
             }
@@ -491,11 +500,20 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         WPROF(0)             // phase A
         win_barrier<ATT>();
         WPROF(1)             // barrier behind the list
+        if (ATT && touch_later) {
+            // (with attenuation the barriers are full ones - a walker's store to the `settled` plane is read by an owner later - and a full
+            // barrier waits for every load of the wave: the table lines are asked for BEHIND it, while the walkers look at their cells' neighbourhoods)
+            const double *line = ev.rtc + (size_t)idx * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((touch_later >> j) & 1u) touch_line(line + j * 8);
+        }
         // ---- phase B, as few waves as the list needs: walk the list, one cell per lane
         {
             // (the list's length and the lane's first entry are asked for together: one LDS round trip, not two - capF >= threads, an
             // entry beyond the length is garbage that `valid` refuses)
-            const uint32_t total_raw = ctl[k], ent_first = Fcur[tid];
+            uint32_t total_raw = ctl[k], ent_first = Fcur[tid];
+            asm volatile("" : "+v"(total_raw), "+v"(ent_first));      // (both in flight before either is waited for: the compiler would sink the second behind the test of the first)
             const uint32_t total = spread ? total_raw : 0u;
             struct WCell { bool valid, cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
             // first half of a cell: is it (still) a candidate, winner source, operands requested
@@ -647,7 +665,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         pc.note(28);         // folded
         if (!(s < s_cap && st.running && (f & 0x00FF0000u) == 0u)) break;
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) :: "memory");      // (the last requests are out of flight: their register is free)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last table-line requests are out of flight: the LDS they land in is free)
     st.steps += n_plain; st.complete += n_plain; st.elapsed = elapsed;
 #ifdef SF_WIN_PROF
     if (lane == 0 && e < 1024)

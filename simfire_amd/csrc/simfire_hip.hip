@@ -52,6 +52,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -126,6 +127,7 @@ struct sf_sim {
     uint8_t *cells_alloc = nullptr, *cells = nullptr;      // blocked cell plane of the resident launch (allocated at its first use)
     bool bl_cur = false;               // the blocked plane holds the sprite masks / status bytes; the row-major planes are stale
     double *burn = nullptr, *rt = nullptr;
+    mutable std::map<unsigned long long, int> occ_cache;      // team kernels: workgroups per CU by hipOccupancyMaxActiveBlocksPerMultiprocessor (team_occupancy)
     double *rtc = nullptr;             // the R table(s) cell-major (k_rt_cellmajor): built when the resident launch first needs it, stale after every change of rt
     bool rtc_valid = false;
     double *lay_all = nullptr;         // [tables][7][H*W] dense: w0 delta Mx sigma elev U Udir (kept for the observation planes)
@@ -234,6 +236,9 @@ hipError_t sf_run4_launch_team2(int att, int diag, unsigned grid, unsigned block
                                 const void *args, size_t args_bytes, int n_steps, int vcap);
 hipError_t sf_run3_launch_plain(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                 const void *args, size_t args_bytes, int n_steps, int vcap, int bsz);
+hipError_t sf_run2_team_occupancy(int att, int diag, unsigned block, size_t lds, int *per_cu);
+hipError_t sf_run2_join_occupancy(int att, unsigned block, size_t lds, int *per_cu);
+hipError_t sf_run4_team2_occupancy(int att, int diag, int mit, unsigned block, size_t lds, int *per_cu);
 hipError_t sf_run2_launch_join(int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int n_steps, int vcap);
 hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
@@ -625,6 +630,18 @@ extern "C" int sf_get_last_launches(sf_sim *s, int32_t *out)
 {
     if (!s || !out) return fail(SF_EINVAL, "sf_get_last_launches: null argument");
     *out = s->last_launches;
+    return SF_OK;
+}
+extern "C" int sf_get_team_fallbacks(sf_sim *s, int32_t *out)
+{
+    if (!s || !out) return fail(SF_EINVAL, "sf_get_team_fallbacks: null argument");
+    *out = 0;
+    if (!s->xdone) return SF_OK;                   // (no team launch yet)
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    uint32_t v = 0;
+    HIPCHK(hipMemcpy(&v, s->xdone + (size_t)2 * s->g.E, sizeof v, hipMemcpyDeviceToHost));
+    *out = (int32_t)v;
     return SF_OK;
 }
 extern "C" int sf_get_tuning(sf_sim *s, int32_t knob, int32_t *value)
@@ -1168,6 +1185,8 @@ static int launch_k_run(sf_sim *s, const StepArgs &a, int n_steps, int waves, in
     return SF_OK;
 }
 
+struct TeamGeo;
+static int team_occupancy(const sf_sim *s, const TeamGeo &t, bool join);
 // Geometry of a team launch (k_run<TEAM>, sf_run_kernels.h): waves per workgroup, list entries, bitmap rows a member keeps in LDS
 // (0 = all), dynamic LDS, workgroup slots the chip holds at once, smallest team an environment needs.
 struct TeamGeo { int waves, vcap, rcap, slots, t_min; size_t lds; bool ok; };
@@ -1195,12 +1214,41 @@ static TeamGeo team_geometry(const sf_sim *s)
     int per_cu = (int)((160 * 1024) / t.lds);
     if (per_cu * t.waves > 32) per_cu = 32 / t.waves;
     if (per_cu > 2) per_cu = 2;
+    // ... and no more than the runtime says a CU holds of THIS kernel with this much LDS (registers count too): a team's members wait for
+    // each other inside the launch, the grid must not be larger than what the chip holds at once
+    const int occ = team_occupancy(s, t, false);
+    if (occ == 0) return t;
+    if (occ > 0 && occ < per_cu) per_cu = occ;
     t.slots = s->n_cu * per_cu;
     t.ok = (long long)g.E * t.t_min <= t.slots;
     return t;
 }
 
 static int team_buffers(sf_sim *s, const TeamGeo &t);
+
+// Workgroups per CU of the team kernel this geometry launches (the smaller figure of its instantiations with / without control lines inside
+// the launch), from the runtime's occupancy calculator; asked once per geometry.  -1: the runtime would not say (the LDS formula stands).
+static int team_occupancy(const sf_sim *s, const TeamGeo &t, bool join)
+{
+    const Geo &g = s->g;
+    const int rows = t.rcap ? t.rcap : g.H;
+    const int which = join ? 2 : (((rows + t.waves * 64 - 1) / (t.waves * 64)) * g.VW <= 1 ? 0 : 1);
+    const int ia = g.att ? 1 : 0, id = g.diag ? 1 : 0;
+    const unsigned long long key = (unsigned long long)which | (unsigned long long)ia << 2 | (unsigned long long)id << 3 | (unsigned long long)t.waves << 8 | (unsigned long long)t.lds << 16;
+    auto it = s->occ_cache.find(key);
+    if (it != s->occ_cache.end()) return it->second;
+    int occ = -1, o2 = -1;
+    hipError_t e = hipSuccess;
+    if (which == 2) e = sf_run2_join_occupancy(ia, (unsigned)t.waves * 64, t.lds, &occ);
+    else if (which == 0) e = sf_run2_team_occupancy(ia, id, (unsigned)t.waves * 64, t.lds, &occ);
+    else {
+        e = sf_run4_team2_occupancy(ia, id, 0, (unsigned)t.waves * 64, t.lds, &occ);
+        if (e == hipSuccess && sf_run4_team2_occupancy(ia, id, 1, (unsigned)t.waves * 64, t.lds, &o2) == hipSuccess && o2 < occ) occ = o2;
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); occ = -1; }
+    s->occ_cache[key] = occ;
+    return occ;
+}
 
 // Teams that GROW inside the launch (k_run<TEAM = 2>, sf_run_kernels.h): one-word rows, one 16-wave workgroup per CU, every environment starts
 // with ONE member; a workgroup whose environment is done (or that had none) joins the team of the running environment that would finish
@@ -1215,6 +1263,7 @@ static TeamGeo join_geometry(const sf_sim *s)
     if (t.vcap > all_vec) t.vcap = (int)((all_vec + 63) / 64 * 64);
     t.lds = run_lds_bytes(g, t.waves, t.vcap, 1, 0);
     if (t.lds > 160 * 1024 || g.TY < 2) return t;
+    if (team_occupancy(s, t, true) == 0) return t;      // (one 16-wave workgroup per CU: the kernel must fit a CU at all)
     t.slots = s->n_cu;
     t.ok = true;
     return t;
@@ -1272,7 +1321,8 @@ static int team_buffers(sf_sim *s, const TeamGeo &t)
     if (!s->xg) {
         int rc = dev_alloc(s, &s->xg, (size_t)g.E * kTeamMax * 3); if (rc) return rc;
         rc = dev_alloc(s, &s->xbuf, (size_t)g.E * kTeamMax * 4 * team_xrow(g)); if (rc) return rc;
-        rc = dev_alloc(s, &s->xdone, (size_t)g.E); if (rc) return rc;
+        rc = dev_alloc(s, &s->xdone, (size_t)2 * g.E + 1); if (rc) return rc;       // members that have left [E] | the teams' start words [E] | teams that started as one
+        HIPCHK(hipMemsetAsync(s->xdone, 0, sizeof(uint32_t) * ((size_t)2 * g.E + 1), s->stream));
         rc = dev_alloc(s, &s->team_size, (size_t)g.E); if (rc) return rc;
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->xerr_pinned), sizeof(uint32_t), hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->xerr_mapped), s->xerr_pinned, 0));
@@ -1329,7 +1379,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     StepArgs a;
     a.loop_db = nullptr;      // (not the closed loop of sf_loop_start)
     a.team_recut = 0;
-    a.team_timeout = 100000ull * (unsigned long long)(s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] < 1 ? 1 : s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS]);
+    // (0 ms: a team whose members do not all arrive at its start in the same instant starts as one at once - tests of that path)
+    a.team_timeout = 100000ull * (unsigned long long)(s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] == 0 ? 2000 : (s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] < 1 ? 1 : s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS]));
+    a.team_start_timeout = s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] == 0 ? 0ull : a.team_timeout;
     s->last_launches = 0;
     const int n_requested = n_steps;
     if (n_steps != 1 || mit_dev || s->last_was_step1) s->step1_polls = 0;       // (another kind of call, or nobody looked at the last update's result)
@@ -2192,6 +2244,7 @@ extern "C" int sf_rollout(sf_sim *s, int32_t n_steps, void *device_dst)
     int rc = step_impl(s, n_steps, nullptr);
     s->async = was_async;
     if (rc) return rc;
+    if (was_async) return update_status_async(s, static_cast<int32_t *>(device_dst));      // asynchronous mode: enqueued, not waited for (sf_sync / the caller's device synchronisation)
     return sf_copy_status_to(s, device_dst);
 }
 

@@ -21,6 +21,18 @@ namespace {
 typedef void (*run_fn)(StepArgs, int, int, int);
 }
 
+// Workgroups of this instantiation (block threads, lds bytes of dynamic LDS) one CU holds at once, as the runtime computes it from the
+// kernel's registers and LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor): what the host sizes a team launch's grid by - the members of a
+// team wait for each other inside the launch, so a grid the chip cannot hold at once would be a team that is never complete.
+static hipError_t occupancy_of(run_fn kern, unsigned block, size_t lds, int *per_cu)
+{
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, reinterpret_cast<const void *>(kern), (int)block, lds);
+}
+
 // One bitmap word per thread.  att: attenuate_line_ros; diag: diagonal_spread.  set_lds: raise the kernel's dynamic-LDS limit first.
 // (two words per thread: sf_run4_launch_team2, simfire_hip_run4.hip)
 hipError_t sf_run2_launch_team(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
@@ -38,6 +50,17 @@ hipError_t sf_run2_launch_team(int att, int diag, unsigned grid, unsigned block,
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, n_steps, vcap, 64);
     return hipSuccess;
+}
+
+hipError_t sf_run2_team_occupancy(int att, int diag, unsigned block, size_t lds, int *per_cu)
+{
+    static const run_fn table[2][2] = {{k_run<1, 0, -1, -1, 1>, k_run<1, 0, 1, -1, 1>}, {k_run<1, 1, -1, -1, 1>, k_run<1, 1, 1, -1, 1>}};
+    return occupancy_of(table[att ? 1 : 0][diag ? 1 : 0], block, lds, per_cu);
+}
+hipError_t sf_run2_join_occupancy(int att, unsigned block, size_t lds, int *per_cu)
+{
+    static const run_fn table[2] = {k_run<1, 0, 1, 0, 2>, k_run<1, 1, 1, 0, 2>};
+    return occupancy_of(table[att ? 1 : 0], block, lds, per_cu);
 }
 
 // Teams that grow inside the launch (k_run<TEAM = 2>): one-word rows, diagonal spread, no control lines inside the launch.

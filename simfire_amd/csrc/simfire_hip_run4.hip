@@ -19,6 +19,25 @@ namespace {
 typedef void (*run_fn)(StepArgs, int, int, int);
 }
 
+// Workgroups of this instantiation (block threads, lds bytes of dynamic LDS) one CU holds at once, as the runtime computes it from the
+// kernel's registers and LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor): what the host sizes a team launch's grid by - the members of a
+// team wait for each other inside the launch, so a grid the chip cannot hold at once would be a team that is never complete.
+static hipError_t occupancy_of(run_fn kern, unsigned block, size_t lds, int *per_cu)
+{
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, reinterpret_cast<const void *>(kern), (int)block, lds);
+}
+
+hipError_t sf_run4_team2_occupancy(int att, int diag, int mit, unsigned block, size_t lds, int *per_cu)
+{
+    static const run_fn table[2][2] = {{k_run<2, 0, -1, -1, 1>, k_run<2, 0, 1, -1, 1>}, {k_run<2, 1, -1, -1, 1>, k_run<2, 1, 1, -1, 1>}};
+    static const run_fn table_c4[2] = {k_run<2, 0, 1, 0, 1>, k_run<2, 1, 1, 0, 1>};
+    return occupancy_of((diag && !mit) ? table_c4[att ? 1 : 0] : table[att ? 1 : 0][diag ? 1 : 0], block, lds, per_cu);
+}
+
 hipError_t sf_run4_launch_team2(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                 const void *args, size_t args_bytes, int n_steps, int vcap)
 {

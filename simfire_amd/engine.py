@@ -283,6 +283,13 @@ class FireEngine:
         self._chk(self._L.sf_get_last_launches(self._h, C.byref(v)))
         return int(v.value)
 
+    def team_fallbacks(self):
+        """Teams of a fixed size that found at their start that not all members were resident and whose environment was stepped by
+        member 0 alone (same results; since the handle was created)."""
+        v = C.c_int32()
+        self._chk(self._L.sf_get_team_fallbacks(self._h, C.byref(v)))
+        return int(v.value)
+
     def get_tuning(self, name):
         v = C.c_int32()
         self._chk(self._L.sf_get_tuning(self._h, _lib.TUNE[name], C.byref(v)))
