@@ -499,6 +499,11 @@ def main():
     eng.set_result_sink(result.data_ptr())          # the harness's tensor of episode returns: registered once
     gathered = torch.zeros((world * w.n_envs, 8), dtype=torch.int32, device=coll_dev) if world > 1 else result
 
+    def enqueue_only(on):
+        """Asynchronous mode of the handle for the rollout calls of a timed region (N = 1 only: see rollout)."""
+        if agent_pts is None:
+            eng.set_async(bool(on) and dist is None)
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
@@ -509,9 +514,9 @@ def main():
         if agent_pts is None:
             # the steps + the per-env result block (episode returns) into the registered tensor: ONE call that only enqueues (asynchronous mode) -
             # the one host wait of a rollout is the caller's: the fence below (a harness whose policy is a kernel waits for nothing)
-            eng.set_async(dist is None)                  # (N > 1: the collective below runs on torch's stream, so the block is waited for first)
+            # (asynchronous mode is switched on by the caller outside its timed region - `enqueue_only` below; N > 1: the collective runs on
+            # torch's stream, so the block is waited for first)
             eng.rollout(k, result.data_ptr())
-            eng.set_async(False)
         else:
             run_steps(eng, k, first, agent_pts)
             eng.copy_status_to(result.data_ptr())
@@ -544,11 +549,13 @@ def main():
             run_steps(eng, a.warmup, 0, agent_pts)
         eng.copy_status_to(result.data_ptr())
         steps_before = result[:, 1].sum().item()
+        enqueue_only(True)
         fence()
         t0 = time.perf_counter()
         rollout(a.steps, a.warmup)
         fence()
         dts.append(time.perf_counter() - t0)
+        enqueue_only(False)
         esteps.append(result[:, 1].sum().item() - steps_before)      # update() calls really made
         blocks.append(result.cpu().numpy())
     # ---------------------------------------------------------------------------------
@@ -699,11 +706,13 @@ def main():
                 run_steps(eng, a.warmup, 0, None)
             eng.copy_status_to(result.data_ptr())
             c0 = result[:, 1].sum().item()
+            enqueue_only(True)
             fence()
             t0c = time.perf_counter()
             rollout(a.steps, a.warmup)
             fence()
             dtc = time.perf_counter() - t0c
+            enqueue_only(False)
             esc = result[:, 1].sum().item() - c0
             also["cold"] = {"value": H * W * esc / dtc, "unit": "cell-updates/s", "ms_per_step": dtc * 1e3 / a.steps, "rehearsal": False,
                             "ignition_seeds": "1234 + 100000 + e (the headline: 1234 + e)", "env_steps_executed": esc,
@@ -728,11 +737,13 @@ def main():
                     run_steps(eng, al.warmup, 0, None)
                     eng.copy_status_to(result.data_ptr())
                     l0 = result[:, 1].sum().item()
+                    enqueue_only(True)
                     fence()
                     t0l = time.perf_counter()
                     rollout(al.steps, al.warmup)
                     fence()
                     dtls.append(time.perf_counter() - t0l)
+                    enqueue_only(False)
                     esl_ = result[:, 1].sum().item() - l0
                 dtl = float(np.median(dtls))
                 blk_l = result.cpu().numpy()

@@ -20,7 +20,7 @@ int sf_step_timed(sf_sim *sim, int32_t n_steps, float *ms_out);
  * to the frontier phase, out[3] = wavefronts that survived the quick reject, out[4] = frontier
  * walks (row iterations with a non-empty work list), out[5] = 16-cell vectors visited, out[6] / out[7] = k_front's records / sprite
  * events or the team kernels' step boundaries (| those through one L2 << 32) / their clocks, out[8] = updates made in the window
- * phase, out[9..15] = 0; summed over all steps since the last reset of the counters. */
+ * phase, out[9] = owner waves of the window phase that looked for new frontier cells (of out[5] / 16 that kept their books), out[10..15] = 0; summed over all steps since the last reset of the counters. */
 int sf_get_counters(sf_sim *sim, int64_t *out /* [16] */, int32_t reset);
 /* The statistics cost a few atomics per active wavefront, so they are off by default. */
 int sf_enable_counters(sf_sim *sim, int32_t on);

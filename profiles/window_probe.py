@@ -25,7 +25,7 @@ for win in (1, 0):
     eng.step(20)
     c = eng.counters(); eng.enable_counters(False)
     print(f"window={win}: 5 steps {t5*1e3:.1f} us, 20 steps {t20*1e3:.1f} us ({t20*50:.2f} us/step); clocks/env max {cost.max():.0f} median {np.median(cost):.0f} min {cost.min():.0f}; "
-          f"window updates {c['window_updates']} of {E*20}; vectors {c['vectors']} active {c['active_cell_updates']}")
+          f"window updates {c['window_updates']} of {E*20}; vectors {c['vectors']} active {c['active_cell_updates']}; owner waves {c['vectors'] // 16} of which looked for new cells {c.get('window_waves_looking', 0)}")
     if win:
         order = np.argsort(cost)
         print("   cost deciles (k clocks):", " ".join(f"{cost[order[int(q*(E-1))]]/1e3:.1f}" for q in np.linspace(0, 1, 11)))

@@ -450,9 +450,21 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
 #endif
     uint32_t *tcnt = reinterpret_cast<uint32_t *>(halo + 2 * g.PV);                // TEAM: [64] vectors with sprites per tile row (the split)
 
+    // (the window phase's first looks at memory - this thread's row of the vector bitmap, its tile's dirty flag - are asked for together with
+    // the environment's state: one memory round trip at the head of the launch, not two.  In assembly, so that they are issued HERE.)
+    constexpr bool kWinPre = (MIT == 0 || MIT == -1) && MAXD == 1 && TEAM == 0;
+    unsigned long long pre_w = 0ull;
+    uint32_t pre_dirty = 0u;
+    if (kWinPre && a.win) {
+        const unsigned long long *pw_ = a.vbits + (long long)e * g.vb_env + tid;
+        const uint8_t *pd_ = a.tdirty + (long long)e * g.TY * g.TX + tid;
+        if (tid < g.H) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre_w) : "v"(pw_) : "memory");
+        if (tid < g.TY * g.TX) asm volatile("global_load_ubyte %0, %1, off" : "=v"(pre_dirty) : "v"(pd_) : "memory");
+    }
     EnvState st = a.commit[e];
     if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
     if ((!st.running && !mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
+    if (kWinPre && a.win) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_w), "+v"(pre_dirty) :: "memory");      // (asked for before the state, which has arrived: no wait left)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * VW;
     if (tid < kRunCtl) ctl[tid] = 0;
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
 #endif
         wpc.note(30);        // launch: state read
+        we.pre_w = pre_w; we.pre_dirty = pre_dirty; we.pre = kWinPre;
         s_begin = run_window<ATT, kWinGen, kWinMit>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result,
                                                     kWinMit ? mit : nullptr, n_steps, &px, &py, &pty, vlist, vcap >= 1024 ? 15 : 11);      // (the duplicate filter's bits in the list's LDS: 4 KB, or 256 bytes on small grids)
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 8: updates made inside a window - a slot of its own, whatever the instantiation)

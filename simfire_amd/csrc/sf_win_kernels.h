@@ -117,6 +117,9 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
     uint16_t *thist;               // [TY][TX][8] of this environment: cached status histograms of the wave tiles
     unsigned long long *vb_glob;   // this environment's rows of the three vector bitmaps in memory: plane 0; planes 1 / 2 are vb_plane further each
     long long vb_plane;
+    unsigned long long pre_w;      // pre: this thread's row of plane 0 and its tile's dirty flag, asked for by k_run together with the environment's state
+    uint32_t pre_dirty;
+    bool pre;
 };
 
 // Returns the updates made (0: the fire does not fit a window - nothing has been touched).  st is folded like in the general loop;
@@ -202,13 +205,16 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         ymin = (int)(0xFFFFFFFFu - a_); ymax1 = (int)b_; vmin = (int)(0xFFFFFFFFu - c_); vmax = (int)d_ - 1;
     } else {
     {
-        const unsigned long long w = tid < g.H ? ev.vb_glob[tid] : 0ull;
+        unsigned long long w = 0ull;
+        uint32_t d0 = 0u;
+        if (ev.pre) { w = ev.pre_w; d0 = ev.pre_dirty; }      // (k_run has waited for them)
+        else w = tid < g.H ? ev.vb_glob[tid] : 0ull;
         const unsigned long long nz = __ballot(w != 0ull);
         const uint32_t c_lo = wave_or((uint32_t)w), c_hi = wave_or((uint32_t)(w >> 32));
         // are the cached status histograms of this environment's tiles all valid?  Then the result block can be brought up to date
         // from what this phase changes (below) instead of a sweep over the tiles' flags and histograms (counts_env)
-        bool dirty = false;
-        for (int t = tid; t < g.TY * g.TX; t += nthr) dirty |= ev.tdirty[t] != 0;
+        bool dirty = ev.pre && tid < g.TY * g.TX && d0 != 0u;
+        for (int t = ev.pre ? tid + nthr : tid; t < g.TY * g.TX; t += nthr) dirty |= ev.tdirty[t] != 0;
         const bool wave_dirty = __ballot(dirty) != 0ull;
         if (lane == 0) {
             uint32_t *sl = wslot + wave * 4;
@@ -338,6 +344,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // the masks of a step (every wave: the walkers need them too) come with the rows, a step ahead
     uint4 t0 = *reinterpret_cast<const uint4 *>(tab + s0 * 8), t1 = *reinterpret_cast<const uint4 *>(tab + s0 * 8 + 4);
     bool pflag = MITW ? __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 5]) != 0 : false;      // control lines inside the window in front of the coming update
+    uint32_t n_look = 0;                                       // (statistics: owner waves that looked for new frontier cells; slot 9)
     uint32_t marked = 0xFFFFFFFFu;                             // bit w: a cell ignited in or next to wave w's rows in the step before (first step: everywhere)
     uint32_t onlist = 0;                                       // this lane's four "on the list" bits as the step before left them
     const int flag_w = r * 2 + (c >> 3), flag_sh = (4 * c) & 31;      // where they sit in the plane of bits
@@ -366,6 +373,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         return (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
     };
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const uint32_t ring_top = open_top ? 0u : 0xFFFFu, ring_bot = open_bot ? (uint32_t)(WR - 1) : 0xFFFFu, ring_left = open_left ? 0u : 0xFFFFu, ring_right = open_right ? 63u : 0xFFFFu;
 #ifdef SF_WIN_PROF
     unsigned long long wp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wp_t = __builtin_readcyclecounter();
 #endif
@@ -411,7 +419,6 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (__ballot((mid | up | dn | pw) != 0u) != 0ull) {    // (wave-uniform)
             pc.note(21);     // rows arrived
             if (stats) n_vec_done += lane == 0 ? 16u : 0u;     // four rows x four vectors swept
-            const uint32_t sv_in = sv;
             // the cells this window ignited in the step before: BURNING (fire.py:587; not in a window's first step: a bit of that age
             // may sit under a control line drawn since)
             {
@@ -462,12 +469,13 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                     }
                 }
             }
-            if (sv != sv_in) wstat[r * 16 + c] = sv;           // (the walkers' view of this lane's cells)
-            if (mid & CLR4) wm[own] = mid & ~CLR4;             // the slot of sprites that were pruned one step ago is recycled
+            wstat[r * 16 + c] = sv;                            // (the walkers' view of this lane's cells; stored whether or not it changed: no branch)
+            wm[own] = mid & ~CLR4;                             // the slot of sprites that were pruned one step ago is recycled
             // new frontier cells can only be next to a cell that ignited in the step before, or under a control line drawn since (see the
             // head of this function): the waves marked by the walkers, and the wave of a patch
             const bool look = spread && (((marked >> wave) & 1u) != 0u || (MITW && __ballot(pw != 0u) != 0ull));       // (wave-uniform)
             if (look) {
+                if (stats && lane == 0) ++n_look;
                 // eligible (fire.py:192-205) & next to a live sprite (fire.py:163-234) & not on the list yet
                 const uint32_t vsrc = (up | dn) & L4;
                 const uint32_t hsrc = diag ? (midL | vsrc) : midL;
@@ -485,12 +493,16 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                         atomicOr(&wflag[flag_w], p4 << flag_sh);           // (eight lanes share a word)
                         const uint32_t ent0 = (uint32_t)(r << 6 | c << 2);
                         const double *line = ev.rtc + (size_t)idx * 8;
+                        const int j0 = __ffs(p4) - 1;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if ((p4 >> j) & 1u) {
-                                Fcur[pos++] = (uint16_t)(ent0 | (uint32_t)j);
-                                if (!ATT) touch_line(line + j * 8);
-                            }
+                        for (int j = 0; j < 4; ++j) {
+                            // (one divergent `if` around the lane's cells, none inside: a cell that is not new stores to the dump and asks for the line
+                            // of the lane's first new cell once more)
+                            const bool on = (p4 >> j) & 1u;
+                            *(on ? Fcur + pos : reinterpret_cast<uint16_t *>(wslot)) = (uint16_t)(ent0 | (uint32_t)j);
+                            pos += on ? 1u : 0u;
+                            if (!ATT) touch_line(line + (on ? j : j0) * 8);
+                        }
                         touch_later = p4;
                     }
                 }
@@ -537,13 +549,16 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                     uint32_t o = lo | hi;
                     o |= o >> 16;
                     o = (o | (o >> 8)) & 0xFFu;
-                    if (o) {
+                    {
+                        // (straight-line: every lane of a walking wave has a cell, almost every cell a live neighbour - the branches around this
+                        // cost more than what they skip; o = 0 computes garbage that the select below drops)
                         const uint32_t rq = ((o << rot) | (o >> nrot)) & nmask;
-                        int slot = (31 - __clz(rq)) - (int)rot;        // bit of the newest sprite in the unrotated masks
-                        if (slot < 0) slot += g.N;
-                        const uint32_t T = __builtin_amdgcn_perm(0u, 1u << slot, 0u);     // that bit in every byte
+                        int slot = (31 - __clz(rq | 1u)) - (int)rot;   // bit of the newest sprite in the unrotated masks
+                        slot += slot < 0 ? g.N : 0;
+                        const uint32_t T = __builtin_amdgcn_perm(0u, 1u << (slot & 7), 0u);     // that bit in every byte
                         const uint32_t cl = lo & T, ch = hi & T;
-                        bestk = cl ? (__ffs(cl) - 1) >> 3 : 4 + ((__ffs(ch) - 1) >> 3);
+                        const int kl = (int)(__builtin_ctz(cl | 0x80000000u) >> 3), kh = 4 + (int)(__builtin_ctz(ch | 0x80000000u) >> 3);
+                        bestk = o ? (cl ? kl : kh) : -1;
                     }
                 }
                 // a candidate: eligible (fire.py:192-205: UNBURNED or a control line) and next to a live sprite (fire.py:163-234)
@@ -560,30 +575,30 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 return q;
             };
             // second half: accumulate, ignite
+            // (LDS stores of lanes that have nothing to store go to a dump nobody reads - the address is selected, the store is not branched
+            // around: a divergent `if` costs a compare, two exec-mask instructions and a branch, ~30 clocks of a chain that has a dozen of them)
             auto back = [&](const WCell &q) -> bool {
-                bool ignited = false;
-                if (q.cand) {
-                    const uint32_t rr = q.pos >> 6, cx = q.pos & 63u, s_post = q.own_spost >> 8;
-                    double b = q.bn;
-                    double ros = q.r_tab * g.update_rate;                                    // fire.py:696,705
-                    if (s_post >= SF_FIRELINE) {                                             // fire.py:271-282
-                        if (ATT) {
-                            const double f = line_factor(s_post);
-                            b = lazy_sub(b, f, q.owed);        // the updates since this cell was last touched (fire.py:278, ros = 0)
-                            ros = ros - f;
-                            ev.settled[(uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx)] = (uint32_t)(st.complete + n_plain) + 1u;      // this update runs to the end: it has a candidate
-                        } else ros = 0.0;
+                const uint32_t rr = q.pos >> 6, cx = q.pos & 63u, s_post = q.own_spost >> 8;
+                double b = q.bn;
+                double ros = q.r_tab * g.update_rate;                                        // fire.py:696,705
+                if (ATT) {
+                    if (q.cand && s_post >= SF_FIRELINE) {                                   // fire.py:271-282
+                        const double f = line_factor(s_post);
+                        b = lazy_sub(b, f, q.owed);            // the updates since this cell was last touched (fire.py:278, ros = 0)
+                        ros = ros - f;
+                        ev.settled[(uint32_t)((wy0 + (int)rr) * g.P + wx0 + (int)cx)] = (uint32_t)(st.complete + n_plain) + 1u;      // this update runs to the end: it has a candidate
                     }
-                    b = b + ros;                                                             // fire.py:710
-                    wb[q.pos] = b;
-                    wdirty[q.pos >> 2] = 1;
-                    if (b > g.pixel_scale) {                                                 // fire.py:568
-                        ignited = true;
-                        reinterpret_cast<uint8_t *>(wm)[(rr + 1u) * 72u + 4u + cx] = (uint8_t)(((q.own_spost & 0xFFu) & ~(CLR4 & 0xFFu)) | b_new);      // fire.py:571-579
-                        const bool on_ring = (rr == 0u && open_top) || (rr == (uint32_t)(WR - 1) && open_bot) || (cx == 0u && open_left) || (cx == 63u && open_right);
-                        if (on_ring) reinterpret_cast<uint8_t *>(ctl + 3 + k)[2] = 1;        // a sprite in the ring: the window is left after this step
-                    }
-                }
+                } else ros = s_post >= SF_FIRELINE ? 0.0 : ros;
+                b = b + ros;                                                                 // fire.py:710
+                const bool ignited = q.cand && b > g.pixel_scale;                            // fire.py:568
+                *(q.cand ? wb + q.pos : reinterpret_cast<double *>(wslot)) = b;
+                *(q.cand ? wdirty + (q.pos >> 2) : reinterpret_cast<uint8_t *>(wslot)) = 1;
+                *(ignited ? reinterpret_cast<uint8_t *>(wm) + (rr + 1u) * 72u + 4u + cx : reinterpret_cast<uint8_t *>(wslot)) =
+                    (uint8_t)(((q.own_spost & 0xFFu) & ~(CLR4 & 0xFFu)) | b_new);           // fire.py:571-579
+                // a sprite in the ring: the window is left after this step (compares against per-window constants: a side that is the grid's
+                // edge gets a row / column no cell has)
+                const bool on_ring = ignited & ((rr == ring_top) | (rr == ring_bot) | (cx == ring_left) | (cx == ring_right));
+                *(on_ring ? reinterpret_cast<uint8_t *>(ctl + 3 + k) + 2 : reinterpret_cast<uint8_t *>(wslot)) = 1;
                 return ignited;
             };
             bool any_cand = false;
@@ -612,6 +627,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 if (c0.valid && !stay) atomicAnd(&wflag[c0.pos >> 5], ~(1u << (c0.pos & 31u)));          // (addresses differ from lane to lane: a plain LDS atomic)
                 if (ib != 0ull) {
                     if (stats) n_ignite += (uint32_t)__popcll(ib);
+                    // (ONE atomic per wave: the lanes' bits ORed over the wave first - atomics of many lanes on one LDS word are taken one after the other)
                     const uint32_t rr = c0.pos >> 6;
                     const uint32_t wm_all = wave_or(ignited ? (1u << ((rr ? rr - 1u : 0u) >> 2)) | (1u << ((rr + 1u) >> 2)) : 0u);
                     if (lane == 0) {
@@ -622,7 +638,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 if (sb != 0ull) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sbase) :: "memory");
                     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)sbase, 0);
-                    if (stay) Fnext[base + (uint32_t)__popcll(sb & lanes_below)] = (uint16_t)c0.pos;
+                    *(stay ? Fnext + base + (uint32_t)__popcll(sb & lanes_below) : reinterpret_cast<uint16_t *>(wslot)) = (uint16_t)c0.pos;
                 }
                 pc.note(25); // updates, ignitions
             }
@@ -671,6 +687,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (lane == 0 && e < 1024)
         for (int q = 0; q < 8; ++q) g_win_prof[((size_t)e * 16 + wave) * 8 + q] = wp_acc[q];
 #endif
+    if (stats && lane == 0 && n_look) atomicAdd(a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow + 9, (unsigned long long)n_look);
     if (tid < 9) ctl[tid] = 0;                                 // (the general loop's list lengths, predicate bytes and batch cursors: rings of three)
     lpc.note(33);            // updates done
     // ---- back to memory: the cells and burn_amounts that changed, the dirty flags of their tiles, the window's part of the vector bitmaps
@@ -737,7 +754,10 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             }
         }
     }
-    __syncthreads();
+    // (with the result block by difference what follows reads LDS only; the general loop, if it takes over, and counts_env read the cells
+    // just stored: then the full barrier)
+    if (by_delta && (s >= n_steps || !st.running)) win_barrier<0>();
+    else __syncthreads();
     lpc.note(34);            // window written back
     if (by_delta) {
         for (int i = tid; i < nty * ntx * 8; i += nthr) {

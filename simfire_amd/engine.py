@@ -481,7 +481,7 @@ class FireEngine:
         return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
                     active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]),
                     records=int(out[6]), sprite_events=int(out[7]),
-                    window_updates=int(out[8]))
+                    window_updates=int(out[8]), window_waves_looking=int(out[9]))
 
     def update_status_device(self):
         self._chk(self._L.sf_update_status_device(self._h))
