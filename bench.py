@@ -33,8 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells", 4: "k_run_tiles", 5: "k_front",
-                6: "k_front + k_run (overflow)"}
+LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells"}
 
 
 def parse(argv=None):
@@ -55,9 +54,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dense", action="store_true", help="visit every tile / vector every step (no skipping)")
     ap.add_argument("--generic", action="store_true", help="plain one-thread-per-cell kernel instead of the tiled kernels")
-    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4],
+    ap.add_argument("--fused", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="-1 automatic, 0 k_select + k_step per step, 1 one fused launch per step, "
-                         "2 one environment-resident launch per rollout (k_run), 3 its tile flavour (k_run_tiles)")
+                         "2 one environment-resident launch per rollout (k_run)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
                          "multi-rank code path on a box with fewer GPUs than ranks)")
@@ -237,9 +236,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
     are the cells the kernel really sweeps: the cells of the wave tiles visited (tiled kernels) or of the
     16-cell vectors visited (k_run).  With a resident launch one launch = the whole K-step rollout."""
     H, W = w.shape
-    # all K steps; k_front: one cell per frontier record visited and per sprite expiry / recycling event
-    front = kind in (5, 6)
-    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16 + ((cnt["records"] + cnt["sprite_events"]) if front else 0)
+    cells = cnt["active_waves"] * tile_cells + cnt["vectors"] * 16
     active = cnt["active_cell_updates"]
     if dense:
         # the dense sweep reads 1 B (the sprite mask) of a quiescent cell and rejects it; charging the 4 B of
@@ -250,7 +247,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
                                                          "(burn R + W, one table entry)")
     sec = kernel_ms * 1e-3
     achieved = alg_bytes / sec / 1e9
-    resident = kind in (2, 4, 5, 6)
+    resident = kind == 2
     launches = 1 if resident else a.steps * (2 if kind == 0 else 1)
     traffic, replayed = None, {}
     if pmc and pmc.get("steps") == a.steps and pmc.get("warmup") == a.warmup and pmc.get("kernel") == LAUNCH_KINDS.get(kind):
@@ -265,8 +262,6 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
             "cells_swept_per_step": cells / a.steps, "active_cell_updates_per_step": active / a.steps,
             "tiles_visited_per_step": cnt["active_waves"] / a.steps, "vectors_visited_per_step": cnt["vectors"] / a.steps,
             "frontier_walks_per_step": cnt["frontier_walks"] / a.steps,
-            "records_visited_per_step": cnt["records"] / a.steps if front else 0.0,
-            "sprite_events_per_step": cnt["sprite_events"] / a.steps if front else 0.0,
             # window-independent rates (the headline counts H x W per environment step, however small the fire)
             "active_cell_updates_per_s": active / sec, "cells_swept_per_s": cells / sec,
             "dense_cell_updates_per_s_kernel": H * W * env_steps / sec,
@@ -313,6 +308,15 @@ def issue_block(w, a, rl, cost, n_cu=256):
            "clocks_max_env": float(clocks.max()), "clocks_median_env": float(np.median(clocks)),
            "clock_ghz_measured": float(clocks.max() / sec / 1e9),
            "source": "sf_get_run_cost (s_memtime stamps of the timed launch) / HIP-event duration"}
+    # The bound this launch runs against is not bytes but a dependent chain: per update of the window phase - an ignition's bit
+    # visible to its neighbours' owner (LDS write -> read 64), the new frontier cell known (>= ~20 dependent instructions at ~5 clocks), its place
+    # on the list (a returning LDS atomic ~100), a barrier (64), the walker's look at the entry (64) and at the 3 x 3 sprite masks (64), the winner
+    # source (>= ~25 dependent instructions), the table entry from the CU's L1 or the XCD's L2 (157 - 241), four f64 operations, a barrier (64):
+    # ~0.9 k shader clocks, from profiles/r05_lds_latency_probe.txt and r03_latency_probe.txt.  Achieved: the slowest environment's clocks per
+    # update of this launch (its fixed part - fire found, window loaded, written back, result block: ~14 k clocks per launch - included).
+    if w.name.startswith("c3") and a.steps <= 64:
+        blk.update({"chain_bound_clocks": 885.0, "chain_clocks_per_update": float(clocks.max() / a.steps), "chain_frac": float(885.0 * a.steps / clocks.max()),
+                    "chain_bound_source": "profiles/r05_lds_latency_probe.txt + profiles/r03_latency_probe.txt, DESIGN.md 5.9"})
     p = profile_file(f"sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
     if p:
         with open(p) as f:
@@ -681,6 +685,9 @@ def main():
         iss = issue_block(w, a, out["roofline"], measure.last_cost)
         if iss:
             out["roofline"]["issue"] = iss
+            for key in ("chain_bound_clocks", "chain_clocks_per_update", "chain_frac"):      # (the latency bound of one update beside the HBM one)
+                if key in iss:
+                    out["roofline"][key] = iss[key]
             ra = out["roofline"].get("random_access")
             if ra and "clock_ghz_measured" in iss:       # the sector rate at the clock the launch really ran at, not an assumed one
                 ra["achieved_sectors_per_clock_per_cu"] *= ra["clock_ghz_assumed"] / iss["clock_ghz_measured"]
@@ -774,6 +781,34 @@ def main():
                     "traffic": tr, "traffic_over_algorithmic": (tr / (rll["algorithmic_bytes_per_launch"] * rll["launches"]) if tr else None),
                     "replayed_from": rll.get("replayed_from"),
                     "note": "1000 updates after 20 on the same batch: fires of hundreds of cells, the general loop + teams that grow inside the launch"}
+            # the closed loop an RL harness issues - update_mitigation(points that depend on the last observation), run(1), the result block, per
+            # call (simulation.py:449-478, 501-553) - on the resident launch driven through host-mapped memory (sf_loop_step): wall us per call
+            # over updates 21 .. 120 of the episode, 4 points per environment and update (an agent's random walk), the default loop (16-wave
+            # workgroups: nothing else fits the chip while it is resident) and the light one (8-wave workgroups: a policy network's kernels run
+            # beside it, tests/test_hip_resident.py)
+            try:
+                from simfire_amd import workloads as _wl
+                walk = _wl.agent_walk(w.n_envs, 4, H, W, 140)
+                blk4 = np.ascontiguousarray(walk.reshape(walk.shape[0], w.n_envs, 4, 4)[..., 1:])
+                cl = {"points_per_env": 4, "updates": "21 .. 120 of the episode", "unit": "us per sf_loop_step call (wall, host)"}
+                for name_, light in (("default", 0), ("light", 1)):
+                    eng.reset(w.init_xy)
+                    eng.step(20)
+                    eng.status()
+                    eng.set_tuning(loop_light=light)
+                    eng.loop_start(4)
+                    for s_ in range(10):
+                        eng.loop_step(blk4[20 + s_])
+                    t0c = time.perf_counter()
+                    for s_ in range(10, 110):
+                        eng.loop_step(blk4[20 + s_])
+                    cl[name_] = (time.perf_counter() - t0c) * 1e4
+                    cl[name_ + "_restarts"] = eng.loop_restarts()
+                    eng.loop_stop()
+                eng.set_tuning(loop_light=0)
+                out["roofline"]["closed_loop"] = cl
+            except Exception as ex:                              # (never lets the line go missing)
+                out["roofline"]["closed_loop"] = {"error": str(ex)}
             # the throughput regime: same workload, 4 x the batch (256 environments do not fill the chip)
             eng.close()
             big = make_workload("c3", a.size, 4 * w.n_envs, 0)

@@ -18,8 +18,8 @@ int sf_step_timed(sf_sim *sim, int32_t n_steps, float *ms_out);
 /* Introspection for benchmarks: out[0] = active cell-updates (cells whose burn_amounts were
  * read+written: candidates and attenuated line cells), out[1] = ignitions, out[2] = cells handed
  * to the frontier phase, out[3] = wavefronts that survived the quick reject, out[4] = frontier
- * walks (row iterations with a non-empty work list), out[5] = 16-cell vectors visited, out[6] / out[7] = k_front's records / sprite
- * events or the team kernels' step boundaries (| those through one L2 << 32) / their clocks, out[8] = updates made in the window
+ * walks (row iterations with a non-empty work list), out[5] = 16-cell vectors visited, out[6] / out[7] = the team kernels'
+ * step boundaries (| those through one L2 << 32) / their clocks, out[8] = updates made in the window
  * phase, out[9] = owner waves of the window phase that looked for new frontier cells (of out[5] / 16 that kept their books), out[10..15] = 0; summed over all steps since the last reset of the counters. */
 int sf_get_counters(sf_sim *sim, int64_t *out /* [16] */, int32_t reset);
 /* The statistics cost a few atomics per active wavefront, so they are off by default. */
@@ -39,13 +39,9 @@ int sf_set_generic(sf_sim *sim, int32_t on);
  * otherwise one fused launch per step up to 12288 wave tiles, k_select + k_step above.
  * 0 = always two launches per step, 1 = always one fused launch per step, 2 = always the resident launch
  * (falls back to the per-step launches while the spread graph / history by-products are on or
- * max_fire_duration > 5), 3 = the tile flavour of the resident launch (k_run_tiles; development / cross-check),
- * 4 = one frontier-resident launch per call (k_front: per environment the burning sprites and their ignition candidates
- * are kept as lists in LDS for all n steps; falls back to 2 in attenuation mode, in the visit-everything mode and when
- * control lines are applied inside the launch). */
+ * max_fire_duration > 5).  (Rounds 2 - 4 carried two measured alternatives that were never the automatic choice, a tile flavour of the
+ * resident launch and a frontier-resident launch `k_front` - modes 3 / 4 of a cross-check build; retired in round 5) */
 int sf_set_fused(sf_sim *sim, int32_t mode);
-/* (modes 3 and 4 are measured alternatives that were never the automatic choice; they are compiled only into the
- * cross-check build, -DSF_EXPERIMENTAL -> libsimfire_hip_exp.so; the product library answers SF_ENOTSUP.) */
 
 /* Launch-geometry knobs of a handle.  RESULTS NEVER DEPEND ON THEM (the tests force several values of each against the
  * oracle); the defaults are the measured choices of DESIGN.md section 5.  This is the only way to change them: the
@@ -61,14 +57,7 @@ enum sf_tuning_knob {
     SF_TUNE_RUN_BATCH = 5,      /* vectors per batch of k_run, 8..64 (default 64) */
     SF_TUNE_RUN_RESULT = 6,     /* 1 = k_run writes the result block itself when its steps are done (default 1) */
     SF_TUNE_RUN_SEGMENT = 7,    /* steps per k_run launch when there are more environments than workgroup slots (default 64; 0 = one launch) */
-    SF_TUNE_FRONT_MIN_STEPS = 8,/* cross-check build only: k_front knobs */
-    SF_TUNE_FRONT_AUTO = 9,
-    SF_TUNE_FRONT_WAVES = 10,
-    SF_TUNE_FRONT_RC = 11,
-    SF_TUNE_FRONT_IC = 12,
-    SF_TUNE_FRONT_TAB = 13,
-    SF_TUNE_FRONT_DEBUG = 14,
-    SF_TUNE_RUN_TEAM = 15,      /* workgroups per environment in the resident launch (k_run<TEAM>: bands of rows, one boundary row exchanged per step):
+    SF_TUNE_RUN_TEAM = 8,      /* workgroups per environment in the resident launch (k_run<TEAM>: bands of rows, one boundary row exchanged per step):
                                  * 0 = automatic (default): teams on grids of more than 1024 columns, where one workgroup cannot hold an
                                  * environment's bitmaps (one member with a window of rows while a call ends with every fire surely young -
                                  * the library keeps an upper bound on the fires' extent since the last reset -, two and more after that),
@@ -76,23 +65,27 @@ enum sf_tuning_knob {
                                  * chip idle; one workgroup per environment otherwise (measured faster);
                                  * 1 = never; 2 / 3 / 4 = every environment split into exactly that many (tests);
                                  * -1 = teams of 1..4 sized from what the environments cost in the launch before, on any grid */
-    SF_TUNE_TEAM_PLACEMENT = 16,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
+    SF_TUNE_TEAM_PLACEMENT = 9,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
                                  * 1 = consecutive slots (spread over the XCDs), 2 = as 0 but the hand-off written through as if they were apart (tests) */
-    SF_TUNE_TEAM_RECUT = 17,    /* teams of a fixed size (forced; or all the chip's workgroup slots taken at the smallest size: C4's share): 1 (default) =
+    SF_TUNE_TEAM_RECUT = 10,    /* teams of a fixed size (forced; or all the chip's workgroup slots taken at the smallest size: C4's share): 1 (default) =
                                  * the whole rollout is ONE launch whose teams cut their bands anew every 2 x SF_TUNE_RUN_SEGMENT steps inside it,
                                  * 0 = one launch per segment (the bands are cut by each launch's prologue) */
-    SF_TUNE_RUN_WINDOW = 18,    /* the window phase of the resident launch (a young fire's cells held in registers while the fire fits 64 x 64 cells): 1 (default) = on,
+    SF_TUNE_RUN_WINDOW = 11,    /* the window phase of the resident launch (a young fire's cells held in registers while the fire fits 64 x 64 cells): 1 (default) = on,
                                  * 0 = off, k > 1 = on, but the window is left after k updates (tests: forces the hand-over to the general loop anywhere) */
-    SF_TUNE_TEAM_TIMEOUT_MS = 19,/* how long a member of a team waits for the others (wall clock, ms; default 2000).  At a team's START (teams of a fixed size) a
+    SF_TUNE_TEAM_TIMEOUT_MS = 12,/* how long a member of a team waits for the others (wall clock, ms; default 2000).  At a team's START (teams of a fixed size) a
                                  * member that has waited this long says ABORT and the environment is stepped by member 0 alone - same results, no error
                                  * (sf_get_team_fallbacks counts them; 0 = at once unless the team is complete in that instant: tests).  A wait that runs out LATER in
                                  * the launch - members that were resident together do not go away - declares the launch void (SF_EHIP at the next call that
                                  * hands data back; sf_reset of every environment recovers the handle) */
-    SF_TUNE_RUN_JOIN = 20,      /* teams that GROW inside the resident launch (k_run<TEAM = 2>: grids up to 1024 cells wide, at most one environment per CU, no control
+    SF_TUNE_RUN_JOIN = 13,      /* teams that GROW inside the resident launch (k_run<TEAM = 2>: grids up to 1024 cells wide, at most one environment per CU, no control
                                  * lines inside the launch): a workgroup whose environment is done joins the running environment that would finish last, at that
                                  * team's next cut.  1 (default) = in calls of 192 updates or more on two or more environments (set by hand: also on one), 0 = never, k > 1 = in calls of k updates or more,
                                  * -k = the same but every free workgroup joins whatever runs, whether the cost model says it pays or not (tests) */
-    SF_TUNE_COUNT = 21
+    SF_TUNE_LOOP_LIGHT = 14,    /* the closed loop (sf_loop_start): 0 (default) = one 16-wave workgroup per environment with a long vector list (132 KB of LDS: with 256
+                                 * environments nothing else fits a CU while the loop is resident); 1 = the LIGHT loop: 8-wave workgroups with a short list (76 KB) -
+                                 * half of every CU's wave slots and more than half of its LDS stay free for the harness's own kernels (a policy network sharing
+                                 * the GPU) beside the resident, mostly sleeping loop.  Read by sf_loop_start. */
+    SF_TUNE_COUNT = 15
 };
 int sf_set_tuning(sf_sim *sim, int32_t knob, int32_t value);
 /* What every environment's workgroup(s) spent in the last environment-resident launch (k_run), in shader clocks / 16:

@@ -10,7 +10,7 @@ STEPS=${2:-1000}
 WARM=${3:-20}
 O=gpurun_out/$R
 mkdir -p $O
-B="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra"
+B="python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra --repeats 2"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/sf_mb profiles/streaming_microbench.hip
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o default -- $B > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o perstep -- $B --fused 0 > $O/bench_under_rocprof_perstep.json 2>/dev/null

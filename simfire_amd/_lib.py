@@ -98,9 +98,8 @@ SIGNATURES = {
 STRING_GETTERS = ("sf_last_error", "sf_version")
 
 # Other builds of the same sources, loaded only by tests (python -m simfire_amd.build --all):
-#   "exp"  -DSF_EXPERIMENTAL: + the measured alternatives k_run_tiles / k_front (sf_set_fused(3 / 4))
 #   "sow"  -DSF_STORE_ORDER_WAIT: k_run with an explicit wait between a vector's 16-byte store and its ignition byte stores
-VARIANTS = {"exp": "libsimfire_hip_exp.so", "sow": "libsimfire_hip_sow.so"}
+VARIANTS = {"sow": "libsimfire_hip_sow.so"}
 
 
 def variant_path(variant):
@@ -109,7 +108,7 @@ def variant_path(variant):
 
 TUNE = {name: i for i, name in enumerate((
     "waves_per_cu", "run_waves", "run_min_envs", "run_vcap", "run_compact", "run_batch", "run_result", "run_segment",
-    "front_min_steps", "front_auto", "front_waves", "front_rc", "front_ic", "front_tab", "front_debug", "run_team", "team_placement", "team_recut", "run_window", "team_timeout_ms", "run_join"))}
+    "run_team", "team_placement", "team_recut", "run_window", "team_timeout_ms", "run_join", "loop_light"))}
 
 _libs = {}
 

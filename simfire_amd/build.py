@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["simfire_hip.hip", "simfire_hip_run2.hip", "simfire_hip_run3.hip", "simfire_hip_run4.hip"]
 OUT = os.path.join(CSRC, "libsimfire_hip.so")
 # builds of the same sources that only tests load (simfire_amd/_lib.py: VARIANTS)
-VARIANT_FLAGS = {"exp": ["-DSF_EXPERIMENTAL"], "sow": ["-DSF_STORE_ORDER_WAIT"]}
+VARIANT_FLAGS = {"sow": ["-DSF_STORE_ORDER_WAIT"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 

@@ -785,117 +785,6 @@ __host__ __device__ inline int run_shared_bytes(const Geo &g)
 #endif
 }
 
-#ifdef SF_EXPERIMENTAL      // k_run_tiles: the tile kernels inside a resident workgroup (measured alternative, sf_set_fused(3); not in the product build)
-constexpr int run_max_waves(int rb) { return rb <= 4 ? 16 : 8; }      // 64 x 128 tiles need more than 128 VGPRs per lane
-template <int RB>
-__global__ __launch_bounds__(run_max_waves(RB) * 64) void k_run_tiles(StepArgs a, int n_steps)
-{
-    extern __shared__ uint4 s_dyn[];
-    const Geo &g = a.g;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
-    uint8_t *lds = reinterpret_cast<uint8_t *>(s_dyn);
-    uint8_t *lds_wave = lds + (size_t)wave * g.lds_wave_bytes;
-    uint8_t *shared = lds + (size_t)n_waves * g.lds_wave_bytes;
-    const int fplane = g.TYp * g.TXp, fplane_p = (fplane + 15) / 16 * 16;
-    const int per_env = g.TY * g.TX, per_env_p = (per_env + 7) / 8 * 8;
-    uint8_t *fcur = shared, *fnext = shared + fplane_p;
-    uint16_t *list = reinterpret_cast<uint16_t *>(shared + 2 * fplane_p);
-    uint32_t *ctl = reinterpret_cast<uint32_t *>(shared + 2 * fplane_p + 2 * per_env_p);
-    const int e = blockIdx.x;
-
-    EnvState st = a.commit[e];
-    if (!st.running) return;                    // frozen: run() no longer calls update (uniform over the workgroup)
-    uint8_t *f_glob = a.tflags + ((long long)a.ring * g.E + e) * fplane;
-    for (int i = tid; i < fplane; i += blockDim.x) { fcur[i] = f_glob[i]; fnext[i] = 0; }
-    if (tid < kRunTCtl) ctl[tid] = 0;
-    __syncthreads();
-
-    PhaseClock pc;
-#ifdef SF_PHASES
-    uint32_t *ph_acc = ctl + kRunTCtl + wave * 16;
-    if (lane < 16) ph_acc[lane] = 0;
-    pc.start(ph_acc);
-#else
-    pc.start();
-#endif
-    uint32_t n_active = 0, n_ignite = 0, n_items_acc = 0, n_phase2 = 0, n_tiles_done = 0;
-    for (int s = 0; s < n_steps && st.running; ++s) {
-        const int k = s % 3, kn = (s + 1) % 3;
-        // ---- select (everything it overwrites was last read before the barrier that ended the previous step)
-        if (tid < 3) ctl[3 * tid + kn] = 0;     // ring slots of the next step
-        for (int base = 0; base < per_env; base += blockDim.x) {
-            const int tile = base + tid;
-            const bool valid = tile < per_env;
-            const int tyw = valid ? tile / g.TX : 0, tx = valid ? tile - tyw * g.TX : 0;
-            const int o = (tyw + 1) * g.TXp + (tx + 1);
-            const uint32_t own = fcur[o], up = fcur[o - g.TXp], dn = fcur[o + g.TXp], lf = fcur[o - 1], rt = fcur[o + 1];
-            const uint32_t ul = fcur[o - g.TXp - 1], ur = fcur[o - g.TXp + 1], dl = fcur[o + g.TXp - 1], dr = fcur[o + g.TXp + 1];
-            // which flag bits make the centre tile live: see k_select
-            const bool near = ((own & 1u) | (up & 8u) | (dn & 4u) | (lf & 32u) | (rt & 16u)) != 0 ||
-                              ((ul & 40u) == 40u) | ((ur & 24u) == 24u) | ((dl & 36u) == 36u) | ((dr & 20u) == 20u);
-            const bool active = valid && (g.dense || near);
-            const unsigned long long bal = __ballot(active);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            uint32_t wbase = 0;
-            if (lane == 0 && bal) wbase = atomicAdd(&ctl[k], (uint32_t)__popcll(bal));
-            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-            if (active) list[wbase + rank] = (uint16_t)tile;
-            if (valid) fnext[o] = 0;
-        }
-        __syncthreads();
-        // ---- update: list entries off a shared cursor (tiles differ a lot in work)
-        const uint32_t n_list = ctl[k];
-        for (;;) {
-            uint32_t j = 0;
-            if (lane == 0) j = atomicAdd(&ctl[6 + k], 1u);
-            j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-            if (j >= n_list) break;
-            const int tile = __builtin_amdgcn_readfirstlane((int)list[j]);
-            const int tyw = tile / g.TX, chunk = tile - tyw * g.TX;
-            pc.mark(0);
-            step_tile<RB>(a, e, tyw, chunk, st, lane, lds_wave, fnext + (tyw + 1) * g.TXp + (chunk + 1),
-                          reinterpret_cast<uint8_t *>(ctl + 3 + k), n_active, n_ignite, n_items_acc, n_phase2, pc);
-            n_tiles_done++;
-        }
-        __syncthreads();
-        // ---- fold (every thread the same arithmetic on the same values)
-        st = fold_state(st, ctl[3 + k], g);
-        st.running = __builtin_amdgcn_readfirstlane(st.running);
-        st.steps = __builtin_amdgcn_readfirstlane(st.steps);
-        st.complete = __builtin_amdgcn_readfirstlane(st.complete);
-        st.time_quit = __builtin_amdgcn_readfirstlane(st.time_quit);
-        uint8_t *t = fcur; fcur = fnext; fnext = t;
-    }
-#ifdef SF_PHASES
-    pc.mark(12);
-    if (lane == 0 && g_wave_log_launch == -2)
-        for (int k = 0; k < 16; ++k) if (pc.acc[k]) atomicAdd(&g_phase[k], (unsigned long long)pc.acc[k]);
-    if (lane == 0 && g_wave_log_launch == -2 && e < 4096) {      // per environment: clocks of the workgroup, tiles, steps
-        if (wave == 0) { g_wave_log[e * 4 + 0] = __builtin_readcyclecounter() - pc.t0; g_wave_log[e * 4 + 2] = (unsigned long long)st.steps; }
-        atomicAdd(&g_wave_log[e * 4 + 1], (unsigned long long)n_tiles_done);
-    }
-#endif
-    // ---- hand the environment back: state, tile activity map (the map the next step reads)
-    if (tid == 0) a.commit[e] = st;
-    for (int i = tid; i < per_env; i += blockDim.x) {
-        const int tyw = i / g.TX, tx = i - tyw * g.TX, o = (tyw + 1) * g.TXp + (tx + 1);
-        f_glob[o] = fcur[o];
-    }
-    if (a.counters && n_tiles_done && lane == 0) {
-        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
-#ifndef SF_PHASES
-        if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
-        if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
-        if (n_items_acc) atomicAdd(&cs[2], (unsigned long long)n_items_acc);
-        atomicAdd(&cs[3], (unsigned long long)n_tiles_done);   // wave tiles visited
-        if (n_phase2) atomicAdd(&cs[4], (unsigned long long)n_phase2);   // frontier walks
-#else
-        atomicAdd(&cs[3], (unsigned long long)n_tiles_done);
-#endif
-    }
-}
-
-#endif  // SF_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------
 // Generic step: one thread per cell, any sprite-plane width (AgeT = uint8_t / uint16_t /

@@ -89,14 +89,6 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
 #include "sf_step_kernels.h"
 #include "sf_aux_kernels.h"
 #include "sf_run_kernels.h"
-#ifdef SF_EXPERIMENTAL
-// Measured alternatives that are never the automatic choice: k_run_tiles (sf_set_fused(3)) and k_front
-// (sf_set_fused(4)).  They are compiled only into the cross-check build libsimfire_hip_exp.so (python -m simfire_amd.build
-// --experimental), which the tests of those two modes load; the product library answers SF_ENOTSUP.
-#include "sf_front_kernels.h"
-#endif
-
-constexpr int kFrontStartCap = 32768;      // k_front: sprite cells per environment at launch start it remembers (more: k_run takes over)
 
 // Launch-geometry knobs of a handle (sf_set_tuning, include/simfire_hip.h: SF_TUNE_*).  Results never depend on them; the
 // defaults are the measured choices of DESIGN.md 5.  The environment is NOT consulted - except, for the measurement scripts
@@ -108,20 +100,19 @@ struct Tuning {
 };
 static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
-    /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* FRONT_MIN_STEPS */ 4, /* FRONT_AUTO */ 0, /* FRONT_WAVES */ 0,
-    /* FRONT_RC */ 0, /* FRONT_IC */ 0, /* FRONT_TAB */ 0, /* FRONT_DEBUG */ 0, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1, /* TEAM_TIMEOUT_MS */ 2000,
-    /* RUN_JOIN */ 1};
+    /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1, /* TEAM_TIMEOUT_MS */ 2000,
+    /* RUN_JOIN */ 1, /* LOOP_LIGHT */ 0};
 static const char *const kTuneName[SF_TUNE_COUNT] = {
     "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
-    "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_FRONT_MIN_STEPS", "SF_TUNE_FRONT_AUTO", "SF_TUNE_FRONT_WAVES", "SF_TUNE_FRONT_RC",
-    "SF_TUNE_FRONT_IC", "SF_TUNE_FRONT_TAB", "SF_TUNE_FRONT_DEBUG", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW", "SF_TUNE_TEAM_TIMEOUT_MS",
-    "SF_TUNE_RUN_JOIN"};
+    "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW", "SF_TUNE_TEAM_TIMEOUT_MS",
+    "SF_TUNE_RUN_JOIN", "SF_TUNE_LOOP_LIGHT"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
     sf_params p;
     Geo g;
     hipStream_t stream = nullptr;
+    int loop_light = 0;                 // 1: the running closed loop is the light one (8-wave workgroups; SF_TUNE_LOOP_LIGHT)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *status = nullptr, *age_alloc = nullptr, *age = nullptr;
     uint8_t *cells_alloc = nullptr, *cells = nullptr;      // blocked cell plane of the resident launch (allocated at its first use)
@@ -169,8 +160,8 @@ struct sf_sim {
     bool vbits_fl_valid = true;        // ... planes 1 / 2 of it too (first / last cell of the vector holds a sprite bit): k_run on rows of several words keeps only
                                        // plane 0 (plain dilation) unless it runs as teams - which need all three (rebuilt when a team launch follows such a launch)
     bool tiles_valid = false;          // tile activity map + seam planes match them (the per-step tiled kernels keep them; k_run does not)
-    int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell, 4 k_run_tiles, 5 k_front
-    int32_t *todo = nullptr;           // k_front: steps it left over per environment [E]
+    int last_kind = -1;                // launch structure of the last sf_step call: 0 k_select + k_step, 1 fused, 2 k_run, 3 per-cell
+    int32_t *todo = nullptr;           // team launches with windows of rows: the steps an environment's team could not make (the catch-up launch's) [E]
     ncclComm_t comm = nullptr;         // sf_comm_init: communicator of the result-block all-gather
     int comm_world = 0;
     // k_run<TEAM>: an environment served by several workgroups (sf_run_kernels.h); allocated at the first team launch
@@ -198,10 +189,7 @@ struct sf_sim {
     int last_team_max = 0;             // upper bound of the team sizes in the last resident launch (0: it was not a team launch)
     int cost_steps = 0;                // steps the per-environment cost array covers (0: nothing recorded since the last reset)
     uint32_t *run_cost = nullptr, *run_order = nullptr;   // k_run: clocks / 16 an environment's workgroup took in the last resident launch [E]; launch order built from it (k_order)
-    uint32_t *wheel = nullptr;         // k_front: the sprite cells an environment held at launch start [E][kFrontStartCap]
-    int32_t *ovf_pinned = nullptr, *ovf_mapped = nullptr;      // k_front: "some environment has steps left over" (pinned, device-mapped)
-    int front_fallbacks = 0;           // sf_step calls in which k_run had to finish what k_front left over
-    size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_join[2] = {}, attr_front = 0;       // dynamic LDS sizes the k_run instantiations / k_front have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_join[2] = {};       // dynamic LDS sizes the k_run instantiations have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     int32_t *status_block = nullptr;   // [E][8]
@@ -243,6 +231,8 @@ hipError_t sf_run2_launch_join(int att, unsigned grid, unsigned block, size_t ld
                                const void *args, size_t args_bytes, int n_steps, int vcap);
 hipError_t sf_run2_launch_loop(int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                const void *args, size_t args_bytes, int vcap);
+hipError_t sf_run3_launch_loop2(int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                                const void *args, size_t args_bytes, int vcap);
 // every entry point except sf_loop_step ends the closed loop (sf_loop_start) first: the handle's stream is busy with the resident launch
 #define LOOP_QUIESCE(s) do { if ((s)->loop_on) { int _rq = sf_loop_stop(s); if (_rq) return _rq; } } while (0)
 static int ensure_rm(sf_sim *s);
@@ -383,12 +373,6 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->run_cost, (size_t)g.E));
     TRY(dev_alloc(s, &s->run_order, (size_t)g.E));
     TRYHIP(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
-#ifdef SF_EXPERIMENTAL
-    if (g.ab == 1) TRY(dev_alloc(s, &s->wheel, (size_t)g.E * kFrontStartCap));
-#endif
-    TRYHIP(hipHostMalloc(reinterpret_cast<void **>(&s->ovf_pinned), sizeof(int32_t), hipHostMallocMapped));
-    TRYHIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->ovf_mapped), s->ovf_pinned, 0));
-    *s->ovf_pinned = 0;
     TRYHIP(hipMemsetAsync(s->todo, 0, (size_t)g.E * sizeof(int32_t), s->stream));
     s->n_tiles_max = (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x;      // RB = 1 is the finest tiling
     TRY(dev_alloc(s, &s->tdirty, s->n_tiles_max));
@@ -424,10 +408,9 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
     for (void *hp : {(void *)s->loop_db, (void *)s->loop_res, (void *)s->loop_pts}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)s->loop_mem, (void *)s->loop_pts_mem}) if (dp) (void)hipFree(dp);
-    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->wheel, s->mit_stage,
+    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
-    if (s->ovf_pinned) (void)hipHostFree(s->ovf_pinned);
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
         if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
         if (s->ev_pts[i]) (void)hipEventDestroy(s->ev_pts[i]);
@@ -570,15 +553,10 @@ extern "C" int sf_set_generic(sf_sim *s, int32_t on)
 }
 
 /* -1 = choose by problem size (default), 0 = always k_select + k_step, 1 = always one fused launch per step,
- * 2 = one environment-resident launch per sf_step call (k_run) whenever the handle's options allow it, 3 = k_run_tiles,
- * 4 = one frontier-resident launch per sf_step call (k_front) whenever they allow it (else as 2) */
+ * 2 = one environment-resident launch per sf_step call (k_run) whenever the handle's options allow it */
 extern "C" int sf_set_fused(sf_sim *s, int32_t mode)
 {
-    if (!s || mode < -1 || mode > 4) return fail(SF_EINVAL, "sf_set_fused: mode must be -1 ... 4");
-#ifndef SF_EXPERIMENTAL
-    if (mode == 3 || mode == 4)
-        return fail(SF_ENOTSUP, "sf_set_fused: modes 3 (k_run_tiles) and 4 (k_front) exist only in the cross-check build (libsimfire_hip_exp.so, -DSF_EXPERIMENTAL)");
-#endif
+    if (!s || mode < -1 || mode > 2) return fail(SF_EINVAL, "sf_set_fused: mode must be -1 ... 2");
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     s->fused_mode = mode;
@@ -1409,27 +1387,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     // per-step by-products (spread graph, history) and not for the wide sprite planes.
     int run_waves = 0, run_vcap = 0;
     size_t run_lds = 0;
-    int runt_waves = 0;                        // tile flavour of the resident launch (sf_set_fused(3))
-    size_t runt_lds = 0;
-#ifdef SF_EXPERIMENTAL
-    if (!generic && !a.parents && !s->history && s->fused_mode == 3) {
-        const int waves_knob = tn.v[SF_TUNE_RUN_WAVES];
-        const int per_env = s->g.TY * s->g.TX;
-        int nw = waves_knob < 1 ? 1 : waves_knob;
-        if (nw > run_max_waves(s->g.RB)) nw = run_max_waves(s->g.RB);
-        if (nw > per_env) nw = per_env;
-        while (nw > 1 && (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g) > 160 * 1024) --nw;
-        const size_t lds = (size_t)nw * s->g.lds_wave_bytes + (size_t)run_shared_bytes(s->g);
-        if (per_env <= 65535 && lds <= 160 * 1024) { runt_waves = nw; runt_lds = lds; }
-    }
-#endif
-    int fr_waves = 0, fr_rc = 0, fr_ic = 0, fr_tab = 0;     // frontier-resident launch (k_front)
-    size_t fr_lds = 0;
     TeamGeo tgeo = {}, jgeo = {};
     bool team_forced = false, team_wide = false, team_auto = false;
-    int fit_waves = 0, fit_vcap = 0;                       // k_run as k_front's overflow fallback (whether or not it is the choice)
-    size_t fit_lds = 0;
-    if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1 && s->fused_mode != 3) {
+    if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1) {
         const int waves_knob = tn.v[SF_TUNE_RUN_WAVES], envs_knob = tn.v[SF_TUNE_RUN_MIN_ENVS], vcap_knob = tn.v[SF_TUNE_RUN_VCAP];
         const Geo &g = s->g;
         int nw = waves_knob < 1 ? 1 : (waves_knob > 16 ? 16 : waves_knob);
@@ -1462,7 +1422,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // (control lines inside the launch: every row needs an owner, so the members' windows of rows have to hold the whole grid between them)
         if (mit_dev && tgeo.rcap > 0 && (long long)team_knob * tgeo.rcap < g.H) team_forced = false;
         team_wide = tgeo.ok && team_knob != 1 && g.VW == 2 && !mit_dev;      // (control lines inside the launch: every row needs an owner, a window of rows leaves some without)
-        const bool wanted = s->fused_mode == 2 || s->fused_mode == 4 || ((n_steps >= 2 || mit_dev || polled) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
+        const bool wanted = s->fused_mode == 2 || ((n_steps >= 2 || mit_dev || polled) && (g.VW == 1 || team_wide) && g.E >= envs_knob);
         // Rows of one word: NOT automatic.  Measured on C3 / C5 (profiles/r03_team/): a member's step is a latency chain that does not get
         // shorter with half the rows, and a team's step boundary costs 5 - 10 k clocks (publish, wait for the slowest member, read), so
         // teams of 8-wave members lose to one 16-wave workgroup per environment until a fire is far larger than these get (C3: 11.0 ->
@@ -1471,49 +1431,22 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // of their own, and teams sized by cost are automatic from the second 64-step segment on (C5, 64 environments: 18.2 -> 17.3 us per
         // step; 128 environments: 9.9 -> 10.6, not automatic).  The gain is small because a member's step is never shorter than the ~12 k
         // clocks of the chain and the team kernel itself is ~10 % slower for an environment that stays whole.
-        team_auto = tgeo.ok && g.VW == 1 && g.E < tgeo.slots && s->fused_mode != 4 && (team_knob == -1 || (team_knob == 0 && g.E >= 2 && g.E * 4 <= s->n_cu && tgeo.waves == 16));
+        team_auto = tgeo.ok && g.VW == 1 && g.E < tgeo.slots && (team_knob == -1 || (team_knob == 0 && g.E >= 2 && g.E * 4 <= s->n_cu && tgeo.waves == 16));
         // (one environment - FireSimulation.run(), C2 -: its fire fits one workgroup for hundreds of steps, and the segments of a team rollout -
         // a plan, a prologue that reads the bitmaps and an epilogue per launch - cost a lone young fire 16 %: 3.23 against 3.74 us per step)
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
-        if (fits) { fit_waves = nw; fit_vcap = vcap; fit_lds = lds; }
-#ifdef SF_EXPERIMENTAL
-        // k_front: the frontier records of an environment in LDS.  Needs k_run as its overflow fallback; not in attenuation
-        // mode, not with control lines inside the launch, not in the visit-everything cross-check mode.
-        const bool front_wanted = s->fused_mode == 4 || (s->fused_mode < 0 && n_steps >= tn.v[SF_TUNE_FRONT_MIN_STEPS] && tn.v[SF_TUNE_FRONT_AUTO]);
-        if (fits && front_wanted && !g.att && !mit_dev && !g.dense && g.H <= 2048 && g.W <= 2048) {
-            const int fw_knob = tn.v[SF_TUNE_FRONT_WAVES], frc_knob = tn.v[SF_TUNE_FRONT_RC], fic_knob = tn.v[SF_TUNE_FRONT_IC], ftab_knob = tn.v[SF_TUNE_FRONT_TAB];
-            const bool many = g.E > s->n_cu;              // more environments than CUs: smaller workgroups, two per CU
-            fr_waves = fw_knob ? fw_knob : (many ? 8 : 16);
-            if (fr_waves > 16) fr_waves = 16;
-            fr_rc = frc_knob ? frc_knob : (many ? 80 : 144);
-            fr_ic = fic_knob ? fic_knob : (many ? 1024 : 2048);
-            // tiles of the cell table: whatever LDS is left (one workgroup per CU, or two when there are more environments than CUs)
-            const size_t budget = many ? 80 * 1024 - 512 : 160 * 1024 - 512;
-            const size_t fixed = front_lds_bytes(g, fr_waves, fr_rc, fr_ic, 0);
-            const size_t per_tile = ((size_t)1 << (2 * front_tile_log(g))) + 4;
-            fr_tab = ftab_knob ? ftab_knob : (fixed < budget ? (int)((budget - fixed) / per_tile) : 0);
-            if (fr_tab > 65000) fr_tab = 65000;
-            if (fr_tab > front_dir_entries(g)) fr_tab = front_dir_entries(g);
-            fr_tab &= ~1;
-            fr_lds = front_lds_bytes(g, fr_waves, fr_rc, fr_ic, fr_tab);
-            if (fr_tab < 8 || fr_lds > 160 * 1024) fr_waves = 0;
-        }
-#endif
     }
-#ifndef SF_EXPERIMENTAL
-    (void)runt_lds; (void)fr_rc; (void)fr_ic; (void)fr_tab; (void)fr_lds; (void)fit_waves; (void)fit_vcap; (void)fit_lds; (void)kFrontStartCap;
-#endif
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
     a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr; a.todo_out = nullptr;
     a.win = tn.v[SF_TUNE_RUN_WINDOW] < 0 ? 0 : tn.v[SF_TUNE_RUN_WINDOW];
-    if (run_waves || fr_waves) {
-        int rc0 = ensure_commit(s);            // k_run / k_front start from commit[] and leave the new states there
+    if (run_waves) {
+        int rc0 = ensure_commit(s);            // k_run starts from commit[] and leaves the new states there
         if (rc0) return rc0;
         // (a team launch reads all three planes of the vector bitmap; a launch of the plain kernel on rows of several words has kept only the first)
         if ((team_forced || team_wide || team_auto) && !s->vbits_fl_valid) s->vbits_valid = false;
         rc0 = ensure_vbits(s);
         if (rc0) return rc0;
-        rc0 = (run_waves && !fr_waves && !runt_waves) ? ensure_bl(s) : ensure_rm(s);
+        rc0 = ensure_bl(s);
         if (rc0) return rc0;
         if (run_waves && a.win) {              // the window phase reads the cell-major copy of the R table
             rc0 = ensure_rtc(s);
@@ -1523,73 +1456,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     } else if (!generic) {
         int rc0 = ensure_tiles(s);
         if (rc0) return rc0;
-        if (runt_waves) { rc0 = ensure_commit(s); if (rc0) return rc0; }
     }
-    if (!(run_waves && !fr_waves && !runt_waves)) { int rc0 = ensure_rm(s); if (rc0) return rc0; }
+    if (!run_waves) { int rc0 = ensure_rm(s); if (rc0) return rc0; }
     a.vbits = s->vbits;
     a.cells = s->cells;
     if (ms) HIPCHK(hipEventRecord(s->ev0, s->stream));
-#ifdef SF_EXPERIMENTAL
-    if (runt_waves) {
-        a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        void (*krun)(StepArgs, int) = s->g.RB == 1 ? k_run_tiles<1> : s->g.RB == 2 ? k_run_tiles<2> : s->g.RB == 4 ? k_run_tiles<4> : k_run_tiles<8>;
-        if (runt_lds > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)runt_lds));
-        hipLaunchKernelGGL(krun, dim3((unsigned)s->g.E), dim3((unsigned)runt_waves * 64), runt_lds, s->stream, a, n_steps);
-        s->vbits_valid = false;
-        s->last_kind = 4;
-        n_steps = 0;
-    } else if (fr_waves) {
-        a.launch = 0; a.from_commit = 1; a.ring = s->ring;
-        if (fr_lds > 64 * 1024 && fr_lds > s->attr_front) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_lds));
-            s->attr_front = fr_lds;
-        }
-        *s->ovf_pinned = 0;
-        const int fdbg = tn.v[SF_TUNE_FRONT_DEBUG];
-        int32_t *dbg_dev = nullptr;
-        if (fdbg) { HIPCHK(hipMalloc(reinterpret_cast<void **>(&dbg_dev), (size_t)s->g.E * 16)); HIPCHK(hipMemsetAsync(dbg_dev, 0, (size_t)s->g.E * 16, s->stream)); }
-        hipLaunchKernelGGL(k_front, dim3((unsigned)s->g.E), dim3((unsigned)fr_waves * 64), fr_lds, s->stream, a, n_steps, fr_rc, fr_ic, fr_tab,
-                           s->wheel, kFrontStartCap, s->todo, s->ovf_mapped, dbg_dev);
-        s->tiles_valid = false; s->vbits_valid = false;     // neither bookkeeping is kept by k_front
-        s->last_kind = 5;
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s->stream));
-        if (dbg_dev) {
-            std::vector<int32_t> d((size_t)s->g.E * 4);
-            HIPCHK(hipMemcpy(d.data(), dbg_dev, d.size() * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipFree(dbg_dev));
-            int mr = 0, mk = 0, mi = 0;
-            for (int e = 0; e < s->g.E; ++e) { mr = std::max(mr, d[4 * e]); mk = std::max(mk, d[4 * e + 1]); mi = std::max(mi, d[4 * e + 2]); }
-            fprintf(stderr, "[k_front] %d steps: max records %d (cap %d), max tiles of the cell table %d (pool %d), max ignitions per step %d (cap %d)\n", n_steps, mr,
-                    fr_rc * fr_waves, mk, fr_tab, mi, fr_ic);
-            if (fdbg > 1)
-                for (int e = 0; e < s->g.E; ++e)
-                    if (d[4 * e + 3]) fprintf(stderr, "   env %d: overflow 0x%x after %d steps; records %d keys %d ign %d\n", e, d[4 * e + 3] & 0xFF, d[4 * e + 3] >> 8, d[4 * e], d[4 * e + 1], d[4 * e + 2]);
-        }
-        if (*s->ovf_pinned) {
-            // some environment outgrew its record / wheel capacity: k_run finishes its steps from the planes
-            s->front_fallbacks++;
-            s->last_kind = 6;
-            const int dbg = tn.v[SF_TUNE_FRONT_DEBUG];
-            if (dbg) {
-                std::vector<int32_t> td((size_t)s->g.E);
-                HIPCHK(hipMemcpy(td.data(), s->todo, td.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-                int n_left = 0; long long sum = 0;
-                for (int32_t v : td) { n_left += v > 0; sum += v; }
-                fprintf(stderr, "[k_front] overflow reasons 0x%x (1 records, 4 ignition list, 8 cell table, 16 start list, 0x20 cell with two sprites / eligible burning cell): %d of %d environments, %lld of %d steps left on average\n",
-                        *s->ovf_pinned & 0xFF, n_left, s->g.E, n_left ? sum / n_left : 0, n_steps);
-            }
-            hipLaunchKernelGGL(k_rebuild_vbits_todo, dim3((unsigned)s->g.E), dim3(256), 0, s->stream, s->g, (const uint8_t *)s->age, s->vbits,
-                               (const int32_t *)s->todo);
-            a.todo = s->todo;
-            { int rc0 = ensure_bl(s); if (rc0) return rc0; }       // (what k_front left in the row-major planes, for every environment)
-            a.cells = s->cells;
-            { int rc0 = launch_k_run(s, a, n_steps, fit_waves, fit_vcap, fit_lds, 64); if (rc0) return rc0; }
-        }
-        n_steps = 0;
-    } else
-#endif
     if (run_waves) {
         a.launch = 0; a.from_commit = 1; a.ring = s->ring;
         const int bsz_knob = tn.v[SF_TUNE_RUN_BATCH];       // vectors per batch (<= 64)
@@ -1918,16 +1789,21 @@ static int loop_launch(sf_sim *s)
     a.loop_db = s->loop_db_dev; a.loop_pts_host = s->loop_pts_dev; a.loop_res_host = s->loop_res_dev;
     a.loop_seq = s->loop_mem; a.loop_done = s->loop_mem + 32; a.loop_pts = s->loop_pts_mem;
     a.loop_timeout = 400000000ull;             // ~0.2 s without a ring: the workgroups leave, the next sf_loop_step starts them again
-    HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t), s->stream));       // nothing forwarded yet (the word may hold the stop of the launch before)
-    const int nw = (g.H + 63) / 64 < 16 ? (g.H + 63) / 64 : 16;
+    hipStream_t st = s->stream;
+    HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t), st));       // nothing forwarded yet (the word may hold the stop of the launch before)
+    // one 16-wave workgroup per environment - or the light loop's 8-wave one (SF_TUNE_LOOP_LIGHT)
+    const int nw_cap = s->loop_light ? 8 : 16;
+    const int nw = (g.H + 63) / 64 < nw_cap ? (g.H + 63) / 64 : nw_cap;
+    const bool two_rows = g.H > nw * 64;                 // (8 waves on up to 1024 rows: two bitmap rows per thread, k_run<2, ...>)
     long long all_vec = (long long)g.H * g.PV;
-    int vcap = 4096;
+    int vcap = s->loop_light ? 1024 : 4096;
     if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
     const size_t lds = run_lds_bytes(g, nw, vcap);
-    // (the closed loop's own instantiations of k_run live in simfire_hip_run2.hip)
-    size_t &attr = s->attr_run[16 + (g.att ? 2 : 0) + (g.diag ? 1 : 0)];
+    // (the closed loop's own instantiations of k_run live in simfire_hip_run2.hip; two rows per thread: simfire_hip_run3.hip)
+    size_t &attr = two_rows ? s->attr_run[20 + (g.att ? 1 : 0)] : s->attr_run[16 + (g.att ? 2 : 0) + (g.diag ? 1 : 0)];
     const bool set_lds = lds > 64 * 1024 && lds > attr;
-    HIPCHK(sf_run2_launch_loop(g.att ? 1 : 0, g.diag ? 1 : 0, (unsigned)g.E, (unsigned)nw * 64, lds, set_lds, s->stream, &a, sizeof a, vcap));
+    if (two_rows) HIPCHK(sf_run3_launch_loop2(g.att ? 1 : 0, (unsigned)g.E, (unsigned)nw * 64, lds, set_lds, st, &a, sizeof a, vcap));
+    else HIPCHK(sf_run2_launch_loop(g.att ? 1 : 0, g.diag ? 1 : 0, (unsigned)g.E, (unsigned)nw * 64, lds, set_lds, st, &a, sizeof a, vcap));
     if (set_lds) attr = lds;
     return SF_OK;
 }
@@ -1940,11 +1816,17 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
     HIPCHK(hipSetDevice(s->p.device));
     const Geo &g = s->g;
     // the resident launch with one workgroup per environment, every environment resident at once
+    // SF_TUNE_LOOP_LIGHT = 1: the loop runs 8-wave workgroups with a short vector list - half of every CU's wave slots and more than half of
+    // its LDS stay free, so the harness's own kernels (a policy network that shares the GPU) run on every CU beside the resident, mostly
+    // sleeping loop.  (A stream with a CU mask - hipExtStreamCreateWithCUMask - was tried first: such a stream is a BLOCKING one, a kernel
+    // on torch's default stream then waits for the resident loop to leave; profiles/cu_mask_probe.hip has the mask's numbering.)
+    const int light = s->tune.v[SF_TUNE_LOOP_LIGHT] > 0 ? 1 : 0;
     if (g.ab != 1 || s->generic || g.VW != 1 || s->graph_on || s->history || g.dense || g.H > 16 * 64 || g.E > s->n_cu ||
         (s->fused_mode >= 0 && s->fused_mode != 2))
         return fail(SF_ENOTSUP, "sf_loop_start: needs the environment-resident launch with every environment resident at once "
                                 "(grids up to 1024 x 1024, max_fire_duration <= 5, no more environments than CUs, no spread graph / history)");
     if (s->loop_on) { int rc0 = sf_loop_stop(s); if (rc0) return rc0; }
+    s->loop_light = light;
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }
     { int rc0 = ensure_vbits(s); if (rc0) return rc0; }
     { int rc0 = ensure_bl(s); if (rc0) return rc0; }

@@ -19,6 +19,24 @@ namespace {
 typedef void (*run_fn)(StepArgs, int, int, int);
 }
 
+// the closed loop of sf_loop_start with two bitmap rows per thread: 8-wave workgroups on 1024 rows, two to a CU - the light loop, which leaves half
+// of every CU to the harness's own kernels (SF_TUNE_LOOP_LIGHT).  Diagonal spread is looked up at run time.
+hipError_t sf_run3_launch_loop2(int att, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
+                                const void *args, size_t args_bytes, int vcap)
+{
+    static const run_fn table[2] = {k_run<2, 0, -1, -2>, k_run<2, 1, -1, -2>};
+    if (args_bytes != sizeof(StepArgs)) return hipErrorInvalidValue;
+    StepArgs a;
+    memcpy(&a, args, sizeof a);
+    const run_fn kern = table[att ? 1 : 0];
+    if (set_lds) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, 0x7FFFFFFF, vcap, 64);
+    return hipSuccess;
+}
+
 // which: 1 / 2 = two / four bitmap words per thread
 hipError_t sf_run3_launch_plain(int which, int att, int diag, unsigned grid, unsigned block, size_t lds, bool set_lds, hipStream_t stream,
                                 const void *args, size_t args_bytes, int n_steps, int vcap, int bsz)

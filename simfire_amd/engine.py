@@ -23,9 +23,9 @@ class FireEngine:
 
     def __init__(self, shape, n_envs=1, max_fire_duration=4, pixel_scale=50.0, update_rate=1.0,
                  max_time=None, attenuate_line_ros=True, diagonal_spread=True, M_f=0.03,
-                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0, per_env_terrain=False, experimental=False, variant=None):
-        # experimental / variant: another build of the library (tests only; _lib.VARIANTS)
-        self._L = _lib.load("exp" if experimental else variant)
+                 particle=(8000.0, 0.0555, 0.01, 32.0), device=0, per_env_terrain=False, variant=None):
+        # variant: another build of the library (tests only; _lib.VARIANTS)
+        self._L = _lib.load(variant)
         self.H, self.W = int(shape[0]), int(shape[1])
         self.n_envs = int(n_envs)
         h, S_T, S_e, p_p = particle

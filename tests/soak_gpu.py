@@ -29,8 +29,8 @@ def world(seed):
               max_time=(None if rng.random() < 0.6 else float(rng.integers(3, 40))),
               attenuate_line_ros=att, diagonal_spread=diag)
     xy = np.column_stack([rng.integers(0, W, E), rng.integers(0, H, E)])
-    eng, o = FireEngine(experimental=True, **kw), fire_dense.DenseOracle(**kw)      # cross-check build: launch structures 3 / 4 are in the draw
-    eng.set_fused(int(rng.integers(-1, 5)))            # automatic, two launches, fused, resident (k_run), resident tiles
+    eng, o = FireEngine(**kw), fire_dense.DenseOracle(**kw)
+    eng.set_fused(min(int(rng.integers(-1, 5)), 2))    # automatic, two launches, fused, resident (k_run; the draws that meant the retired k_run_tiles / k_front: k_run - same stream of random numbers as before, so that the worlds of earlier soaks stay the worlds they were)
     # teams (k_run<TEAM>): never / cost-sized / every environment split in 2 .. 4; members on one XCD, spread, written through
     eng.set_tuning(run_team=int(rng.choice([0, 0, 1, -1, 2, 3, 4])), team_placement=int(rng.integers(3)))
     # teams of a fixed size: new bands inside the launch every 2 .. 10 steps (or the default 128), or one launch per segment
@@ -87,7 +87,7 @@ def world(seed):
         elif r < 0.50:
             eng.set_generic(bool(rng.integers(2)))
         elif r < 0.56:
-            eng.set_fused(int(rng.integers(-1, 5)))        # hand-over between the launch structures mid-run
+            eng.set_fused(min(int(rng.integers(-1, 5)), 2))    # hand-over between the launch structures mid-run
             eng.set_tuning(run_team=int(rng.choice([0, 1, -1, 2, 3, 4])), team_placement=int(rng.integers(3)))
         elif r < 0.59:
             e = int(rng.integers(E))       # burn_amounts round trip: settles whatever is owed, must change nothing

@@ -523,14 +523,14 @@ def test_c4_wind_field_workload():
     _workload_pair(w, 120, 60)
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("name", ["g3_lines_a1", "g4_lines_on_burning", "g7_early_return", "g6_runtime"])
 def test_launch_structures(name, fused):
-    """One fused launch per step (small problems), k_select + persistent k_step (large ones) and the two
-    environment-resident launches (2: k_run over the vector bitmap, 3: k_run_tiles; here with one step per
-    call) are schedules of the same update: force each on the golden trajectories."""
+    """One fused launch per step (small problems), k_select + persistent k_step (large ones) and the
+    environment-resident launch (k_run over the vector bitmap; here with one step per call) are schedules of
+    the same update: force each on the golden trajectories."""
     d = _golden.load_traj(name)
-    eng = _engine(d, experimental=fused in (3, 4))      # launch structures 3 / 4 exist only in the cross-check build
+    eng = _engine(d)
     eng.set_fused(fused)
     eng.set_rtable(d["rtable"])
     eng.reset([d["init_pos"]])
@@ -538,12 +538,12 @@ def test_launch_structures(name, fused):
     assert (eng.burn(0) == d["burn"]).all()
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 def test_c3_both_launch_structures(fused):
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
     w = workloads.c3(512, 6)
-    eng = FireEngine(M_f=w.M_f, experimental=fused in (3, 4), **w.engine_kwargs())
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
     eng.set_fused(fused)
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**w.engine_kwargs())
@@ -858,7 +858,7 @@ def test_history_ring_equals_per_update_maps(mode):
 
 
 @pytest.mark.parametrize("fill", [0.5, 1.0])
-@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 def test_frontier_larger_than_list_window(fill, fused):
     """With rate-of-spread attenuation every control-line cell is a frontier cell of every step.  A
     64 x 64 wave tile then holds up to 4096 of them, far more than one walk window of the per-wave
@@ -868,7 +868,7 @@ def test_frontier_larger_than_list_window(fill, fused):
     H, W = 130, 200
     kw = dict(shape=(H, W), max_fire_duration=4, pixel_scale=30.0, update_rate=1.0, attenuate_line_ros=True)
     R8 = rng.choice([12.0, 30.0, 400.0, 1500.0, 2500.0], size=(8, H, W))
-    eng = FireEngine(experimental=fused in (3, 4), **kw)
+    eng = FireEngine(**kw)
     eng.set_fused(fused)
     eng.set_rtable(R8)
     o = fire_dense.DenseOracle(**kw)

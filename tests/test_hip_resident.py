@@ -18,10 +18,9 @@ from oracle import fire_dense
 pytestmark = pytest.mark.gpu
 
 
-def _pair(kw, R8, inits, M_f=None, exp=False):
-    """exp: load the cross-check build of the library (launch structures 3 = k_run_tiles and 4 = k_front exist only there)."""
+def _pair(kw, R8, inits, M_f=None):
     from simfire_amd.engine import FireEngine
-    eng = FireEngine(experimental=exp, **kw)
+    eng = FireEngine(**kw)
     o = fire_dense.DenseOracle(**kw)
     for x in (eng, o):
         x.set_rtable(R8)
@@ -41,15 +40,14 @@ def _same(eng, o, n_envs, burn_envs=None, tag=None):
 
 
 # ------------------------------------------------------------------ resident launch
-@pytest.mark.parametrize("mode", [2, 3, 4])
 @pytest.mark.parametrize("name", _golden.traj_names())
-def test_resident_replays_golden_trajectories(name, mode):
-    """sf_step(1) through the resident launches (2: k_run, vector bitmap; 3: k_run_tiles) on every golden
-    trajectory: fire_map / status / elapsed_time per step and the final burn_amounts equal the reference's."""
+def test_resident_replays_golden_trajectories(name):
+    """sf_step(1) through the resident launch (k_run, vector bitmap) on every golden trajectory: fire_map / status /
+    elapsed_time per step and the final burn_amounts equal the reference's."""
     from simfire_amd.engine import FireEngine
     d = _golden.load_traj(name)
-    eng = FireEngine(M_f=float(d["M_f"]), experimental=mode in (3, 4), **_golden.engine_kwargs(d))
-    eng.set_fused(mode)
+    eng = FireEngine(M_f=float(d["M_f"]), **_golden.engine_kwargs(d))
+    eng.set_fused(2)
     eng.set_rtable(d["rtable"])
     eng.reset([d["init_pos"]])
     _golden.replay(eng, d)
@@ -76,8 +74,9 @@ def test_resident_chunked_random_worlds(seed):
     if rng.random() < 0.5:
         R8[:, :, W // 2:] = 0.0                                  # fires die against the barren half
     inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
-    eng, o = _pair(kw, R8, inits, exp=seed % 3 != 0)
-    eng.set_fused(2 + seed % 3)
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.set_tuning(run_window=[1, 0, 3][seed % 3])             # (the window phase on, off, left after three updates)
     eng.set_rows_per_band(int(rng.choice([1, 2, 2, 4, 8])))
     done = 0
     while done < 90:
@@ -404,9 +403,9 @@ def test_resident_hands_over_to_per_step_kernels_and_back():
     R8 = rng.choice([0.0, 7.5, 12.0, 30.0, 400.0, 1500.0], size=(8, H, W))
     R8[:, :, 250:] = 0.0
     inits = [(5, 5), (160, 70), (90, 140), (320, 10), (200, 100)]      # (320, 10) sits in barren ground: QUIT early
-    eng, o = _pair(kw, R8, inits, exp=True)
+    eng, o = _pair(kw, R8, inits)
     eng.set_async(True)
-    sched = [(2, 7), (0, 3), (3, 4), (4, 6), (2, 1), (1, 4), (4, 1), (2, 9), ("generic", 2), (4, 3), (3, 5), (0, 2), (2, 11), (3, 1), (1, 1), (2, 30)]
+    sched = [(2, 7), (0, 3), (1, 4), (2, 6), (2, 1), (1, 4), (2, 1), (2, 9), ("generic", 2), (2, 3), (1, 5), (0, 2), (2, 11), (0, 1), (1, 1), (2, 30)]
     for i, (mode, n) in enumerate(sched):
         if mode == "generic":
             eng.set_generic(True)
@@ -425,14 +424,14 @@ def test_resident_hands_over_to_per_step_kernels_and_back():
     assert not eng.status()[0][:, 0].all()
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("mode", [2])
 def test_resident_dense_mode_and_status_histograms(mode):
     """Dense cross-check mode inside k_run (every tile of the environment on the LDS list every step),
     and the per-tile status histograms behind the result block stay right when k_run is the only writer."""
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
     w = workloads.c3(256, 3)
-    eng = FireEngine(M_f=w.M_f, experimental=mode == 3, **w.engine_kwargs())
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**w.engine_kwargs())
     o.set_rtable(eng.get_rtable())
@@ -450,12 +449,12 @@ def test_resident_dense_mode_and_status_histograms(mode):
         _same(eng, o, 3, tag=(dense, n))
 
 
-def _c3_small(fused, exp, **knobs):
+def _c3_small(fused, **knobs):
     from simfire_amd import workloads
     from simfire_amd.engine import FireEngine
     w = workloads.c3(512, 4)
     kw = w.engine_kwargs()
-    eng = FireEngine(M_f=w.M_f, experimental=exp, **kw)
+    eng = FireEngine(M_f=w.M_f, **kw)
     eng.set_tuning(**knobs)
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**kw)
@@ -474,20 +473,11 @@ def _c3_small(fused, exp, **knobs):
     return kinds
 
 
-@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("waves", [1, 3, 16])
-def test_resident_any_workgroup_size(waves, mode):
-    """Fewer waves than live tiles: the waves of the workgroup take several tiles per step off the shared
-    cursor (their LDS scratch is reused); the result must not depend on the workgroup size (sf_set_tuning)."""
-    _c3_small(mode, mode == 3, run_waves=waves, run_vcap=256)
-
-
-@pytest.mark.parametrize("caps", [(4, 2048, 0), (144, 6, 0), (144, 2048, 12), (16, 64, 40)])
-def test_front_overflow_is_finished_by_k_run(caps):
-    """k_front with tiny record / ignition-list / cell-table (tile pool) capacities: whatever overflows is derived state, the
-    environment stops at a step boundary and k_run does the steps left over - same result, and the hand-over really happened."""
-    kinds = _c3_small(4, True, front_rc=caps[0], front_ic=caps[1], front_tab=caps[2])
-    assert 6 in kinds, kinds
+def test_resident_any_workgroup_size(waves):
+    """Fewer waves than the grid has rows / a short vector list: the waves of the workgroup take several batches per step off the
+    shared cursor; the result must not depend on the workgroup size (sf_set_tuning)."""
+    _c3_small(2, run_waves=waves, run_vcap=256)
 
 
 def test_store_order_wait_build():
@@ -516,13 +506,13 @@ def test_store_order_wait_build():
                 assert (eng.fire_map(e) == o.fire_map(e)).all() and (eng.burn(e) == o.burn(e)).all()
 
 
-def test_product_build_refuses_the_experimental_launch_structures():
-    """sf_set_fused(3 / 4) (k_run_tiles, k_front) are compiled only into the cross-check build: the product library
-    says so instead of silently running something else."""
+def test_retired_launch_structures_are_refused():
+    """sf_set_fused(3 / 4) - k_run_tiles and k_front, the measured alternatives of rounds 2 - 4, retired in round 5 - are no launch
+    structures any more: the library says so (SF_EINVAL) instead of silently running something else."""
     from simfire_amd.engine import FireEngine
     eng = FireEngine((32, 48))
-    for mode in (3, 4):
-        with pytest.raises(NotImplementedError):
+    for mode in (3, 4, 5):
+        with pytest.raises(ValueError):
             eng.set_fused(mode)
     eng.set_fused(2)
 
@@ -530,7 +520,7 @@ def test_product_build_refuses_the_experimental_launch_structures():
 # ------------------------------------------------------------------ BASELINE-size batches, every launch structure
 def _workload_run(w, chunks, fused, agent_pts=None, threads=32, burn_envs=(0, 1), graph=False, dense=False, waves_per_cu=None):
     from simfire_amd.engine import FireEngine
-    eng = FireEngine(M_f=w.M_f, experimental=fused in (3, 4), **w.engine_kwargs())
+    eng = FireEngine(M_f=w.M_f, **w.engine_kwargs())
     eng.set_layers(*w.layers())
     o = fire_dense.DenseOracle(**w.engine_kwargs())
     o.set_rtable(eng.get_rtable())                    # common table: step parity must then be bit-exact
@@ -569,7 +559,7 @@ def _workload_run(w, chunks, fused, agent_pts=None, threads=32, burn_envs=(0, 1)
     return eng, o
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3, 4])
+@pytest.mark.parametrize("fused", [0, 2])
 def test_c3_full_grid_32_envs(fused):
     """C3 grid (1024^2), 32 environments = 16384 wave tiles: above the fused-launch limit, so fused = 0 is
     k_select (3 x 3 tile flags over 16 x 32 tiles per environment) + persistent k_step; fused = 2 is k_run."""
@@ -577,14 +567,14 @@ def test_c3_full_grid_32_envs(fused):
     _workload_run(workloads.c3(1024, 32), [100, 150], fused)
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3, 4])
+@pytest.mark.parametrize("fused", [0, 2])
 def test_c3_benched_batch_256_envs(fused):
     """The batch bench.py times: 1024^2 x 256 environments, 150 steps, every environment's final map."""
     from simfire_amd import workloads
     _workload_run(workloads.c3(1024, 256), [150], fused, burn_envs=(0, 100, 255))
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3, 4])
+@pytest.mark.parametrize("fused", [0, 2])
 def test_c4_full_grid_8_envs(fused):
     """C4 grid (2048^2, varying wind), 8 environments = 16384 wave tiles of 32 x 64 per environment."""
     from simfire_amd import workloads
@@ -595,7 +585,7 @@ def test_c4_full_grid_8_envs(fused):
     _workload_run(w, [60, 90], fused)
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3])
+@pytest.mark.parametrize("fused", [0, 2])
 def test_c5_full_grid_agents(fused):
     """C5 at its grid: 1024^2 x 32 environments x 64 agents writing one control-line cell per step
     (lazy attenuation, lines on burning cells), scatter + step pairs enqueued asynchronously.
@@ -616,7 +606,7 @@ def test_persistent_waves_take_several_tiles_with_graph():
 
 
 # ------------------------------------------------------------------ seam behaviours
-@pytest.mark.parametrize("mode", ["fused0", "fused1", "run", "run_tiles", "generic"])
+@pytest.mark.parametrize("mode", ["fused0", "fused1", "run", "generic"])
 def test_update_after_runtime_quit_keeps_pruning(mode):
     """RothermelFireManager.update called again after the runtime QUIT still prunes and ages the sprites
     (fire.py:631-633 run before the check at 641): with sf_set_prune_after_quit the device does the same -
@@ -629,12 +619,12 @@ def test_update_after_runtime_quit_keeps_pruning(mode):
               attenuate_line_ros=True, diagonal_spread=True)
     R8 = rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W))
     init = (30, 20)
-    eng = FireEngine(experimental=mode == "run_tiles", **kw)
+    eng = FireEngine(**kw)
     eng.set_prune_after_quit(True)
     if mode == "generic":
         eng.set_generic(True)
     else:
-        eng.set_fused({"fused0": 0, "fused1": 1, "run": 2, "run_tiles": 3}[mode])
+        eng.set_fused({"fused0": 0, "fused1": 1, "run": 2}[mode])
     eng.set_rtable(R8)
     eng.reset([init])
     s = fire_sprites.SpriteFire((H, W), init, 4, 20.0, 1.0, rtable=R8, max_time=6.0, attenuate_line_ros=True)
@@ -689,7 +679,7 @@ def test_result_block_counts_follow_every_kind_of_status_write():
     rng = np.random.default_rng(77)
     H, W, E = 90, 200, 3
     kw = dict(shape=(H, W), n_envs=E, max_fire_duration=3, pixel_scale=20.0, update_rate=1.0)
-    eng = FireEngine(experimental=True, **kw)      # (cross-check build: launch structure 3 exists only there)
+    eng = FireEngine(**kw)
     eng.set_rtable(rng.choice([7.5, 12.0, 30.0, 400.0], size=(8, H, W)))
     eng.reset([(10, 10), (100, 45), (190, 80)])
 
@@ -700,7 +690,7 @@ def test_result_block_counts_follow_every_kind_of_status_write():
             assert (st[e, 2:8] == np.bincount(maps[e].ravel(), minlength=6)).all(), (tag, e)
 
     check("reset")
-    for i, mode in enumerate([0, 1, 2, 3, 2, 0]):
+    for i, mode in enumerate([0, 1, 2, 1, 2, 0]):
         eng.set_fused(mode)
         eng.step(3 + i)
         check(("step", mode))
@@ -743,7 +733,7 @@ def test_bench_two_ranks_on_one_gpu_shard_the_hip_engine():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["envs_total"] == 16 and j["verified"] is True
-    assert j["config"]["env_steps_executed"] > 0 and j["roofline"]["kernel"] in ("k_front", "k_run", "k_step_fused", "k_select + k_step")
+    assert j["config"]["env_steps_executed"] > 0 and j["roofline"]["kernel"] in ("k_run", "k_step_fused", "k_select + k_step")
 
 
 def _bench(*args, timeout=1500):
@@ -781,6 +771,91 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(workload):
     assert all(v > 0 for v in rl["per_rank_kernel_ms"]) and all(v > 0 for v in rl["per_rank_gbs"])
     assert abs(rl["per_rank_gbs"][0] - rl["achieved"]) <= 1e-6 * rl["achieved"]
     assert abs(sum(rl["per_rank_gbs"]) - rl["aggregate_gbs"]) <= 1e-6 * rl["aggregate_gbs"]
+
+
+def test_closed_loop_that_leaves_half_of_every_cu_to_the_harness_own_kernels():
+    """SF_TUNE_LOOP_LIGHT = 1: the closed loop's resident launch as 8-wave workgroups with a short vector list (two bitmap rows per thread:
+    k_run<2, ..., -2>; 76 KB of LDS instead of 132) - half of every CU's wave slots and registers and more than half of its LDS belong to the
+    harness.  Here the harness evaluates a policy network (an MLP of three 512-wide layers on the 256 environments' observations, fp16) on
+    torch's default stream in front of every other step: the loop's answers stay equal to the oracle's (points that depend on the last
+    result, lines on burning cells), the policy's kernels run to completion WHILE the loop is resident - it is never restarted -, and a
+    step beside them costs no more than 1.5 x a step of the same loop alone.  (Beside the DEFAULT loop - 256 workgroups of 16 waves, every
+    CU's registers taken - not even a one-line elementwise kernel starts before the loop gives up its CUs after 0.17 s without a ring:
+    profiles/loop_share_probe.py.  A kernel that wants a CU's whole register file - a 4096^3 GEMM - does not fit beside the light loop
+    either; with up to 128 environments half the CUs are free for it.)"""
+    import time
+    import torch
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    E, K = 256, 4
+    w = workloads.c3(1024, E)
+    kw = w.engine_kwargs()
+    eng = FireEngine(M_f=w.M_f, **kw)
+    eng.set_layers(*w.layers())
+    n_chk = 24                                                  # (the oracle follows the first environments; the relay's own is among them)
+    kwo = dict(kw, n_envs=n_chk)
+    o = fire_dense.DenseOracle(**kwo)
+    o.set_rtable(eng.get_rtable())
+    eng.reset(w.init_xy); o.reset(w.init_xy[:n_chk])
+    eng.step(12); o.step(12, 8)
+    rng = np.random.default_rng(3)
+    H, W = w.shape
+    # the oracle's side first (its points depend on ITS last result, which is the loop's if the loop is right): the loop below is then
+    # driven at the harness's pace, not at the CPU oracle's
+    n_steps, plan, want = 60, [], []
+    last = None
+    for s_ in range(n_steps):
+        pts = np.zeros((E, K, 3), dtype=np.int32)
+        pts[..., 0] = rng.integers(0, W, size=(E, K)); pts[..., 1] = rng.integers(0, H, size=(E, K)); pts[..., 2] = rng.integers(2, 7, size=(E, K))
+        for e in range(n_chk):
+            burning = np.argwhere(o.fire_map(e) == 1)
+            if len(burning) and (last is None or last[e, 3] > 0):
+                y, x = burning[rng.integers(len(burning))]
+                pts[e, 0] = (int(x), int(y), 3 + s_ % 3)
+        o.apply_mitigation([(e, int(p[0]), int(p[1]), int(p[2])) for e in range(n_chk) for p in pts[e]])
+        o.step(1, 8)
+        so, eo = o.status()
+        last = so.copy()
+        plan.append(pts); want.append((so.copy(), eo.copy()))
+    W1 = torch.randn(512, 512, dtype=torch.float16, device="cuda") / 23.0
+    W2 = torch.randn(512, 512, dtype=torch.float16, device="cuda") / 23.0
+    W3 = torch.randn(512, 64, dtype=torch.float16, device="cuda") / 23.0
+    obs = torch.randn(E, 512, dtype=torch.float16, device="cuda")
+
+    def policy():
+        return torch.relu(torch.relu(obs @ W1) @ W2) @ W3
+    ref = policy().float().abs().sum().item()
+    torch.cuda.synchronize()
+    eng.set_tuning(loop_light=1)
+    eng.loop_start(K)
+    t_alone, t_beside, mm_done_inside = [], [], 0
+    for s_ in range(n_steps):
+        beside = s_ >= 20 and s_ % 2 == 0
+        ev = None
+        if beside:
+            c = policy()                                        # (enqueued on torch's stream, not waited for)
+            ev = torch.cuda.Event(); ev.record()
+        t0 = time.perf_counter()
+        status, elapsed = eng.loop_step(plan[s_])
+        dt = time.perf_counter() - t0
+        so, eo = want[s_]
+        assert (status[:n_chk] == so).all() and (elapsed[:n_chk] == eo).all(), s_
+        if beside:
+            ev.synchronize()                                    # the policy's kernels finish although the loop never left the chip
+            mm_done_inside += 1
+            assert abs(c.float().abs().sum().item() - ref) <= 1e-3 * ref
+            t_beside.append(dt)
+        elif s_ >= 20:
+            t_alone.append(dt)
+    restarts = eng.loop_restarts()
+    eng.loop_stop()
+    for e in (0, n_chk - 1):
+        assert (eng.fire_map(e) == o.fire_map(e)).all()
+    alone, beside_t = float(np.median(t_alone)) * 1e6, float(np.median(t_beside)) * 1e6
+    print(f"light closed loop (8-wave workgroups), C3 x 256, K = 4: {alone:.1f} us per step alone, {beside_t:.1f} us beside a policy MLP "
+          f"({mm_done_inside} evaluations, {restarts} restarts of the loop)")
+    assert restarts == 0                                        # (the loop was resident all along: the policy ran beside it)
+    assert beside_t <= 1.5 * alone + 5.0, (alone, beside_t)
 
 
 def test_bench_eight_ranks_without_workload_also_report_their_shares_of_c4_and_c5():
