@@ -205,8 +205,11 @@ def measure(eng, w, a, agent_pts, dense):
     same deterministic rollout with the statistics atomics on to get the work actually performed."""
     eng.set_dense(dense)
     eng.reset(w.init_xy)
+    measure.warm_cost = None
     if a.warmup:
         timed_steps(eng, a.warmup, 0, agent_pts)
+        if eng.last_launch_kind() == 2 and eng.last_launches() == 1:
+            measure.warm_cost = eng.run_cost()      # (the warm-up launch's clocks: with the timed launch's, what an update costs and what a launch costs)
     st0, _ = eng.status()
     kernel_ms = timed_steps(eng, a.steps, a.warmup, agent_pts)
     kind = eng.last_launch_kind()
@@ -317,6 +320,14 @@ def issue_block(w, a, rl, cost, n_cu=256):
     if w.name.startswith("c3") and a.steps <= 64:
         blk.update({"chain_bound_clocks": 885.0, "chain_clocks_per_update": float(clocks.max() / a.steps), "chain_frac": float(885.0 * a.steps / clocks.max()),
                     "chain_bound_source": "profiles/r05_lds_latency_probe.txt + profiles/r03_latency_probe.txt, DESIGN.md 5.9"})
+        wc = getattr(measure, "warm_cost", None)
+        if wc is not None and 0 < a.warmup < a.steps and float(wc.max()) > 0:
+            # two launches, two unknowns: clocks = fixed + updates x per-update (the slowest environment of each launch; the warm-up launch is the
+            # episode's first, so its fixed part runs on colder caches than the timed one's: the split is a little pessimistic about the update)
+            cw = float(wc.astype(np.float64).max() * 16.0)
+            per_update = (float(clocks.max()) - cw) / (a.steps - a.warmup)
+            blk.update({"update_clocks": per_update, "launch_fixed_clocks": cw - a.warmup * per_update, "chain_frac_of_update": 885.0 / per_update if per_update > 0 else None,
+                        "update_clocks_note": "clocks(timed launch) - clocks(warm-up launch) over the difference in updates; launch_fixed_clocks: fire found, window loaded, written back, result block"})
     p = profile_file(f"sq_counters_{w.name}_s{a.steps}_w{a.warmup}.json")
     if p:
         with open(p) as f:
@@ -685,7 +696,7 @@ def main():
         iss = issue_block(w, a, out["roofline"], measure.last_cost)
         if iss:
             out["roofline"]["issue"] = iss
-            for key in ("chain_bound_clocks", "chain_clocks_per_update", "chain_frac"):      # (the latency bound of one update beside the HBM one)
+            for key in ("chain_bound_clocks", "chain_clocks_per_update", "chain_frac", "update_clocks", "launch_fixed_clocks"):      # (the latency bound of one update beside the HBM one)
                 if key in iss:
                     out["roofline"][key] = iss[key]
             ra = out["roofline"].get("random_access")

@@ -111,9 +111,8 @@ int sf_get_last_launches(sf_sim *sim, int32_t *n_out);
 int sf_get_team_fallbacks(sf_sim *sim, int32_t *n_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
- * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = k_run_tiles, 5 = one
- * frontier-resident launch (k_front), 6 = k_front, and k_run for the steps of environments that outgrew k_front's
- * record capacity, -1 = none yet. */
+ * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, -1 = none yet.  (4 - 6 were the retired
+ * structures' numbers.) */
 int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);

@@ -1,5 +1,5 @@
 """Development aid: shader clocks per wave and phase of the window loop of k_run (library built with -DSF_WIN_PROF: profiles/win_prof.sh).
-usage: win_prof.py <steps> <warmup> [envs]"""
+usage: win_prof.py <steps> <warmup> [envs] [json out]      (WL=c4 in the environment: C4's share, 2048 x 2048 under simplex wind, instead of C3)"""
 import ctypes, sys, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -7,7 +7,7 @@ from simfire_amd import workloads
 from simfire_amd.engine import FireEngine
 steps, warm = int(sys.argv[1]), int(sys.argv[2])
 E = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-w = workloads.c3(1024, E)
+w = workloads.c4(2048, E) if os.environ.get("WL") == "c4" else workloads.c3(1024, E)
 eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
 eng.set_layers(*w.layers())
 for rep in range(2):
@@ -16,11 +16,13 @@ for rep in range(2):
         eng.step(warm)
     ms = eng.step_timed(steps)
 prof = np.zeros((1024, 16, 8), dtype=np.uint64)
-eng._L.sf_debug_win_prof.argtypes = [ctypes.c_void_p]
-eng._L.sf_debug_win_prof(prof.ctypes.data_as(ctypes.c_void_p))
+rd = eng._L.sf_debug_win_prof4 if os.environ.get("WL") == "c4" else eng._L.sf_debug_win_prof      # (the two-word team kernels are a translation unit of their own)
+rd.argtypes = [ctypes.c_void_p]
+rd(prof.ctypes.data_as(ctypes.c_void_p))
 p = prof[:E].astype(np.float64) / steps
 names = ["phase A", "barrier 1", "walk front", "walk wait", "walk back", "rest of B", "barrier 2", "fold + rows"]
-print(f"{steps} updates after {warm}: {ms*1e3:.1f} us; clocks per update and wave, mean over environments")
+cost = eng.run_cost().astype(np.float64) * 16
+print(f"{w.name}: {steps} updates after {warm}: {ms*1e3:.1f} us; clocks per environment max {cost.max()/1e3:.1f} k median {np.median(cost)/1e3:.1f} k; clocks per update and wave, mean over environments")
 tot = p.sum(axis=2)
 print("   wave  " + "  ".join(f"{n:>11s}" for n in names) + "        total")
 for wv in range(16):

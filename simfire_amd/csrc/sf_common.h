@@ -88,6 +88,7 @@ struct StepArgs {
     uint8_t *cells;      // k_run only: blocked cell plane (bl_vec), quad 0 of env 0; the row-major planes are stale while it is current
     double *burn;
     const double *rt;
+    unsigned long long *win_hint;   // k_run's window phase, per environment: (first column + 1) | (last column + 1) << 16 of the fire, (the window's first column + 1) << 32 | (its first row + 1) << 48 when the phase last ended; 0 = unknown (advice for placing the window)
     const double *rtc;   // k_run's window phase: the same table cell-major, [H][P][8] per table (k_rt_cellmajor); same per-environment stride as rt
     EnvState *commit;    // [E]   state between API calls
     EnvState *tmp;       // [2][E] state entering launch i (parity i & 1)

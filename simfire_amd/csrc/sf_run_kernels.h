@@ -388,9 +388,48 @@ __device__ __forceinline__ uint4 find_team(const JoinArgs a, uint32_t *sc)
 // and serves it to the end; then the next one.  The simulations are independent (simulation.py:202-214) and the in-place update does not care
 // who computes which rows: results do not depend on who joined whom when (tests: every free workgroup joins at once; by the cost model; from
 // the own XCD / from anywhere).
+// The kernel-argument segment, line by line, asked for at the head of the kernel: k_run reads its ~800-byte argument block where it uses it
+// (scalar loads through the kernel-argument segment), ~50 loads in the straight-line code in front of and behind the step loop, most of them
+// waited for on the spot - and the FIRST look at each of the block's 13 lines is a miss of the scalar cache (SQ_INSTS_SMEM: 51 per wave and
+// launch; a launch's fixed part is ~19 k clocks of which the counted instructions explain a fraction).  Thirteen loads in flight at once,
+// one wait: what follows finds its line in the cache.
+template <int OFF>
+__device__ __forceinline__ uint32_t kernarg_line(const void *ka)
+{
+    uint32_t d;
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(d) : "s"(ka), "n"(OFF));
+    return d;
+}
+template <int BYTES>
+__device__ __forceinline__ void kernarg_touch()
+{
+    const void *ka = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0, d8 = 0, d9 = 0, d10 = 0, d11 = 0, d12 = 0, d13 = 0, d14 = 0, d15 = 0;
+    static_assert(BYTES <= 16 * 64, "more lines than this touches");
+    d0 = kernarg_line<0>(ka);
+    if (BYTES > 1 * 64) d1 = kernarg_line<1 * 64>(ka);
+    if (BYTES > 2 * 64) d2 = kernarg_line<2 * 64>(ka);
+    if (BYTES > 3 * 64) d3 = kernarg_line<3 * 64>(ka);
+    if (BYTES > 4 * 64) d4 = kernarg_line<4 * 64>(ka);
+    if (BYTES > 5 * 64) d5 = kernarg_line<5 * 64>(ka);
+    if (BYTES > 6 * 64) d6 = kernarg_line<6 * 64>(ka);
+    if (BYTES > 7 * 64) d7 = kernarg_line<7 * 64>(ka);
+    if (BYTES > 8 * 64) d8 = kernarg_line<8 * 64>(ka);
+    if (BYTES > 9 * 64) d9 = kernarg_line<9 * 64>(ka);
+    if (BYTES > 10 * 64) d10 = kernarg_line<10 * 64>(ka);
+    if (BYTES > 11 * 64) d11 = kernarg_line<11 * 64>(ka);
+    if (BYTES > 12 * 64) d12 = kernarg_line<12 * 64>(ka);
+    if (BYTES > 13 * 64) d13 = kernarg_line<13 * 64>(ka);
+    if (BYTES > 14 * 64) d14 = kernarg_line<14 * 64>(ka);
+    if (BYTES > 15 * 64) d15 = kernarg_line<15 * 64>(ka);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3), "+s"(d4), "+s"(d5), "+s"(d6), "+s"(d7), "+s"(d8), "+s"(d9), "+s"(d10), "+s"(d11), "+s"(d12),
+                 "+s"(d13), "+s"(d14), "+s"(d15));
+}
+
 template <int MAXD, int ATT, int DIAG, int MIT, int TEAM = 0>
 __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_steps_launch, int vcap, int bsz)
 {
+    kernarg_touch<(int)sizeof(StepArgs) + 12>();
     // The argument block is read where it is used, through the kernel-argument segment (constant address space: scalar loads), instead of
     // being taken by value - by value the compiler loads all of it in the entry block and spills most of it at once (239 of the join kernel's
     // 345 spilled SGPRs were written there).  Measured per instantiation (profiles/r04_resource_usage.txt): the plain and the team kernels spill
@@ -461,10 +500,20 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         if (tid < g.H) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre_w) : "v"(pw_) : "memory");
         if (tid < g.TY * g.TX) asm volatile("global_load_ubyte %0, %1, off" : "=v"(pre_dirty) : "v"(pd_) : "memory");
     }
+    // (and two words every launch with a window phase / a catch-up list reads for its environment: the phase's advice on where the fire stood,
+    // the updates k_run's last launch left over.  Written as plain loads the compiler makes each a round trip of its own in front of the state's -
+    // a vector load, a wait, a readfirstlane: they are not scalar loads because the kernel also writes these arrays.)
+    constexpr bool kWinAny = ((MIT == 0 && MAXD <= 2) || (MIT == -1 && MAXD == 1 && TEAM == 0 && DIAG == 1)) && TEAM != 2;
+    unsigned long long hint_v = 0ull;
+    int32_t todo_v = 0;
+    constexpr bool kWinAdvice = kWinAny && !(MAXD == 1 && TEAM == 0);      // (the window code's general path: sf_win_kernels.h, ADV)
+    if (kWinAdvice && a.win && a.win_hint) { const unsigned long long *ph_ = a.win_hint + e; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hint_v) : "v"(ph_) : "memory"); }
+    if (a.todo) { const int32_t *pt_ = a.todo + e; asm volatile("global_load_dword %0, %1, off" : "=v"(todo_v) : "v"(pt_) : "memory"); }
     EnvState st = a.commit[e];
-    if (a.todo) n_steps = a.todo[e];            // the steps k_front left over for this environment (usually none)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_w), "+v"(pre_dirty), "+v"(hint_v), "+v"(todo_v) :: "memory");      // (asked for before the state, which has arrived: no wait left)
+    const unsigned long long hint_pre = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hint_v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hint_v >> 32)) << 32);
+    if (a.todo) n_steps = __builtin_amdgcn_readfirstlane(todo_v);            // the steps k_front left over for this environment (usually none)
     if ((!st.running && !mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
-    if (kWinPre && a.win) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_w), "+v"(pre_dirty) :: "memory");      // (asked for before the state, which has arrived: no wait left)
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * VW;
     if (tid < kRunCtl) ctl[tid] = 0;
@@ -504,7 +553,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
 #endif
         wpc.note(30);        // launch: state read
-        we.pre_w = pre_w; we.pre_dirty = pre_dirty; we.pre = kWinPre;
+        we.pre_w = pre_w; we.pre_dirty = pre_dirty; we.pre = kWinPre; we.hint = hint_pre;
         s_begin = run_window<ATT, kWinGen, kWinMit>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result,
                                                     kWinMit ? mit : nullptr, n_steps, &px, &py, &pty, vlist, vcap >= 1024 ? 15 : 11);      // (the duplicate filter's bits in the list's LDS: 4 KB, or 256 bytes on small grids)
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 8: updates made inside a window - a slot of its own, whatever the instantiation)
@@ -1567,9 +1616,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
 #endif
     // ---- hand the environment back: state, vector bitmap
     wpc.note(35);            // steps done
-    __syncthreads();
+    if (general) __syncthreads();              // (a launch that never left the window phase: that phase ended on a barrier, nothing here reads another wave's work)
     if (tid == 0) {
         if (!TEAM || tm == 0) a.commit[e] = st;      // (every member has folded the same predicates into the same state)
+        if (kWinAdvice && general && a.win_hint && (!TEAM || tm == 0)) a.win_hint[e] = 0ull;      // (the loop above has moved the fire: what the window phase knew of it is no advice any more)
         if (a.cost) {            // what this environment cost: the order / the team sizes of the next launch (k_order, k_team_plan)
             const unsigned long long c = (__builtin_readcyclecounter() - clk0) >> 4;
             const uint32_t c32 = c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c;
@@ -1692,7 +1742,9 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
     for (int i = t; i < E * kTeamMax * 3; i += 1024) xg[i] = 0ull;
     if (t < E) { xdone[t] = 0u; xdone[E + t] = 0u; if (!keep_cost) cost[t] = 0u; }      // (members that have left / the teams' start words; [2 E]: teams that started as one, kept)
     if (xj) {           // k_run<TEAM = 2>: every environment starts with one member (t_min = t_max = 1), nobody waits, the board is empty
-        if (t < E) { xj[t] = 1u; xj[E + t] = 0u; xcut[t] = 0ull; }
+        // (the XCC id of member 0: no id yet - a workgroup that sees an environment's board before the id of THIS launch passes it by, it never
+        // acts on the id a launch before left there)
+        if (t < E) { xj[t] = 1u; xj[E + t] = 0u; xj[2 * E + 2 + t] = 0xFFFFFFFFu; xcut[t] = 0ull; }
         if (t < 2) xj[2 * E + t] = 0u;
     }
     auto member = [&](int T) -> uint32_t { const uint32_t share = c / (uint32_t)T; return T <= 1 ? c : (share > floor_c ? share : floor_c) + ovh; };

@@ -33,8 +33,7 @@ namespace {
 // was used (tests: SF_TUNE_RUN_WINDOW = k leaves it after k steps; 0 = never).
 // ------------------------------------------------------------------------------------------
 constexpr int kWinCols = 64;                 // cells per window row: 16 lanes (one DPP row) x 4 cells
-constexpr int kWinCtl = 9;                   // control words of the window phase in k_run's ctl[]: [9] first row, [10] last row + 1, [11..12] columns
-                                             // (vector bits) that hold sprites, [13] a sprite in the ring at entry
+constexpr int kWinCtl = 9;                   // control words of the window phase in k_run's ctl[]: [9] stale advice (a sprite beside a window placed to four cells), [13] the fire is at the ring already, [14..15] control lines inside the window
 
 __device__ __forceinline__ uint32_t dpp_from_left(uint32_t v)      // lane - 1 inside a row of 16 lanes, 0 for the first
 {
@@ -120,6 +119,7 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
     unsigned long long pre_w;      // pre: this thread's row of plane 0 and its tile's dirty flag, asked for by k_run together with the environment's state
     uint32_t pre_dirty;
     bool pre;
+    unsigned long long hint;       // a.win_hint[e] (0: none)
 };
 
 // Returns the updates made (0: the fire does not fit a window - nothing has been touched).  st is folded like in the general loop;
@@ -146,6 +146,8 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
 // and is taken by the cell's owner lane in its phase A (the owner has the old type in its status register: the make-up of the attenuation
 // where the TYPE changes is the owner's); the others - 99.6 % on a 1024 x 1024 grid - go to the planes in memory as in k_run's loop, by
 // the last wave alone, off everybody else's path: cells outside the window hold no sprite and are read by nobody in this phase.
+// (Measured and dropped, round 5: a second copy of this code for workgroups of sixteen waves with the planes' places in LDS, the lists' capacity
+// and every stride known at compile time - the same launch time, a third more compile time.)
 template <int ATT, int GEN, int MITW>
 __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, EnvState &st, const int n_steps, const bool diag, uint32_t *wl,
                                           uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done, PhaseClock &lpc, const int e, bool &result_done,
@@ -157,6 +159,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     PhaseClock pc;           // (timeline of one step; lpc: timeline of the launch)
     pc.start();
     if (g.H < WR || g.PV < 4 || g.dense || n_steps <= 0 || !st.running || !a.win || !ev.rtc) return 0;       // (uniform)
+    // (ADV: only on the general path - rows of several bitmap words, C4's 2048-wide grids in teams of one, where a fire lost to the ring costs
+    // its environment 40 k clocks of a 110 k launch.  On the headline's path (GEN = 0) the operational fires keep inside a window placed by
+    // vectors for the driver's 25 updates, and the code of the advice - ~340 more instructions per wave and launch, a dozen scalar loads -
+    // was measured to cost every launch 3.4 k clocks of 97 k.)
+    constexpr bool ADV = GEN != 0;
+    const uint32_t hint = ADV ? (uint32_t)ev.hint : 0u, hint_w = ADV ? (uint32_t)(ev.hint >> 32) : 0u;      // (first column + 1) | (last column + 1) << 16 of the fire, (first column + 1) | (first row + 1) << 16 of the window when this phase last ended, 0 = unknown: ADVICE (below; asked for by k_run with the environment's state)
     // ---- LDS
     double *const wb = reinterpret_cast<double *>(wl);                                   // burn_amounts of the window
     uint32_t *const tab = wl + (size_t)WR * 128;                                         // masks of a step by slot of its number
@@ -241,21 +249,90 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     }
     lpc.note(31);            // where the fire is
     const int hb = ymax1 - ymin, wv = vmax - vmin + 1;
-    if (hb > WR || wv > 4) return 0;
-    int wy0 = ymin - ((WR - hb) >> 1), wv0 = vmin - ((4 - wv) >> 1);
-    wy0 = wy0 < 0 ? 0 : (wy0 > g.H - WR ? g.H - WR : wy0);
-    wv0 = wv0 < 0 ? 0 : (wv0 > g.PV - 4 ? g.PV - 4 : wv0);
-    const int wx0 = wv0 << 4;
+    if (hb > WR || wv > (ADV ? 5 : 4)) return 0;
+    // Where the window goes.  The bitmap knows the fire to the row and to the 16-cell vector; a fire that spreads a cell per update every way
+    // is 11 cells across after 5 updates and 51 after 25, so a window placed by vectors alone - its middle up to 8 cells off the fire's -
+    // loses such a fire to the ring a few updates before the call ends, and its environment to the general loop (found on C4's share: three
+    // environments of 128 cost 155 k clocks, the others 107 k).  So the phase leaves ADVICE behind when it ends (a.win_hint): the fire's first
+    // and last column, and where the window was.  If the advice still agrees with the bitmap (same first / last vector), in this order:
+    //   1. the window stays WHERE IT WAS if that leaves the fire room for this call on every open side (it advances a cell per update at
+    //      most): what the launch before loaded and wrote is what this one finds in its XCD's L2 - measured: a window moved by one vector
+    //      costs the launch ~3.5 k clocks, one loaded cold ~9 k;
+    //   2. else the vector position that leaves the most room on the tighter side, if that is room enough;
+    //   3. else around the fire's middle to FOUR cells (a lane's dword).  The window then cuts through a vector at either end (five sectors a
+    //      row instead of four), and what the advice cannot vouch for is checked: the cells of those two vectors OUTSIDE the window are loaded
+    //      with the window (lanes 0 .. 3 of a row, one dword each) and must hold no sprite - else the advice was stale: it is dropped and this
+    //      launch goes without the window phase (the next one places by vectors).
+    // Without advice: the middle of the fire's vectors and rows, as before.
+    const int s_reach = (a.win > 1 && a.win < n_steps ? a.win : n_steps) + 1;      // how far the fire can get in this phase, + 1: the cells its last update looks at
+    int wx0 = -1, wy0 = -1;
+    {
+        const int hx0 = (int)(hint & 0xFFFFu) - 1, hx1 = (int)(hint >> 16) - 1, px0 = (int)(hint_w & 0xFFFFu) - 1, py0 = (int)(hint_w >> 16) - 1;
+        const int x_last = (g.PV - 4) << 4;                        // the last position the pitch allows
+        if (ADV && hint && hx0 >= 0 && hx1 >= hx0 && (hx0 >> 4) == vmin && (hx1 >> 4) == vmax && hx1 - hx0 <= kWinCols - 3) {
+            auto room = [&](int w0) {                              // cells between the fire and the window's ring, on the tighter side (a side that is the grid's edge has no ring)
+                const int l = w0 > 0 ? hx0 - w0 : 1 << 20, rr = w0 + kWinCols < g.W ? w0 + kWinCols - 1 - hx1 : 1 << 20;
+                return l < rr ? l : rr;
+            };
+            if (px0 >= 0 && px0 <= x_last && !(px0 & 3) && px0 <= hx0 && px0 + kWinCols - 1 >= hx1 && room(px0) >= s_reach) wx0 = px0;
+            else {
+                int best = -1, best_room = -1;
+                for (int v0 = vmax - 3 > 0 ? vmax - 3 : 0; v0 <= vmin && (v0 << 4) <= x_last; ++v0) {
+                    const int m = room(v0 << 4);
+                    if (m > best_room) { best_room = m; best = v0 << 4; }
+                }
+                if (best_room < s_reach) {
+                    int c4 = ((hx0 + hx1 - (kWinCols - 1) + 4) >> 3) << 2;
+                    c4 = c4 < 0 ? 0 : (c4 > x_last ? x_last : c4);
+                    if (c4 <= hx0 && c4 + kWinCols - 1 >= hx1 && room(c4) > best_room) best = c4;
+                }
+                wx0 = best;
+            }
+            // rows: where the window was, if the fire (known to the row) has room there
+            if (py0 >= 0 && py0 <= g.H - WR && py0 <= ymin && py0 + WR >= ymax1 && (py0 == 0 || ymin - py0 >= s_reach) && (py0 + WR >= g.H || py0 + WR - ymax1 >= s_reach)) wy0 = py0;
+        }
+    }
+    if (wy0 < 0) {
+        wy0 = ymin - ((WR - hb) >> 1);
+        wy0 = wy0 < 0 ? 0 : (wy0 > g.H - WR ? g.H - WR : wy0);
+    }
+    if (wx0 < 0) {
+        if (wv > 4) return 0;
+        int wv0 = vmin - ((4 - wv) >> 1);
+        wv0 = wv0 < 0 ? 0 : (wv0 > g.PV - 4 ? g.PV - 4 : wv0);
+        wx0 = wv0 << 4;
+    }
+    const int wvA_in = wx0 >> 4, woff_in = ADV ? (wx0 >> 2) & 3 : 0;     // first vector the window touches; dwords of it that lie in front of the window
+    const int wnv_in = woff_in ? 5 : 4;                        // vectors it touches
     // the ring: outermost cells of the window on the sides that are not the grid's edge.  A sprite there could ignite a cell outside.
-    const bool open_top = wy0 > 0, open_bot = wy0 + WR < g.H, open_left = wv0 > 0, open_right = (wv0 + 4) * 16 < g.W;
+    const bool open_top = wy0 > 0, open_bot = wy0 + WR < g.H, open_left = wx0 > 0, open_right = wx0 + kWinCols < g.W;
     // ---- load: two dwords + four doubles per lane
     const int r = tid >> 4, c = tid & 15;
     const int y = wy0 + r, x = wx0 + 4 * c;
     uint8_t *const cellp = ev.cells + bl_cell(g, y, x);
     const uint32_t idx = (uint32_t)(y * g.P + x);
+    // The result block by difference: where every cached tile histogram of the environment is valid, the last result row is too
+    // (whoever validates a histogram writes the row: counts_env), and what this phase changes is known cell by cell.
+    const int ty0 = wy0 >> th_log, tx0 = wvA_in >> g.logLC;
+    const int nty = ((wy0 + WR - 1) >> th_log) - ty0 + 1, ntx = ((wvA_in + wnv_in - 1) >> g.logLC) - tx0 + 1;
+    const bool mitw = MITW && mit != nullptr;
+    const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15 && !mitw;      // (control lines change cells outside the window too: counts_env)
+    // (Measured and dropped: loading only what the fire can reach in this phase - rows and vectors within s_reach of the sprites'; a 5-update
+    // call needs a fifth of the window.  The short call got 0.4 us faster and the call after it 3.4 us slower: the whole window loaded by one
+    // launch is what the next launch finds in its XCD's L2.)
+    // EVERY load of the way in is issued here, back to back, and none sits in a branch of its own: a load under a condition of its own makes
+    // the compiler wait for it on the spot (found in the ISA: the check beside the window and the old result row had each become a round
+    // trip of their own in front of the burn_amounts).  A lane that has nothing to ask for asks for its own cell again.
+    const bool chk = woff_in && c < 4;                         // a window placed to four cells: the sprite masks of its end vectors' cells outside it
+    const bool l_row = by_delta && tid >= 120 && tid < 128;    // the old result row
+    const uint32_t *const p_chk = reinterpret_cast<const uint32_t *>(chk ? ev.cells + bl_cell(g, y, ((c < woff_in ? wvA_in : wvA_in + 4) << 4) + 4 * c) : cellp);
+    const int32_t *const p_row = l_row ? a.res_block + e * 8 + (tid - 120) : reinterpret_cast<const int32_t *>(cellp);
+    const double2 b01 = *reinterpret_cast<const double2 *>(ev.burn + idx), b23 = *reinterpret_cast<const double2 *>(ev.burn + idx + 2);
     const uint32_t ag0 = *reinterpret_cast<const uint32_t *>(cellp), sv0 = *reinterpret_cast<const uint32_t *>(cellp + kBlStatus);
+    const uint32_t v_chk = *p_chk;
+    const int32_t v_row = *p_row;
+    const uint32_t beside = chk ? v_chk : 0u;
     {
-        const double2 b01 = *reinterpret_cast<const double2 *>(ev.burn + idx), b23 = *reinterpret_cast<const double2 *>(ev.burn + idx + 2);
         double2 *dst = reinterpret_cast<double2 *>(wb + (r * 16 + c) * 4);
         dst[0] = b01; dst[1] = b23;
     }
@@ -268,12 +345,6 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     wm[own] = ag0;
     wstat[r * 16 + c] = sv0;
     wdirty[r * 16 + c] = 0;
-    // The result block by difference: where every cached tile histogram of the environment is valid, the last result row is too
-    // (whoever validates a histogram writes the row: counts_env), and what this phase changes is known cell by cell.
-    const int ty0 = wy0 >> th_log, tx0 = wv0 >> g.logLC;
-    const int nty = ((wy0 + WR - 1) >> th_log) - ty0 + 1, ntx = ((wv0 + 3) >> g.logLC) - tx0 + 1;
-    const bool mitw = MITW && mit != nullptr;
-    const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15 && !mitw;      // (control lines change cells outside the window too: counts_env)
     const int mit_wave = (nthr >> 6) - 1;
     // the control-line wave's view of ONE step's points (made a step ahead): valid, column, row, the type that stands on its cell, inside the window
     bool m_ok = false, m_in = false;
@@ -311,7 +382,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (lane == 0) ctl[kWinCtl + 5 + (sp & 1)] = any_in ? 1u : 0u;
     };
     if (MITW && mitw && tid >> 6 == mit_wave) mit_classify(0);    // (the first step's points were asked for before this phase)
-    for (int i = tid; i < 128; i += nthr) dt[i] = (by_delta && i >= 120) ? a.res_block[e * 8 + (i - 120)] : 0;      // (workgroups of one wave exist: small grids)
+    // (Measured and dropped: the tiles' cached histograms asked for here as well, so that the way out only stores - the same launch time.)
+    if (tid < 128) dt[tid] = l_row ? v_row : 0;
+    for (int i = tid + nthr; i < 128; i += nthr) dt[i] = (by_delta && i >= 120) ? a.res_block[e * 8 + (i - 120)] : 0;      // (workgroups of one wave exist: small grids)
     if (tid < 18) { wm[tid] = 0; wm[(WR + 1) * 18 + tid] = 0; }
     if (tid < WR) { wm[(tid + 1) * 18] = 0; wm[(tid + 1) * 18 + 17] = 0; }
     if (tid < g.N) {
@@ -325,7 +398,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         row[7] = 0;
     }
     if (ag0 & ring) ctl[kWinCtl + 4] = 1;
+    if (beside) ctl[kWinCtl + 0] = 1;
     __syncthreads();
+    if (ADV && __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 0]) != 0) {             // (uniform) stale advice: a sprite beside the window.  Nothing has been touched.
+        if (tid == 0) a.win_hint[e] = 0ull;
+        return 0;
+    }
     if (__builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 4]) != 0) return 0;      // (uniform) the fire is at the window's edge already
     lpc.note(32);            // window loaded
     uint32_t sv = sv0;
@@ -716,42 +794,45 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         *reinterpret_cast<double2 *>(ev.burn + idx + 2) = src[1];
     }
     {
+        // (derived anew from the one value the loop has kept: three scalar registers fewer across it)
+        int wx0_ = wx0;
+        asm volatile("" : "+s"(wx0_));
+        const int wvA = wx0_ >> 4, woff = ADV ? (wx0_ >> 2) & 3 : 0, wnv = woff ? 5 : 4;
         // bit v of a row: the 16-cell vector holds a sprite bit / holds one in its first cell / in its last cell.  A vector = four lanes.
+        // Stored without a look at what is there: while this phase runs EVERY sprite of the environment is inside the window (that is what it
+        // was entered on, and the ring rule keeps it so), so outside the vectors the window touches a row's words are zero in all three planes
+        // (and so are the cells of its end vectors that lie beside a window placed to four cells: checked on the way in).
         const unsigned long long any = __ballot(ag != 0u), fst = __ballot((ag & 0xFFu) != 0u), lst = __ballot((ag >> 24) != 0u);
         if (c == 0) {
             const int q = (lane >> 4) * 16;                    // this row's 16 lanes in the ballots
-            const uint32_t a16 = (uint32_t)(any >> q) & 0xFFFFu, f16 = (uint32_t)(fst >> q) & 0xFFFFu, l16 = (uint32_t)(lst >> q) & 0xFFFFu;
-            uint32_t nb4 = 0, nf4 = 0, nl4 = 0;
+            // (the row's 16 lanes in the frame of the first vector the window touches: bit i = dword i of that vector and its right neighbours)
+            const uint32_t a20 = ((uint32_t)(any >> q) & 0xFFFFu) << woff, f20 = ((uint32_t)(fst >> q) & 0xFFFFu) << woff, l20 = ((uint32_t)(lst >> q) & 0xFFFFu) << woff;
+            uint32_t nb5 = 0, nf5 = 0, nl5 = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                nb4 |= ((a16 >> (4 * j)) & 0xFu) ? 1u << j : 0u;
-                nf4 |= ((f16 >> (4 * j)) & 1u) << j;
-                nl4 |= ((l16 >> (4 * j + 3)) & 1u) << j;
+            for (int j = 0; j < 5; ++j) {
+                nb5 |= ((a20 >> (4 * j)) & 0xFu) ? 1u << j : 0u;
+                nf5 |= ((f20 >> (4 * j)) & 1u) << j;
+                nl5 |= ((l20 >> (4 * j + 3)) & 1u) << j;
             }
             if (GEN) {
-                // (the window's four vectors may sit in two words of the row)
-                for (int ww = wv0 >> 6; ww <= (wv0 + 3) >> 6; ++ww) {
-                    const int j0 = ww * 64 - wv0 > 0 ? ww * 64 - wv0 : 0, j1 = ww * 64 + 64 - wv0 < 4 ? ww * 64 + 64 - wv0 : 4;      // its vectors [j0, j1) of the window
-                    const int sh = wv0 + j0 - ww * 64;
-                    const unsigned long long m = (1ull << (j1 - j0)) - 1ull, keep = ~(m << sh);
+                // (the window's vectors may sit in two words of the row)
+                for (int ww = wvA >> 6; ww <= (wvA + wnv - 1) >> 6; ++ww) {
+                    const int j0 = ww * 64 - wvA > 0 ? ww * 64 - wvA : 0, j1 = ww * 64 + 64 - wvA < wnv ? ww * 64 + 64 - wvA : wnv;      // its vectors [j0, j1) of the window
+                    const int sh = wvA + j0 - ww * 64;
+                    const unsigned long long m = (1ull << (j1 - j0)) - 1ull;
                     unsigned long long *w0 = ev.vb_glob + y * VW + ww, *w1 = w0 + ev.vb_plane, *w2 = w1 + ev.vb_plane;
-                    const unsigned long long o0 = *w0, o1 = *w1, o2 = *w2;
-                    const unsigned long long v0 = (o0 & keep) | ((((unsigned long long)nb4 >> j0) & m) << sh), v1 = (o1 & keep) | ((((unsigned long long)nf4 >> j0) & m) << sh),
-                                             v2 = (o2 & keep) | ((((unsigned long long)nl4 >> j0) & m) << sh);
-                    if (v0 != o0) *w0 = v0;
-                    if (v1 != o1) *w1 = v1;
-                    if (v2 != o2) *w2 = v2;
+                    *w0 = (((unsigned long long)nb5 >> j0) & m) << sh; *w1 = (((unsigned long long)nf5 >> j0) & m) << sh; *w2 = (((unsigned long long)nl5 >> j0) & m) << sh;
                 }
             } else {
-            const unsigned long long keep = ~(0xFull << wv0);
             unsigned long long *w0 = ev.vb_glob + y, *w1 = w0 + ev.vb_plane, *w2 = w1 + ev.vb_plane;
-            const unsigned long long o0 = *w0, o1 = *w1, o2 = *w2;
-            const unsigned long long v0 = (o0 & keep) | ((unsigned long long)nb4 << wv0), v1 = (o1 & keep) | ((unsigned long long)nf4 << wv0),
-                                     v2 = (o2 & keep) | ((unsigned long long)nl4 << wv0);
-            if (v0 != o0) *w0 = v0;
-            if (v1 != o1) *w1 = v1;
-            if (v2 != o2) *w2 = v2;
+            *w0 = (unsigned long long)nb5 << wvA; *w1 = (unsigned long long)nf5 << wvA; *w2 = (unsigned long long)nl5 << wvA;
             }
+        }
+        // the advice for the launch that comes next: the fire's first and last column as this phase leaves it (per wave; folded behind the barrier)
+        if (ADV && a.win_hint) {
+            const uint32_t lo = ag ? 0xFFFFFFFFu - (uint32_t)(x + ((__ffs((int)ag) - 1) >> 3)) : 0u, hi = ag ? (uint32_t)(x + ((31 - __clz((int)ag)) >> 3)) + 1u : 0u;
+            const uint32_t mlo = wave_umax(lo), mhi = wave_umax(hi);
+            if (lane == 0) { wslot[wave * 4] = mlo; wslot[wave * 4 + 1] = mhi; }
         }
     }
     // (with the result block by difference what follows reads LDS only; the general loop, if it takes over, and counts_env read the cells
@@ -759,6 +840,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (by_delta && (s >= n_steps || !st.running)) win_barrier<0>();
     else __syncthreads();
     lpc.note(34);            // window written back
+    if (ADV && a.win_hint && tid < 16) {
+        const int n_waves = nthr >> 6;
+        const uint32_t mlo = row16_max(tid < n_waves ? wslot[tid * 4] : 0u), mhi = row16_max(tid < n_waves ? wslot[tid * 4 + 1] : 0u);
+        if (tid == 0) a.win_hint[e] = mhi ? (unsigned long long)(((0xFFFFFFFFu - mlo) + 1u) | (mhi << 16)) | ((unsigned long long)((uint32_t)(wx0 + 1) | ((uint32_t)(wy0 + 1) << 16)) << 32) : 0ull;
+    }
     if (by_delta) {
         for (int i = tid; i < nty * ntx * 8; i += nthr) {
             const int tl = i >> 3, q = i & 7, d = dt[i];

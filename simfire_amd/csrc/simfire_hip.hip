@@ -121,6 +121,7 @@ struct sf_sim {
     mutable std::map<unsigned long long, int> occ_cache;      // team kernels: workgroups per CU by hipOccupancyMaxActiveBlocksPerMultiprocessor (team_occupancy)
     double *rtc = nullptr;             // the R table(s) cell-major (k_rt_cellmajor): built when the resident launch first needs it, stale after every change of rt
     bool rtc_valid = false;
+    unsigned long long *win_hint = nullptr;      // k_run's window phase: where the fire stood and where the window was when the phase last ended, per environment; 0 = unknown.  ADVICE only (sf_win_kernels.h)
     double *lay_all = nullptr;         // [tables][7][H*W] dense: w0 delta Mx sigma elev U Udir (kept for the observation planes)
     double *layer(int table, int i) const { return lay_all + ((size_t)table * 7 + i) * (size_t)g.H * g.W; }
     int8_t *history = nullptr;         // sf_enable_history: [E][history_cap][H][W] fire maps after each update
@@ -372,7 +373,9 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     TRY(dev_alloc(s, &s->todo, (size_t)g.E));
     TRY(dev_alloc(s, &s->run_cost, (size_t)g.E));
     TRY(dev_alloc(s, &s->run_order, (size_t)g.E));
+    TRY(dev_alloc(s, &s->win_hint, (size_t)g.E));
     TRYHIP(hipMemsetAsync(s->run_cost, 0, (size_t)g.E * sizeof(uint32_t), s->stream));
+    TRYHIP(hipMemsetAsync(s->win_hint, 0, (size_t)g.E * sizeof(unsigned long long), s->stream));
     TRYHIP(hipMemsetAsync(s->todo, 0, (size_t)g.E * sizeof(int32_t), s->stream));
     s->n_tiles_max = (size_t)g.E * ((size_t)(g.H + g.LR - 1) / g.LR) * g.chunks_x;      // RB = 1 is the finest tiling
     TRY(dev_alloc(s, &s->tdirty, s->n_tiles_max));
@@ -408,7 +411,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
     for (void *hp : {(void *)s->loop_db, (void *)s->loop_res, (void *)s->loop_pts}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)s->loop_mem, (void *)s->loop_pts_mem}) if (dp) (void)hipFree(dp);
-    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->mit_stage,
+    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->win_hint, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
@@ -880,6 +883,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     s->status_fresh = false;
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
     if (n == g.E) s->cost_steps = 0;                         // new episodes: what the environments cost before says nothing about them
+    HIPCHK(hipMemsetAsync(s->win_hint + env0, 0, (size_t)n * sizeof(unsigned long long), s->stream));      // (where the old fires stood says nothing about the new ones)
     if (n == g.E) {
         // everything is rewritten, nothing to convert: into the blocked plane if the resident launch is what steps this handle
         // (it did last, or nothing has stepped yet and it is the automatic choice), else into the row-major planes
@@ -1366,7 +1370,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     const bool polled = n_steps == 1 && !mit_dev && s->step1_polls >= 2;
     a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr; a.thist = s->thist;
     a.order = nullptr; a.cost = nullptr;
-    a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt; a.rtc = nullptr;
+    a.g = s->g; a.status = s->status; a.age = s->age; a.cells = nullptr; a.burn = s->burn; a.rt = s->rt; a.rtc = nullptr; a.win_hint = nullptr;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = s->counters_on ? s->counters : nullptr;
     a.parents = s->graph_on ? s->parents : nullptr;
     const dim3 block(kWaves * 64);
@@ -1452,6 +1456,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             rc0 = ensure_rtc(s);
             if (rc0) return rc0;
             a.rtc = s->rtc;
+            a.win_hint = s->win_hint;
+            { const char *dk = getenv("SF_DEBUG_KNOBS"); if (dk && dk[0] == '1' && getenv("SF_NO_WIN_HINT")) a.win_hint = nullptr; }      // (measurement scripts: the window phase without its advice)
         }
     } else if (!generic) {
         int rc0 = ensure_tiles(s);
@@ -1779,7 +1785,7 @@ static int loop_launch(sf_sim *s)
     const Geo &g = s->g;
     StepArgs a;
     memset(&a, 0, sizeof a);
-    a.g = g; a.status = s->status; a.age = s->age; a.cells = s->cells; a.burn = s->burn; a.rt = s->rt; a.rtc = nullptr;
+    a.g = g; a.status = s->status; a.age = s->age; a.cells = s->cells; a.burn = s->burn; a.rt = s->rt; a.rtc = nullptr; a.win_hint = nullptr;
     a.commit = s->commit; a.tmp = s->tmp; a.flags = s->flags; a.counters = nullptr; a.tflags = s->tflags; a.tile_list = s->tile_list;
     a.n_active = s->n_active; a.seam = s->seam; a.settled = s->settled; a.tdirty = s->tdirty; a.thist = s->thist; a.vbits = s->vbits;
     a.launch = 0; a.from_commit = 1; a.ring = s->ring;

@@ -57,3 +57,11 @@ hipError_t sf_run4_launch_team2(int att, int diag, unsigned grid, unsigned block
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a, n_steps, vcap, 64);
     return hipSuccess;
 }
+
+#ifdef SF_WIN_PROF
+// (profiles/win_prof.sh: this unit's own copy of the window loop's phase clocks - C4's team kernels live here)
+extern "C" int sf_debug_win_prof4(unsigned long long *out /* [1024][16][8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_win_prof), sizeof(unsigned long long) * 1024 * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

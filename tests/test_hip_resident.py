@@ -1370,6 +1370,76 @@ def test_window_phase_random_worlds(seed, win):
         assert cnt["window_updates"] > 0, "the window phase never ran"
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_window_placed_by_the_advice_of_the_launch_before(wide):
+    """The window phase of the general path (rows of several bitmap words: grids wider than 1024 columns, stepped by teams of one while the
+    fires are young - C4) leaves ADVICE behind (a.win_hint: the fire's first and last column and where the window was when the phase ended);
+    the next launch keeps the window where it was while the fire has room there, else puts it where the fire has the most room - to the
+    vector, or around the fire's middle to four cells.  Fires that spread a cell per update in every direction, ignited at 36 consecutive
+    columns (every alignment to the vectors, twice over; the columns straddle column 1024): 5 updates, then 20 - the driver's window.
+    Placed by vectors alone a third of them reach the window's edge before the call ends; placed by advice EVERY update of every environment
+    runs in the window phase.  Equal to the oracle after both calls.  (`wide` off: the same world on one-word rows, the headline's path,
+    which places by vectors only - sf_win_kernels.h, ADV: equal to the oracle, and some updates leave the window.)"""
+    H, W = (96, 1100) if wide else (1024, 320)         # (one-word rows: a thread per grid row, the window has a sixteenth as many rows as the workgroup threads - 64 on 1024 rows)
+    E = 36
+    kw = dict(shape=(H, W), n_envs=E, max_fire_duration=4, pixel_scale=20.0, update_rate=1.0, attenuate_line_ros=False, diagonal_spread=True)
+    R8 = np.full((8, H, W), 1500.0)
+    x0 = 1000 if wide else 120
+    inits = [(x0 + i, (40 if wide else 500) + (i % 5)) for i in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    eng.enable_counters(True)
+    eng.step(5); o.step(5)
+    _same(eng, o, E, tag="5")
+    xs = [np.nonzero((o.fire_map(e) == 1).any(axis=0))[0] for e in range(E)]
+    assert all(len(x) and x.max() - x.min() == 10 for x in xs), "the world is not the one this test was written for: a cell per update each way"
+    eng.counters(reset=True)
+    eng.step(20); o.step(20)
+    _same(eng, o, E, tag="25")
+    if not wide:
+        assert 0 < eng.counters()["window_updates"] < 20 * E
+        return
+    assert eng.counters()["window_updates"] == 20 * E
+    # the same world without the advice (a reset drops it; 5 + 20 updates made as 1 + 24: the one-update call leaves advice, so the
+    # comparison is the window phase switched off and on again): fewer updates in the window - the assertion above is not vacuous
+    eng.reset(inits); o.reset(inits)
+    eng.set_tuning(run_window=0)
+    eng.step(5); o.step(5)
+    eng.set_tuning(run_window=1)
+    eng.counters(reset=True)
+    eng.step(20); o.step(20)
+    _same(eng, o, E, tag="25, placed by vectors")
+    assert eng.counters()["window_updates"] < 20 * E
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_window_advice_that_has_gone_stale(seed):
+    """The advice is only advice: whatever moved the fire since it was left - updates by the per-step kernels (which know nothing of it), a
+    fire map loaded by the host, control lines, a reset - the next resident launch either sees that it no longer matches the bitmap, or finds
+    a sprite beside the window it placed (the check on the way in) and goes without the window phase once.  Random worlds; calls that
+    alternate between the resident launch and the per-step kernels; equal to the oracle after every call."""
+    rng = np.random.default_rng(52000 + seed)
+    H, W = int(rng.integers(64, 200)), int(rng.integers(80, 300))
+    E = int(rng.integers(2, 6))
+    kw, R8 = _window_world(rng, H, W, E)
+    if seed % 2:
+        R8 = np.full((8, H, W), 1500.0)            # (fires that fill their vectors fast: advice and bitmap agree on the vectors, not on the cells)
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    done = 0
+    while done < 60:
+        mode = int(rng.choice([2, 2, 0, 1]))
+        eng.set_fused(mode)
+        n = int(rng.integers(1, 5)) if mode != 2 else int(rng.integers(1, 12))
+        if rng.random() < 0.2:
+            e0, x, y = int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H))
+            eng.reset_env(e0, x, y)
+            o.reset_env(e0, x, y)
+        eng.step(n); o.step(n)
+        done += n
+        _same(eng, o, E, tag=(seed, mode, done))
+
+
 def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path):
     """Everything around the one RCCL call of the C ABI for a world of EIGHT ranks, on one GPU: tests/fake_rccl.cpp (test
     infrastructure, loaded instead of librccl through SIMFIRE_RCCL_LIB) lets eight handles of one process play the ranks.  Checked:
