@@ -29,9 +29,16 @@ python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_wi
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 # round 5's probes: what a window step's chain is made of, the LDS-DMA form of a load, host stores into device memory, CU masks,
 # what runs beside the resident closed loop, C5's window per environment, the closed loop's time per call
-for pr in lds_latency_probe lds_dma_probe bar_write_probe cu_mask_probe; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/$pr profiles/$pr.hip 2>/dev/null && timeout 120 /tmp/$pr > $O/$pr.txt 2>&1
+# (second half of the round: what a launch of k_run's shape costs with nothing in it, the shader clock of short kernels)
+for pr in lds_latency_probe lds_dma_probe bar_write_probe cu_mask_probe launch_floor_probe clock_ramp_probe; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w -o /tmp/$pr profiles/$pr.hip 2>/dev/null && timeout 120 /tmp/$pr > $O/$pr.txt 2>&1
 done
+# the fixed part of a resident launch (events, the kernel's own clock, rocprofv3 side by side); the closed loop's floor; C4's share in the window phase
+bash profiles/launch_fixed.sh 2>/dev/null | grep -v amdgpu.ids > $O/launch_fixed.txt
+python profiles/loop_floor_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/loop_floor_probe.txt
+python profiles/c4_window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c4_window_probe.txt
+SF_DEBUG_KNOBS=1 SF_NO_WIN_HINT=1 python profiles/c4_window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c4_window_probe_without_advice.txt
+WL=c4 bash profiles/win_prof.sh 20 5 128 2>/dev/null | grep -v amdgpu.ids > $O/phase_clocks_window_c4_s20.txt
 (python profiles/loop_share_probe.py 256 1; python profiles/loop_share_probe.py 256 0) 2>/dev/null | grep -v amdgpu.ids > $O/loop_share_probe.txt
 python profiles/c5_window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c5_window_probe.txt
 (python profiles/loop_probe.py c3 300 256 4 loop; SF_DEBUG_KNOBS=1 SF_TUNE_LOOP_LIGHT=1 python profiles/loop_probe.py c3 300 256 4 loop; python profiles/loop_probe.py c5 300 64 64 loop) 2>/dev/null | grep -v amdgpu.ids > $O/loop_probe.txt

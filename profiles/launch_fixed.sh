@@ -9,8 +9,8 @@ rows = [r for r in csv.DictReader(open(glob.glob("/tmp/lfx/**/*kernel_trace.csv"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 lines = open("/tmp/lfx_lines.txt").read().splitlines()
-# the probe ends with 4 launches per n (seven values of n) of which the last 3 are printed
-dur = dur[-28:]
+# the probe ends with 4 launches per n (six values of n) of which the last 3 are printed
+dur = dur[-24:]
 k = 0
 for i in range(len(dur)):
     if i % 4 == 0:

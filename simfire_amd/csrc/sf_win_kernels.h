@@ -162,7 +162,8 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // (ADV: only on the general path - rows of several bitmap words, C4's 2048-wide grids in teams of one, where a fire lost to the ring costs
     // its environment 40 k clocks of a 110 k launch.  On the headline's path (GEN = 0) the operational fires keep inside a window placed by
     // vectors for the driver's 25 updates, and the code of the advice - ~340 more instructions per wave and launch, a dozen scalar loads -
-    // was measured to cost every launch 3.4 k clocks of 97 k.)
+    // was measured to cost every launch 3.4 k clocks of 97 k.  Nor with control lines inside the launch: C5's 20 updates 84.3 -> 86.5 us, no
+    // update more in the window phase.)
     constexpr bool ADV = GEN != 0;
     const uint32_t hint = ADV ? (uint32_t)ev.hint : 0u, hint_w = ADV ? (uint32_t)(ev.hint >> 32) : 0u;      // (first column + 1) | (last column + 1) << 16 of the fire, (first column + 1) | (first row + 1) << 16 of the window when this phase last ended, 0 = unknown: ADVICE (below; asked for by k_run with the environment's state)
     // ---- LDS
@@ -329,8 +330,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     const int32_t *const p_row = l_row ? a.res_block + e * 8 + (tid - 120) : reinterpret_cast<const int32_t *>(cellp);
     const double2 b01 = *reinterpret_cast<const double2 *>(ev.burn + idx), b23 = *reinterpret_cast<const double2 *>(ev.burn + idx + 2);
     const uint32_t ag0 = *reinterpret_cast<const uint32_t *>(cellp), sv0 = *reinterpret_cast<const uint32_t *>(cellp + kBlStatus);
-    const uint32_t v_chk = *p_chk;
-    const int32_t v_row = *p_row;
+    // (on the headline's path - no advice, no check - the old result row keeps its own branch: eight lanes' load behind the others' measured
+    // ~1 k clocks per launch cheaper than every lane loading its own cell a second time)
+    uint32_t v_chk = 0;
+    int32_t v_row = 0;
+    if (ADV) v_chk = *p_chk;
+    if (ADV || l_row) v_row = *p_row;
     const uint32_t beside = chk ? v_chk : 0u;
     {
         double2 *dst = reinterpret_cast<double2 *>(wb + (r * 16 + c) * 4);
