@@ -1623,8 +1623,8 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         if (a.cost) {            // what this environment cost: the order / the team sizes of the next launch (k_order, k_team_plan)
             const unsigned long long c = (__builtin_readcyclecounter() - clk0) >> 4;
             const uint32_t c32 = c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c;
-            if (TEAM) atomicAdd(&a.cost[e], c32);     // (zeroed before the launch: the sum over the members)
-            else a.cost[e] = c32;
+            if (TEAM && tn > 1) atomicAdd(&a.cost[e], c32);     // (zeroed before the launch by k_team_plan: the sum over the members)
+            else a.cost[e] = c32;                               // (a team of one: nobody else writes it - and no plan kernel has to have zeroed it)
         }
     }
     if (TEAM) {
@@ -1770,7 +1770,8 @@ __global__ __launch_bounds__(1024) void k_team_plan(int E, int G, int t_min, int
         return s_sum;
     };
     uint32_t lo = 0, hi = 0;
-    {
+    if (t_min < t_max) {                  // (teams of one size - forced, or teams of ONE while the fires are young, C4's driver window: nothing to search;
+                                          // the search below is up to 28 rounds of three barriers, ~7 us of a 60 us launch)
         __syncthreads();
         if (t == 0) s_sum = 0;
         __syncthreads();

@@ -175,6 +175,7 @@ struct sf_sim {
     uint8_t *xbuf = nullptr;
     uint32_t *xerr_pinned = nullptr, *xerr_mapped = nullptr;
     int team_slots = 0;                // entries of team_tab
+    long long team_plan_ones = 0;      // != 0: team_tab / team_size hold the plan "every environment one workgroup" for this (E, slots, placement) - k_team_plan need not run again for it
     // LOOP mode (sf_loop_start): the resident launch driven step by step through host-mapped memory
     bool loop_on = false;
     int loop_k = 0;                    // points per environment and step
@@ -1263,6 +1264,7 @@ static int launch_k_run_join(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     s->jlog_valid = true;
     hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, 1, 1, 0u, 0u, 1, s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, 0,
                        s->xj, s->xcut);
+    s->team_plan_ones = 0;             // (this plan spreads the environments over the XCDs: not the table a launch of fixed teams of one keeps)
     a.cost = s->run_cost;
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
     a.xrow = team_xrow(g); a.team_rcap = 0;
@@ -1299,6 +1301,7 @@ static int team_buffers(sf_sim *s, const TeamGeo &t)
         if (s->team_tab) { HIPCHK(hipFree(s->team_tab)); s->team_tab = nullptr; }
         { int rc = dev_alloc(s, &s->team_tab, (size_t)t.slots); if (rc) return rc; }
         s->team_slots = t.slots;
+        s->team_plan_ones = 0;
     }
     if (!s->xg) {
         int rc = dev_alloc(s, &s->xg, (size_t)g.E * kTeamMax * 3); if (rc) return rc;
@@ -1324,8 +1327,15 @@ static int launch_k_run_team(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const uint32_t ovh = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 6500 / 16);
     const uint32_t floor_c = (uint32_t)((long long)(steps_before > 0 ? steps_before : 0) * 12000 / 16);
     // (the plan also clears the granules, the "left" counters and the cost array it has read: the members add their clocks)
-    hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, floor_c, s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0,
-                       s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, keep_cost ? 1 : 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    // Teams of ONE (C4's young fires in the driver's window): the plan does not depend on what anything cost, teams of one touch neither
+    // the granules nor the counters and store their cost - the table of the launch before stands, and the call is one launch instead of two
+    // (k_team_plan + the gap behind it: ~5 us of a 57 us call).
+    const int scatter = s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 1 ? 1 : 0;
+    const long long ones_key = (t_min == 1 && t_max == 1) ? 1 + (long long)scatter + 2ll * t.slots + ((long long)g.E << 32) : 0;
+    if (!ones_key || s->team_plan_ones != ones_key)
+        hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, s->stream, g.E, t.slots, t_min, t_max, ovh, floor_c, scatter,
+                           s->run_cost, s->team_tab, s->team_size, s->xg, s->xdone, keep_cost ? 1 : 0, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    s->team_plan_ones = ones_key;
     a.cost = keep_cost ? nullptr : s->run_cost;
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
     a.xrow = team_xrow(g); a.team_rcap = t.rcap;

@@ -1440,6 +1440,26 @@ def test_window_advice_that_has_gone_stale(seed):
         _same(eng, o, E, tag=(seed, mode, done))
 
 
+def test_teams_of_one_keep_their_plan_from_call_to_call():
+    """A call whose teams are all of ONE workgroup (2048-wide grids while the fires are young: C4's driver window) does not launch the plan
+    kernel again when the call before had the same plan - the table stands, teams of one touch neither the granules nor the counters and
+    store their cost.  Calls of teams of one, a call of forced teams of two in between (its plan must be made, and the one after it again),
+    a change of the placement knob: equal to the oracle after every call, team sizes as asked."""
+    rng = np.random.default_rng(777)
+    H, W, E = 160, 1100, 5
+    kw, R8 = _window_world(rng, H, W, E, att=False)
+    inits = [(int(rng.integers(900, 1090)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    eng.set_fused(2)
+    for n, team, place in ((5, 0, 0), (7, 0, 0), (6, 2, 0), (5, 0, 0), (4, 0, 0), (3, 0, 1), (6, 0, 1), (5, 3, 2), (4, 0, 0)):
+        eng.set_tuning(run_team=team, team_placement=place)
+        eng.step(n); o.step(n)
+        _same(eng, o, E, tag=(n, team, place))
+        assert eng.last_launch_kind() == 2
+        ts = eng.team_sizes()
+        assert (ts == (team if team else 1)).all(), (n, team, ts)
+
+
 def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path):
     """Everything around the one RCCL call of the C ABI for a world of EIGHT ranks, on one GPU: tests/fake_rccl.cpp (test
     infrastructure, loaded instead of librccl through SIMFIRE_RCCL_LIB) lets eight handles of one process play the ranks.  Checked:
