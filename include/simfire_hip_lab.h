@@ -53,7 +53,8 @@ enum sf_tuning_knob {
     SF_TUNE_RUN_WAVES = 1,      /* waves per workgroup of the resident launch k_run, 1..16 (default 16; 8 when there are more environments than CUs) */
     SF_TUNE_RUN_MIN_ENVS = 2,   /* automatic mode picks k_run from this many environments (default 1) */
     SF_TUNE_RUN_VCAP = 3,       /* entries of k_run's vector list in LDS (default 4096; longer lists are taken in chunks) */
-    SF_TUNE_RUN_COMPACT = 4,    /* 1 = 8-wave workgroups, two per CU, when there are more environments than CUs (default 1) */
+    SF_TUNE_RUN_COMPACT = 4,    /* 1 = 8-wave workgroups, two per CU, when there are more environments than CUs (default 1) - except in a call that ends with every fire
+                                 * surely inside a window of 64 rows (the library's bound on the fires' rows since the last reset): 16-wave workgroups hold that window */
     SF_TUNE_RUN_BATCH = 5,      /* vectors per batch of k_run, 8..64 (default 64) */
     SF_TUNE_RUN_RESULT = 6,     /* 1 = k_run writes the result block itself when its steps are done (default 1) */
     SF_TUNE_RUN_SEGMENT = 7,    /* steps per k_run launch when there are more environments than workgroup slots (default 64; 0 = one launch) */
