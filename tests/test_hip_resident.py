@@ -1460,6 +1460,33 @@ def test_teams_of_one_keep_their_plan_from_call_to_call():
         assert (ts == (team if team else 1)).all(), (n, team, ts)
 
 
+def test_more_environments_than_cus_young_and_old():
+    """More environments than the chip has CUs: while the library's bound on the fires' rows says a call ends with every fire inside a
+    window of 64 rows, the launch keeps 16-wave workgroups (rounds of one per CU); after that 8-wave workgroups, two to a CU.  300
+    environments on a 640 x 48 grid, calls on either side of the switch and across it, a reset of some environments in between (the bound
+    is the handle's, not the environment's): equal to the oracle after every call."""
+    rng = np.random.default_rng(4242)
+    H, W, E = 640, 48, 300
+    kw, R8 = _window_world(rng, H, W, E, att=False)
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    for n in (5, 12, 9, 30, 6):
+        eng.step(n); o.step(n)
+        st, el = eng.status(); so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), n
+        for e in (0, 1, 127, 128, 255, 256, 257, 299):
+            assert (eng.fire_map(e) == o.fire_map(e)).all(), (n, e)
+            assert (eng.burn(e) == o.burn(e)).all(), (n, e)
+        assert eng.last_launch_kind() == 2
+    for e0 in (3, 256, 299):
+        eng.reset_env(e0, 7, 300); o.reset_env(e0, 7, 300)
+    eng.step(8); o.step(8)
+    st, el = eng.status(); so, eo = o.status()
+    assert (st == so).all() and (el == eo).all()
+    for e in (3, 4, 256, 299):
+        assert (eng.fire_map(e) == o.fire_map(e)).all(), e
+
+
 def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path):
     """Everything around the one RCCL call of the C ABI for a world of EIGHT ranks, on one GPU: tests/fake_rccl.cpp (test
     infrastructure, loaded instead of librccl through SIMFIRE_RCCL_LIB) lets eight handles of one process play the ranks.  Checked:
