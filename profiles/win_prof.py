@@ -7,14 +7,23 @@ from simfire_amd import workloads
 from simfire_amd.engine import FireEngine
 steps, warm = int(sys.argv[1]), int(sys.argv[2])
 E = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-w = workloads.c4(2048, E) if os.environ.get("WL") == "c4" else workloads.c3(1024, E)
+WL = os.environ.get("WL", "c3")
+w = workloads.c4(2048, E) if WL == "c4" else (workloads.c5(1024, E) if WL == "c5" else workloads.c3(1024, E))
+pts = None
+if WL == "c5":      # control lines inside the launch: 64 agents per environment
+    H_, W_ = w.shape
+    pts = np.ascontiguousarray(workloads.agent_walk(w.n_envs, w.agents_per_env, H_, W_, steps + warm).reshape(steps + warm, w.n_envs, w.agents_per_env, 4)[..., 1:])
 eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
 eng.set_layers(*w.layers())
 for rep in range(2):
     eng.reset(w.init_xy)
-    if warm:
-        eng.step(warm)
-    ms = eng.step_timed(steps)
+    if pts is not None:
+        eng.step_mitigated(pts[:warm])
+        ms = eng.step_mitigated(pts[warm:warm + steps], timed=True)
+    else:
+        if warm:
+            eng.step(warm)
+        ms = eng.step_timed(steps)
 prof = np.zeros((1024, 16, 8), dtype=np.uint64)
 rd = eng._L.sf_debug_win_prof4 if os.environ.get("WL") == "c4" else eng._L.sf_debug_win_prof      # (the two-word team kernels are a translation unit of their own)
 rd.argtypes = [ctypes.c_void_p]
@@ -36,3 +45,9 @@ if len(sys.argv) > 4:
                                      "walker_wave0": {n: float(walk[:, q].mean()) for q, n in enumerate(names)}, "total_per_update": float(tot[:, 0].mean())}},
               open(sys.argv[4], "w"), indent=1)
 print("   busiest phase-A wave per env: phase A mean %.0f, max over envs %.0f" % (p[np.arange(E), busy, 0].mean(), p[np.arange(E), busy, 0].max()))
+if WL == "c5":      # the most and the least expensive environment, wave by wave
+    order = np.argsort(-cost)
+    for tag, e in (("most expensive", order[0]), ("median", order[E // 2])):
+        print(f"   {tag} environment {e} ({cost[e]/1e3:.1f} k clocks):")
+        for wv in (0, 1, 7, 8, 14, 15):
+            print(f"      wave {wv:2d}  " + "  ".join(f"{p[e, wv, q]:11.0f}" for q in range(8)) + f"  {tot[e, wv]:11.0f}")

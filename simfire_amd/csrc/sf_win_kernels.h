@@ -479,6 +479,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (MITW && mitw && wave == mit_wave) {
             // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80), the points OUTSIDE the window:
             // k_run's one-wave scheme on the planes in memory.  The coming step's points are asked for first.
+            // (Measured and dropped, round 5: this wave's loads a step AHEAD - the points of step s + 2 and the operands of step s + 1's cells as
+            // LDS-DMA requests at the top of step s, classification moved up here from behind the walk - so that it waits for no round trip of
+            // its own at the top of a step: bit-exact, and C5's 20 updates 84.3 -> 89.7 us.  This wave's phase A is ~0.9 k clocks of scattered
+            // byte stores and their address arithmetic whether it waits for loads or not; with the classification in front of barrier 1
+            // instead of beside the walk it is 3.7 k clocks against the other waves' 1.8 k, 2.6 k before.)
             const bool ok = m_ok && !m_in;
             const int fin = m_fin;
             const uint32_t o = (uint32_t)(m_y * g.P + m_x);
