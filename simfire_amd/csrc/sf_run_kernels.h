@@ -64,12 +64,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (the nontemp
 // burn [WR][64] f64 | step masks [8][8] u32 | status-count changes [16][8] i32 | per-wave slots [16][4] u32 |
 // mask plane [WR + 2][18] u32 (a zero dword left / right of every row, a zero row above / below) | "burn changed" bytes [WR][16] |
 // the frontier lists of this step and the next [2][WR x 64] u16 | control-line patches [2][WR][64] bytes |
-// status plane [WR][64] bytes | "on the frontier list" bits [WR x 64].
+// status plane [WR][64] bytes | "on the frontier list" bits [WR x 64] | with control lines and attenuation: the old contents of the cells a step's points
+// fall on outside the window, 1 KB.
 __host__ __device__ inline size_t win_lds_bytes(int n_waves)
 {
     const int WR = n_waves * 4;
     return (size_t)WR * 64 * 8 + 8 * 8 * 4 + 128 * 4 + 64 * 4 + (size_t)(WR + 2) * 18 * 4 + (size_t)WR * 16 + (size_t)2 * WR * 64 * 2 + (size_t)2 * WR * 64 +
-           (size_t)WR * 64 + (size_t)WR * 8;
+           (size_t)WR * 64 + (size_t)WR * 8 + 256 * 4;
 }
 // dwords of the strip-buffer region of k_run: the general loop's strip buffers (+ the walk's owner markers) or the window phase's planes,
 // whichever is larger (16 waves: the strips, 79 872 bytes against 68 752; one wave - small grids -: the window)

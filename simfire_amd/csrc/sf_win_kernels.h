@@ -177,6 +177,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     uint32_t *const wpatch = reinterpret_cast<uint32_t *>(wlist + 2 * capF);             // MITW: [2][WR][16] control-line types drawn inside the window, by parity of the step (a byte per cell, 0 = none)
     uint32_t *const wstat = wpatch + 2 * WR * 16;                                        // status bytes of the window [WR][16] (the owners' registers, for the walkers)
     uint32_t *const wflag = wstat + WR * 16;                                             // a bit per cell: it is on the frontier list [WR x 2]
+    uint32_t *const wmit = wflag + WR * 2;                                               // MITW + ATT: [4][64] the old contents of the cells the step's points outside the window fall on (status dword | burn lo | burn hi | settled)
     if (MITW) { wpatch[tid] = 0; wpatch[nthr + tid] = 0; }   // (both patch planes: [2][WR x 16] dwords = two per thread; in front of the barrier below)
     if (tid < WR * 2) wflag[tid] = 0;
     // ---- where is the fire?  Rows and vector columns that hold a sprite bit, from the vector bitmap in memory: thread y looks at row y.
@@ -358,6 +359,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // the control-line wave's view of ONE step's points (made a step ahead): valid, column, row, the type that stands on its cell, inside the window
     bool m_ok = false, m_in = false;
     int m_x = 0, m_y = 0, m_fin = 0;
+    const uint32_t wmit_lds = (MITW && ATT) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)wmit) : 0u;
+    auto dma_dword = [&](const void *src, uint32_t lds_byte) {      // an LDS-DMA load: lane i's dword lands at LDS[lds_byte + 4 i], no register is held, nothing waits
+        uint32_t m0_was;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_was) : "s"(lds_byte), "v"(src) : "memory");
+    };
     auto mit_classify = [&](int sp) {
         // points of launch step sp are in the wave's registers (*ppx, *ppy, *ppty): which are real, which type stands where two share a
         // cell (the reference writes FIRELINE, then SCRATCHLINE, then WETLINE: the highest), which fall inside the window -> its patch plane
@@ -478,29 +485,25 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         const uint32_t rot = t1.z & 0xFFu, nrot = (t1.z >> 8) & 0xFFu, exp_sh = (t1.z >> 16) & 0xFFu, prev_sh = t1.z >> 24;
         if (MITW && mitw && wave == mit_wave) {
             // FireSimulation.update_mitigation before this update (simulation.py:449-478, mitigation.py:60-80), the points OUTSIDE the window:
-            // k_run's one-wave scheme on the planes in memory.  The coming step's points are asked for first.
-            // (Measured and dropped, round 5: this wave's loads a step AHEAD - the points of step s + 2 and the operands of step s + 1's cells as
-            // LDS-DMA requests at the top of step s, classification moved up here from behind the walk - so that it waits for no round trip of
-            // its own at the top of a step: bit-exact, and C5's 20 updates 84.3 -> 89.7 us.  This wave's phase A is ~0.9 k clocks of scattered
-            // byte stores and their address arithmetic whether it waits for loads or not; with the classification in front of barrier 1
-            // instead of beside the walk it is 3.7 k clocks against the other waves' 1.8 k, 2.6 k before.)
-            const bool ok = m_ok && !m_in;
-            const int fin = m_fin;
-            const uint32_t o = (uint32_t)(m_y * g.P + m_x);
-            uint8_t *cell = ev.cells + bl_cell(g, m_y, m_x & ~3) + kBlStatus + (m_x & 3);
+            // k_run's one-wave scheme on the planes in memory - but BESIDE the walk, not in front of phase A.  Nothing in this update looks at
+            // a cell outside the window (no sprite is on the ring, so no neighbour of a sprite lies outside), so all that has to happen before
+            // the update is what the patches - written a step ahead - did for the points INSIDE.  Here, at the top of the step, the wave only
+            // ASKS: for the coming step's points, and (attenuation) for the old type, burn_amount and settled count of this step's cells - LDS-DMA
+            // loads, no register held, nothing waited for.  Behind barrier 1, while the walkers walk, it takes them from LDS, makes the cells up
+            // for what they are owed, stores, and classifies the coming step's points.  (Until round 5 all of this stood here, in front of the
+            // wave's phase A: C5, 2.6 k clocks against the other waves' 1.8 k - a round trip of its own and ~0.9 k clocks of scattered byte stores
+            // - and barrier 1 waited for it.)
             if (s + 1 < n_total && lane < a.mit_k) {
                 const int32_t *pp = mit + (((long long)(s + 1) * g.E + e) * a.mit_k + lane) * 3;
                 *ppx = pp[0]; *ppy = pp[1]; *ppty = pp[2];
             }
-            uint32_t was = 0, owed_since = 0;
-            double bn = 0.0;
-            if (ATT && ok) { was = *cell & 7u; bn = ev.burn[o]; owed_since = ev.settled[o]; }
-            if (ATT && ok && was != (uint32_t)fin) {
-                if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)(st.complete + n_plain) - owed_since);
-                ev.settled[o] = (uint32_t)(st.complete + n_plain);
+            if (ATT && m_ok && !m_in) {
+                const uint32_t o = (uint32_t)(m_y * g.P + m_x);
+                dma_dword(ev.cells + bl_cell(g, m_y, m_x & ~3) + kBlStatus, wmit_lds);
+                dma_dword(ev.burn + o, wmit_lds + 256u);
+                dma_dword(reinterpret_cast<const char *>(ev.burn + o) + 4, wmit_lds + 512u);
+                dma_dword(ev.settled + o, wmit_lds + 768u);
             }
-            if (ok) *cell = (uint8_t)fin;
-            if (ok) ev.tdirty[(m_y >> th_log) * g.TX + ((m_x >> 4) >> g.logLC)] = 1;
         }
         uint32_t touch_later = 0;                               // ATT: the lane's new frontier cells of this step (their table lines are asked for behind the barrier)
         // (control lines drawn inside the window in front of this update, if any: the owner lanes take them in phase A)
@@ -613,12 +616,14 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 if ((touch_later >> j) & 1u) touch_line(line + j * 8);
         }
         // ---- phase B, as few waves as the list needs: walk the list, one cell per lane
+        bool mit_wave_walks = false;               // MITW + ATT: the control-line wave has list entries of its own this step (a list of more than 960 cells)
         {
             // (the list's length and the lane's first entry are asked for together: one LDS round trip, not two - capF >= threads, an
             // entry beyond the length is garbage that `valid` refuses)
             uint32_t total_raw = ctl[k], ent_first = Fcur[tid];
             asm volatile("" : "+v"(total_raw), "+v"(ent_first));      // (both in flight before either is waited for: the compiler would sink the second behind the test of the first)
             const uint32_t total = spread ? total_raw : 0u;
+            if (MITW && ATT) mit_wave_walks = (uint32_t)(tid - lane) < total;      // (wave-uniform)
             struct WCell { bool valid, cand; uint32_t pos, own_spost; uint32_t owed; double bn, r_tab; };
             // first half of a cell: is it (still) a candidate, winner source, operands requested
             auto front = [&](uint32_t i, uint32_t ent) {
@@ -736,11 +741,35 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             }
             if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
         }
-        if (MITW && mitw && wave == mit_wave && s + 1 < n_total) mit_classify(s + 1);      // (its points have arrived by now; patches for the next step)
+        if (MITW && mitw && wave == mit_wave) {
+            // this step's points outside the window (see the top of the step): their cells' old contents have landed in LDS by now
+            const bool ok = m_ok && !m_in;
+            const int fin = m_fin;
+            const uint32_t o = (uint32_t)(m_y * g.P + m_x);
+            uint8_t *cell = ev.cells + bl_cell(g, m_y, m_x & ~3) + kBlStatus + (m_x & 3);
+            if (ATT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (requests made behind the compiler's back, a phase ago)
+                if (ok) {
+                    const volatile uint32_t *mp = wmit;
+                    const uint32_t was = (mp[lane] >> (8 * (m_x & 3))) & 7u, owed_since = mp[192 + lane];
+                    const double bn = __hiloint2double((int)mp[128 + lane], (int)mp[64 + lane]);
+                    if (was != (uint32_t)fin) {
+                        if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)(st.complete + n_plain) - owed_since);
+                        ev.settled[o] = (uint32_t)(st.complete + n_plain);
+                    }
+                }
+            }
+            if (ok) *cell = (uint8_t)fin;
+            if (ok) ev.tdirty[(m_y >> th_log) * g.TX + ((m_x >> 4) >> g.logLC)] = 1;
+            if (s + 1 < n_total) mit_classify(s + 1);      // (its points have arrived by now; patches for the next step)
+        }
         pc.note(26);         // at the barrier
         WPROF(5)             // rest of phase B
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the marks above were made behind the compiler's back)
-        win_barrier<ATT>();
+        // (the control-line wave's stores to cells outside the window are read by nobody but itself, a step later: it does not wait for them
+        // here - unless it has walked, a list of more than 960 cells: a walker's stores to the `settled` plane are read by the cells' owners)
+        if (MITW && ATT && mitw && wave == mit_wave && !mit_wave_walks) win_barrier<0>();
+        else win_barrier<ATT>();
         WPROF(6)             // barrier at the end of the step
         pc.note(27);         // through the barrier
         // ---- fold (every thread the same arithmetic on the same values); the next step's rows, masks, list bits and marks are requested with the predicates
