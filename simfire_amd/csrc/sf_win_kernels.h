@@ -321,7 +321,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // (control lines change cells outside the window too: counts_env.  Measured and dropped, round 5: the control-line wave keeping the books
     // of those cells point by point - per-tile counts in LDS, added to the cached histograms on the way out, no sweep at the end: bit-exact, the
     // median environment of C5 173 k -> 150 k clocks, and the launch not a microsecond shorter - it ends with the environments whose agents draw
-    // INSIDE the window, 192 k clocks either way.)
+    // INSIDE the window, 192 k clocks either way.  Measured again with the control-line wave's work beside the walk (below): 78.9 -> 81.3 us.)
     const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15 && !mitw;
     // (Measured and dropped: loading only what the fire can reach in this phase - rows and vectors within s_reach of the sprites'; a 5-update
     // call needs a fifth of the window.  The short call got 0.4 us faster and the call after it 3.4 us slower: the whole window loaded by one
