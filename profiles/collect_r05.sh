@@ -39,6 +39,8 @@ python profiles/loop_floor_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/loop_f
 python profiles/c4_window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c4_window_probe.txt
 SF_DEBUG_KNOBS=1 SF_NO_WIN_HINT=1 python profiles/c4_window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c4_window_probe_without_advice.txt
 WL=c4 bash profiles/win_prof.sh 20 5 128 2>/dev/null | grep -v amdgpu.ids > $O/phase_clocks_window_c4_s20.txt
+WL=c5 bash profiles/win_prof.sh 20 5 64 2>/dev/null | grep -v amdgpu.ids > $O/phase_clocks_window_c5_s20.txt
+python profiles/c5_call_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c5_call_probe.txt
 (python profiles/loop_share_probe.py 256 1; python profiles/loop_share_probe.py 256 0) 2>/dev/null | grep -v amdgpu.ids > $O/loop_share_probe.txt
 python profiles/c5_window_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/c5_window_probe.txt
 (python profiles/loop_probe.py c3 300 256 4 loop; SF_DEBUG_KNOBS=1 SF_TUNE_LOOP_LIGHT=1 python profiles/loop_probe.py c3 300 256 4 loop; python profiles/loop_probe.py c5 300 64 64 loop) 2>/dev/null | grep -v amdgpu.ids > $O/loop_probe.txt

@@ -49,5 +49,6 @@ for src, dst in (("r05/phase_clocks_window_c3_s20.json", f"r05_phase_clocks_wind
                  ("r05/cu_mask_probe.txt", "r05_cu_mask_probe.txt"), ("r05/loop_share_probe.txt", "r05_loop_share_probe.txt"), ("r05/c5_window_probe.txt", "r05_c5_window_probe.txt"),
                  ("r05/loop_probe.txt", "r05_loop_probe.txt"), ("r05/launch_floor_probe.txt", "r05_launch_floor_probe.txt"), ("r05/clock_ramp_probe.txt", "r05_clock_ramp_probe.txt"),
                  ("r05/launch_fixed.txt", "r05_launch_fixed.txt"), ("r05/loop_floor_probe.txt", "r05_loop_floor_probe.txt"), ("r05/c4_window_probe.txt", "r05_c4_window_probe.txt"),
-                 ("r05/c4_window_probe_without_advice.txt", "r05_c4_window_probe_without_advice.txt"), ("r05/phase_clocks_window_c4_s20.txt", "r05_phase_clocks_window_c4_share_driver_window.txt")):
+                 ("r05/c4_window_probe_without_advice.txt", "r05_c4_window_probe_without_advice.txt"), ("r05/phase_clocks_window_c4_s20.txt", "r05_phase_clocks_window_c4_share_driver_window.txt"),
+                 ("r05/phase_clocks_window_c5_s20.txt", "r05_phase_clocks_window_c5_driver_window.txt"), ("r05/c5_call_probe.txt", "r05_c5_call_probe.txt")):
     cp(src, dst)
