@@ -1471,7 +1471,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             if (rc0) return rc0;
             a.rtc = s->rtc;
             a.win_hint = s->win_hint;
-            { const char *dk = getenv("SF_DEBUG_KNOBS"); if (dk && dk[0] == '1' && getenv("SF_NO_WIN_HINT")) a.win_hint = nullptr; }      // (measurement scripts: the window phase without its advice)
+            {   // (measurement scripts: the window phase without its advice; looked up once per process)
+                static const bool no_hint = [] { const char *dk = getenv("SF_DEBUG_KNOBS"); return dk && dk[0] == '1' && getenv("SF_NO_WIN_HINT") != nullptr; }();
+                if (no_hint) a.win_hint = nullptr;
+            }
         }
     } else if (!generic) {
         int rc0 = ensure_tiles(s);
