@@ -432,6 +432,62 @@ def side_workload(name, a, device, torch, n_check, tile_cells, env_offset=0, wor
     return out
 
 
+def api_tick(a, device, ticks=100, young=20):
+    """us per `update_mitigation(points); run(1)` pair through the reference-shaped classes (see the call site)."""
+    from simfire_amd.simulation import BatchedFireSimulation, FireSimulation
+    out = {"unit": "us per update_mitigation + run(1) pair (wall: host + device)", "updates": f"{young + 1} .. {young + ticks} of the episode"}
+    w2 = make_workload("c2", a.size, 1, 0)
+    H, W = w2.shape
+    sim = FireSimulation(w2.config(), device=device)
+    sim.run(young)
+    x0, y0 = (int(v) for v in w2.init_xy[0])
+    walk = [((x0 + 40 + i) % W, (y0 + 37 + (i % 7)) % H, 3 + i % 3) for i in range(ticks + 10)]
+    for i in range(10):
+        sim.update_mitigation([walk[i]]); sim.run(1)
+    fm = sim.fire_map
+    t0 = time.perf_counter()
+    for i in range(10, 10 + ticks):
+        sim.update_mitigation([walk[i]])
+        sim.run(1)
+    out["fire_simulation_1024"] = (time.perf_counter() - t0) / ticks * 1e6
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        sim.run(1)
+    out["fire_simulation_1024_run1_only"] = (time.perf_counter() - t0) / ticks * 1e6
+    out["fire_map_in_place"] = bool(sim.fire_map is fm)
+    out["fire_map_equals_device"] = bool((sim.fire_map == sim._engine.fire_map(0)).all())
+    sim._engine.close()
+    w3 = make_workload("c3", a.size, 256, 0)
+    bs = BatchedFireSimulation(w3.config(), w3.n_envs, ignitions=w3.init_xy, device=device)
+    bs.run(young, return_maps=False)
+    E = w3.n_envs
+    pts = np.zeros((ticks + 10, E, 4), dtype=np.int64)
+    pts[..., 0] = np.arange(E)[None, :]
+    pts[..., 1] = (w3.init_xy[None, :, 0] + 40 + np.arange(ticks + 10)[:, None]) % W
+    pts[..., 2] = (w3.init_xy[None, :, 1] + 37) % H
+    pts[..., 3] = 3
+    for i in range(10):
+        bs.update_mitigation(pts[i]); bs.run(1, return_maps=False)
+    t0 = time.perf_counter()
+    for i in range(10, 10 + ticks):
+        bs.update_mitigation(pts[i])
+        bs.run(1, return_maps=False)
+    out["batched_256_envs"] = (time.perf_counter() - t0) / ticks * 1e6
+    bs.reset()
+    bs.run(young, return_maps=False)
+    blk = np.ascontiguousarray(pts[:, :, None, 1:]).astype(np.int32)
+    bs.loop_start(1)
+    for i in range(10):
+        bs.loop_step(blk[i])
+    t0 = time.perf_counter()
+    for i in range(10, 10 + ticks):
+        bs.loop_step(blk[i])
+    out["batched_256_envs_loop_step"] = (time.perf_counter() - t0) / ticks * 1e6
+    bs.loop_stop()
+    bs._engine.close()
+    return out
+
+
 def load_pmc(w, steps, warmup):
     """PMC traffic of a window, if profiles/collect_pmc.sh has been run for it (one file per window: ..._s<K>_w<W>.json)."""
     path = profile_file(f"pmc_traffic_{w.name}_s{steps}_w{warmup}.json")
@@ -847,6 +903,16 @@ def main():
                 "value": H * W * done / dt2, "unit": "cell-updates/s", "ms_per_step": dt2 * 1e3 / a.steps,
                 "kernel_ms_per_step": kms2 / a.steps, "steps_executed": done, "running_at_end": int(st2[0, 0]),
                 "burned_cells": int(st2[0, 4]), "kernel": LAUNCH_KINDS.get(e2.last_launch_kind(), "?")}
+            # The tick as SimHarness issues it, through the UNCHANGED Python surface (simulation.py:449-478, 501-553):
+            # `sim.update_mitigation([(x, y, type)]); fire_map, active = sim.run(1)` per call - wall us per pair, host + device, over updates
+            # 21 .. 120 of the episode.  FireSimulation at 1024 x 1024 (C2's layers): fire_map is ONE int64 host array brought up to date from the
+            # cells that changed (sf_get_fire_map_delta); BatchedFireSimulation with C3's 256 environments: one point per environment and
+            # tick, the result block per call (return_maps=False: observations stay on the device), and the same tick through the resident
+            # closed loop (loop_step).
+            try:
+                also["c2_api_tick"] = api_tick(a, device)
+            except Exception as ex:                              # (never lets the line go missing)
+                also["c2_api_tick"] = {"error": repr(ex)}
             # one GPU's share of BASELINE configs C4 and C5, each checked against the oracle on a sample of its environments
             also["c4_share"] = side_workload("c4", a, device, torch, 16, tile_cells)
             also["c5"] = side_workload("c5", a, device, torch, 32, tile_cells)

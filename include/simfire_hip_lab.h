@@ -45,9 +45,9 @@ int sf_set_fused(sf_sim *sim, int32_t mode);
 
 /* Launch-geometry knobs of a handle.  RESULTS NEVER DEPEND ON THEM (the tests force several values of each against the
  * oracle); the defaults are the measured choices of DESIGN.md section 5.  This is the only way to change them: the
- * library does not read the environment - except that, for the measurement scripts under profiles/, a process started
- * with SF_DEBUG_KNOBS=1 takes the initial values of new handles from variables named like the enumerators
- * (SF_TUNE_RUN_WAVES=8 ...).  No reference counterpart (the reference has no launch geometry). */
+ * library does not read the environment (the Python laboratory binding, simfire_amd/engine.py, turns SF_TUNE_* variables into
+ * calls of this function when SF_DEBUG_KNOBS=1 is set - for the measurement scripts under profiles/).  No reference counterpart
+ * (the reference has no launch geometry). */
 enum sf_tuning_knob {
     SF_TUNE_WAVES_PER_CU = 0,   /* persistent waves per CU of k_step (default 24) */
     SF_TUNE_RUN_WAVES = 1,      /* waves per workgroup of the resident launch k_run, 1..16 (default 16; 8 when there are more environments than CUs) */

@@ -24,6 +24,6 @@ eng.step_mitigated(pts[5:25])
 c = eng.counters(); eng.enable_counters(False)
 wu = c.get("window_updates", 0)
 print(f"20 updates: {t20*1e3:.1f} us ({t20*50:.2f} us/update); clocks/env max {cost.max():.0f} median {np.median(cost):.0f} min {cost.min():.0f}; "
-      f"window updates {wu} of {E*20}; records slot {c['records']}; vectors {c['vectors']} active {c['active_cell_updates']}")
+      f"window updates {wu} of {E*20}; vectors {c['vectors']} active {c['active_cell_updates']}")
 order = np.argsort(cost)
 print("   cost deciles (k clocks):", " ".join(f"{cost[order[int(q*(E-1))]]/1e3:.1f}" for q in np.linspace(0, 1, 11)))

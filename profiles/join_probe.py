@@ -29,6 +29,6 @@ for label, tune in (("join off", dict(run_join=0)), ("join on, no cut (the kerne
     line = f"{label:38s}: {ms / steps * 1e3:6.2f} us per update; team sizes {np.bincount(sizes, minlength=5).tolist()}; clocks max env {cost.max() / steps:.0f} per update, sum / (256 x max) {cost.sum() / (256 * cost.max()):.2f}"
     if label.startswith("counters"):
         c = eng.counters()
-        line += f"; team step boundaries {c['records'] & 0xFFFFFFFF} ({c['records'] >> 32} through one L2), {c['sprite_events'] / max(c['records'] & 0xFFFFFFFF, 1):.0f} clocks each"
+        line += f"; team step boundaries {c['team_boundaries']} ({c['team_boundaries_one_l2']} through one L2), {c['team_boundary_clocks'] / max(c['team_boundaries'], 1):.0f} clocks each"
     print(line, flush=True)
     eng.close()

@@ -25,9 +25,9 @@ for c in range(calls):
     eng.counters(reset=True)
     ms = eng.step_timed(n)
     cn = eng.counters()
-    if cn["records"]:
-        nb, nl = cn["records"] & 0xFFFFFFFF, cn["records"] >> 32
-        print("         team step boundaries %d (through one L2: %d), clocks per boundary %.0f" % (nb, nl, cn["sprite_events"] / max(nb, 1)))
+    if cn["team_boundaries"]:
+        nb, nl = cn["team_boundaries"], cn["team_boundaries_one_l2"]
+        print("         team step boundaries %d (through one L2: %d), clocks per boundary %.0f" % (nb, nl, cn["team_boundary_clocks"] / max(nb, 1)))
     ts = eng.team_sizes()
     cost = eng.run_cost().astype(np.float64) * 16 / n
     print("call %2d: %.2f us/step | teams %s | clocks/step per env (sum over members): max %.0f p90 %.0f median %.0f sum/max %.1f" % (

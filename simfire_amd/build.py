@@ -114,8 +114,11 @@ def build(force=False, verbose=False, variants=(), jobs=None):
             for o in objs:
                 if os.path.exists(o):
                     os.remove(o)
-        for f in os.listdir(CSRC):                              # hipcc's temporaries of an interrupted compile
-            if f.startswith(".lib") and f.endswith(".tmp"):
+        # hipcc's temporaries of an interrupted compile of THIS build's objects (another process may be building beside this one:
+        # parallel test workers, a variant build - its temporaries are not ours to delete)
+        mine = tuple(os.path.basename(o) for _, _, objs in plans for o in objs)
+        for f in os.listdir(CSRC):
+            if f.endswith(".tmp") and f.startswith(mine) and mine:
                 os.remove(os.path.join(CSRC, f))
     return OUT
 

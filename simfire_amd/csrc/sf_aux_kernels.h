@@ -155,13 +155,48 @@ __global__ void k_unpack_f64(int H, int W, int P, const double *pitched, double 
 #endif
 // (cells: the blocked cell plane when it is the current one - sf_common.h, bl_vec - else null)
 #ifndef SF_RUN_UNIT
-__global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cells, int env0, uint8_t *dense)
+// (snap: the reference point of sf_get_fire_map_delta - the map as the host last saw it -, or null: a whole map handed out IS the new reference point)
+__global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cells, int env0, uint8_t *dense, uint8_t *snap)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, i = blockIdx.z;
     if (x >= g.W) return;
     const uint8_t st = cells ? cells[(long long)(env0 + i) * g.cells_env + bl_cell(g, y, x) + kBlStatus]
                              : status[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x];
     dense[((long long)i * g.H + y) * g.W + x] = st & 7u;
+    if (snap) snap[(long long)(env0 + i) * g.plane_env + (long long)y * g.P + x] = st & 7u;
+}
+#endif
+
+// FireSimulation.run hands back the fire_map the manager has mutated IN PLACE (fire.py:140, 587, 719; simulation.py:546-553): a host that
+// keeps its own copy of the map needs only the cells an update changed.  One thread per 16-cell vector compares the status bytes with the
+// reference point (the map as the host last saw it: snap, u8 [H][P] of this environment), appends (y * W + x) << 3 | BurnStatus for every
+// cell that differs to out[1 ...] (out[0] = how many there are, also beyond cap) and brings the reference point up to date.
+// A dense sweep of 2 bytes per cell - 2 MB at 1024 x 1024, a microsecond of HBM time; what crosses PCIe is the list.
+#ifndef SF_RUN_UNIT
+__global__ __launch_bounds__(256) void k_map_delta(Geo g, const uint8_t *status, const uint8_t *cells, int e, uint8_t *snap, uint32_t *out, int cap)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (v >= g.PV) return;
+    const uint8_t *src = cells ? cells + (long long)e * g.cells_env + bl_vec(g, y, v) + (y & 1) * 16 + kBlStatus
+                               : status + (long long)e * g.plane_env + (long long)y * g.P + v * 16;
+    uint4 now = *reinterpret_cast<const uint4 *>(src);
+    now = and4(now, 0x07070707u);
+    uint4 *ref = reinterpret_cast<uint4 *>(snap + (long long)y * g.P + v * 16);
+    const uint4 was = *ref;
+    const uint4 d = make_uint4(now.x ^ was.x, now.y ^ was.y, now.z ^ was.z, now.w ^ was.w);
+    if (!any4(d)) return;
+    *ref = now;
+    uint32_t m16 = pack4(nz01(d.x)) | (pack4(nz01(d.y)) << 4) | (pack4(nz01(d.z)) << 8) | (pack4(nz01(d.w)) << 12);
+    const int x0 = v * 16;
+    if (x0 + 16 > g.W) m16 &= (1u << (g.W - x0)) - 1u;          // (pitch padding is no cell)
+    if (!m16) return;
+    uint32_t pos = atomicAdd(out, (uint32_t)__popc(m16));
+    while (m16) {
+        const int b = __ffs(m16) - 1;
+        m16 &= m16 - 1;
+        if (pos < (uint32_t)cap) out[1 + pos] = ((uint32_t)(y * g.W + x0 + b) << 3) | ((pick(now, b >> 2) >> (8 * (b & 3))) & 7u);
+        ++pos;
+    }
 }
 #endif
 

@@ -83,17 +83,16 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *sf_last_error(void) { return g_err.c_str(); }
-extern "C" const char *sf_version(void) { return "simfire_hip 0.1 (gfx950)"; }
+extern "C" const char *sf_version(void) { return "simfire_hip 0.2 (gfx950)"; }      // 0.2: the knob numbers and the 16 counter slots of simfire_hip_lab.h as they stand since round 5; sf_get_fire_map_delta
 
 #include "sf_common.h"
 #include "sf_step_kernels.h"
 #include "sf_aux_kernels.h"
 #include "sf_run_kernels.h"
 
-// Launch-geometry knobs of a handle (sf_set_tuning, include/simfire_hip.h: SF_TUNE_*).  Results never depend on them; the
-// defaults are the measured choices of DESIGN.md 5.  The environment is NOT consulted - except, for the measurement scripts
-// under profiles/, when SF_DEBUG_KNOBS=1 is set: then sf_create takes initial values from variables named like the enum
-// (SF_TUNE_RUN_WAVES=8 ...).
+// Launch-geometry knobs of a handle (sf_set_tuning, include/simfire_hip_lab.h: SF_TUNE_*).  Results never depend on them; the
+// defaults are the measured choices of DESIGN.md 5.  The library does not read the environment for them (the measurement scripts under
+// profiles/ set them through the Python binding, simfire_amd/engine.py: SF_DEBUG_KNOBS).
 struct Tuning {
     int v[SF_TUNE_COUNT];
     bool set[SF_TUNE_COUNT];
@@ -102,10 +101,6 @@ static const int kTuneDefault[SF_TUNE_COUNT] = {
     /* SF_TUNE_WAVES_PER_CU */ 24, /* RUN_WAVES */ 16, /* RUN_MIN_ENVS */ 1, /* RUN_VCAP */ 4096, /* RUN_COMPACT */ 1,
     /* RUN_BATCH */ 64, /* RUN_RESULT */ 1, /* RUN_SEGMENT */ 64, /* RUN_TEAM */ 0, /* TEAM_PLACEMENT */ 0, /* TEAM_RECUT */ 1, /* RUN_WINDOW */ 1, /* TEAM_TIMEOUT_MS */ 2000,
     /* RUN_JOIN */ 1, /* LOOP_LIGHT */ 0};
-static const char *const kTuneName[SF_TUNE_COUNT] = {
-    "SF_TUNE_WAVES_PER_CU", "SF_TUNE_RUN_WAVES", "SF_TUNE_RUN_MIN_ENVS", "SF_TUNE_RUN_VCAP", "SF_TUNE_RUN_COMPACT", "SF_TUNE_RUN_BATCH",
-    "SF_TUNE_RUN_RESULT", "SF_TUNE_RUN_SEGMENT", "SF_TUNE_RUN_TEAM", "SF_TUNE_TEAM_PLACEMENT", "SF_TUNE_TEAM_RECUT", "SF_TUNE_RUN_WINDOW", "SF_TUNE_TEAM_TIMEOUT_MS",
-    "SF_TUNE_RUN_JOIN", "SF_TUNE_LOOP_LIGHT"};
 
 // ----------------------------------------------------------------------------- handle
 struct sf_sim {
@@ -121,6 +116,7 @@ struct sf_sim {
     mutable std::map<unsigned long long, int> occ_cache;      // team kernels: workgroups per CU by hipOccupancyMaxActiveBlocksPerMultiprocessor (team_occupancy)
     double *rtc = nullptr;             // the R table(s) cell-major (k_rt_cellmajor): built when the resident launch first needs it, stale after every change of rt
     bool rtc_valid = false;
+    std::vector<char> rtc_stale;       // per table: its cell-major copy does not match rt (all of them until the copy exists)
     unsigned long long *win_hint = nullptr;      // k_run's window phase: where the fire stood and where the window was when the phase last ended, per environment; 0 = unknown.  ADVICE only (sf_win_kernels.h)
     double *lay_all = nullptr;         // [tables][7][H*W] dense: w0 delta Mx sigma elev U Udir (kept for the observation planes)
     double *layer(int table, int i) const { return lay_all + ((size_t)table * 7 + i) * (size_t)g.H * g.W; }
@@ -194,6 +190,12 @@ struct sf_sim {
     size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_join[2] = {};       // dynamic LDS sizes the k_run instantiations have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
+    // sf_get_fire_map_delta: the fire maps as the host last saw them (u8 [E][H][P], allocated at the first call), per environment whether that
+    // reference point exists, the list of changed cells on the device ([0] = count) and its pinned landing zone
+    uint8_t *snap = nullptr;
+    std::vector<char> snap_valid;
+    uint32_t *delta_dev = nullptr, *delta_pinned = nullptr;
+    int delta_cap = 0;
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -316,15 +318,7 @@ extern "C" int sf_create(const sf_params *p, sf_sim **out)
     g.LR = 64 / g.LC;
     g.chunks_x = (g.PV + g.LC - 1) / g.LC;
     g.dense = 0;
-    {
-        const char *dk = getenv("SF_DEBUG_KNOBS");
-        const bool from_env = dk && atoi(dk) != 0;
-        for (int i = 0; i < SF_TUNE_COUNT; ++i) {
-            s->tune.v[i] = kTuneDefault[i]; s->tune.set[i] = false;
-            const char *v = from_env ? getenv(kTuneName[i]) : nullptr;
-            if (v) { s->tune.v[i] = atoi(v); s->tune.set[i] = true; }
-        }
-    }
+    for (int i = 0; i < SF_TUNE_COUNT; ++i) { s->tune.v[i] = kTuneDefault[i]; s->tune.set[i] = false; }
     g.md = p->max_fire_duration; g.N = g.md + 3;
     g.ab = g.N <= 8 ? 1 : (g.N <= 16 ? 2 : 4);
     g.rt_env = p->per_env_terrain ? (long long)8 * g.H * P : 0;   // 1-byte plane: SWAR kernels; wider: generic per-cell kernel
@@ -415,6 +409,8 @@ extern "C" int sf_destroy(sf_sim *s)
     void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->win_hint, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
+    if (s->delta_pinned) (void)hipHostFree(s->delta_pinned);
+    for (void *dp : {(void *)s->snap, (void *)s->delta_dev}) if (dp) (void)hipFree(dp);
     for (int i = 0; i < sf_sim::kPtsRing; ++i) {
         if (s->pts_pinned[i]) (void)hipHostFree(s->pts_pinned[i]);
         if (s->ev_pts[i]) (void)hipEventDestroy(s->ev_pts[i]);
@@ -657,6 +653,8 @@ static int table_range(sf_sim *s, int env, const char *who, int *lo, int *hi)
 static void mark_tables(sf_sim *s, int lo, int hi)
 {
     for (int i = lo; i < hi; ++i) s->rt_set[i] = 1;
+    if (s->rtc_stale.size() != s->rt_set.size()) s->rtc_stale.assign(s->rt_set.size(), 1);
+    for (int i = lo; i < hi; ++i) s->rtc_stale[i] = 1;      // (only these tables' cell-major copies are rebuilt: ensure_rtc)
     s->rtc_valid = false;
     s->have_rt = true;
     for (char c : s->rt_set) if (!c) s->have_rt = false;
@@ -902,6 +900,10 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
     HIPCHK(hipMemsetAsync(s->burn + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(double), s->stream));
     if (s->parents) HIPCHK(hipMemsetAsync(s->parents + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
     if (s->settled) HIPCHK(hipMemsetAsync(s->settled + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env * sizeof(uint32_t), s->stream));
+    if (s->snap) {      // sf_get_fire_map_delta: a reset map is all UNBURNED but for the ignition cell, which the next delta reports
+        HIPCHK(hipMemsetAsync(s->snap + (size_t)env0 * g.plane_env, 0, (size_t)n * g.plane_env, s->stream));
+        for (int i = 0; i < n; ++i) s->snap_valid[env0 + i] = 1;
+    }
     int rc = ensure_stage(s, (size_t)n * 2 * sizeof(int32_t));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->stage, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
@@ -1025,6 +1027,7 @@ extern "C" int sf_load_fire_map(sf_sim *s, int32_t env, const uint8_t *map)
         if (map[i] > SF_WETLINE) return fail(SF_EINVAL, "sf_load_fire_map: value %d at cell %zu is not a BurnStatus", map[i], i);
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     s->fire_rows = 0;                  // (a map from outside: its fire may be of any size)
+    if (s->snap) s->snap_valid[env] = 0;      // (sf_get_fire_map_delta: no reference point any more)
     int rc = ensure_stage(s, n);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H);
@@ -1083,9 +1086,19 @@ static int ensure_rtc(sf_sim *s)
     if (s->rtc_valid) return SF_OK;
     const Geo &g = s->g;
     const size_t n_tab = s->rt_set.size(), tab = (size_t)8 * g.plane_env;
-    if (!s->rtc) { int rc = dev_alloc(s, &s->rtc, tab * n_tab); if (rc) return rc; }
+    if (!s->rtc) {
+        // (the copy doubles the handle's largest allocation with per-environment terrain; the window phase it serves is optional: a handle
+        // that cannot have it runs without - the caller switches the phase off for the call, results never depend on it)
+        if (hipMalloc(reinterpret_cast<void **>(&s->rtc), tab * n_tab * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); s->rtc = nullptr; return SF_ENOTSUP; }
+        s->bytes += (int64_t)(tab * n_tab * sizeof(double));
+        s->rtc_stale.assign(n_tab, 1);
+    }
+    if (s->rtc_stale.size() != n_tab) s->rtc_stale.assign(n_tab, 1);
     for (size_t i = 0; i < n_tab; ++i)
-        hipLaunchKernelGGL(k_rt_cellmajor, dim3((g.P + 255) / 256, g.H), dim3(256), 0, s->stream, g.H, g.P, (const double *)(s->rt + i * tab), s->rtc + i * tab);
+        if (s->rtc_stale[i]) {
+            hipLaunchKernelGGL(k_rt_cellmajor, dim3((g.P + 255) / 256, g.H), dim3(256), 0, s->stream, g.H, g.P, (const double *)(s->rt + i * tab), s->rtc + i * tab);
+            s->rtc_stale[i] = 0;
+        }
     HIPCHK(hipGetLastError());
     s->rtc_valid = true;
     return SF_OK;
@@ -1280,13 +1293,6 @@ static int launch_k_run_join(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     const int place = s->tune.v[SF_TUNE_TEAM_PLACEMENT];
     a.join_local = place == 1 ? 0 : (place == 2 ? 2 : 1);
     a.join_floor = eager ? 0 : 12000; a.join_ovh = eager ? 0 : (a.join_local == 1 ? 3000 : 12000);
-    {   // (measurement scripts only, like the knobs: SF_DEBUG_KNOBS=1 SF_JOIN_FLOOR=.. SF_JOIN_OVH=..)
-        const char *dk = getenv("SF_DEBUG_KNOBS");
-        if (dk && atoi(dk) != 0 && !eager) {
-            if (const char *v = getenv("SF_JOIN_FLOOR")) a.join_floor = atoi(v);
-            if (const char *v = getenv("SF_JOIN_OVH")) a.join_ovh = atoi(v);
-        }
-    }
     const int ia = g.att ? 1 : 0;
     const bool set_lds = t.lds > 64 * 1024 && t.lds > s->attr_join[ia];
     HIPCHK(sf_run2_launch_join(ia, (unsigned)t.slots, (unsigned)t.waves * 64, t.lds, set_lds, s->stream, &a, sizeof a, n_steps, t.vcap));
@@ -1468,13 +1474,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         if (rc0) return rc0;
         if (run_waves && a.win) {              // the window phase reads the cell-major copy of the R table
             rc0 = ensure_rtc(s);
-            if (rc0) return rc0;
-            a.rtc = s->rtc;
-            a.win_hint = s->win_hint;
-            {   // (measurement scripts: the window phase without its advice; looked up once per process)
-                static const bool no_hint = [] { const char *dk = getenv("SF_DEBUG_KNOBS"); return dk && dk[0] == '1' && getenv("SF_NO_WIN_HINT") != nullptr; }();
-                if (no_hint) a.win_hint = nullptr;
-            }
+            if (rc0 == SF_ENOTSUP) a.win = 0;          // (no memory for the cell-major table: this call goes without the window phase)
+            else if (rc0) return rc0;
+            else { a.rtc = s->rtc; a.win_hint = s->win_hint; }
         }
     } else if (!generic) {
         int rc0 = ensure_tiles(s);
@@ -1978,8 +1980,9 @@ static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H, n);
-    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env0, (uint8_t *)s->stage);
+    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env0, (uint8_t *)s->stage, s->snap);
     HIPCHK(hipGetLastError());
+    if (s->snap) for (int i = 0; i < n; ++i) s->snap_valid[env0 + i] = 1;      // (a whole map handed out is the new reference point of sf_get_fire_map_delta)
     HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return check_team_error(s, "sf_get_fire_map(s)");
@@ -2002,6 +2005,64 @@ extern "C" int sf_get_fire_maps(sf_sim *s, uint8_t *out)
         if (rc) return rc;
     }
     return SF_OK;
+}
+
+/* The cells of environment env whose BurnStatus differs from the map the host last saw - through this function, sf_get_fire_map(s) or sf_reset
+ * (whose map is all UNBURNED: the ignition cell is reported) -: cells_out[i] = (y * W + x) << 3 | BurnStatus, *n_out of them, in no particular
+ * order.  *n_out = -1: there is no reference point (first call for this environment, or sf_load_fire_map came in between) or more than cap
+ * cells changed - fetch the whole map with sf_get_fire_map; either way the current map is the reference point from now on.
+ * The host-side counterpart of the reference's in-place mutation of ONE fire_map array (fire.py:140, 587, 719; simulation.py:546-553). */
+extern "C" int sf_get_fire_map_delta(sf_sim *s, int32_t env, uint32_t *cells_out, int32_t cap, int32_t *n_out)
+{
+    if (!s || !n_out || cap < 0 || (cap > 0 && !cells_out)) return fail(SF_EINVAL, "sf_get_fire_map_delta: bad argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_fire_map_delta: environment %d out of range", env);
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    constexpr int kInline = 1024;      // entries that travel with the count (one copy, one wait)
+    if (!s->snap) {
+        int rc = dev_alloc(s, &s->snap, (size_t)g.E * g.plane_env);
+        if (rc) return rc;
+        s->snap_valid.assign((size_t)g.E, 0);
+    }
+    if (cap > s->delta_cap || !s->delta_dev) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (s->delta_dev) { HIPCHK(hipFree(s->delta_dev)); s->delta_dev = nullptr; }
+        if (s->delta_pinned) { HIPCHK(hipHostFree(s->delta_pinned)); s->delta_pinned = nullptr; }
+        const int c = cap > kInline ? cap : kInline;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->delta_dev), ((size_t)c + 1) * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->delta_pinned), ((size_t)c + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        s->delta_cap = c;
+    }
+    if (s->last_was_step1) { s->last_was_step1 = false; if (s->step1_polls < 1000) s->step1_polls++; }      // (a look at the result of a single update, like a status query)
+    uint8_t *snap_e = s->snap + (size_t)env * g.plane_env;
+    if (!s->snap_valid[env]) {
+        // no reference point: the current map becomes it, the caller fetches the whole map
+        dim3 blk(256), grd((g.W + 255) / 256, g.H, 1);
+        int rc = ensure_stage(s, (size_t)g.H * g.W);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env, (uint8_t *)s->stage, s->snap);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->snap_valid[env] = 1;
+        *n_out = -1;
+        return check_team_error(s, "sf_get_fire_map_delta");
+    }
+    HIPCHK(hipMemsetAsync(s->delta_dev, 0, sizeof(uint32_t), s->stream));
+    hipLaunchKernelGGL(k_map_delta, dim3((g.PV + 255) / 256, g.H), dim3(256), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env,
+                       snap_e, s->delta_dev, cap);
+    HIPCHK(hipGetLastError());
+    const int first = cap < kInline ? cap : kInline;
+    HIPCHK(hipMemcpyAsync(s->delta_pinned, s->delta_dev, ((size_t)first + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const uint32_t n = s->delta_pinned[0];
+    if (n > (uint32_t)cap) { *n_out = -1; return check_team_error(s, "sf_get_fire_map_delta"); }      // (the reference point is current: the caller fetches the whole map)
+    if (n > (uint32_t)first) {
+        HIPCHK(hipMemcpyAsync(s->delta_pinned + 1 + first, s->delta_dev + 1 + first, ((size_t)n - first) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    if (n) memcpy(cells_out, s->delta_pinned + 1, (size_t)n * sizeof(uint32_t));
+    *n_out = (int32_t)n;
+    return check_team_error(s, "sf_get_fire_map_delta");
 }
 
 extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)

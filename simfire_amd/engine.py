@@ -5,6 +5,7 @@ This is the only module that touches the HIP library; the reference-shaped class
 NumPy host arrays (copied during the call); nothing here depends on torch.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -38,6 +39,13 @@ class FireEngine:
             per_env_terrain=int(bool(per_env_terrain)))
         self._h = C.c_void_p()
         self._chk(self._L.sf_create(C.byref(self.params), C.byref(self._h)))
+        if os.environ.get("SF_DEBUG_KNOBS") == "1":
+            # measurement scripts under profiles/ only: initial knob values from variables named like the enumerators
+            # (SF_TUNE_RUN_WAVES=8 ...) - read HERE, in the laboratory binding; the library itself never looks at the environment
+            for name in _lib.TUNE:
+                v = os.environ.get("SF_TUNE_" + name.upper())
+                if v is not None:
+                    self.set_tuning(**{name: int(v)})
 
     def _chk(self, rc):
         _lib.check(rc, self._L)
@@ -172,6 +180,20 @@ class FireEngine:
         out = np.empty((self.n_envs, self.H, self.W), dtype=np.uint8)
         self._chk(self._L.sf_get_fire_maps(self._h, _ptr(out)))
         return out
+
+    def fire_map_delta(self, env=0, cap=4096):
+        """Cells of ``env``'s fire map that changed since the host last saw it (through this call, ``fire_map`` / ``fire_maps`` or ``reset``):
+        (flat indices int64 [n], BurnStatus values uint8 [n]), or ``None`` when there is no reference point or more than ``cap`` cells changed -
+        fetch the whole map then (``sf_get_fire_map_delta``)."""
+        buf = getattr(self, "_delta_buf", None)
+        if buf is None or buf.shape[0] < cap:
+            buf = self._delta_buf = np.empty(int(cap), dtype=np.uint32)
+        n = C.c_int32(0)
+        self._chk(self._L.sf_get_fire_map_delta(self._h, int(env), _ptr(buf), int(cap), C.byref(n)))
+        if n.value < 0:
+            return None
+        cells = buf[:n.value]
+        return (cells >> 3).astype(np.int64), (cells & 7).astype(np.uint8)
 
     def burn(self, env=0):
         out = np.empty((self.H, self.W), dtype=np.float64)
@@ -480,7 +502,7 @@ class FireEngine:
         self._chk(self._L.sf_get_counters(self._h, _ptr(out), int(bool(reset))))
         return dict(active_cell_updates=int(out[0]), ignitions=int(out[1]), frontier_items=int(out[2]),
                     active_waves=int(out[3]), frontier_walks=int(out[4]), vectors=int(out[5]),
-                    records=int(out[6]), sprite_events=int(out[7]),
+                    team_boundaries=int(out[6] & 0xFFFFFFFF), team_boundaries_one_l2=int(out[6] >> 32), team_boundary_clocks=int(out[7]),
                     window_updates=int(out[8]), window_waves_looking=int(out[9]))
 
     def update_status_device(self):

@@ -72,6 +72,13 @@ def fuel_planes(fuels):
                          FuelModelToFuel[int(c)].M_x, FuelModelToFuel[int(c)].sigma] for c in codes])
         p = tab[inv.reshape(-1)].reshape(fuels.shape + (4,))
         return p[..., 0].copy(), p[..., 1].copy(), p[..., 2].copy(), p[..., 3].copy()
-    flat = fuels.reshape(-1)
-    out = np.array([[f.w_0, f.delta, f.M_x, f.sigma] for f in flat], dtype=np.float64)
+    # an object array is an array of pointers: the (few) distinct objects are looked at once each, not every cell in a Python loop
+    # (0.6 s per 1024 x 1024 plane)
+    import ctypes
+    c = np.ascontiguousarray(fuels)
+    ptrs = np.frombuffer(ctypes.string_at(c.ctypes.data, c.nbytes), dtype=np.uintp)
+    _, first, inv = np.unique(ptrs, return_index=True, return_inverse=True)
+    flat = c.reshape(-1)
+    tab = np.array([[flat[i].w_0, flat[i].delta, flat[i].M_x, flat[i].sigma] for i in first], dtype=np.float64)
+    out = tab[inv.reshape(-1)]
     return tuple(out[:, i].reshape(fuels.shape).copy() for i in range(4))

@@ -9,6 +9,7 @@ is a device scatter, ``fire_map`` is copied out when ``run`` returns.
 ``BatchedFireSimulation`` adds a leading environment axis (many independent simulations that
 share terrain and wind) - the form the hardware wants.
 """
+import ctypes as C
 import warnings
 from datetime import datetime
 from pathlib import Path
@@ -75,6 +76,88 @@ _SHARED_FIELDS = (("area", "screen_size"), ("area", "pixel_scale"), ("fire", "ma
                   ("mitigation", "ros_attenuation"), ("environment", "moisture"))
 
 
+class _Flag:
+    """Shared by a ``_TrackedMap`` and all its views: somebody wrote through one of them."""
+    __slots__ = ("dirty",)
+
+    def __init__(self):
+        self.dirty = False
+
+
+class _TrackedMap(np.ndarray):
+    """``FireSimulation.fire_map`` as it is handed out: a plain int64 [H, W] array for every reader, which NOTES writes made through it
+    (and through views of it) so that ``run`` / ``update_mitigation`` can take a caller's in-place edits over without comparing 8 MB of
+    host memory per call (round 5 did: ~2 ms of NumPy around a 30 us device update at 1024 x 1024).  Caught: item / slice / mask
+    assignment, in-place operators and ufuncs with ``out=``, ``fill`` / ``put`` / ``sort`` / ``partition`` / ``setfield``, ``np.copyto`` /
+    ``np.putmask`` / ``np.place`` / ``np.put`` / ``np.put_along_axis`` / ``np.fill_diagonal``.  NOT caught: writes through a base-class view
+    (``np.asarray(m)``, ``m.view(np.ndarray)``), the buffer protocol or another library - after those, assign the array back
+    (``sim.fire_map = sim.fire_map``) or call ``sim.invalidate_fire_map()``."""
+    _MUTATORS = frozenset(("copyto", "putmask", "place", "put", "put_along_axis", "fill_diagonal"))
+
+    def __new__(cls, arr, flag):
+        obj = np.asarray(arr).view(cls)
+        obj._flag = flag
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._flag = getattr(obj, "_flag", None)
+
+    def _touch(self):
+        if self._flag is not None:
+            self._flag.dirty = True
+
+    def __setitem__(self, key, value):
+        self._touch()
+        np.ndarray.__setitem__(self, key, value)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        plain = tuple(x.view(np.ndarray) if isinstance(x, _TrackedMap) else x for x in inputs)
+        if out is not None:
+            for o in out:
+                if isinstance(o, _TrackedMap):
+                    o._touch()
+            kwargs["out"] = tuple(o.view(np.ndarray) if isinstance(o, _TrackedMap) else o for o in out)
+        res = getattr(ufunc, method)(*plain, **kwargs)
+        if out is not None and len(out) == 1 and isinstance(out[0], _TrackedMap):
+            return out[0]                                    # (`m += 1` must hand back the tracked array, not a base-class view)
+        return res
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func.__name__ in self._MUTATORS and args and isinstance(args[0], _TrackedMap):
+            args[0]._touch()
+        out = kwargs.get("out")
+        for o in (out if isinstance(out, tuple) else (out,)):
+            if isinstance(o, _TrackedMap):
+                o._touch()
+        return super().__array_function__(func, types, args, kwargs)
+
+    def fill(self, value):
+        self._touch()
+        return np.ndarray.fill(self, value)
+
+    def put(self, *a, **k):
+        self._touch()
+        return np.ndarray.put(self, *a, **k)
+
+    def sort(self, *a, **k):
+        self._touch()
+        return np.ndarray.sort(self, *a, **k)
+
+    def partition(self, *a, **k):
+        self._touch()
+        return np.ndarray.partition(self, *a, **k)
+
+    def setfield(self, *a, **k):
+        self._touch()
+        return np.ndarray.setfield(self, *a, **k)
+
+    def __reduce__(self):
+        return (np.asarray, (self.view(np.ndarray).copy(),))         # (pickles / deep copies as a plain array)
+
+    def __deepcopy__(self, memo):
+        return self.view(np.ndarray).copy()
+
+
 def _hash_bytes(buf) -> int:
     """64-bit content hash of a contiguous buffer: xxh3 where the wheel is importable (~10 GB/s), zlib.crc32 otherwise."""
     try:
@@ -95,7 +178,24 @@ def _fingerprint(a) -> int:
     if a.dtype != object:
         flat = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
         return _hash_bytes(flat) ^ hash((a.shape, str(a.dtype)))
-    return hash(tuple((f.w_0, f.delta, f.M_x, f.sigma) for f in a.reshape(-1)))
+    # An object array of ``Fuel`` (``cfg.terrain.fuel_layer.data`` of functional fuel layers): its memory is an array of POINTERS - which
+    # object sits where is hashed as bytes (8 MB at 1024 x 1024: ~1 ms), and WHAT the (few) distinct objects hold is read from the objects
+    # themselves, so an in-place edit of one ``Fuel`` shows as well as a swapped cell.  (Round 5 walked every element in Python: 0.6 s per
+    # reset at 1024 x 1024.)  Which objects are distinct is found once per pointer plane (np.unique, ~60 ms) and remembered.
+    c = np.ascontiguousarray(a)
+    ptrs = np.frombuffer(C.string_at(c.ctypes.data, c.nbytes), dtype=np.uintp)
+    key = (_hash_bytes(ptrs), c.shape)
+    objs = _FUEL_OBJECTS.get(key)
+    if objs is None:
+        _, first = np.unique(ptrs, return_index=True)
+        objs = [c.reshape(-1)[i] for i in first]             # (references: the pointers stay these objects' for as long as the entry lives)
+        if len(_FUEL_OBJECTS) > 64:
+            _FUEL_OBJECTS.clear()
+        _FUEL_OBJECTS[key] = objs
+    return hash((key, tuple((getattr(f, "w_0", None), getattr(f, "delta", None), getattr(f, "M_x", None), getattr(f, "sigma", None)) for f in objs)))
+
+
+_FUEL_OBJECTS: dict = {}
 
 
 class FireSimulation:
@@ -140,10 +240,12 @@ class FireSimulation:
         if cfg.simulation.draw_spread_graph:
             self._engine.enable_spread_graph(True)
         self._engine.reset([(x, y)])
-        self.fire_map = np.full(cfg.area.screen_size, int(BurnStatus.UNBURNED))      # int64, simulation.py:561-566
-        self.fire_map[y, x] = int(BurnStatus.BURNING)
-        self._device_map = self.fire_map.copy()
-        self.agent_positions = np.zeros_like(self.fire_map)
+        fresh = np.full(cfg.area.screen_size, int(BurnStatus.UNBURNED))               # int64, simulation.py:561-566
+        fresh[y, x] = int(BurnStatus.BURNING)
+        self._adopt_map(fresh)                                                        # (the device's map IS this one: nothing to upload)
+        self._steps_done = 0
+        self.agent_positions = np.zeros(cfg.area.screen_size, dtype=np.int64)
+        self._agent_flag.dirty = False            # (all zeros: every id's cells are known - none)
         self.agents.clear()
         self.elapsed_steps = 0
         self.elapsed_time = 0.0
@@ -170,19 +272,67 @@ class FireSimulation:
             slope_dir = property(lambda s: sim._engine.get_slopes()[1])
         return _View()
 
+    # -------------------------------------------------------------------------- fire_map
+    # The reference's ``fire_map`` is ONE int64 array that the manager mutates in place and ``run`` hands back (fire.py:140, 587, 719;
+    # simulation.py:546-553), and that callers may edit or replace (``load_mitigation`` does, simulation.py:425-447).  Here the state lives
+    # on the GPU and the host array is its mirror: ``run`` brings it up to date from the CELLS THAT CHANGED (``sf_get_fire_map_delta``: a
+    # few hundred bytes over PCIe instead of the whole map widened to int64 - ~2 ms of NumPy per call at 1024 x 1024 in round 5), in place,
+    # and what a caller writes into it is noticed by the array itself (``_TrackedMap``) instead of by a compare of the whole map per call.
+    @property
+    def fire_map(self) -> np.ndarray:
+        return self._fire_map
+
+    @fire_map.setter
+    def fire_map(self, value) -> None:
+        self._adopt_map(value)
+        self._map_flag.dirty = True               # (an array from outside: the device has to see it)
+
+    def _adopt_map(self, value) -> None:
+        arr = np.asarray(value)
+        if isinstance(arr, _TrackedMap):
+            arr = arr.view(np.ndarray)
+        if arr.dtype != np.int64 or not arr.flags.writeable:
+            arr = arr.astype(np.int64)            # (the reference's maps are int64, simulation.py:561-564; an int64 array is adopted as it is
+        self._map_flag = _Flag()                  #  and mutated in place from then on, like the reference mutates what load_mitigation stored)
+        self._fire_map = _TrackedMap(arr, self._map_flag)
+
+    def invalidate_fire_map(self) -> None:
+        """``fire_map`` was written behind its back (through a base-class view, the buffer protocol, another library): the next ``run`` /
+        ``update_mitigation`` uploads it whole."""
+        self._map_flag.dirty = True
+
+    #: ``True``: compare the whole map with the device's before every run / update_mitigation, as round 5 did (catches every kind of
+    #: write at ~1 ms per call at 1024 x 1024); default: trust the array's own bookkeeping (``_TrackedMap``)
+    strict_fire_map_sync = False
+
     # ------------------------------------------------------------------------------- run
     def _sync_to_device(self) -> None:
         """``fire_map`` is a public attribute that callers may edit or replace; take that over."""
-        if self.fire_map.shape != self._device_map.shape or not np.array_equal(self.fire_map, self._device_map):
-            self._engine.load_fire_map(0, self.fire_map)
-            self._device_map = np.array(self.fire_map, dtype=np.int64)
+        if self.strict_fire_map_sync and not self._map_flag.dirty:
+            self._map_flag.dirty = not np.array_equal(self._fire_map.view(np.ndarray), self._engine.fire_map(0))
+        if self._map_flag.dirty:
+            plain = self._fire_map.view(np.ndarray)
+            if plain.shape != tuple(self.config.area.screen_size):
+                raise ValueError(f"fire_map shape {plain.shape} != {tuple(self.config.area.screen_size)}")
+            self._engine.load_fire_map(0, plain)
+            self._map_flag.dirty = False
+
+    def _refresh_map(self) -> None:
+        """The host mirror after device updates: only the cells that changed cross PCIe (``sf_get_fire_map_delta``); the whole map when
+        there is no reference point or too much changed (a long ``run``)."""
+        plain = self._fire_map.view(np.ndarray)
+        delta = self._engine.fire_map_delta(0)
+        if delta is None:
+            plain[...] = self._engine.fire_map(0)
+        elif len(delta[0]):
+            plain.reshape(-1)[delta[0]] = delta[1]
 
     def run(self, time: Union[str, int]) -> Tuple[np.ndarray, bool]:
         """simulation.py:501-553: up to ``time`` updates while the fire is RUNNING."""
         total = _total_updates(time, self.config.simulation.update_rate)
         self._sync_to_device()
         if self.fire_status == GameStatus.RUNNING and total > 0:
-            before = int(self._engine.status()[0][0, 1])
+            before = self._steps_done
             if self.config.simulation.save_data:
                 from .savedata import validate
                 validate(self.config.simulation.data_type)      # (raises before the device is stepped)
@@ -190,11 +340,11 @@ class FireSimulation:
             else:
                 self._engine.step(total)
             st, el = self._engine.status()
-            self.elapsed_steps += int(st[0, 1]) - before
+            self._steps_done = int(st[0, 1])
+            self.elapsed_steps += self._steps_done - before
             self.elapsed_time = float(el[0])
             self.fire_status = GameStatus.RUNNING if st[0, 0] else GameStatus.QUIT
-            self.fire_map = self._engine.fire_map(0).astype(np.int64)
-            self._device_map = self.fire_map.copy()
+            self._refresh_map()
         self.active = self.fire_status == GameStatus.RUNNING
         return self.fire_map, self.active
 
@@ -250,11 +400,11 @@ class FireSimulation:
             # the reference writes fire_map[y, x] (mitigation.py:75-78): NumPy indexing, negative indices wrap
             pts = [(e, x % W, y % H, t) for (e, x, y, t) in pts]
             self._engine.apply_mitigation(pts)
+            plain = self._fire_map.view(np.ndarray)          # (the device has these writes: not a caller's edit)
             for kind in (BurnStatus.FIRELINE, BurnStatus.SCRATCHLINE, BurnStatus.WETLINE):
                 for (_, x, y, t) in pts:
                     if t == kind:
-                        self.fire_map[y, x] = int(kind)
-            self._device_map = self.fire_map.copy()
+                        plain[y, x] = int(kind)
 
     def load_mitigation(self, mitigation_map: np.ndarray) -> None:
         """simulation.py:425-447: the map replaces ``fire_map`` if all values are BurnStatus values."""
@@ -267,11 +417,30 @@ class FireSimulation:
             message = (f"Invalid values in {mitigation_map} - values need to be within {category_values}... Skipping")
         warnings.warn(message)
 
+    @property
+    def agent_positions(self) -> np.ndarray:
+        return self._agent_positions
+
+    @agent_positions.setter
+    def agent_positions(self, value) -> None:
+        self._agent_flag = _Flag()
+        self._agent_flag.dirty = True             # (an array from outside: nothing is known about where which id sits)
+        self._agent_positions = _TrackedMap(np.asarray(value), self._agent_flag)
+
     def update_agent_positions(self, points: Iterable[Tuple[int, int, int]]) -> None:
-        """simulation.py:480-499"""
+        """simulation.py:480-499: every cell that holds the agent's id is cleared, then its new cell is written.  The reference scans the
+        whole map per agent (``agent_positions[agent_positions == agent_id] = 0``: 8 MB per agent and call at 1024 x 1024); the cells that can
+        hold an id are the ones this method wrote it to, so while nobody else has written into ``agent_positions`` (the array notes that
+        itself, ``_TrackedMap``) only the agent's last cell is looked at."""
+        plain = self._agent_positions.view(np.ndarray)
         for column, row, agent_id in points:
-            self.agent_positions[self.agent_positions == agent_id] = 0
-            self.agent_positions[row][column] = agent_id
+            if self._agent_flag.dirty or agent_id == 0:
+                plain[plain == agent_id] = 0
+            else:
+                last = self.agents.get(agent_id)
+                if last is not None and plain[last[1]][last[0]] == agent_id:
+                    plain[last[1]][last[0]] = 0
+            plain[row][column] = agent_id
             self.agents[agent_id] = (column, row)
 
     # ----------------------------------------------------------------------- observation

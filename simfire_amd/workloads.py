@@ -43,6 +43,24 @@ class Workload:
     def layers(self):
         return (self.w_0, self.delta, self.M_x, self.sigma, self.elevation, self.U, self.U_dir)
 
+    def config(self, env=0):
+        """A ``Config`` that holds this workload's layers and scalars (``Config.from_arrays``; ignition of environment ``env``): what the
+        reference-shaped ``FireSimulation`` / ``BatchedFireSimulation`` are built from.  Needs the FBFM13 raster (``extra['codes']``)."""
+        from .config import Config
+        x, y = (int(v) for v in self.init_xy[env])
+        d = {"area": {"screen_size": [int(self.shape[0]), int(self.shape[1])], "pixel_scale": self.pixel_scale},
+             "display": {"fire_size": 2, "control_line_size": 2, "agent_size": 4},
+             "simulation": {"update_rate": self.update_rate, "runtime": "1000h" if self.max_time is None else f"{int(self.max_time)}m", "headless": True,
+                            "draw_spread_graph": False, "record": False, "save_data": False, "data_type": "npy", "sf_home": "~/.simfire"},
+             "mitigation": {"ros_attenuation": bool(self.attenuate_line_ros)},
+             "terrain": {"topography": {"type": "functional", "functional": {"function": "flat"}},
+                         "fuel": {"type": "functional", "functional": {"function": "chaparral", "chaparral": {"seed": 1113}}}},
+             "fire": {"fire_initial_position": {"type": "static", "static": {"position": f"({x}, {y})"}},
+                      "max_fire_duration": int(self.max_fire_duration), "diagonal_spread": bool(self.diagonal_spread)},
+             "environment": {"moisture": self.M_f},
+             "wind": {"function": "simple", "simple": {"speed": 0, "direction": 0}}}
+        return Config.from_arrays(d, self.extra["codes"], self.elevation, self.U, self.U_dir)
+
 
 def operational_terrain(H, W):
     """Section 8d C2: FBFM13 code raster in 16x16 patches, sinusoidal elevation (ft)."""
