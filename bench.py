@@ -46,7 +46,11 @@ def parse(argv=None):
     ap.add_argument("--also-envs", type=int, default=None, help="environments per GPU of the C4 / C5 companions (default: BASELINE's shares, 128 / 64)")
     ap.add_argument("--repeats", type=int, default=7,
                     help="reset + warm-up + timed K-step rollout repetitions; `value` / `ms_per_step` are the MEDIAN, the spread is config.repeat_spread")
-    ap.add_argument("--envs", type=int, default=None, help="environments per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (--scaling strong: in total)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): per-GPU work fixed - BASELINE's per-GPU shares on every rank; strong: the TOTAL batch fixed - BASELINE's "
+                         "whole batches (C3 256, C4 1024 x 2048^2, C5 512 environments) split over the ranks, so that the 1 / 2 / 4-GPU points hold "
+                         "more environments than CUs")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--rows-per-band", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle run (no cpu_baseline, no verification)")
@@ -379,7 +383,7 @@ def side_workload(name, a, device, torch, n_check, tile_cells, env_offset=0, wor
     agents per environment drawing control lines before every update), measured like the main line - wall time of the
     rollout + result block, kernel time, roofline block - and checked against the oracle on the first n_check environments."""
     from simfire_amd import workloads
-    n_envs = a.also_envs or {"c4": 128, "c5": 64}[name]
+    n_envs = a.also_share[name]
     w = make_workload(name, a.size, n_envs, env_offset * n_envs)
     H, W = w.shape
     agent_pts = None
@@ -516,7 +520,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    envs_local = a.envs or {"c2": 1, "c3": 256, "c4": 128, "c5": 64}[a.workload]
+    if a.scaling == "strong":
+        # the total batch is BASELINE's (configs 3 - 5: 256 / 1024 / 512 environments), split over the ranks in contiguous blocks of the env axis
+        total = a.envs or {"c2": 1, "c3": 256, "c4": 1024, "c5": 512}[a.workload]
+        if total % world:
+            raise SystemExit(f"bench.py --scaling strong: {total} environments do not split evenly over {world} ranks")
+        envs_local = total // world
+        if a.also_envs is None:
+            a.also_share = {"c4": 1024 // world if 1024 % world == 0 else 128, "c5": 512 // world if 512 % world == 0 else 64}
+        else:
+            if a.also_envs % world:
+                raise SystemExit(f"bench.py --scaling strong: --also-envs {a.also_envs} does not split evenly over {world} ranks")
+            a.also_share = {"c4": a.also_envs // world, "c5": a.also_envs // world}
+    else:
+        envs_local = a.envs or {"c2": 1, "c3": 256, "c4": 128, "c5": 64}[a.workload]
+        a.also_share = {"c4": a.also_envs or 128, "c5": a.also_envs or 64}
 
     if a.plumbing_only:
         # the N > 1 plumbing without a GPU: rendezvous, one all-gather of a result block, one JSON line
@@ -702,7 +720,7 @@ def main():
             slowest = max(r["ms_per_step"] for r in every)
             side[name if name == "c5" else "c4"] = {
                 "workload": every[0]["workload"], "grid": every[0]["grid"], "envs_per_gpu": every[0]["envs_per_gpu"], "envs_total": every[0]["envs_per_gpu"] * world,
-                "agents_per_env": every[0]["agents_per_env"], "n_gpus": world, "scaling": "weak",
+                "agents_per_env": every[0]["agents_per_env"], "n_gpus": world, "scaling": a.scaling,
                 "value": Hs * Ws * sum(r["env_steps_executed"] for r in every) / (slowest * 1e-3 * a.steps), "unit": "cell-updates/s",
                 "ms_per_step": slowest, "verified": (None if any(r["verified"] is None for r in every) else all(r["verified"] for r in every)),
                 "per_rank_ms_per_step": [r["ms_per_step"] for r in every], "per_rank_kernel_ms_per_step": [r["kernel_ms_per_step"] for r in every],
@@ -718,7 +736,7 @@ def main():
             "unit": "cell-updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt * 1e3 / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "u8 status + u8 sprite masks + f64 burn_amounts", "data": "synthetic",
             "verified": verified, "rehearsal": not a.no_rehearsal, "repeats": a.repeats,
             "verification": (None if verified is None else

@@ -773,6 +773,23 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(workload):
     assert abs(sum(rl["per_rank_gbs"]) - rl["aggregate_gbs"]) <= 1e-6 * rl["aggregate_gbs"]
 
 
+@pytest.mark.parametrize("workload", ["c3", "c5"])
+def test_bench_eight_ranks_strong_scaling_dry_run_on_one_gpu(workload):
+    """`--scaling strong`: the TOTAL batch is fixed and split over the ranks in contiguous blocks of the env axis (BASELINE configs 4 / 5 at
+    1 / 2 / 4 GPUs = more environments than CUs per GPU) - here 24 environments over 8 ranks of the HIP engine on the one GPU of the box; the
+    line says "strong", every rank holds total / N environments, the all-gathered block holds all of them."""
+    j = _bench("--gpus", 8, "--backend", "gloo", "--workload", workload, "--scaling", "strong", "--size", 128, "--envs", 24, "--steps", 14, "--warmup", 3,
+               "--no-extra", "--cpu-threads", 2)
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["envs_per_gpu"] == 3 and j["config"]["envs_total"] == 24
+    assert j["ranks_seen_by_collective"] == 8 and j["verified"] is True
+    # the same total on two ranks: twelve environments each
+    j2 = _bench("--gpus", 2, "--backend", "gloo", "--workload", workload, "--scaling", "strong", "--size", 128, "--envs", 24, "--steps", 14, "--warmup", 3,
+                "--no-extra", "--cpu-threads", 4)
+    assert j2["n_gpus"] == 2 and j2["config"]["envs_per_gpu"] == 12 and j2["config"]["envs_total"] == 24 and j2["verified"] is True
+    # the episodes are the same episodes however they are split (ignition seeds / agent walks follow the GLOBAL environment number)
+    assert j2["config"]["env_steps_executed"] == j["config"]["env_steps_executed"] and j2["config"]["burned_cells_total"] == j["config"]["burned_cells_total"]
+
+
 def test_closed_loop_that_leaves_half_of_every_cu_to_the_harness_own_kernels():
     """SF_TUNE_LOOP_LIGHT = 1: the closed loop's resident launch as 8-wave workgroups with a short vector list (two bitmap rows per thread:
     k_run<2, ..., -2>; 76 KB of LDS instead of 132) - half of every CU's wave slots and registers and more than half of its LDS belong to the

@@ -235,6 +235,15 @@ def test_bench_self_launch_plumbing():
     assert j["n_gpus"] == 2 and j["gathered_rows"] == 6 and j["ok"] is True
     one = subprocess.run([sys.executable, bench, "--plumbing-only", "--envs", "3"], capture_output=True, text=True, timeout=300)
     assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    # --scaling strong: --envs is the TOTAL, split over the ranks in contiguous blocks of the env axis
+    strong = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-only", "--scaling", "strong", "--envs", "6"], capture_output=True,
+                            text=True, timeout=300)
+    assert strong.returncode == 0, strong.stdout + strong.stderr
+    j = json.loads([l for l in strong.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["gathered_rows"] == 6 and j["ok"] is True
+    odd = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-only", "--scaling", "strong", "--envs", "5"], capture_output=True,
+                         text=True, timeout=300)
+    assert odd.returncode != 0 and "do not split evenly" in odd.stderr
 
 
 @pytest.mark.parametrize("data_type", ["npy", "jsonl", "json", "h5"])
