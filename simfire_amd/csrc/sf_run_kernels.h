@@ -1638,6 +1638,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 vb_glob[2ll * g.E * g.vb_env + i] = vl[i];
             }
     }
+    wpc.note(49);            // state committed, bitmaps handed back
     if (a.counters && lane == 0) {
         unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
         if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);

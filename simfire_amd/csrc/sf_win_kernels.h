@@ -233,6 +233,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             sl[2] = c_lo; sl[3] = c_hi;
         }
     }
+    lpc.note(41);            // own row looked at, slot written
     __syncthreads();
     unsigned long long cmask;
     {
@@ -323,6 +324,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // median environment of C5 173 k -> 150 k clocks, and the launch not a microsecond shorter - it ends with the environments whose agents draw
     // INSIDE the window, 192 k clocks either way.  Measured again with the control-line wave's work beside the walk (below): 78.9 -> 81.3 us.)
     const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15 && !mitw;
+    lpc.note(42);            // window placed
     // (Measured and dropped: loading only what the fire can reach in this phase - rows and vectors within s_reach of the sprites'; a 5-update
     // call needs a fifth of the window.  The short call got 0.4 us faster and the call after it 3.4 us slower: the whole window loaded by one
     // launch is what the next launch finds in its XCD's L2.)
@@ -342,6 +344,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (ADV) v_chk = *p_chk;
     if (ADV || l_row) v_row = *p_row;
     const uint32_t beside = chk ? v_chk : 0u;
+    lpc.note(43);            // loads issued
     {
         double2 *dst = reinterpret_cast<double2 *>(wb + (r * 16 + c) * 4);
         dst[0] = b01; dst[1] = b23;
@@ -415,6 +418,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     }
     if (ag0 & ring) ctl[kWinCtl + 4] = 1;
     if (beside) ctl[kWinCtl + 0] = 1;
+    lpc.note(44);            // cells arrived, LDS filled
     __syncthreads();
     if (ADV && __builtin_amdgcn_readfirstlane((int)ctl[kWinCtl + 0]) != 0) {             // (uniform) stale advice: a sprite beside the window.  Nothing has been touched.
         if (tid == 0) a.win_hint[e] = 0ull;
@@ -511,7 +515,8 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (MITW && pflag) pw = wpatch[(s & 1) * WR * 16 + r * 16 + c];
         // ---- phase A, the waves with a sprite bit in or next to their four rows: the bookkeeping of their own cells (BURNING, control lines,
         // prune, slot recycling), and - next to last step's ignitions or under a new control line - the cells that join the frontier list
-        if (__ballot((mid | up | dn | pw) != 0u) != 0ull) {    // (wave-uniform)
+        const bool act_now = __ballot((mid | up | dn | pw) != 0u) != 0ull;
+        if (act_now) {    // (wave-uniform)
             pc.note(21);     // rows arrived
             if (stats) n_vec_done += lane == 0 ? 16u : 0u;     // four rows x four vectors swept
             // the cells this window ignited in the step before: BURNING (fire.py:587; not in a window's first step: a bit of that age
@@ -544,7 +549,8 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 wpatch[(s & 1) * WR * 16 + r * 16 + c] = 0;
             }
             const uint32_t midL = mid & L4;
-            if (__ballot(midL != 0u) != 0ull && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[0] = 1;      // FLAG_LIVE (fire.py:637)
+            // (every lane the same byte: one LDS write, the address selected - a branch around a store of lane 0 cost 2 % of the step)
+            *((__ballot(midL != 0u) != 0ull) ? reinterpret_cast<uint8_t *>(ctl + 3 + k) : reinterpret_cast<uint8_t *>(wslot)) = 1;      // FLAG_LIVE (fire.py:637)
             // S1 prune: cells whose sprite reached max_fire_duration become BURNED
             {
                 const uint32_t s7 = sv & 0x07070707u;
@@ -773,6 +779,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         WPROF(6)             // barrier at the end of the step
         pc.note(27);         // through the barrier
         // ---- fold (every thread the same arithmetic on the same values); the next step's rows, masks, list bits and marks are requested with the predicates
+        // All sixteen waves leave the barrier at once and ask the LDS for their next rows, masks and flags - 24 LDS cycles a wave, 384 in a row,
+        // and the waves that hold the fire wait their turn among the ones that hold nothing (measured: the rows arrive 300 ... 740 clocks behind the
+        // barrier, by the order in which the waves were served).  A wave that had no sprite bit in or next to its rows has nothing to do before the
+        // next barrier but to find that out again: it lets the others ask first.
+        if (!act_now) __builtin_amdgcn_s_sleep(4);
         const uint32_t fv = ctl[3 + k], mk = ctl[6 + k];
         up = wm[own - 18]; mid = wm[own]; dn = wm[own + 18];
         onlist = (wflag[flag_w] >> flag_sh) & 0xFu;
@@ -836,6 +847,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         *reinterpret_cast<double2 *>(ev.burn + idx) = src[0];
         *reinterpret_cast<double2 *>(ev.burn + idx + 2) = src[1];
     }
+    lpc.note(45);            // cells / burn stored
     {
         // (derived anew from the one value the loop has kept: three scalar registers fewer across it)
         int wx0_ = wx0;
@@ -880,6 +892,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     }
     // (with the result block by difference what follows reads LDS only; the general loop, if it takes over, and counts_env read the cells
     // just stored: then the full barrier)
+    lpc.note(46);            // bitmap rows stored
     if (by_delta && (s >= n_steps || !st.running)) win_barrier<0>();
     else __syncthreads();
     lpc.note(34);            // window written back
@@ -893,6 +906,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             const int tl = i >> 3, q = i & 7, d = dt[i];
             if (d) ev.thist[((ty0 + tl / ntx) * g.TX + tx0 + tl % ntx) * 8 + q] += (uint16_t)d;       // (mod 2^16: a negative change wraps to the right count)
         }
+        lpc.note(47);        // tile histograms brought up to date
         if (tid < 8) {
             // lanes 3 .. 7 of wave 0: the cells per BurnStatus 1 .. 5 = the old row + what every tile of the window gained or lost (a lane per
             // status: the sums of up to fifteen LDS words side by side, not one after the other); lane 2: UNBURNED = H * W - the others
@@ -912,6 +926,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             if (tid == 0) a.res_elapsed[e] = st.elapsed;
         }
         result_done = true;
+        lpc.note(48);        // result row written
     }
     return s;
 }
