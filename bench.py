@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells"}
+LAUNCH_KINDS = {0: "k_select + k_step", 1: "k_step_fused", 2: "k_run", 3: "k_step_cells", 4: "k_win + k_run"}
 
 
 def parse(argv=None):
@@ -217,9 +217,9 @@ def measure(eng, w, a, agent_pts, dense):
     st0, _ = eng.status()
     kernel_ms = timed_steps(eng, a.steps, a.warmup, agent_pts)
     kind = eng.last_launch_kind()
-    measure.last_cost = eng.run_cost() if kind == 2 else None      # clocks / 16 per environment in that launch (k_run)
-    measure.last_teams = eng.team_sizes() if kind == 2 else None   # workgroups per environment (zeros: one each, one launch for the whole rollout)
-    measure.last_launches = eng.last_launches() if kind == 2 else 0
+    measure.last_cost = eng.run_cost() if kind in (2, 4) else None      # clocks / 16 per environment in that launch (k_run)
+    measure.last_teams = eng.team_sizes() if kind in (2, 4) else None   # workgroups per environment (zeros: one each, one launch for the whole rollout)
+    measure.last_launches = eng.last_launches() if kind in (2, 4) else 0
     st1, _ = eng.status()
     env_steps = int((st1[:, 1] - st0[:, 1]).sum())
     eng.reset(w.init_xy)
@@ -254,7 +254,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
                                                          "(burn R + W, one table entry)")
     sec = kernel_ms * 1e-3
     achieved = alg_bytes / sec / 1e9
-    resident = kind == 2
+    resident = kind in (2, 4)      # (4: the window kernel k_win in front of k_run - more environments than CUs, young fires; the two launches make the rollout)
     launches = 1 if resident else a.steps * (2 if kind == 0 else 1)
     traffic, replayed = None, {}
     if pmc and pmc.get("steps") == a.steps and pmc.get("warmup") == a.warmup and pmc.get("kernel") == LAUNCH_KINDS.get(kind):

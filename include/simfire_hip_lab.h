@@ -53,8 +53,9 @@ enum sf_tuning_knob {
     SF_TUNE_RUN_WAVES = 1,      /* waves per workgroup of the resident launch k_run, 1..16 (default 16; 8 when there are more environments than CUs) */
     SF_TUNE_RUN_MIN_ENVS = 2,   /* automatic mode picks k_run from this many environments (default 1) */
     SF_TUNE_RUN_VCAP = 3,       /* entries of k_run's vector list in LDS (default 4096; longer lists are taken in chunks) */
-    SF_TUNE_RUN_COMPACT = 4,    /* 1 = 8-wave workgroups, two per CU, when there are more environments than CUs (default 1) - except in a call that ends with every fire
-                                 * surely inside a window of 64 rows (the library's bound on the fires' rows since the last reset): 16-wave workgroups hold that window */
+    SF_TUNE_RUN_COMPACT = 4,    /* more environments than CUs: 1 (default) = two workgroups to a CU - while the fires may still fit their windows (the library's bound on the
+                                 * fires' rows since the last reset) the window phase as a kernel of its own, k_win, in front of k_run (which then makes what is left), and
+                                 * k_run in 8-wave workgroups; 0 = neither; 2 = k_win in front whatever the number of environments (tests) */
     SF_TUNE_RUN_BATCH = 5,      /* vectors per batch of k_run, 8..64 (default 64) */
     SF_TUNE_RUN_RESULT = 6,     /* 1 = k_run writes the result block itself when its steps are done (default 1) */
     SF_TUNE_RUN_SEGMENT = 7,    /* steps per k_run launch when there are more environments than workgroup slots (default 64; 0 = one launch) */
@@ -112,8 +113,9 @@ int sf_get_last_launches(sf_sim *sim, int32_t *n_out);
 int sf_get_team_fallbacks(sf_sim *sim, int32_t *n_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
- * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, -1 = none yet.  (4 - 6 were the retired
- * structures' numbers.) */
+ * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = the window kernel k_win in front of k_run (more
+ * environments than CUs while their fires are young: two workgroups to a CU), -1 = none yet.  (4 - 6 once were the numbers of
+ * structures retired in round 5.) */
 int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */
 int sf_set_dense(sf_sim *sim, int32_t dense);

@@ -109,7 +109,11 @@ struct StepArgs {
     int mit_k;
     int win;             // k_run only: 0 = no window phase (sf_win_kernels.h), 1 = young fires are stepped inside a window of cells held in registers,
                          // k > 1 = the same, but the window is left after k updates (tests)
-    const int32_t *todo; // k_run only: steps to do per environment (what k_front left over), or null = n_steps for all
+    const int32_t *todo; // k_run only: steps to do per environment (what the launch in front left over), or null = n_steps for all
+    int todo_skip;       // k_run only, with todo: 1 = a workgroup whose environment has nothing left returns at once (k_win in front has written that environment's state and result row)
+    uint32_t *todo_cnt;  // k_win / the k_run launch behind it: how many environments have updates left, and which (k_win appends; workgroup i of the launch
+    uint32_t *todo_list; // behind takes environment todo_list[i], workgroups beyond the count return before they look at anything else); null = not
+    uint32_t *todo_cnt_next;   // k_win: the count the next k_win launch will append to (cleared by this one)
     // k_run only: the per-environment result block written by the launch itself when its steps are done (null = not)
     int32_t *res_block;  // [E][8] running, update() calls made, cells per BurnStatus 0..5 (sf_get_status)
     double *res_elapsed; // [E]

@@ -453,6 +453,13 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         const uint32_t tt = a.team_tab[blockIdx.x];
         if (tt == kTeamUnused) { if (TEAM != 2) return; no_work = true; }      // (TEAM = 2: a slot without an environment looks for a team to join)
         else { e_ = (int)(tt & 0xFFFFu); tm_ = (int)((tt >> 16) & 0xFFu); tn_ = (int)(tt >> 24); }
+    } else if (a.todo_cnt) {
+        // behind k_win: only the environments whose fires outgrew their windows have anything left - most workgroups leave here, after one
+        // scalar load of a word every workgroup of the launch reads (an empty workgroup that first read its environment's state cost the launch
+        // a memory round trip per round of workgroups: 26 us for 1024 environments)
+        const uint32_t n_left = *a.todo_cnt;
+        if (blockIdx.x >= n_left) return;
+        e_ = (int)a.todo_list[blockIdx.x];
     } else e_ = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
     int j_s0 = -1;            // TEAM = 2: >= 0 - this workgroup JOINS environment e_ as member tm_ of a team of tn_ in front of update j_s0
     // TEAM = 2: a workgroup serves one environment after the other (find_team below); everything else: one pass
@@ -513,8 +520,11 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     EnvState st = a.commit[e];
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_w), "+v"(pre_dirty), "+v"(hint_v), "+v"(todo_v) :: "memory");      // (asked for before the state, which has arrived: no wait left)
     const unsigned long long hint_pre = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hint_v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hint_v >> 32)) << 32);
-    if (a.todo) n_steps = __builtin_amdgcn_readfirstlane(todo_v);            // the steps k_front left over for this environment (usually none)
+    if (a.todo) n_steps = __builtin_amdgcn_readfirstlane(todo_v);            // the steps the launch in front (k_win; a team launch with windows of rows) left over for this environment (usually none)
     if ((!st.running && !mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
+    // (behind k_win: the environments that made all their updates inside their windows - most of them - have their state, their bitmap rows and
+    // their row of the result block in memory already)
+    if (!TEAM && a.todo && a.todo_skip && n_steps == 0) return;
     unsigned long long *vb_glob = a.vbits + (long long)e * g.vb_env;
     const int n_words = g.H * VW;
     if (tid < kRunCtl) ctl[tid] = 0;
@@ -1682,6 +1692,93 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     if (TEAM != 2) return;
     }
 }
+
+// k_win: the window phase as a kernel of its own, for batches of MORE ENVIRONMENTS THAN CUs while their fires are young.
+// A window step is a chain of dependent instructions (VALU issue 0.3, two thirds of the wave-cycles waiting: DESIGN.md 5.9), so two
+// environments on one CU should step almost as fast as one - but k_run's workgroup takes 132 KB of LDS and 106 - 125 VGPRs (the general loop's
+// bitmaps, list and strips; its registers), one to a CU.  The window code alone needs 63 VGPRs and 69 KB: TWO 16-wave workgroups to a CU, eight
+// waves to a SIMD.  Every environment makes as many of the call's updates as its fire stays inside a window and notes what is left
+// (todo_out[e]); the host's next launch - k_run with `todo` - makes those (workgroups with nothing left return at once), and is left out
+// where the host can PROVE that nothing is left (a fire spans one cell after sf_reset and grows a cell per side and update at most).
+// Same update as everywhere: RothermelFireManager.update, fire.py:616-719; independent environments: simulation.py:202-214.
+// (Round 4 measured this kernel in front of k_run for 256 environments - one per CU, nothing to overlap: the second launch cost more than the
+// smaller kernel saved.  It is the launch structure only where a CU has several environments to work on.)
+#ifndef SF_RUN_UNIT
+template <int ATT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_win(StepArgs a, const int n_steps_launch)
+{
+    kernarg_touch<(int)sizeof(StepArgs) + 4>();
+    extern __shared__ uint4 s_dyn[];
+    const Geo &g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int e = (int)blockIdx.x;
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+    uint32_t *const wl = reinterpret_cast<uint32_t *>(s_dyn);                       // the window's planes (win_lds_bytes)
+    uint32_t *const ctl = wl + (win_lds_bytes(n_waves) + 15) / 16 * 4;              // control words, like k_run's
+    // (this thread's row of the vector bitmap and its tile's dirty flag travel with the state: one round trip at the head of the launch)
+    unsigned long long pre_w = 0ull;
+    uint32_t pre_dirty = 0u;
+    {
+        const unsigned long long *pw_ = a.vbits + (long long)e * g.vb_env + (tid < g.H ? tid : 0);
+        const uint8_t *pd_ = a.tdirty + (long long)e * g.TY * g.TX + (tid < g.TY * g.TX ? tid : 0);
+        pre_w = *pw_;
+        pre_dirty = *pd_;
+        if (tid >= g.H) pre_w = 0ull;
+        if (tid >= g.TY * g.TX) pre_dirty = 0u;
+    }
+    EnvState st = a.commit[e];
+    int n_steps = n_steps_launch;
+    if (!st.running || n_steps < 0) n_steps = 0;              // frozen: run() no longer calls update (uniform over the workgroup)
+    if (tid < kRunCtl) ctl[tid] = 0;
+    const int th_log = 31 - __builtin_clz((unsigned)(g.LR * g.RB));
+    uint32_t n_active = 0, n_ignite = 0, n_vec_done = 0;
+    bool win_result = false;
+    PhaseClock wpc;
+    WinEnv we;
+    we.cells = a.cells + (long long)e * g.cells_env;
+    we.burn = a.burn + (long long)e * g.plane_env;
+    we.settled = a.settled ? a.settled + (long long)e * g.plane_env : nullptr;
+    we.rtc = a.rtc ? a.rtc + (long long)e * g.rt_env : nullptr;
+    we.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+    we.thist = a.thist + (long long)e * g.TY * g.TX * 8;
+    we.vb_glob = a.vbits + (long long)e * g.vb_env;
+    we.vb_plane = (long long)g.E * g.vb_env;
+    we.pre_w = pre_w; we.pre_dirty = pre_dirty; we.pre = true; we.hint = 0ull;
+    __syncthreads();
+    wpc.start();
+    // (A second window around a fire that reaches its ring while it still fits one - a loop around this call - was built and measured: the loop
+    // costs the kernel its registers, 116 bytes of scratch and 194 spilled SGPRs under the 64 / 96 of eight waves to a SIMD, 62 -> 85 us on five
+    // updates of 1024 environments.  Such a fire's remaining updates are the launch behind's, which places its own window anew.)
+    const int s_done = run_window<ATT, 0, 0, 1>(a, we, st, n_steps, g.diag != 0, wl, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result);
+    // what is left for the host's next launch: nothing once the call's updates are made or the fire is out (fire.py:637-643)
+    const bool finished = s_done >= n_steps || !st.running;
+    if (tid == 0) {
+        if (s_done > 0) a.commit[e] = st;
+        a.todo_out[e] = finished ? 0 : n_steps - s_done;
+        if (!finished && a.todo_cnt) a.todo_list[atomicAdd(a.todo_cnt, 1u)] = (uint32_t)e;
+        // (two counts that take turns: this launch clears the one the NEXT k_win appends to - the launch that read it last is over, stream order -;
+        // a fill launch in front of every k_win cost the stream 4 us, workgroups of the launch behind counting themselves out 8)
+        if (blockIdx.x == 0 && a.todo_cnt_next) *a.todo_cnt_next = 0u;
+        if (a.cost) {
+            const unsigned long long c = (__builtin_readcyclecounter() - clk0) >> 4;
+            a.cost[e] = c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c;
+        }
+        if (a.counters && s_done) atomicAdd(a.counters + (size_t)((blockIdx.x * 16) & (kCounterShards - 1)) * kCounterRow + 8, (unsigned long long)s_done);
+    }
+    if (a.counters && lane == 0) {
+        unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
+        if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+        if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+        if (n_vec_done) atomicAdd(&cs[5], (unsigned long long)n_vec_done);
+    }
+    // the environment's row of the result block, unless the window phase has brought it up to date itself or k_run comes behind for this environment
+    if (a.res_block && finished && !win_result) {
+        __syncthreads();
+        counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
+                   reinterpret_cast<int32_t (*)[6]>(wl));
+    }
+}
+#endif
 
 // Launch order of the environments for the resident launch when there are more of them than the chip holds workgroups: the
 // most expensive first (cost = clocks of the environment's workgroup in the launch before; 1024 linear buckets, counting sort),

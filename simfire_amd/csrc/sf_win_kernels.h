@@ -148,7 +148,12 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
 // the last wave alone, off everybody else's path: cells outside the window hold no sprite and are read by nobody in this phase.
 // (Measured and dropped, round 5: a second copy of this code for workgroups of sixteen waves with the planes' places in LDS, the lists' capacity
 // and every stride known at compile time - the same launch time, a third more compile time.)
-template <int ATT, int GEN, int MITW>
+// PL4 = 1 (k_win): without advice the window goes around the middle of the fire's VECTOR SPAN to four cells (a lane's dword) instead of to
+// the vector: a fire known to the 16-cell vector only sits anywhere in its vectors, and a window placed to the vector gives a fire of one
+// vector 16 cells of room on one side and 32 on the other - it reaches the ring after 16 updates although 24 fit either side.  The window
+// then covers the whole span (it is 64 cells, the span at most 48 when it is not placed to the vector anyway), so no sprite can lie beside it:
+// nothing to check, unlike a window placed by advice.
+template <int ATT, int GEN, int MITW, int PL4 = 0>
 __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, EnvState &st, const int n_steps, const bool diag, uint32_t *wl,
                                           uint32_t *ctl, const int th_log, uint32_t &n_active, uint32_t &n_ignite, uint32_t &n_vec_done, PhaseClock &lpc, const int e, bool &result_done,
                                           const int32_t *mit = nullptr, const int n_total = 0, int32_t *ppx = nullptr, int32_t *ppy = nullptr, int32_t *ppty = nullptr, uint32_t *duptab = nullptr, const int dup_log2 = 11)
@@ -304,8 +309,18 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         int wv0 = vmin - ((4 - wv) >> 1);
         wv0 = wv0 < 0 ? 0 : (wv0 > g.PV - 4 ? g.PV - 4 : wv0);
         wx0 = wv0 << 4;
+        if (PL4) {
+            // (only where the window placed to the vector - whole sectors and lines on the way in and out - may not hold the fire for this call:
+            // the fire can be anywhere in its vectors' span)
+            const int lv = wx0 > 0 ? (vmin << 4) - wx0 : 1 << 20, rv = wx0 + kWinCols < g.W ? wx0 + kWinCols - 1 - ((vmax << 4) + 15) : 1 << 20;
+            if (lv < s_reach || rv < s_reach) {
+                int c4 = (vmin << 4) + 8 * wv - 32;               // the span's middle in the window's middle (a multiple of 8)
+                const int x_last = (g.PV - 4) << 4;
+                wx0 = c4 < 0 ? 0 : (c4 > x_last ? x_last : c4);
+            }
+        }
     }
-    const int wvA_in = wx0 >> 4, woff_in = ADV ? (wx0 >> 2) & 3 : 0;     // first vector the window touches; dwords of it that lie in front of the window
+    const int wvA_in = wx0 >> 4, woff_in = (ADV || PL4) ? (wx0 >> 2) & 3 : 0;     // first vector the window touches; dwords of it that lie in front of the window
     const int wnv_in = woff_in ? 5 : 4;                        // vectors it touches
     // the ring: outermost cells of the window on the sides that are not the grid's edge.  A sprite there could ignite a cell outside.
     const bool open_top = wy0 > 0, open_bot = wy0 + WR < g.H, open_left = wx0 > 0, open_right = wx0 + kWinCols < g.W;
@@ -852,7 +867,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         // (derived anew from the one value the loop has kept: three scalar registers fewer across it)
         int wx0_ = wx0;
         asm volatile("" : "+s"(wx0_));
-        const int wvA = wx0_ >> 4, woff = ADV ? (wx0_ >> 2) & 3 : 0, wnv = woff ? 5 : 4;
+        const int wvA = wx0_ >> 4, woff = (ADV || PL4) ? (wx0_ >> 2) & 3 : 0, wnv = woff ? 5 : 4;
         // bit v of a row: the 16-cell vector holds a sprite bit / holds one in its first cell / in its last cell.  A vector = four lanes.
         // Stored without a look at what is there: while this phase runs EVERY sprite of the environment is inside the window (that is what it
         // was entered on, and the ring rule keeps it so), so outside the vectors the window touches a row's words are zero in all three planes

@@ -52,6 +52,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -186,8 +187,10 @@ struct sf_sim {
     int loop_restarts = 0;             // times the launch had left by itself (timeout) and was started again
     int last_team_max = 0;             // upper bound of the team sizes in the last resident launch (0: it was not a team launch)
     int cost_steps = 0;                // steps the per-environment cost array covers (0: nothing recorded since the last reset)
+    uint32_t *todo_cnt = nullptr;      // k_win: how many environments it left updates for (their numbers: run_order); two counts, by the parity of win_seq
+    unsigned win_seq = 0;              // k_win launches so far
     uint32_t *run_cost = nullptr, *run_order = nullptr;   // k_run: clocks / 16 an environment's workgroup took in the last resident launch [E]; launch order built from it (k_order)
-    size_t attr_run[24] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_join[2] = {};       // dynamic LDS sizes the k_run instantiations have been enabled for (hipFuncSetAttribute is not free)
+    size_t attr_run[32] = {}, attr_team[8] = {}, attr_team_c4[2] = {}, attr_join[2] = {};       // dynamic LDS sizes the k_run instantiations have been enabled for (hipFuncSetAttribute is not free)
     uint8_t *parents = nullptr;        // spread-graph parent masks, allocated by sf_enable_spread_graph
     bool graph_on = false;
     // sf_get_fire_map_delta: the fire maps as the host last saw them (u8 [E][H][P], allocated at the first call), per environment whether that
@@ -406,7 +409,7 @@ extern "C" int sf_destroy(sf_sim *s)
     if (s->xerr_pinned) (void)hipHostFree(s->xerr_pinned);
     for (void *hp : {(void *)s->loop_db, (void *)s->loop_res, (void *)s->loop_pts}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)s->loop_mem, (void *)s->loop_pts_mem}) if (dp) (void)hipFree(dp);
-    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->win_hint, s->mit_stage,
+    void *ptrs[] = {s->team_tab, s->team_size, s->xdone, s->xg, s->xbuf, s->xj, s->xcut, s->jlog, s->status, s->age_alloc, s->cells_alloc, s->burn, s->rt, s->rtc, s->lay_all, s->history, s->smag, s->sdir, s->commit, s->tmp, s->flags, s->counters, s->tflags, s->tile_list, s->n_active, s->seam, s->settled, s->tdirty, s->thist, s->vbits, s->todo, s->run_cost, s->run_order, s->todo_cnt, s->win_hint, s->mit_stage,
                     s->status_block, s->elapsed_dev, s->stage, s->parents};
     if (s->status_pinned) (void)hipHostFree(s->status_pinned);
     if (s->delta_pinned) (void)hipHostFree(s->delta_pinned);
@@ -1282,7 +1285,7 @@ static int launch_k_run_join(sf_sim *s, StepArgs &a, int n_steps, const TeamGeo 
     a.team_tab = s->team_tab; a.xg = s->xg; a.xbuf = s->xbuf; a.xdone = s->xdone; a.xerr = s->xerr_mapped;
     a.xrow = team_xrow(g); a.team_rcap = 0;
     a.team_far = s->tune.v[SF_TUNE_TEAM_PLACEMENT] == 2;
-    a.order = nullptr; a.todo = nullptr; a.todo_out = nullptr;
+    a.order = nullptr; a.todo = nullptr; a.todo_out = nullptr; a.todo_skip = 0; a.todo_cnt = nullptr; a.todo_list = nullptr; a.todo_cnt_next = nullptr;
     a.team_recut = recut;
     a.xj = s->xj; a.xcut = s->xcut; a.tsize = s->team_size; a.jlog = s->jlog;
     // (k_team_plan's model of a team: the chain no member's update gets shorter than, what belonging to a team costs per update; eager - tests -:
@@ -1409,6 +1412,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     size_t run_lds = 0;
     TeamGeo tgeo = {}, jgeo = {};
     bool team_forced = false, team_wide = false, team_auto = false;
+    bool win_first = false;            // k_win in front of k_run (more environments than CUs, young fires)
     if (!generic && !a.parents && !s->history && s->fused_mode != 0 && s->fused_mode != 1) {
         const int waves_knob = tn.v[SF_TUNE_RUN_WAVES], envs_knob = tn.v[SF_TUNE_RUN_MIN_ENVS], vcap_knob = tn.v[SF_TUNE_RUN_VCAP];
         const Geo &g = s->g;
@@ -1427,6 +1431,17 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // Not while every fire is surely young (the bound on the fires' rows since the last reset says this call ends with every fire inside a
         // window of 64 rows): an 8-wave workgroup holds a window of 32 rows only, a fire 33 rows tall leaves it for the general loop -
         // measured on 1024 environments in the driver's window: 11.3 us per update in 8-wave workgroups, 9.6 in 16-wave ones.
+        // ... and while the fires may still fit their windows (the bound on the fires' rows since the last reset) the window phase runs as a
+        // kernel of its own in front, k_win: 63 VGPRs and 69 KB of LDS - two 16-wave workgroups to a CU, whose dependent chains fill each other's
+        // gaps (sf_run_kernels.h).  The k_run launch behind it makes what is left - the updates of fires that outgrew their windows - in the
+        // 8-wave workgroups of this regime.  (Round 5 kept 16-wave k_run workgroups in rounds of 256 while every fire was surely young: 9.8 us per
+        // update on 1024 environments in the driver's window.)  SF_TUNE_RUN_COMPACT = 2: the window kernel in front whatever the batch size (tests).
+        win_first = tn.v[SF_TUNE_RUN_WINDOW] != 0 && tn.v[SF_TUNE_RUN_COMPACT] != 0 && (g.E > s->n_cu || tn.v[SF_TUNE_RUN_COMPACT] == 2) && !mit_dev && g.VW == 1 &&
+                    g.H >= 64 && g.H <= 1024 && g.PV >= 4 && !g.dense && s->fire_rows > 0 && s->fire_rows <= 62 && n_steps <= 64 && !tn.set[SF_TUNE_RUN_WAVES] &&
+                    g.diag && tn.v[SF_TUNE_RUN_TEAM] <= 1 && s->fused_mode != 2;
+        // (the launch behind k_win: while every fire surely ends the call inside 64 rows, 16-wave workgroups - an environment whose fire reached the
+        // ring of a window placed to the vector gets a new window of 64 rows around where the fire stands now, 2 us per update instead of the
+        // general loop's 6 in an 8-wave workgroup; everybody else's workgroup returns at once)
         const bool all_young = tn.v[SF_TUNE_RUN_WINDOW] != 0 && s->fire_rows > 0 && s->fire_rows + 2LL * n_steps <= 60;
         if (tn.v[SF_TUNE_RUN_COMPACT] && g.E > s->n_cu && nw > 8 && min_nw <= 8 && !tn.set[SF_TUNE_RUN_WAVES] && !all_young) {
             const int vcap2 = vcap > 1024 ? 1024 : vcap;
@@ -1461,7 +1476,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         if (fits && wanted) { run_waves = nw; run_vcap = vcap; run_lds = lds; }
     }
     if (mit_dev && !run_waves) return SF_INTERNAL_NO_RESIDENT;      // the caller falls back to scatter + step pairs
-    a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr; a.todo_out = nullptr;
+    a.mit = mit_dev; a.mit_k = mit_k; a.todo = nullptr; a.todo_out = nullptr; a.todo_skip = 0; a.todo_cnt = nullptr; a.todo_list = nullptr; a.todo_cnt_next = nullptr;
     a.win = tn.v[SF_TUNE_RUN_WINDOW] < 0 ? 0 : tn.v[SF_TUNE_RUN_WINDOW];
     if (run_waves) {
         int rc0 = ensure_commit(s);            // k_run starts from commit[] and leaves the new states there
@@ -1500,7 +1515,8 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // The rollout is cut into segments, and every segment starts its environments in the order of what they cost in the one
         // before (k_order: most expensive first) - the tail of a segment is then made of the cheapest environments.
         const int seg_knob = tn.v[SF_TUNE_RUN_SEGMENT];
-        const bool balance = seg_knob > 0 && s->g.E > s->n_cu * (run_waves <= 8 ? 2 : 1);       // (with every environment resident from the start there is nothing to order)
+        win_first = win_first && a.win && a.rtc;
+        const bool balance = seg_knob > 0 && s->g.E > s->n_cu * (run_waves <= 8 ? 2 : 1) && !win_first;       // (with every environment resident from the start there is nothing to order; nor behind k_win: the few environments that have updates left)
         a.cost = s->run_cost;
         // Teams (k_run<TEAM>): forced by sf_set_tuning; always on grids of two-word rows; on one-word rows in long calls, which are then
         // cut into segments like above - the first one runs one workgroup per environment and records what every environment costs,
@@ -1508,7 +1524,37 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         const bool team_any = (team_forced || team_wide || team_auto) && bsz == 64;
         const bool team_segments = team_any && seg_knob > 0 && !balance;
         s->last_team_max = 0;
-        for (int done = 0; done < n_steps;) {
+        bool win_only = false;
+        if (win_first) {
+            // k_win: every environment's updates inside its window; what is left goes to s->todo
+            const size_t wlds = (win_lds_bytes(16) + 15) / 16 * 16 + kRunCtl * 4;
+            typedef void (*win_fn)(StepArgs, int);
+            const win_fn wk = s->g.att ? k_win<1> : k_win<0>;
+            size_t &wattr = s->attr_run[30 + (s->g.att ? 1 : 0)];
+            if (wlds > 64 * 1024 && wlds > wattr) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+                wattr = wlds;
+            }
+            a.todo_out = s->todo; a.order = nullptr;
+            // (two counts that take turns, both zero to begin with: every k_win clears the one its successor appends to)
+            if (!s->todo_cnt) { int rc0 = dev_alloc(s, &s->todo_cnt, (size_t)16); if (rc0) return rc0; HIPCHK(hipMemsetAsync(s->todo_cnt, 0, 16 * sizeof(uint32_t), s->stream)); }
+            a.todo_cnt = s->todo_cnt + (s->win_seq & 1); a.todo_cnt_next = s->todo_cnt + ((s->win_seq + 1) & 1); a.todo_list = s->run_order;      // (the order array: no ordered segments in a call k_win goes in front of)
+            s->win_seq++;
+            if (res_knob) { a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink; }
+            hipLaunchKernelGGL(wk, dim3((unsigned)s->g.E), dim3(1024), wlds, s->stream, a, n_steps);
+            HIPCHK(hipGetLastError());
+            a.todo_out = nullptr; a.res_block = nullptr; a.res_elapsed = nullptr; a.res_sink = nullptr;
+            s->last_launches++;
+            // Is anything left for sure not?  A fire that spans F cells (rows and columns alike: one cell after sf_reset, a cell more per side and
+            // update, fire.py:163-234) sits in a window placed to the row and - where a window placed to the vector may not hold it for the call -
+            // around the middle of the (F + 14) / 16 + 1 vectors it can straddle at worst (run_window, PL4): (64 - F) / 2 rows and 32 - 8 x vectors
+            // columns lie between it and the window's ring on every open side, and it needs one per update (+ 1: the ring itself).
+            const int F = s->fire_rows, wv = (F + 14) / 16 + 1;
+            const int room = wv > 3 ? 0 : std::min((64 - F) / 2, 32 - 8 * wv);
+            win_only = n_steps + 1 <= room && a.win == 1;      // (SF_TUNE_RUN_WINDOW = k > 1 leaves the window after k updates: tests)
+            a.todo = s->todo; a.todo_skip = 1;
+        }
+        for (int done = 0; done < n_steps && !win_only;) {
             int seg = balance && n_steps - done > seg_knob + seg_knob / 2 ? seg_knob : n_steps - done;
             // (two-word rows: twice the segment - every launch costs a plan, a prologue that reads the environment's whole bitmap and an
             // epilogue; measured on C4's share: 64 / 128 / 256 steps per launch = 26.3 / 26.1 / 26.8 us per step - the cuts have to follow the fires)
@@ -1548,10 +1594,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             // this replaces wherever it applies (they remain for calls with control lines inside the launch: C5);
             // ONE environment - FireSimulation.run(), C2 - keeps the plain kernel: its fire is young for hundreds of updates, and this kernel has no window
             // phase - measured on C2, 300 updates after 20: 5.1 against 6.0 us per update.  The knob set by hand wins.)
-            const bool use_join = join_knob != 0 && !team_forced && !team_wide && ((s->g.E >= 2 && !tn.set[SF_TUNE_RUN_TEAM]) || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
+            const bool use_join = !win_first && join_knob != 0 && !team_forced && !team_wide && ((s->g.E >= 2 && !tn.set[SF_TUNE_RUN_TEAM]) || tn.set[SF_TUNE_RUN_JOIN]) && !balance && !mit_dev && bsz == 64 && done == 0 &&
                                   n_steps >= join_min && !tn.set[SF_TUNE_RUN_WAVES] && !tn.set[SF_TUNE_RUN_VCAP] && jgeo.ok;
             if (use_join) { seg = n_steps; a.team_recut = 0; }
-            const bool use_team = !use_join && team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
+            const bool use_team = !win_first && !use_join && team_any && !balance && (team_forced || team_wide || (s->cost_steps > 0 && n_steps - done >= seg_knob / 2));
             if (balance) {
                 hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s->stream, s->g.E, (const uint32_t *)s->run_cost, s->run_order);
                 a.order = s->run_order;
@@ -1595,9 +1641,10 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             done += seg;
             s->last_launches++;
         }
+        if (win_only) s->cost_steps = n_steps;
         s->status_fresh = res_knob != 0;
         s->tiles_valid = false;                // the tile activity map / seam planes are not kept by k_run
-        s->last_kind = 2;
+        s->last_kind = win_first && a.todo ? 4 : 2;
         n_steps = 0;                           // nothing left for the per-step loop
     } else if (n_steps > 0) {
         s->vbits_valid = false;                // the per-step kernels do not keep the vector bitmap
@@ -1825,7 +1872,7 @@ static int loop_launch(sf_sim *s)
     if (vcap > all_vec) vcap = (int)((all_vec + 63) / 64 * 64);
     const size_t lds = run_lds_bytes(g, nw, vcap);
     // (the closed loop's own instantiations of k_run live in simfire_hip_run2.hip; two rows per thread: simfire_hip_run3.hip)
-    size_t &attr = two_rows ? s->attr_run[20 + (g.att ? 1 : 0)] : s->attr_run[16 + (g.att ? 2 : 0) + (g.diag ? 1 : 0)];
+    size_t &attr = two_rows ? s->attr_run[28 + (g.att ? 1 : 0)] : s->attr_run[24 + (g.att ? 1 : 0)];      // (slots of their own: a slot shared with another kernel would leave one of the two without its attribute)
     const bool set_lds = lds > 64 * 1024 && lds > attr;
     if (two_rows) HIPCHK(sf_run3_launch_loop2(g.att ? 1 : 0, (unsigned)g.E, (unsigned)nw * 64, lds, set_lds, st, &a, sizeof a, vcap));
     else HIPCHK(sf_run2_launch_loop(g.att ? 1 : 0, g.diag ? 1 : 0, (unsigned)g.E, (unsigned)nw * 64, lds, set_lds, st, &a, sizeof a, vcap));

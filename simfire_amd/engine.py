@@ -322,8 +322,8 @@ class FireEngine:
         self._chk(self._L.sf_set_prune_after_quit(self._h, int(bool(on))))
 
     def last_launch_kind(self):
-        """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, 4 k_run_tiles,
-        5 frontier-resident launch (k_front), 6 k_front + k_run for left-over steps, -1 none yet."""
+        """0 k_select + k_step, 1 fused launch per step, 2 resident launch (k_run), 3 per-cell kernel, 4 the window kernel k_win in front of
+        k_run (more environments than CUs, young fires), -1 none yet."""
         v = C.c_int32(-1)
         self._chk(self._L.sf_last_step_launch(self._h, C.byref(v)))
         return int(v.value)

@@ -1504,6 +1504,91 @@ def test_more_environments_than_cus_young_and_old():
         assert (eng.fire_map(e) == o.fire_map(e)).all(), e
 
 
+@pytest.mark.parametrize("win", [1, 3])
+@pytest.mark.parametrize("seed", range(8))
+def test_window_kernel_in_front_of_the_resident_launch_random_worlds(seed, win):
+    """k_win (sf_run_kernels.h): the window phase as a kernel of its own in front of k_run - the launch structure for more environments than CUs
+    while their fires are young (two 16-wave workgroups to a CU), forced here on small batches (SF_TUNE_RUN_COMPACT = 2).  Every environment
+    makes as many of a call's updates as its fire stays inside its window, the k_run launch behind it makes what is left (SF_TUNE_RUN_WINDOW = 3:
+    the window is left after three updates, so there always is something left) or is left out where the host can prove there is nothing.
+    Random worlds as for the window phase inside k_run: exact R ties, attenuation on / off, runtime cut-off, barren cells, ignitions at the
+    grid's edges and corners, control lines (also on burning cells) and resets between calls, fires that go out.  Equal to the oracle after
+    every call; the new structure really ran."""
+    rng = np.random.default_rng(97000 + seed)
+    H, W = int(rng.integers(64, 400)), int(rng.integers(64, 400))
+    E = int(rng.integers(1, 7))
+    kw, R8 = _window_world(rng, H, W, E)
+    inits = []
+    for _ in range(E):
+        q = rng.random()
+        if q < 0.3:
+            inits.append((int(rng.choice([0, 1, W - 2, W - 1])), int(rng.choice([0, 1, H - 2, H - 1]))))
+        else:
+            inits.append((int(rng.integers(W)), int(rng.integers(H))))
+    eng, o = _pair(kw, R8, inits)
+    eng.set_tuning(run_compact=2, run_window=win)
+    eng.enable_counters(True)
+    kinds, launches = [], []
+    done = 0
+    while done < 70:
+        n = int(rng.integers(2, 24))
+        if rng.random() < 0.4:
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6)))
+                   for _ in range(int(rng.integers(1, 30)))]
+            e0 = int(rng.integers(E))
+            burning = np.argwhere(o.fire_map(e0) == 1)
+            if len(burning):
+                y, x = burning[rng.integers(len(burning))]
+                pts += [(e0, int(x), int(y), int(rng.integers(3, 6))), (e0, int(x) + 1, int(y), int(rng.integers(3, 6)))]
+                pts = [p for p in pts if p[1] < W]
+            eng.apply_mitigation(pts)
+            o.apply_mitigation(pts)
+        if rng.random() < 0.15 and done > 10:
+            e0, x, y = int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H))
+            eng.reset_env(e0, x, y)
+            o.reset_env(e0, x, y)
+        eng.step(n)
+        o.step(n)
+        done += n
+        kinds.append(eng.last_launch_kind())
+        launches.append(eng.last_launches())
+        _same(eng, o, E, tag=(seed, win, done))
+    assert kinds[0] == 4 and set(kinds) <= {2, 4}, kinds
+    # the first call starts from fires of one cell: nothing can be left of a short call, and the launch behind k_win is left out (win = 1)
+    assert all(l in (1, 2) for k, l in zip(kinds, launches) if k == 4)
+    assert eng.counters()["window_updates"] > 0
+
+
+def test_window_kernel_two_workgroups_to_a_cu_on_more_environments_than_cus():
+    """600 environments on a 256 x 128 grid - more than the chip has CUs: while the fires may fit their windows every call is k_win (two
+    16-wave workgroups to a CU) + k_run for what is left (8-wave workgroups in ordered segments), afterwards k_run alone.  Calls of a few updates
+    as an RL harness issues them, control lines in between, some environments on barren ground (out at once), some reset half-way: result
+    block of every environment and a sample of maps / burn_amounts equal to the oracle after every call."""
+    rng = np.random.default_rng(515)
+    H, W, E = 256, 128, 600
+    kw, R8 = _window_world(rng, H, W, E, att=False)
+    R8[:, :, :8] = 0.0
+    inits = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(E)]
+    eng, o = _pair(kw, R8, inits)
+    kinds = []
+    sample = (0, 1, 255, 256, 257, 511, 512, 599)
+    for i, n in enumerate((5, 7, 2, 9, 12, 20, 6)):
+        if i in (2, 4):
+            pts = [(int(rng.integers(E)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(300)]
+            eng.apply_mitigation(pts); o.apply_mitigation(pts)
+        if i == 3:
+            for e0 in (5, 300, 599):
+                eng.reset_env(e0, 64, 128); o.reset_env(e0, 64, 128)
+        eng.step(n); o.step(n)
+        kinds.append(eng.last_launch_kind())
+        st, el = eng.status(); so, eo = o.status()
+        assert (st == so).all() and (el == eo).all(), (i, n)
+        for e in sample:
+            assert (eng.fire_map(e) == o.fire_map(e)).all(), (i, e)
+            assert (eng.burn(e) == o.burn(e)).all(), (i, e)
+    assert kinds[:3] == [4, 4, 4] and kinds[-1] == 2, kinds
+
+
 def test_c_abi_collective_world_of_eight_ranks_with_a_stand_in_for_rccl(tmp_path):
     """Everything around the one RCCL call of the C ABI for a world of EIGHT ranks, on one GPU: tests/fake_rccl.cpp (test
     infrastructure, loaded instead of librccl through SIMFIRE_RCCL_LIB) lets eight handles of one process play the ranks.  Checked:

@@ -553,7 +553,7 @@ def test_simulation_fire_map_is_one_array_mutated_in_place_and_edits_are_taken_o
     from simfire_amd.config import Config
     from simfire_amd.simulation import FireSimulation
     y = yaml.safe_load(open(os.path.join(CFG, "functional_config.yml")))
-    y["area"]["screen_size"] = [40, 56]
+    y["area"]["screen_size"] = [80, 96]
     y["terrain"]["topography"]["functional"]["function"] = "flat"
     y["simulation"]["headless"] = True
     sim = FireSimulation(Config(config_dict=y))
@@ -590,26 +590,27 @@ def test_simulation_fire_map_is_one_array_mutated_in_place_and_edits_are_taken_o
         assert (fm == o.fire_map(0)).all(), t
     assert (sim._engine.burn(0) == o.burn(0)).all()
     # a write behind the array's back is NOT noticed ... until the caller says so (documented on _TrackedMap)
-    np.asarray(fm)[0, 0] = 3
+    # (the far corner: the fire, a cell per update at most from (16, 16), is nowhere near it)
+    np.asarray(fm)[H - 1, W - 1] = 3
     sim.run(1); o.step(1)
-    assert sim._engine.fire_map(0)[0, 0] == 0
-    fm[0, 0] = 0                                              # (undo on the host side: that write IS noticed and uploads the map as it stands)
-    np.asarray(fm)[1, 1] = 4
+    assert sim._engine.fire_map(0)[H - 1, W - 1] == 0
+    fm[H - 1, W - 1] = 0                                      # (undo on the host side: that write IS noticed and uploads the map as it stands)
+    np.asarray(fm)[H - 2, W - 2] = 4
     sim.invalidate_fire_map()
-    o.apply_mitigation([(0, 1, 1, 4)])
+    o.apply_mitigation([(0, W - 2, H - 2, 4)])
     sim.run(1); o.step(1)
-    assert (sim.fire_map == o.fire_map(0)).all() and sim._engine.fire_map(0)[1, 1] == 4
+    assert (sim.fire_map == o.fire_map(0)).all() and sim._engine.fire_map(0)[H - 2, W - 2] == 4
     # a replaced map (load_mitigation's assignment): adopted as it is when it is int64 - and mutated in place from then on
     repl = np.array(sim.fire_map)
     repl[H - 1, :] = 3
     sim.fire_map = repl
-    o.apply_mitigation([(0, xx, H - 1, 3) for xx in range(W)])
+    o.apply_mitigation([(0, xx, H - 1, 3) for xx in range(W)])      # (also over the line cell (H - 2, W - 2)'s neighbour row: plain assignment, like the map)
     m, _ = sim.run(2); o.step(2)
     assert np.shares_memory(m, repl) and (repl == o.fire_map(0)).all()
     # strict mode: every call compares the whole map (round 5's behaviour)
     sim.strict_fire_map_sync = True
-    np.asarray(sim.fire_map)[2, 2] = 5
-    o.apply_mitigation([(0, 2, 2, 5)])
+    np.asarray(sim.fire_map)[H - 3, 2] = 5
+    o.apply_mitigation([(0, 2, H - 3, 5)])
     sim.run(1); o.step(1)
     assert (sim.fire_map == o.fire_map(0)).all()
 
