@@ -117,6 +117,9 @@ struct StepArgs {
     // k_run only: the per-environment result block written by the launch itself when its steps are done (null = not)
     int32_t *res_block;  // [E][8] running, update() calls made, cells per BurnStatus 0..5 (sf_get_status)
     double *res_elapsed; // [E]
+    int row_valid;       // k_run / k_win: every environment's row of res_block (and the sink's copy) is CURRENT when the launch starts (a resident launch, a
+                         // reset or a status query wrote it and nothing has changed a status byte since): the window phase brings it up to date from
+                         // what it changes instead of recounting tiles, and an environment that has nothing to do leaves it alone
     int32_t *res_sink;   // the caller's registered copy of the block (sf_set_result_sink), or null
     uint16_t *thist;     // [E][TY][TX][8] cached per-tile status histograms behind the block
     const uint32_t *order; // k_run only: workgroup i takes environment order[i] (most expensive first, k_order), or null = i

@@ -497,28 +497,41 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
 #endif
     uint32_t *tcnt = reinterpret_cast<uint32_t *>(halo + 2 * g.PV);                // TEAM: [64] vectors with sprites per tile row (the split)
 
-    // (the window phase's first looks at memory - this thread's row of the vector bitmap, its tile's dirty flag - are asked for together with
-    // the environment's state: one memory round trip at the head of the launch, not two.  In assembly, so that they are issued HERE.)
+    // (the window phase's first look at memory - this thread's row of the vector bitmap - and two words every launch with a window phase / a
+    // catch-up list reads for its environment - the phase's advice on where the fire stood, the updates the launch in front left over - are asked
+    // for together with the environment's state: ONE memory round trip at the head of the launch.  Written as plain loads the compiler makes the
+    // uniform ones a round trip of their own each in front of the state's - a vector load, a wait, a readfirstlane: they are not scalar loads
+    // because the kernel also writes these arrays.  So the loads AND their wait are one assembly statement (round 5 had the wait in a statement
+    // of its own: nothing told the compiler that the outputs of the first were not ready before the second - ADVICE r5); a load that a launch
+    // has no use for asks for the environment's state once more.)
     constexpr bool kWinPre = (MIT == 0 || MIT == -1) && MAXD == 1 && TEAM == 0;
-    unsigned long long pre_w = 0ull;
-    uint32_t pre_dirty = 0u;
-    if (kWinPre && a.win) {
-        const unsigned long long *pw_ = a.vbits + (long long)e * g.vb_env + tid;
-        const uint8_t *pd_ = a.tdirty + (long long)e * g.TY * g.TX + tid;
-        if (tid < g.H) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre_w) : "v"(pw_) : "memory");
-        if (tid < g.TY * g.TX) asm volatile("global_load_ubyte %0, %1, off" : "=v"(pre_dirty) : "v"(pd_) : "memory");
-    }
-    // (and two words every launch with a window phase / a catch-up list reads for its environment: the phase's advice on where the fire stood,
-    // the updates k_run's last launch left over.  Written as plain loads the compiler makes each a round trip of its own in front of the state's -
-    // a vector load, a wait, a readfirstlane: they are not scalar loads because the kernel also writes these arrays.)
     constexpr bool kWinAny = ((MIT == 0 && MAXD <= 2) || (MIT == -1 && MAXD == 1 && TEAM == 0 && DIAG == 1)) && TEAM != 2;
-    unsigned long long hint_v = 0ull;
-    int32_t todo_v = 0;
     constexpr bool kWinAdvice = kWinAny && !(MAXD == 1 && TEAM == 0);      // (the window code's general path: sf_win_kernels.h, ADV)
-    if (kWinAdvice && a.win && a.win_hint) { const unsigned long long *ph_ = a.win_hint + e; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hint_v) : "v"(ph_) : "memory"); }
-    if (a.todo) { const int32_t *pt_ = a.todo + e; asm volatile("global_load_dword %0, %1, off" : "=v"(todo_v) : "v"(pt_) : "memory"); }
-    EnvState st = a.commit[e];
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_w), "+v"(pre_dirty), "+v"(hint_v), "+v"(todo_v) :: "memory");      // (asked for before the state, which has arrived: no wait left)
+    unsigned long long pre_w = 0ull, hint_v = 0ull;
+    int32_t todo_v = 0;
+    EnvState st;
+    {
+        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+        const EnvState *const ps = a.commit + e;
+        const bool want_pre = kWinPre && a.win && tid < g.H, want_hint = kWinAdvice && a.win && a.win_hint, want_todo = a.todo != nullptr;
+        const void *const p_pre = want_pre ? (const void *)(a.vbits + (long long)e * g.vb_env + tid) : (const void *)ps;
+        const void *const p_hint = want_hint ? (const void *)(a.win_hint + e) : (const void *)ps;
+        const void *const p_todo = want_todo ? (const void *)(a.todo + e) : (const void *)ps;
+        u32x2v v_pre, v_hint, v_hi;
+        u32x4 v_lo;
+        uint32_t v_todo;
+        asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %6, off\n\tglobal_load_dword %2, %7, off\n\t"
+                     "global_load_dwordx4 %3, %8, off\n\tglobal_load_dwordx2 %4, %8, off offset:16\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v_pre), "=&v"(v_hint), "=&v"(v_todo), "=&v"(v_lo), "=&v"(v_hi)
+                     : "v"(p_pre), "v"(p_hint), "v"(p_todo), "v"(ps)
+                     : "memory");
+        if (want_pre) pre_w = (unsigned long long)v_pre.x | ((unsigned long long)v_pre.y << 32);
+        if (want_hint) hint_v = (unsigned long long)v_hint.x | ((unsigned long long)v_hint.y << 32);
+        if (want_todo) todo_v = (int32_t)v_todo;
+        st.running = __builtin_amdgcn_readfirstlane((int)v_lo.x); st.steps = __builtin_amdgcn_readfirstlane((int)v_lo.y);
+        st.complete = __builtin_amdgcn_readfirstlane((int)v_lo.z); st.time_quit = __builtin_amdgcn_readfirstlane((int)v_lo.w);
+        st.elapsed = __hiloint2double(__builtin_amdgcn_readfirstlane((int)v_hi.y), __builtin_amdgcn_readfirstlane((int)v_hi.x));
+    }
     const unsigned long long hint_pre = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hint_v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hint_v >> 32)) << 32);
     if (a.todo) n_steps = __builtin_amdgcn_readfirstlane(todo_v);            // the steps the launch in front (k_win; a team launch with windows of rows) left over for this environment (usually none)
     if ((!st.running && !mit) || n_steps < 0) n_steps = 0;       // frozen: run() no longer calls update (uniform over the workgroup)
@@ -564,7 +577,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
 #endif
         wpc.note(30);        // launch: state read
-        we.pre_w = pre_w; we.pre_dirty = pre_dirty; we.pre = kWinPre; we.hint = hint_pre;
+        we.pre_w = pre_w; we.pre = kWinPre; we.hint = hint_pre;
         s_begin = run_window<ATT, kWinGen, kWinMit>(a, we, st, n_steps, diag, vlist + vcap, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result,
                                                     kWinMit ? mit : nullptr, n_steps, &px, &py, &pty, vlist, vcap >= 1024 ? 15 : 11);      // (the duplicate filter's bits in the list's LDS: 4 KB, or 256 bytes on small grids)
         if (a.counters && tid == 0 && s_begin)           // (statistics slot 8: updates made inside a window - a slot of its own, whatever the instantiation)
@@ -1681,7 +1694,9 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
             return;
         }
     }
-    if (a.res_block && !(win_result && !general)) {
+    // (not where the window phase has brought the row up to date itself, and not for an environment this launch had nothing to do on while the
+    // host says its row is current - a fire that is out, in a long call: a sweep of 512 tile flags per launch for nothing)
+    if (a.res_block && !(win_result && !general) && !(a.row_valid && !general && n_steps == 0 && !mit)) {
         __syncthreads();
         wpc.note(36);        // state / bitmaps handed back
         counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
@@ -1715,17 +1730,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const unsigned long long clk0 = __builtin_readcyclecounter();
     uint32_t *const wl = reinterpret_cast<uint32_t *>(s_dyn);                       // the window's planes (win_lds_bytes)
     uint32_t *const ctl = wl + (win_lds_bytes(n_waves) + 15) / 16 * 4;              // control words, like k_run's
-    // (this thread's row of the vector bitmap and its tile's dirty flag travel with the state: one round trip at the head of the launch)
-    unsigned long long pre_w = 0ull;
-    uint32_t pre_dirty = 0u;
-    {
-        const unsigned long long *pw_ = a.vbits + (long long)e * g.vb_env + (tid < g.H ? tid : 0);
-        const uint8_t *pd_ = a.tdirty + (long long)e * g.TY * g.TX + (tid < g.TY * g.TX ? tid : 0);
-        pre_w = *pw_;
-        pre_dirty = *pd_;
-        if (tid >= g.H) pre_w = 0ull;
-        if (tid >= g.TY * g.TX) pre_dirty = 0u;
-    }
+    // (this thread's row of the vector bitmap travels with the state: one round trip at the head of the launch)
+    unsigned long long pre_w = a.vbits[(long long)e * g.vb_env + (tid < g.H ? tid : 0)];
+    if (tid >= g.H) pre_w = 0ull;
     EnvState st = a.commit[e];
     int n_steps = n_steps_launch;
     if (!st.running || n_steps < 0) n_steps = 0;              // frozen: run() no longer calls update (uniform over the workgroup)
@@ -1743,7 +1750,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     we.thist = a.thist + (long long)e * g.TY * g.TX * 8;
     we.vb_glob = a.vbits + (long long)e * g.vb_env;
     we.vb_plane = (long long)g.E * g.vb_env;
-    we.pre_w = pre_w; we.pre_dirty = pre_dirty; we.pre = true; we.hint = 0ull;
+    we.pre_w = pre_w; we.pre = true; we.hint = 0ull;
     __syncthreads();
     wpc.start();
     // (A second window around a fire that reaches its ring while it still fits one - a loop around this call - was built and measured: the loop

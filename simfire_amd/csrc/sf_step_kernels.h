@@ -957,7 +957,7 @@ __global__ void k_commit(Geo g, EnvState *commit, const EnvState *tmp, uint32_t 
 
 #ifndef SF_RUN_UNIT
 __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, uint8_t *cells, EnvState *commit, uint8_t *tflags, int ring,
-                           unsigned long long *vbits, const int32_t *xy, int env0, int n, uint8_t *tdirty)
+                           unsigned long long *vbits, const int32_t *xy, int env0, int n, uint8_t *tdirty, int32_t *res_block, double *res_elapsed, int32_t *res_sink)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -986,6 +986,13 @@ __global__ void k_init_env(Geo g, uint8_t *status, uint8_t *age, uint8_t *cells,
     s.running = 1; s.steps = 0; s.complete = 0; s.elapsed = 0.0;
     s.time_quit = g.has_max_time && (g.update_rate > g.max_time || 0.0 > g.max_time);
     commit[e] = s;
+    // the environment's row of the result block is known as well (sf_get_status: running, update() calls made, cells per BurnStatus): all
+    // UNBURNED but the ignition cell - the launches that follow bring it up to date by difference (StepArgs::row_valid)
+    if (res_block) {
+        const int32_t row[8] = {1, 0, g.H * g.W - 1, 1, 0, 0, 0, 0};
+        for (int k = 0; k < 8; ++k) { res_block[e * 8 + k] = row[k]; if (res_sink) res_sink[e * 8 + k] = row[k]; }
+        res_elapsed[e] = 0.0;
+    }
 }
 #endif
 

@@ -116,8 +116,7 @@ struct WinEnv {                    // per-environment bases (wave-uniform)
     uint16_t *thist;               // [TY][TX][8] of this environment: cached status histograms of the wave tiles
     unsigned long long *vb_glob;   // this environment's rows of the three vector bitmaps in memory: plane 0; planes 1 / 2 are vb_plane further each
     long long vb_plane;
-    unsigned long long pre_w;      // pre: this thread's row of plane 0 and its tile's dirty flag, asked for by k_run together with the environment's state
-    uint32_t pre_dirty;
+    unsigned long long pre_w;      // pre: this thread's row of plane 0, asked for by k_run together with the environment's state
     bool pre;
     unsigned long long hint;       // a.win_hint[e] (0: none)
 };
@@ -191,7 +190,6 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (!GEN && g.H > nthr) return 0;
     uint32_t *const wslot = wl + (size_t)WR * 128 + 64 + 128;                            // [waves][4]: per wave first row, last row + 1 (0: none), column bits
     int ymin, ymax1, vmin, vmax;
-    bool hist_clean;
     if (GEN) {
         // any rows per thread, any words per row: complements for the minima, maxima over the wave, then over the waves
         uint32_t iy = 0, y1 = 0, iv = 0, v1 = 0;               // ~first row, last row + 1, ~first vector, last vector + 1 (0: none)
@@ -203,37 +201,27 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                     iy = iy > a_ ? iy : a_; y1 = (uint32_t)y + 1u; iv = iv > b_ ? iv : b_; v1 = v1 > c_ ? v1 : c_;
                 }
             }
-        bool dirty = false;
-        for (int t = tid; t < g.TY * g.TX; t += nthr) dirty |= ev.tdirty[t] != 0;
-        const bool wave_dirty = __ballot(dirty) != 0ull;
         const uint32_t miy = wave_umax(iy), may = wave_umax(y1), miv = wave_umax(iv), mav = wave_umax(v1);
         if (lane == 0) {
             uint32_t *sl = wslot + wave * 4;
-            sl[0] = miy; sl[1] = may | (wave_dirty ? 0x80000000u : 0u); sl[2] = miv; sl[3] = mav;
+            sl[0] = miy; sl[1] = may; sl[2] = miv; sl[3] = mav;
         }
         __syncthreads();
         const int n_waves = nthr >> 6;
         const uint4 sl = lane < n_waves ? *reinterpret_cast<const uint4 *>(wslot + lane * 4) : make_uint4(0, 0, 0, 0);
-        const uint32_t a_ = row16_max(sl.x), b_ = row16_max(sl.y & 0x7FFFFFFFu), c_ = row16_max(sl.z), d_ = row16_max(sl.w);
-        hist_clean = (row16_or(sl.y) & 0x80000000u) == 0u;
+        const uint32_t a_ = row16_max(sl.x), b_ = row16_max(sl.y), c_ = row16_max(sl.z), d_ = row16_max(sl.w);
         if (!b_) return 0;                                     // no sprite anywhere: the general loop's next update says QUIT
         ymin = (int)(0xFFFFFFFFu - a_); ymax1 = (int)b_; vmin = (int)(0xFFFFFFFFu - c_); vmax = (int)d_ - 1;
     } else {
     {
         unsigned long long w = 0ull;
-        uint32_t d0 = 0u;
-        if (ev.pre) { w = ev.pre_w; d0 = ev.pre_dirty; }      // (k_run has waited for them)
+        if (ev.pre) w = ev.pre_w;                              // (k_run has waited for it)
         else w = tid < g.H ? ev.vb_glob[tid] : 0ull;
         const unsigned long long nz = __ballot(w != 0ull);
         const uint32_t c_lo = wave_or((uint32_t)w), c_hi = wave_or((uint32_t)(w >> 32));
-        // are the cached status histograms of this environment's tiles all valid?  Then the result block can be brought up to date
-        // from what this phase changes (below) instead of a sweep over the tiles' flags and histograms (counts_env)
-        bool dirty = ev.pre && tid < g.TY * g.TX && d0 != 0u;
-        for (int t = ev.pre ? tid + nthr : tid; t < g.TY * g.TX; t += nthr) dirty |= ev.tdirty[t] != 0;
-        const bool wave_dirty = __ballot(dirty) != 0ull;
         if (lane == 0) {
             uint32_t *sl = wslot + wave * 4;
-            sl[0] = (nz ? (uint32_t)(wave * 64 + __ffsll((long long)nz) - 1) : 0u) | (wave_dirty ? 0x80000000u : 0u);
+            sl[0] = nz ? (uint32_t)(wave * 64 + __ffsll((long long)nz) - 1) : 0u;
             sl[1] = nz ? (uint32_t)(wave * 64 + 64 - __clzll((long long)nz)) : 0u;
             sl[2] = c_lo; sl[3] = c_hi;
         }
@@ -245,9 +233,8 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         const int n_waves = nthr >> 6;
         const uint4 sl = lane < n_waves ? *reinterpret_cast<const uint4 *>(wslot + lane * 4) : make_uint4(0, 0, 0, 0);
         // first row: the smallest (first row + 1) among the waves that hold any = maximum of its complement
-        const uint32_t inv = sl.y ? 0xFFFFFFFFu - (sl.x & 0x7FFFFFFFu) : 0u;
+        const uint32_t inv = sl.y ? 0xFFFFFFFFu - sl.x : 0u;
         const uint32_t mi = row16_max(inv), ma = row16_max(sl.y), clo = row16_or(sl.z), chi = row16_or(sl.w);
-        hist_clean = (row16_or(sl.x) & 0x80000000u) == 0u;
         ymin = mi ? (int)(0xFFFFFFFFu - mi) : 0;
         ymax1 = (int)ma;
         cmask = (unsigned long long)clo | ((unsigned long long)chi << 32);
@@ -338,7 +325,14 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     // of those cells point by point - per-tile counts in LDS, added to the cached histograms on the way out, no sweep at the end: bit-exact, the
     // median environment of C5 173 k -> 150 k clocks, and the launch not a microsecond shorter - it ends with the environments whose agents draw
     // INSIDE the window, 192 k clocks either way.  Measured again with the control-line wave's work beside the walk (below): 78.9 -> 81.3 us.)
-    const bool by_delta = hist_clean && a.res_block != nullptr && nty * ntx <= 15 && !mitw;
+    // Round 6: what makes the last result row trustworthy is the HOST's word (a.row_valid: a resident launch, a reset or a status query wrote the
+    // block and no status byte has changed since), not a sweep of this environment's 512 tile flags - and the tiles' cached histograms are not
+    // kept up any more: the tiles this phase changes are marked for a recount by whoever next counts tiles (counts_env: the general loop's end,
+    // a status query behind per-step launches), a byte store each instead of a read-modify-write of their histograms on the way out.  With control
+    // lines inside the launch the control-line wave keeps the books of the cells it writes OUTSIDE the window (it has their old types: attenuation
+    // mode), the owners' own difference covers the ones inside - C5's launches ended on a 38 k-clock recount of every tile its agents had touched.
+    const bool by_delta = a.row_valid && a.res_block != nullptr && nty * ntx <= 14 && (!mitw || ATT);
+    int32_t *const dmit = dt + 14 * 8;                        // MITW: cells per BurnStatus gained / lost outside the window, by the control-line wave
     lpc.note(42);            // window placed
     // (Measured and dropped: loading only what the fire can reach in this phase - rows and vectors within s_reach of the sprites'; a 5-update
     // call needs a fifth of the window.  The short call got 0.4 us faster and the call after it 3.4 us slower: the whole window loaded by one
@@ -375,7 +369,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     wdirty[r * 16 + c] = 0;
     const int mit_wave = (nthr >> 6) - 1;
     // the control-line wave's view of ONE step's points (made a step ahead): valid, column, row, the type that stands on its cell, inside the window
-    bool m_ok = false, m_in = false;
+    bool m_ok = false, m_in = false, m_first = true;          // (m_first: no lower lane holds a point on the same cell - the one that keeps the cell's books)
     int m_x = 0, m_y = 0, m_fin = 0;
     const uint32_t wmit_lds = (MITW && ATT) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)wmit) : 0u;
     auto dma_dword = [&](const void *src, uint32_t lds_byte) {      // an LDS-DMA load: lane i's dword lands at LDS[lds_byte + 4 i], no register is held, nothing waits
@@ -390,8 +384,10 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         m_ok = lane < a.mit_k && ty >= SF_FIRELINE && ty <= SF_WETLINE && qx >= 0 && qx < g.W && qy >= 0 && qy < g.H;
         m_x = m_ok ? qx : 0; m_y = m_ok ? qy : 0;
         int fin = ty;
+        bool first = true;
         const unsigned long long above = __ballot(m_ok && ty > SF_FIRELINE);
-        if (above && (__ballot(m_ok && ty != SF_WETLINE) != 0ull)) {            // (all of one type: nothing to settle)
+        // (all of one type: nothing to settle - unless the result block is kept by difference: then one lane per CELL keeps the cell's books)
+        if (by_delta || (above && (__ballot(m_ok && ty != SF_WETLINE) != 0ull))) {
             const uint32_t o = (uint32_t)(m_y * g.P + m_x);
             const uint32_t h = (o * 2654435761u) >> (32 - dup_log2), bit = 1u << (h & 31);      // (a bit per hashed cell: 2^dup_log2 bits of LDS; a false hit only costs the exact answer below)
             if (m_ok) duptab[h >> 5] = 0;
@@ -401,15 +397,17 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             const uint32_t clash = m_ok ? (atomicOr(&duptab[h >> 5], bit) & bit) : 0u;
             if (__ballot(clash != 0) != 0ull) {
                 const uint32_t key = m_ok ? o : 0xFFFFFFFFu;
-                for (unsigned long long hi = above; hi; hi &= hi - 1) {
+                for (unsigned long long hi = by_delta ? __ballot(m_ok) : above; hi; hi &= hi - 1) {
                     const int j = __ffsll((long long)hi) - 1;
                     const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
                     const int tj = __builtin_amdgcn_readlane(ty, j);
                     if (key == kj && tj > fin) fin = tj;
+                    if (key == kj && j < lane) first = false;
                 }
             }
         }
         m_fin = fin;
+        m_first = first;
         m_in = m_ok && m_y >= wy0 && m_y < wy0 + WR && m_x >= wx0 && m_x < wx0 + kWinCols;
         if (m_in) reinterpret_cast<uint8_t *>(wpatch + (sp & 1) * WR * 16)[(m_y - wy0) * 64 + (m_x - wx0)] = (uint8_t)fin;      // (duplicates store the same type)
         const bool any_in = __ballot(m_in) != 0ull;
@@ -777,6 +775,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                     if (was != (uint32_t)fin) {
                         if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)(st.complete + n_plain) - owed_since);
                         ev.settled[o] = (uint32_t)(st.complete + n_plain);
+                        // the result block by difference: this cell leaves one BurnStatus for another (one lane per cell: the step's other points
+                        // on it saw the same old type and store the same new one)
+                        if (by_delta && m_first) { atomicAdd(dmit + was, -1); atomicAdd(dmit + fin, 1); }
                     }
                 }
             }
@@ -855,7 +856,8 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 const int d = __popc(((sv0 ^ kk) + 0x7F7F7F7Fu) & 0x80808080u) - __popc(((sv ^ kk) + 0x7F7F7F7Fu) & 0x80808080u);      // bytes == q: now - before
                 if (d) atomicAdd(dtile + q, d);                // (addresses differ from lane to lane: plain LDS atomics)
             }
-        } else ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+        }
+        ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;      // (the tile's cached histogram is stale either way: whoever counts tiles next recounts it)
     }
     if (wdirty[r * 16 + c]) {
         const double2 *src = reinterpret_cast<const double2 *>(wb + (r * 16 + c) * 4);
@@ -917,18 +919,13 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         if (tid == 0) a.win_hint[e] = mhi ? (unsigned long long)(((0xFFFFFFFFu - mlo) + 1u) | (mhi << 16)) | ((unsigned long long)((uint32_t)(wx0 + 1) | ((uint32_t)(wy0 + 1) << 16)) << 32) : 0ull;
     }
     if (by_delta) {
-        for (int i = tid; i < nty * ntx * 8; i += nthr) {
-            const int tl = i >> 3, q = i & 7, d = dt[i];
-            if (d) ev.thist[((ty0 + tl / ntx) * g.TX + tx0 + tl % ntx) * 8 + q] += (uint16_t)d;       // (mod 2^16: a negative change wraps to the right count)
-        }
-        lpc.note(47);        // tile histograms brought up to date
         if (tid < 8) {
             // lanes 3 .. 7 of wave 0: the cells per BurnStatus 1 .. 5 = the old row + what every tile of the window gained or lost (a lane per
             // status: the sums of up to fifteen LDS words side by side, not one after the other); lane 2: UNBURNED = H * W - the others
             // (counts_env); lanes 0 / 1: running, update() calls made
             int32_t v = 0;
             if (tid >= 3) {
-                v = dt[120 + tid];
+                v = dt[120 + tid] + (MITW ? dmit[tid - 2] : 0);
                 for (int tl = 0; tl < nty * ntx; ++tl) v += dt[tl * 8 + tid - 2];
             }
             int32_t others = v;                            // (lanes 0 .. 2 hold 0)

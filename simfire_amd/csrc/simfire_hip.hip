@@ -882,7 +882,8 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
             return fail(SF_EINVAL, "reset: ignition (%d, %d) of environment %d is outside the %dx%d grid", xy[2 * i],
                         xy[2 * i + 1], env0 + i, g.H, g.W);
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
-    s->status_fresh = false;
+    // (the rows of the environments that are reset are written below: a block that was current stays current, a full reset makes it so)
+    if (n == g.E) s->status_fresh = true;
     { int rc0 = ensure_commit(s); if (rc0) return rc0; }     // the other environments' states must be current in commit[]
     if (n == g.E) s->cost_steps = 0;                         // new episodes: what the environments cost before says nothing about them
     HIPCHK(hipMemsetAsync(s->win_hint + env0, 0, (size_t)n * sizeof(unsigned long long), s->stream));      // (where the old fires stood says nothing about the new ones)
@@ -924,7 +925,7 @@ static int reset_range(sf_sim *s, int env0, int n, const int32_t *xy)
         HIPCHK(hipMemsetAsync(s->thist + (size_t)env0 * per_env * 8, 0, (size_t)n * per_env * 8 * sizeof(uint16_t), s->stream));
     }
     hipLaunchKernelGGL(k_init_env, dim3((n + 255) / 256), dim3(256), 0, s->stream, g, s->status, s->age, s->bl_cur ? s->cells : nullptr, s->commit,
-                       s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n, hist_known ? s->tdirty : nullptr);
+                       s->tflags, s->ring, s->vbits, (const int32_t *)s->stage, env0, n, hist_known ? s->tdirty : nullptr, s->status_block, s->elapsed_dev, s->sink);
     HIPCHK(hipGetLastError());
     if (!s->bl_cur) {                   // (the tile bookkeeping is not kept while the blocked plane is current: tiles_valid is false)
         rc = rebuild_seams(s, env0, n);
@@ -1376,9 +1377,11 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
     if (ms) *ms = 0.f;
     if (n_steps == 0) return SF_OK;
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    const bool row_was_fresh = s->status_fresh;      // the result block on the device is current as this call starts
     s->status_fresh = false;
     StepArgs a;
     a.loop_db = nullptr;      // (not the closed loop of sf_loop_start)
+    a.row_valid = 0;
     a.team_recut = 0;
     // (0 ms: a team whose members do not all arrive at its start in the same instant starts as one at once - tests of that path)
     a.team_timeout = 100000ull * (unsigned long long)(s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] == 0 ? 2000 : (s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS] < 1 ? 1 : s->tune.v[SF_TUNE_TEAM_TIMEOUT_MS]));
@@ -1536,6 +1539,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                 wattr = wlds;
             }
             a.todo_out = s->todo; a.order = nullptr;
+            a.row_valid = (row_was_fresh && res_knob) ? 1 : 0;
             // (two counts that take turns, both zero to begin with: every k_win clears the one its successor appends to)
             if (!s->todo_cnt) { int rc0 = dev_alloc(s, &s->todo_cnt, (size_t)16); if (rc0) return rc0; HIPCHK(hipMemsetAsync(s->todo_cnt, 0, 16 * sizeof(uint32_t), s->stream)); }
             a.todo_cnt = s->todo_cnt + (s->win_seq & 1); a.todo_cnt_next = s->todo_cnt + ((s->win_seq + 1) & 1); a.todo_list = s->run_order;      // (the order array: no ordered segments in a call k_win goes in front of)
@@ -1604,6 +1608,9 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
             }
             a.mit = mit_dev ? mit_dev + (size_t)done * s->g.E * mit_k * 3 : nullptr;
             if (res_knob && done + seg == n_steps) { a.res_block = s->status_block; a.res_elapsed = s->elapsed_dev; a.res_sink = s->sink; }
+            // (the block is current for the call's FIRST launch only if it was when the call started - and only that launch may go by it: the
+            // launches before the last one of a call do not write it)
+            a.row_valid = (row_was_fresh && done == 0 && !win_first && res_knob) ? 1 : 0;
             if (use_join) {
                 const int recut = seg_knob >= 4 ? seg_knob / 2 : 2;
                 int rc0 = launch_k_run_join(s, a, seg, jgeo, recut, join_knob < 0);
@@ -1625,7 +1632,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
                                 : launch_k_run_team(s, a, seg, tgeo, team_forced ? tk : (windows ? 1 : tgeo.t_min), team_fixed && !team_forced ? tgeo.t_min : t_max, s->cost_steps);
                 if (rc0) return rc0;
                 if (windows) {
-                    a.todo = s->todo; a.todo_out = nullptr;
+                    a.todo = s->todo; a.todo_out = nullptr; a.row_valid = 0;      // (the launch in front may have changed what the block counts)
                     rc0 = launch_k_run_team(s, a, seg, tgeo, tgeo.t_min, tgeo.t_min, 0, true);
                     if (rc0) return rc0;
                     a.todo = nullptr;
@@ -2178,6 +2185,7 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
         hipLaunchKernelGGL(k_counts_tiles, dim3((unsigned)g.E), dim3(1024), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), s->tdirty, s->thist,
                            (const EnvState *)s->commit, s->status_block, s->elapsed_dev, copy_to ? copy_to : sink2);
         if (copy_to && sink2) HIPCHK(hipMemcpyAsync(sink2, s->status_block, sizeof(int32_t) * 8 * g.E, hipMemcpyDeviceToDevice, s->stream));
+        s->status_fresh = true;            // (the block - and the registered sink's copy - is current until something changes a status byte)
     } else {
         { int rc0 = ensure_rm(s); if (rc0) return rc0; }
         HIPCHK(hipMemsetAsync(s->status_block, 0, sizeof(int32_t) * 8 * g.E, s->stream));
