@@ -15,7 +15,8 @@ NAMES = {15: "step start", 1: "interest+ranks", 2: "list+barrierA", 3: "cursor+n
          20: "win start", 21: "win rows arrived", 22: "win frontier known", 23: "win winners+req", 24: "win table arrived", 25: "win updated", 26: "win at barrier",
          27: "win thru barrier", 28: "win folded", 30: "launch start", 31: "fire found", 32: "window loaded", 33: "updates done", 34: "written back",
          35: "steps done", 36: "handed back", 37: "result block", 41: "slot written", 42: "placed", 43: "loads issued", 44: "LDS filled",
-         45: "cells stored", 46: "bitmap stored", 47: "hist updated", 48: "row written", 49: "state committed"}
+         45: "cells stored", 46: "bitmap stored", 47: "hist updated", 48: "row written", 49: "state committed",
+         50: "lines applied", 51: "next classified", 52: "lines start"}
 
 
 def main():

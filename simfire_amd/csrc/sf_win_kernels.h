@@ -514,13 +514,11 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 const int32_t *pp = mit + (((long long)(s + 1) * g.E + e) * a.mit_k + lane) * 3;
                 *ppx = pp[0]; *ppy = pp[1]; *ppty = pp[2];
             }
-            if (ATT && m_ok && !m_in) {
-                const uint32_t o = (uint32_t)(m_y * g.P + m_x);
-                dma_dword(ev.cells + bl_cell(g, m_y, m_x & ~3) + kBlStatus, wmit_lds);
-                dma_dword(ev.burn + o, wmit_lds + 256u);
-                dma_dword(reinterpret_cast<const char *>(ev.burn + o) + 4, wmit_lds + 512u);
-                dma_dword(ev.settled + o, wmit_lds + 768u);
-            }
+            // (the cell's old TYPE only: its burn_amount and settled count matter where a line of another type is drawn over a line - an agent
+            // crossing another's track, a lane or two in a step now and then -, and are fetched then, behind the barrier; asked for with every
+            // point they were three more scattered lines per point and step through a CU that moves 0.2 ... 1 of them per clock, in front of the
+            // wait the wave's own stores go through: C5's control-line wave came to the end-of-step barrier a thousand clocks behind the walkers)
+            if (ATT && m_ok && !m_in) dma_dword(ev.cells + bl_cell(g, m_y, m_x & ~3) + kBlStatus, wmit_lds);
         }
         uint32_t touch_later = 0;                               // ATT: the lane's new frontier cells of this step (their table lines are asked for behind the barrier)
         // (control lines drawn inside the window in front of this update, if any: the owner lanes take them in phase A)
@@ -624,6 +622,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         }
         pc.note(23);         // list written
         WPROF(0)             // phase A
+        // (Measured and dropped, round 6: the control-line wave asking for the burn_amount / settled count of the few cells whose line gives way
+        // to a line of another type HERE, in front of the barrier, so that its tail finds them there: anything in front of this barrier delays
+        // everybody - C5's 20 updates 71.7 -> 80.1 us.)
         win_barrier<ATT>();
         WPROF(1)             // barrier behind the list
         if (ATT && touch_later) {
@@ -761,6 +762,7 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             if (any_cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;     // FLAG_CAND (fire.py:651)
         }
         if (MITW && mitw && wave == mit_wave) {
+            pc.note(52);     // the control-line wave behind its walk
             // this step's points outside the window (see the top of the step): their cells' old contents have landed in LDS by now
             const bool ok = m_ok && !m_in;
             const int fin = m_fin;
@@ -770,10 +772,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (requests made behind the compiler's back, a phase ago)
                 if (ok) {
                     const volatile uint32_t *mp = wmit;
-                    const uint32_t was = (mp[lane] >> (8 * (m_x & 3))) & 7u, owed_since = mp[192 + lane];
-                    const double bn = __hiloint2double((int)mp[128 + lane], (int)mp[64 + lane]);
+                    const uint32_t was = (mp[lane] >> (8 * (m_x & 3))) & 7u;
                     if (was != (uint32_t)fin) {
-                        if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(bn, line_factor(was), (uint32_t)(st.complete + n_plain) - owed_since);
+                        if (was >= SF_FIRELINE) ev.burn[o] = lazy_sub(ev.burn[o], line_factor(was), (uint32_t)(st.complete + n_plain) - ev.settled[o]);
                         ev.settled[o] = (uint32_t)(st.complete + n_plain);
                         // the result block by difference: this cell leaves one BurnStatus for another (one lane per cell: the step's other points
                         // on it saw the same old type and store the same new one)
@@ -783,7 +784,9 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
             }
             if (ok) *cell = (uint8_t)fin;
             if (ok) ev.tdirty[(m_y >> th_log) * g.TX + ((m_x >> 4) >> g.logLC)] = 1;
+            pc.note(50);     // this step's control lines outside the window applied
             if (s + 1 < n_total) mit_classify(s + 1);      // (its points have arrived by now; patches for the next step)
+            pc.note(51);     // the coming step's points classified
         }
         pc.note(26);         // at the barrier
         WPROF(5)             // rest of phase B
