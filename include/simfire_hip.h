@@ -159,11 +159,11 @@ int sf_get_fire_map(sf_sim *sim, int32_t env, uint8_t *out);
 int sf_get_fire_maps(sf_sim *sim, uint8_t *out /* [n_envs][H*W] */);
 /* The reference mutates ONE host array in place - fire_map is written where a sprite is pruned, a cell ignites or a line is drawn
  * (fire.py:140, 587; mitigation.py:75-78) and handed back by FireSimulation.run (simulation.py:546-553).  A host that keeps its own copy of
- * the map gets the same effect from the cells that CHANGED since it last looked: cells_out[i] = (y * W + x) << 3 | BurnStatus for every cell
- * of environment env that differs from the map this function, sf_get_fire_map(s) or sf_reset (all UNBURNED: the ignition cell is reported)
- * last showed the host; *n_out of them, in no particular order.  *n_out = -1: no reference point yet (first call; sf_load_fire_map in
- * between) or more than cap cells changed - fetch the whole map with sf_get_fire_map.  Either way the current map is the reference point
- * from now on.  (One dense device-side compare, 2 bytes per cell; what crosses PCIe is the list: a run(1) costs the host O(changed cells).) */
+ * the map gets the same effect from the cells that CHANGED since it last asked: cells_out[i] = (y * W + x) << 3 | BurnStatus for every cell
+ * of environment env that differs from the REFERENCE POINT - the map as it was when this function was last called for the environment, or the
+ * all-UNBURNED map of sf_reset (the ignition cell is reported); *n_out of them, in no particular order.  *n_out = -1: no reference point yet
+ * (first call; sf_load_fire_map in between) or more than cap cells changed - fetch the whole map with sf_get_fire_map before anything steps.
+ * Either way the current map is the reference point from now on; sf_get_fire_map(s) never moves it.  (One dense device-side compare, 2 bytes per cell; what crosses PCIe is the list: a run(1) costs the host O(changed cells).) */
 int sf_get_fire_map_delta(sf_sim *sim, int32_t env, uint32_t *cells_out /* [cap] */, int32_t cap, int32_t *n_out);
 int sf_get_burn(sf_sim *sim, int32_t env, double *out);
 int sf_set_burn(sf_sim *sim, int32_t env, const double *burn);

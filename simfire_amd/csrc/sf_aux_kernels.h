@@ -155,7 +155,7 @@ __global__ void k_unpack_f64(int H, int W, int P, const double *pitched, double 
 #endif
 // (cells: the blocked cell plane when it is the current one - sf_common.h, bl_vec - else null)
 #ifndef SF_RUN_UNIT
-// (snap: the reference point of sf_get_fire_map_delta - the map as the host last saw it -, or null: a whole map handed out IS the new reference point)
+// (snap: the reference point of sf_get_fire_map_delta to be set to this map - when that call finds none -, or null)
 __global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cells, int env0, uint8_t *dense, uint8_t *snap)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, i = blockIdx.z;

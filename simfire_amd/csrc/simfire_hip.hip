@@ -1441,7 +1441,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // update on 1024 environments in the driver's window.)  SF_TUNE_RUN_COMPACT = 2: the window kernel in front whatever the batch size (tests).
         win_first = tn.v[SF_TUNE_RUN_WINDOW] != 0 && tn.v[SF_TUNE_RUN_COMPACT] != 0 && (g.E > s->n_cu || tn.v[SF_TUNE_RUN_COMPACT] == 2) && !mit_dev && g.VW == 1 &&
                     g.H >= 64 && g.H <= 1024 && g.PV >= 4 && !g.dense && s->fire_rows > 0 && s->fire_rows <= 62 && n_steps <= 64 && !tn.set[SF_TUNE_RUN_WAVES] &&
-                    g.diag && tn.v[SF_TUNE_RUN_TEAM] <= 1 && s->fused_mode != 2;
+                    g.diag && (tn.v[SF_TUNE_RUN_TEAM] == 0 || tn.v[SF_TUNE_RUN_TEAM] == 1) && s->fused_mode != 2;
         // (the launch behind k_win: while every fire surely ends the call inside 64 rows, 16-wave workgroups - an environment whose fire reached the
         // ring of a window placed to the vector gets a new window of 64 rows around where the fire stands now, 2 us per update instead of the
         // general loop's 6 in an 8-wave workgroup; everybody else's workgroup returns at once)
@@ -1524,7 +1524,7 @@ static int step_impl(sf_sim *s, int n_steps, float *ms, const int32_t *mit_dev =
         // Teams (k_run<TEAM>): forced by sf_set_tuning; always on grids of two-word rows; on one-word rows in long calls, which are then
         // cut into segments like above - the first one runs one workgroup per environment and records what every environment costs,
         // the following ones size the teams from that (k_team_plan) and cut the bands where the fires are by then.
-        const bool team_any = (team_forced || team_wide || team_auto) && bsz == 64;
+        const bool team_any = (team_forced || team_wide || team_auto) && bsz == 64 && !win_first;      // (behind k_win: ONE launch of the plain kernel for what is left - found by the soak, world 6005034: teams sized by cost cut the call into segments, and every segment's launch made the left-over updates again)
         const bool team_segments = team_any && seg_knob > 0 && !balance;
         s->last_team_max = 0;
         bool win_only = false;
@@ -2034,9 +2034,8 @@ static int get_maps(sf_sim *s, int env0, int n, uint8_t *out)
     int rc = ensure_stage(s, bytes);
     if (rc) return rc;
     dim3 blk(256), grd((g.W + 255) / 256, g.H, n);
-    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env0, (uint8_t *)s->stage, s->snap);
+    hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env0, (uint8_t *)s->stage, (uint8_t *)nullptr);
     HIPCHK(hipGetLastError());
-    if (s->snap) for (int i = 0; i < n; ++i) s->snap_valid[env0 + i] = 1;      // (a whole map handed out is the new reference point of sf_get_fire_map_delta)
     HIPCHK(hipMemcpyAsync(out, s->stage, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return check_team_error(s, "sf_get_fire_map(s)");
@@ -2061,10 +2060,12 @@ extern "C" int sf_get_fire_maps(sf_sim *s, uint8_t *out)
     return SF_OK;
 }
 
-/* The cells of environment env whose BurnStatus differs from the map the host last saw - through this function, sf_get_fire_map(s) or sf_reset
- * (whose map is all UNBURNED: the ignition cell is reported) -: cells_out[i] = (y * W + x) << 3 | BurnStatus, *n_out of them, in no particular
- * order.  *n_out = -1: there is no reference point (first call for this environment, or sf_load_fire_map came in between) or more than cap
- * cells changed - fetch the whole map with sf_get_fire_map; either way the current map is the reference point from now on.
+/* The cells of environment env whose BurnStatus differs from the reference point - the map as it was when THIS function was last called for the
+ * environment, or the all-UNBURNED map of sf_reset (the ignition cell is reported) -: cells_out[i] = (y * W + x) << 3 | BurnStatus, *n_out of
+ * them, in no particular order.  *n_out = -1: there is no reference point (first call for this environment, or sf_load_fire_map came in between)
+ * or more than cap cells changed - fetch the whole map with sf_get_fire_map before anything steps; either way the current map is the reference
+ * point from now on.  (sf_get_fire_map itself never moves the reference point: a look at the map for another purpose does not make a mirror
+ * kept from the deltas miss a cell.)
  * The host-side counterpart of the reference's in-place mutation of ONE fire_map array (fire.py:140, 587, 719; simulation.py:546-553). */
 extern "C" int sf_get_fire_map_delta(sf_sim *s, int32_t env, uint32_t *cells_out, int32_t cap, int32_t *n_out)
 {

@@ -182,9 +182,9 @@ class FireEngine:
         return out
 
     def fire_map_delta(self, env=0, cap=4096):
-        """Cells of ``env``'s fire map that changed since the host last saw it (through this call, ``fire_map`` / ``fire_maps`` or ``reset``):
+        """Cells of ``env``'s fire map that changed since this method was last called for it (or since ``reset``, whose map is all UNBURNED):
         (flat indices int64 [n], BurnStatus values uint8 [n]), or ``None`` when there is no reference point or more than ``cap`` cells changed -
-        fetch the whole map then (``sf_get_fire_map_delta``)."""
+        fetch the whole map then, before anything steps (``sf_get_fire_map_delta``; ``fire_map`` / ``fire_maps`` never move the reference point)."""
         buf = getattr(self, "_delta_buf", None)
         if buf is None or buf.shape[0] < cap:
             buf = self._delta_buf = np.empty(int(cap), dtype=np.uint32)

@@ -49,6 +49,12 @@ def world(seed):
     if os.environ.get("SOAK_DEBUG"):
         print("tuning", {k: eng.get_tuning(k) for k in ("run_join", "run_window", "run_waves", "run_segment", "team_placement", "run_team")}, flush=True)
         print("world", seed, "H W E", H, W, E, "md", md, "att diag", att, diag, "fused", eng.get_tuning("run_team"), {k: eng.get_tuning(k) for k in ("run_team", "team_placement", "run_segment", "team_recut")}, flush=True)
+    # round 6 (draws from a stream of their own, so that the worlds of earlier soaks stay the worlds they were): the window kernel k_win in
+    # front of k_run whatever the batch size (two workgroups to a CU; forced: run_compact = 2), and a host mirror of every environment's map
+    # kept from sf_get_fire_map_delta
+    rng2 = np.random.default_rng(seed + 10**9)
+    eng.set_tuning(run_compact=int(rng2.choice([1, 2, 2, 0])))
+    mirror = [None] * E
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
@@ -82,6 +88,8 @@ def world(seed):
             x, y = int(rng.integers(W)), int(rng.integers(H))
             eng.reset_env(e, x, y)
             o.reset_env(e, x, y)
+            if mirror[e] is not None:
+                mirror[e][...] = 0             # (a reset map is the all-UNBURNED map: the reference point of the next delta, include/simfire_hip.h)
         elif r < 0.47:
             eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
         elif r < 0.50:
@@ -175,6 +183,14 @@ def world(seed):
             st, el = eng.status()
             so, eo = o.status()
             assert (st == so).all() and (el == eo).all(), (seed, t, "status")
+        if rng2.random() < 0.5:
+            e = int(rng2.integers(E))
+            d = eng.fire_map_delta(e, cap=int(rng2.choice([4096, 64, 3])))
+            if d is None or mirror[e] is None:
+                mirror[e] = eng.fire_map(e).astype(np.int64)
+            else:
+                mirror[e].reshape(-1)[d[0]] = d[1]
+            assert (mirror[e] == o.fire_map(e)).all(), (seed, t, e, "fire_map mirror kept from the deltas")
         if rng.random() < 0.5 or t == steps - 1:
             for e in range(E):
                 assert (eng.fire_map(e) == o.fire_map(e)).all(), (seed, t, e, "fire_map")

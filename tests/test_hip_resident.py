@@ -1985,12 +1985,14 @@ def test_teams_on_a_chip_that_holds_fewer_workgroups_than_the_host_believes():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [900540, 2000064, 2000357, 2000495, 5007397])
+@pytest.mark.parametrize("seed", [900540, 2000064, 2000357, 2000495, 5007397, 6005034])
 def test_worlds_the_soak_found(seed):
     """Random worlds of tests/soak_gpu.py that once failed, replayed: 900540 - the window phase in a workgroup of one wave (result block by
     difference initialised by 'the first 128 threads'); 2000064 / 2000357 / 2000495 - teams that grow inside the launch on grids with fewer
     tile rows than members; 5007397 - two-word rows with teams sized by cost: the per-environment entry for the host's catch-up launch was
     only written on the way into the loop, so a call whose updates the window phase made left a stale one behind (here: k_front's
-    left-overs in the cross-check build) and the catch-up launch made the update a second time."""
+    left-overs in the cross-check build) and the catch-up launch made the update a second time; 6005034 (round 6) - k_win in front of k_run
+    with teams sized by cost switched on half-way: the call behind k_win was cut into the team rollout's segments, and every segment's launch made
+    the left-over updates again."""
     import soak_gpu
     assert soak_gpu.world(seed) > 0
