@@ -278,7 +278,7 @@ def roofline_block(w, a, kernel_ms, cnt, tile_cells, kind, env_steps, pmc, dense
 
 
 def issue_block(w, a, rl, cost, n_cu=256):
-    """What bounds the resident launch is not HBM but instruction issue on the CUs of the largest fires.
+    """What bounds the resident launch is not HBM but instruction issue on the CUs of the largest fires (NOTEBOOK.md 5.4).
     In-run, from the kernel's own clock stamps (sf_get_run_cost: shader clocks every environment's workgroups spent in
     the timed launch): `cu_balance` = sum(cost) / (max(cost) x min(envs, CUs)) - 1.0 would be every CU busy for the
     whole launch - and the shader clock the launch really ran at (max(cost) / the HIP-event duration; DVFS).  The SQ
@@ -306,7 +306,7 @@ def issue_block(w, a, rl, cost, n_cu=256):
                         "cu_busy_share_note": "sum over environments and members of the clocks spent on them / (slots x launch time x 2.4 GHz): lower bound (the real "
                                               "clock is lower); includes the members' waits for each other; without teams the same figure is cu_balance",
                         "note": "k_run<TEAM = 2>: every environment starts with one workgroup; workgroups whose environment is done join a running "
-                                "environment of their own XCD at that team's next cut inside the launch (DESIGN.md 5.8)"})
+                                "environment of their own XCD at that team's next cut inside the launch (NOTEBOOK.md 5.8)"})
         return blk
     clocks = cost.astype(np.float64) * 16.0
     slots = min(len(cost), n_cu)
@@ -315,7 +315,7 @@ def issue_block(w, a, rl, cost, n_cu=256):
            "clocks_max_env": float(clocks.max()), "clocks_median_env": float(np.median(clocks)),
            "clock_ghz_measured": float(clocks.max() / sec / 1e9),
            "source": "sf_get_run_cost (s_memtime stamps of the timed launch) / HIP-event duration"}
-    # The bound this launch runs against is not bytes but a dependent chain: per update of the window phase - an ignition's bit
+    # The bound this launch runs against is not bytes but a dependent chain (NOTEBOOK.md 5.9): per update of the window phase - an ignition's bit
     # visible to its neighbours' owner (LDS write -> read 64), the new frontier cell known (>= ~20 dependent instructions at ~5 clocks), its place
     # on the list (a returning LDS atomic ~100), a barrier (64), the walker's look at the entry (64) and at the 3 x 3 sprite masks (64), the winner
     # source (>= ~25 dependent instructions), the table entry from the CU's L1 or the XCD's L2 (157 - 241), four f64 operations, a barrier (64):
@@ -323,7 +323,7 @@ def issue_block(w, a, rl, cost, n_cu=256):
     # update of this launch (its fixed part - fire found, window loaded, written back, result block: ~14 k clocks per launch - included).
     if w.name.startswith("c3") and a.steps <= 64:
         blk.update({"chain_bound_clocks": 885.0, "chain_clocks_per_update": float(clocks.max() / a.steps), "chain_frac": float(885.0 * a.steps / clocks.max()),
-                    "chain_bound_source": "profiles/r05_lds_latency_probe.txt + profiles/r03_latency_probe.txt, DESIGN.md 5.9"})
+                    "chain_bound_source": "profiles/r05_lds_latency_probe.txt + profiles/r03_latency_probe.txt, NOTEBOOK.md 5.9"})
         wc = getattr(measure, "warm_cost", None)
         if wc is not None and 0 < a.warmup < a.steps and float(wc.max()) > 0:
             # two launches, two unknowns: clocks = fixed + updates x per-update (the slowest environment of each launch; the warm-up launch is the
@@ -354,7 +354,7 @@ def issue_block(w, a, rl, cost, n_cu=256):
 
 
 def random_access_block(traffic, kernel_ms, n_cu=256, clock_ghz=2.4):
-    """The roofline a scatter of 1 - 16-byte accesses runs against: 64-byte sectors the fabric moved per
+    """The roofline a scatter of 1 - 16-byte accesses runs against (NOTEBOOK.md 5.5): 64-byte sectors the fabric moved per
     clock and CU in the timed launch (PMC traffic of profiles/collect_pmc.sh) next to what profiles/scatter_probe.hip
     measured for every CU touching one line per lane at once (profiles/r02_scatter_probe.txt)."""
     probe = {}

@@ -40,11 +40,11 @@ int sf_set_generic(sf_sim *sim, int32_t on);
  * 0 = always two launches per step, 1 = always one fused launch per step, 2 = always the resident launch
  * (falls back to the per-step launches while the spread graph / history by-products are on or
  * max_fire_duration > 5).  (Rounds 2 - 4 carried two measured alternatives that were never the automatic choice, a tile flavour of the
- * resident launch and a frontier-resident launch `k_front` - modes 3 / 4 of a cross-check build; retired in round 5) */
+ * resident launch and a frontier-resident launch `k_front` - modes 3 / 4 of a cross-check build; retired in round 5, NOTEBOOK.md 5.5.) */
 int sf_set_fused(sf_sim *sim, int32_t mode);
 
 /* Launch-geometry knobs of a handle.  RESULTS NEVER DEPEND ON THEM (the tests force several values of each against the
- * oracle); the defaults are the measured choices of DESIGN.md section 5.  This is the only way to change them: the
+ * oracle); the defaults are the measured choices of NOTEBOOK.md section 5.  This is the only way to change them: the
  * library does not read the environment (the Python laboratory binding, simfire_amd/engine.py, turns SF_TUNE_* variables into
  * calls of this function when SF_DEBUG_KNOBS=1 is set - for the measurement scripts under profiles/).  No reference counterpart
  * (the reference has no launch geometry). */
@@ -64,7 +64,7 @@ enum sf_tuning_knob {
                                  * environment's bitmaps (one member with a window of rows while a call ends with every fire surely young -
                                  * the library keeps an upper bound on the fires' extent since the last reset -, two and more after that),
                                  * and - sized by cost, in long calls - where two to a quarter as many environments as CUs leave most of the
-                                 * chip idle; one workgroup per environment otherwise (measured faster);
+                                 * chip idle; one workgroup per environment otherwise (measured faster, NOTEBOOK.md 5.6);
                                  * 1 = never; 2 / 3 / 4 = every environment split into exactly that many (tests);
                                  * -1 = teams of 1..4 sized from what the environments cost in the launch before, on any grid */
     SF_TUNE_TEAM_PLACEMENT = 9,/* where the members of a team sit: 0 = the workgroup slots of one XCD (default: their per-step hand-off stays in one L2),
@@ -114,7 +114,7 @@ int sf_get_team_fallbacks(sf_sim *sim, int32_t *n_out);
 int sf_get_tuning(sf_sim *sim, int32_t knob, int32_t *value_out);
 /* Which launch structure the last sf_step / sf_step_timed call used: 0 = k_select + k_step per step, 1 = one fused
  * launch per step, 2 = one environment-resident launch (k_run), 3 = per-cell kernel, 4 = the window kernel k_win in front of k_run (more
- * environments than CUs while their fires are young: two workgroups to a CU), -1 = none yet.  (4 - 6 once were the numbers of
+ * environments than CUs while their fires are young: two workgroups to a CU; NOTEBOOK.md 5.12), -1 = none yet.  (4 - 6 once were the numbers of
  * structures retired in round 5.) */
 int sf_last_step_launch(sf_sim *sim, int32_t *kind_out);
 /* 1 = visit every tile every step instead of consulting the tile activity map (cross-check) */

@@ -1,5 +1,5 @@
 // Development aid: dependent-load latency of one wave on MI355X, in shader clocks (s_memtime), by working-set size.
-// Calibrates the "memory round trip" figures of DESIGN.md 5.x.   hipcc --offload-arch=gfx950 -O3 -o /tmp/latency_probe profiles/latency_probe.hip
+// Calibrates the "memory round trip" figures of NOTEBOOK.md 5.x.   hipcc --offload-arch=gfx950 -O3 -o /tmp/latency_probe profiles/latency_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 // Probe (development aid): what the dependent chain of a window step is made of, in shader clocks on one CU with a 16-wave workgroup
 // resident (the window phase's situation): a dependent LDS read, a returning LDS atomic, a workgroup barrier (all 16 waves arriving
 // together; one wave arriving late by a fixed amount of work), a dependent VALU instruction.  These are the terms of
-// roofline.chain_bound_clocks (bench.py).
+// roofline.chain_bound_clocks (bench.py, NOTEBOOK.md 5.9).
 // build + run:  hipcc --offload-arch=gfx950 -O2 -o /tmp/lds_latency_probe profiles/lds_latency_probe.hip && /tmp/lds_latency_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>

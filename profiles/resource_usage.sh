@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 echo "# kernel resource usage, product build (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage), round 5"
 echo "# $(/opt/rocm/bin/hipcc --version | grep 'HIP version')"
 echo "# k_run<MAXD, ATT, DIAG, MIT, TEAM>: MIT 0 = sf_step (with the window phase where MAXD <= 2, TEAM != 2), -1 = sf_step_mitigated, -2 = the closed loop;"
-echo "#   TEAM 1 = teams of a size fixed for the launch, 2 = teams that grow inside the launch (DESIGN.md 5.8)"
+echo "#   TEAM 1 = teams of a size fixed for the launch, 2 = teams that grow inside the launch (NOTEBOOK.md 5.8)"
 echo "# The argument block: by value in k_run<*, *, *, 0, 0>, <2, *, *, *, 1>, <*, *, *, -2, *>, <*, *, *, *, 2>; read through the kernel-argument segment in the others (sf_run_kernels.h)"
 echo "# translation unit | kernel | VGPRs | SGPRs | SGPR spills | VGPR spills | scratch B/lane | waves/SIMD"
 echo

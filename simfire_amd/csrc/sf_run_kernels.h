@@ -42,7 +42,7 @@ namespace {
 // is enough); inside a step the update is in place, like in the tiled kernels: concurrent writers only touch
 // the two mask slots (t and t - md - 2) that every reader masks out, and a vector is written only by the wave
 // that holds it in its batch.
-// What bounds it: the busiest CUs are bound by instruction issue - ~950 instructions per batch
+// What bounds it (NOTEBOOK.md 5.4): the busiest CUs are bound by instruction issue - ~950 instructions per batch
 // of 64 vectors and their ~70 frontier cells - not by memory; a young fire's step is one wave's dependent chain.
 // The tile activity map / seam planes of the per-step kernels are not maintained here (the host rebuilds
 // them when it switches back), the vector bitmaps are not maintained there (k_rebuild_vbits).
@@ -213,7 +213,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
                 // These byte stores follow the 16-byte stores of the vector pass to the same lines.  What orders them: on gfx9-class
                 // hardware loads and stores share ONE in-order completion counter (vmcnt; a store leaves it when its data has been
                 // written to the L2 - the compiler's own wait-count model for this target relies on the same fact, and it is why a
-                // wait for a load here also waits for every earlier store).  The decision `bn > pixel_scale` above
+                // wait for a load here also waits for every earlier store, NOTEBOOK.md 5.4).  The decision `bn > pixel_scale` above
                 // depends on c.bn, a load issued AFTER the vector pass's stores: the wait in front of it has retired them.  Evidence
                 // besides the argument: profiles/store_order_probe.hip (0 of 5.2e9 inverted), the soak runs, and the
                 // -DSF_STORE_ORDER_WAIT build (explicit wait; test_store_order_wait_build runs both).
@@ -380,9 +380,9 @@ __device__ __forceinline__ uint4 find_team(const JoinArgs a, uint32_t *sc)
 // the whole rollout is one launch - a rollout cut into launches lasts the SUM of the launches' slowest environments): every team_recut
 // steps the members cut their bands anew - each writes its bitmap rows back and releases (agent scope) before that step's granule, acquires
 // behind the wait for everybody's, cuts the bands from the global bitmap as the prologue does, loads its new band and halo rows, and
-// lines up once more before anyone writes again (cut_bands / load_band / store_band below).
+// lines up once more before anyone writes again (cut_bands / load_band / store_band below; NOTEBOOK.md 5.6).
 //
-// TEAM = 2: teams that GROW inside the launch (one-word rows, no control lines inside the launch, no window phase).  Every
+// TEAM = 2: teams that GROW inside the launch (NOTEBOOK.md 5.8; one-word rows, no control lines inside the launch, no window phase).  Every
 // environment starts with one workgroup; the kernel's body is a loop over ASSIGNMENTS: a workgroup whose environment is done (or whose slot
 // had none) looks for a running environment of its own XCD to join (find_team above), is taken in at that team's next cut - the cuts of
 // TEAM = 1, every team_recut updates, at which member 0 also looks who has put a name down and tells the team its new size with its granule -
@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
 }
 
 // k_win: the window phase as a kernel of its own, for batches of MORE ENVIRONMENTS THAN CUs while their fires are young.
-// A window step is a chain of dependent instructions (VALU issue 0.3, two thirds of the wave-cycles waiting: DESIGN.md 5.9), so two
+// A window step is a chain of dependent instructions (VALU issue 0.3, two thirds of the wave-cycles waiting: NOTEBOOK.md 5.9), so two
 // environments on one CU should step almost as fast as one - but k_run's workgroup takes 132 KB of LDS and 106 - 125 VGPRs (the general loop's
 // bitmaps, list and strips; its registers), one to a CU.  The window code alone needs 63 VGPRs and 69 KB: TWO 16-wave workgroups to a CU, eight
 // waves to a SIMD.  Every environment makes as many of the call's updates as its fire stays inside a window and notes what is left

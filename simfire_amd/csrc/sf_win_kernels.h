@@ -9,7 +9,7 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // A young fire's step on the general path of k_run is ONE wave's dependent chain of ~1 800 instructions (interest sweep over all
-// bitmap rows, a list, a batch of vectors, a walk) whatever the size of the fire: 12 k clocks per update while
+// bitmap rows, a list, a batch of vectors, a walk; NOTEBOOK.md 5.6) whatever the size of the fire: 12 k clocks per update while
 // fifteen waves wait at a barrier.  As long as the whole fire fits a WINDOW of (threads / 16) rows x 64 cells, the workgroup
 // instead keeps the window ON THE CU for as many steps as it stays inside - sprite masks and burn_amounts in LDS, status bytes in
 // registers:

@@ -92,7 +92,7 @@ extern "C" const char *sf_version(void) { return "simfire_hip 0.2 (gfx950)"; }  
 #include "sf_run_kernels.h"
 
 // Launch-geometry knobs of a handle (sf_set_tuning, include/simfire_hip_lab.h: SF_TUNE_*).  Results never depend on them; the
-// defaults are the measured choices of DESIGN.md 5.  The library does not read the environment for them (the measurement scripts under
+// defaults are the measured choices of NOTEBOOK.md 5.  The library does not read the environment for them (the measurement scripts under
 // profiles/ set them through the Python binding, simfire_amd/engine.py: SF_DEBUG_KNOBS).
 struct Tuning {
     int v[SF_TUNE_COUNT];

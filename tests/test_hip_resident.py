@@ -1030,7 +1030,7 @@ def test_mitigated_rollout_equals_update_mitigation_run_pairs(mode, att, K):
 @pytest.mark.parametrize("mode", [-1, 2, 0])
 def test_agents_back_on_their_own_lines_keep_owing_under_the_same_factor(mode):
     """Attenuation mode: a line redrawn in ITS OWN type - an agent walking back and forth on its track, what a random walk does all the
-    time - is not settled again inside the resident launch (k1 + k2 subtractions are k1 and then k2); a line
+    time - is not settled again inside the resident launch (k1 + k2 subtractions are k1 and then k2, NOTEBOOK.md 5.1); a line
     redrawn in ANOTHER type is.  Agents that oscillate between two cells, agents that cross each other's tracks in other types,
     two agents of different types on one cell in one step - with a fire that reaches the lines (the walk then needs the exact
     burn value) - against the oracle's eager subtraction, burn_amounts bit for bit every few steps."""
