@@ -165,6 +165,11 @@ int sf_get_fire_maps(sf_sim *sim, uint8_t *out /* [n_envs][H*W] */);
  * (first call; sf_load_fire_map in between) or more than cap cells changed - fetch the whole map with sf_get_fire_map before anything steps.
  * Either way the current map is the reference point from now on; sf_get_fire_map(s) never moves it.  (One dense device-side compare, 2 bytes per cell; what crosses PCIe is the list: a run(1) costs the host O(changed cells).) */
 int sf_get_fire_map_delta(sf_sim *sim, int32_t env, uint32_t *cells_out /* [cap] */, int32_t cap, int32_t *n_out);
+/* FireSimulation.run(n) as ONE call and ONE wait (simulation.py:501-553: the loop of update() calls, then what the caller reads - fire_map,
+ * elapsed_steps, elapsed_time, active): sf_step(n_steps), environment env's row of the result block (as sf_get_status) and its elapsed_time, and
+ * the cells of its fire_map that changed (as sf_get_fire_map_delta; *n_out = -1: fetch the whole map) - enqueued behind each other, waited for once. */
+int sf_run_delta(sf_sim *sim, int32_t n_steps, int32_t env, int32_t *status_row /* [8] */, double *elapsed_time /* [1] or NULL */,
+                 uint32_t *cells_out /* [cap] */, int32_t cap, int32_t *n_out);
 int sf_get_burn(sf_sim *sim, int32_t env, double *out);
 int sf_set_burn(sf_sim *sim, int32_t env, const double *burn);
 

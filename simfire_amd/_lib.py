@@ -55,6 +55,7 @@ SIGNATURES = {
     "sf_get_fire_map": [_VP, _I32, _VP],
     "sf_get_fire_maps": [_VP, _VP],
     "sf_get_fire_map_delta": [_VP, _I32, _VP, _I32, C.POINTER(_I32)],
+    "sf_run_delta": [_VP, _I32, _I32, _VP, _VP, _VP, _I32, C.POINTER(_I32)],
     "sf_get_burn": [_VP, _I32, _VP],
     "sf_set_burn": [_VP, _I32, _VP],
     "sf_get_status": [_VP, _VP, _VP],

@@ -173,9 +173,15 @@ __global__ void k_unpack_status(Geo g, const uint8_t *status, const uint8_t *cel
 // cell that differs to out[1 ...] (out[0] = how many there are, also beyond cap) and brings the reference point up to date.
 // A dense sweep of 2 bytes per cell - 2 MB at 1024 x 1024, a microsecond of HBM time; what crosses PCIe is the list.
 #ifndef SF_RUN_UNIT
-__global__ __launch_bounds__(256) void k_map_delta(Geo g, const uint8_t *status, const uint8_t *cells, int e, uint8_t *snap, uint32_t *out, int cap)
+constexpr int kDeltaHead = 11;      // words in front of the list: the count, a result row, its elapsed_time
+// (out[0] counts on from launch to launch - base is what it stood at before this one -, so that nothing has to zero it: a fill launch in front
+// of every query cost the stream 4 us)
+__global__ __launch_bounds__(256) void k_map_delta(Geo g, const uint8_t *status, const uint8_t *cells, int e, uint8_t *snap, uint32_t *out, int cap, uint32_t base,
+                                                   const int32_t *row, const double *el)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (row && y == 0 && v < 10)       // sf_run_delta: the environment's row of the result block and its elapsed_time travel with the count (one copy)
+        out[1 + v] = v < 8 ? (uint32_t)row[v] : reinterpret_cast<const uint32_t *>(el)[v - 8];
     if (v >= g.PV) return;
     const uint8_t *src = cells ? cells + (long long)e * g.cells_env + bl_vec(g, y, v) + (y & 1) * 16 + kBlStatus
                                : status + (long long)e * g.plane_env + (long long)y * g.P + v * 16;
@@ -190,11 +196,11 @@ __global__ __launch_bounds__(256) void k_map_delta(Geo g, const uint8_t *status,
     const int x0 = v * 16;
     if (x0 + 16 > g.W) m16 &= (1u << (g.W - x0)) - 1u;          // (pitch padding is no cell)
     if (!m16) return;
-    uint32_t pos = atomicAdd(out, (uint32_t)__popc(m16));
+    uint32_t pos = atomicAdd(out, (uint32_t)__popc(m16)) - base;
     while (m16) {
         const int b = __ffs(m16) - 1;
         m16 &= m16 - 1;
-        if (pos < (uint32_t)cap) out[1 + pos] = ((uint32_t)(y * g.W + x0 + b) << 3) | ((pick(now, b >> 2) >> (8 * (b & 3))) & 7u);
+        if (pos < (uint32_t)cap) out[kDeltaHead + pos] = ((uint32_t)(y * g.W + x0 + b) << 3) | ((pick(now, b >> 2) >> (8 * (b & 3))) & 7u);
         ++pos;
     }
 }

@@ -199,6 +199,7 @@ struct sf_sim {
     std::vector<char> snap_valid;
     uint32_t *delta_dev = nullptr, *delta_pinned = nullptr;
     int delta_cap = 0;
+    uint32_t delta_base = 0;           // what the list's count stood at after the last query (it counts on: nothing zeroes it)
     int32_t *status_block = nullptr;   // [E][8]
     double *elapsed_dev = nullptr;     // [E]
     void *stage = nullptr;             // dense staging for host copies
@@ -2067,12 +2068,11 @@ extern "C" int sf_get_fire_maps(sf_sim *s, uint8_t *out)
  * point from now on.  (sf_get_fire_map itself never moves the reference point: a look at the map for another purpose does not make a mirror
  * kept from the deltas miss a cell.)
  * The host-side counterpart of the reference's in-place mutation of ONE fire_map array (fire.py:140, 587, 719; simulation.py:546-553). */
-extern "C" int sf_get_fire_map_delta(sf_sim *s, int32_t env, uint32_t *cells_out, int32_t cap, int32_t *n_out)
+// the buffers of the delta query; the launch of k_map_delta (or, without a reference point, of the snapshot) on the handle's stream.  *mode: 0 = the list
+// is on its way into delta_pinned, 1 = no reference point (the current map has become it): the caller fetches the whole map
+static int delta_enqueue(sf_sim *s, int env, int cap, int *mode, bool with_row = false)
 {
-    if (!s || !n_out || cap < 0 || (cap > 0 && !cells_out)) return fail(SF_EINVAL, "sf_get_fire_map_delta: bad argument");
     const Geo &g = s->g;
-    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_fire_map_delta: environment %d out of range", env);
-    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
     constexpr int kInline = 1024;      // entries that travel with the count (one copy, one wait)
     if (!s->snap) {
         int rc = dev_alloc(s, &s->snap, (size_t)g.E * g.plane_env);
@@ -2084,12 +2084,12 @@ extern "C" int sf_get_fire_map_delta(sf_sim *s, int32_t env, uint32_t *cells_out
         if (s->delta_dev) { HIPCHK(hipFree(s->delta_dev)); s->delta_dev = nullptr; }
         if (s->delta_pinned) { HIPCHK(hipHostFree(s->delta_pinned)); s->delta_pinned = nullptr; }
         const int c = cap > kInline ? cap : kInline;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->delta_dev), ((size_t)c + 1) * sizeof(uint32_t)));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->delta_pinned), ((size_t)c + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->delta_dev), ((size_t)c + kDeltaHead) * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->delta_pinned), ((size_t)c + kDeltaHead + 16) * sizeof(uint32_t), hipHostMallocDefault));      // (+ 16: a row that could not travel with a list, sf_run_delta)
+        HIPCHK(hipMemsetAsync(s->delta_dev, 0, sizeof(uint32_t), s->stream));
         s->delta_cap = c;
+        s->delta_base = 0;
     }
-    if (s->last_was_step1) { s->last_was_step1 = false; if (s->step1_polls < 1000) s->step1_polls++; }      // (a look at the result of a single update, like a status query)
-    uint8_t *snap_e = s->snap + (size_t)env * g.plane_env;
     if (!s->snap_valid[env]) {
         // no reference point: the current map becomes it, the caller fetches the whole map
         dim3 blk(256), grd((g.W + 255) / 256, g.H, 1);
@@ -2097,27 +2097,83 @@ extern "C" int sf_get_fire_map_delta(sf_sim *s, int32_t env, uint32_t *cells_out
         if (rc) return rc;
         hipLaunchKernelGGL(k_unpack_status, grd, blk, 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env, (uint8_t *)s->stage, s->snap);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s->stream));
         s->snap_valid[env] = 1;
-        *n_out = -1;
-        return check_team_error(s, "sf_get_fire_map_delta");
+        *mode = 1;
+        return SF_OK;
     }
-    HIPCHK(hipMemsetAsync(s->delta_dev, 0, sizeof(uint32_t), s->stream));
     hipLaunchKernelGGL(k_map_delta, dim3((g.PV + 255) / 256, g.H), dim3(256), 0, s->stream, g, (const uint8_t *)s->status, (const uint8_t *)(s->bl_cur ? s->cells : nullptr), env,
-                       snap_e, s->delta_dev, cap);
+                       s->snap + (size_t)env * g.plane_env, s->delta_dev, cap, s->delta_base,
+                       with_row ? (const int32_t *)(s->status_block + (size_t)env * 8) : nullptr, (const double *)(s->elapsed_dev + env));
     HIPCHK(hipGetLastError());
     const int first = cap < kInline ? cap : kInline;
-    HIPCHK(hipMemcpyAsync(s->delta_pinned, s->delta_dev, ((size_t)first + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    const uint32_t n = s->delta_pinned[0];
-    if (n > (uint32_t)cap) { *n_out = -1; return check_team_error(s, "sf_get_fire_map_delta"); }      // (the reference point is current: the caller fetches the whole map)
+    HIPCHK(hipMemcpyAsync(s->delta_pinned, s->delta_dev, ((size_t)first + kDeltaHead) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    *mode = 0;
+    return SF_OK;
+}
+// behind the wait for the stream: the list out of the landing zone (a second copy if it is longer than what travelled with the count)
+static int delta_finish(sf_sim *s, int cap, uint32_t *cells_out, int32_t *n_out)
+{
+    constexpr int kInline = 1024;
+    const int first = cap < kInline ? cap : kInline;
+    const uint32_t n = s->delta_pinned[0] - s->delta_base;
+    s->delta_base = s->delta_pinned[0];
+    if (n > (uint32_t)cap) { *n_out = -1; return SF_OK; }      // (the reference point is current: the caller fetches the whole map)
     if (n > (uint32_t)first) {
-        HIPCHK(hipMemcpyAsync(s->delta_pinned + 1 + first, s->delta_dev + 1 + first, ((size_t)n - first) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->delta_pinned + kDeltaHead + first, s->delta_dev + kDeltaHead + first, ((size_t)n - first) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
     }
-    if (n) memcpy(cells_out, s->delta_pinned + 1, (size_t)n * sizeof(uint32_t));
+    if (n) memcpy(cells_out, s->delta_pinned + kDeltaHead, (size_t)n * sizeof(uint32_t));
     *n_out = (int32_t)n;
+    return SF_OK;
+}
+
+extern "C" int sf_get_fire_map_delta(sf_sim *s, int32_t env, uint32_t *cells_out, int32_t cap, int32_t *n_out)
+{
+    if (!s || !n_out || cap < 0 || (cap > 0 && !cells_out)) return fail(SF_EINVAL, "sf_get_fire_map_delta: bad argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_get_fire_map_delta: environment %d out of range", env);
+    HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
+    if (s->last_was_step1) { s->last_was_step1 = false; if (s->step1_polls < 1000) s->step1_polls++; }      // (a look at the result of a single update, like a status query)
+    int mode = 0;
+    { int rc = delta_enqueue(s, env, cap, &mode); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (mode == 1) *n_out = -1;
+    else { int rc = delta_finish(s, cap, cells_out, n_out); if (rc) return rc; }
     return check_team_error(s, "sf_get_fire_map_delta");
+}
+
+static int update_status_async(sf_sim *s, int32_t *copy_to);
+/* FireSimulation.run(n) as ONE call and ONE wait (simulation.py:501-553: the loop of update() calls, then the attributes a caller reads - fire_map,
+ * elapsed_steps, elapsed_time, active): sf_step(n_steps) on every environment of the handle, then environment env's row of the result block
+ * (sf_get_status), its elapsed_time and the cells of its fire_map that changed (sf_get_fire_map_delta) - three calls' worth of launches and copies
+ * enqueued behind each other, waited for once.  *n_out as for sf_get_fire_map_delta (-1: fetch the whole map). */
+extern "C" int sf_run_delta(sf_sim *s, int32_t n_steps, int32_t env, int32_t *status_row, double *elapsed, uint32_t *cells_out, int32_t cap, int32_t *n_out)
+{
+    if (!s || !status_row || !n_out || cap < 0 || (cap > 0 && !cells_out)) return fail(SF_EINVAL, "sf_run_delta: bad argument");
+    const Geo &g = s->g;
+    if (env < 0 || env >= g.E) return fail(SF_EINVAL, "sf_run_delta: environment %d out of range", env);
+    const bool was_async = s->async;
+    s->async = true;                               // (the steps are only enqueued: the one wait is below)
+    int rc = step_impl(s, n_steps, nullptr);
+    s->async = was_async;
+    if (rc) return rc;
+    rc = update_status_async(s, nullptr);          // (nothing to launch behind a resident launch: it has left the block behind itself)
+    if (rc) return rc;
+    int mode = 0;
+    rc = delta_enqueue(s, env, cap, &mode, true);
+    if (rc) return rc;
+    uint32_t *land = s->delta_pinned + 1;          // the row and its elapsed_time have travelled with the list's count ...
+    if (mode == 1) {                               // ... unless there was no list
+        land = s->delta_pinned + s->delta_cap + kDeltaHead;
+        HIPCHK(hipMemcpyAsync(land, s->status_block + (size_t)env * 8, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(land + 8, s->elapsed_dev + env, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    memcpy(status_row, land, 8 * sizeof(int32_t));
+    if (elapsed) memcpy(elapsed, land + 8, sizeof(double));
+    if (mode == 1) *n_out = -1;
+    else { rc = delta_finish(s, cap, cells_out, n_out); if (rc) return rc; }
+    return check_team_error(s, "sf_run_delta");
 }
 
 extern "C" int sf_get_burn(sf_sim *s, int32_t env, double *out)
@@ -2166,7 +2222,7 @@ extern "C" int sf_set_burn(sf_sim *s, int32_t env, const double *burn)
     return SF_OK;
 }
 
-static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
+static int update_status_async(sf_sim *s, int32_t *copy_to)
 {
     const Geo &g = s->g;
     HIPCHK(hipSetDevice(s->p.device)); LOOP_QUIESCE(s);
@@ -2206,7 +2262,7 @@ static int update_status_async(sf_sim *s, int32_t *copy_to = nullptr)
 extern "C" int sf_update_status_device(sf_sim *s)
 {
     if (!s) return fail(SF_EINVAL, "sf_update_status_device: null handle");
-    int rc = update_status_async(s);
+    int rc = update_status_async(s, nullptr);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     return SF_OK;
@@ -2215,7 +2271,7 @@ extern "C" int sf_update_status_device(sf_sim *s)
 extern "C" int sf_get_status(sf_sim *s, int32_t *status, double *elapsed)
 {
     if (!s || !status) return fail(SF_EINVAL, "sf_get_status: null argument");
-    int rc = update_status_async(s);
+    int rc = update_status_async(s, nullptr);
     if (rc) return rc;
     const size_t nb_st = sizeof(int32_t) * 8 * s->g.E, nb_el = sizeof(double) * s->g.E;
     if (!s->status_pinned) HIPCHK(hipHostMalloc(&s->status_pinned, nb_st + nb_el, hipHostMallocDefault));
@@ -2359,7 +2415,7 @@ extern "C" int sf_allgather_status(sf_sim *s, void *device_out)
 {
     if (!s || !device_out) return fail(SF_EINVAL, "sf_allgather_status: null argument");
     if (!s->comm) return fail(SF_ESTATE, "sf_allgather_status: call sf_comm_init first");
-    int rc = update_status_async(s);                // the block of this rank's shard (fresh already after a resident launch)
+    int rc = update_status_async(s, nullptr);                // the block of this rank's shard (fresh already after a resident launch)
     if (rc) return rc;
     // on the handle's stream: behind the steps in flight and the refresh, no host wait in between
     RCCLCHK(g_rccl.AllGather(s->status_block, device_out, (size_t)8 * s->g.E, ncclInt32, s->comm, s->stream));

@@ -195,6 +195,23 @@ class FireEngine:
         cells = buf[:n.value]
         return (cells >> 3).astype(np.int64), (cells & 7).astype(np.uint8)
 
+    def run_delta(self, n, env=0, cap=4096):
+        """``step(n)``, environment ``env``'s result row and elapsed_time, and the cells of its fire map that changed - one call, one wait
+        (``sf_run_delta``).  Returns (row int32 [8], elapsed_time float, delta as ``fire_map_delta`` returns it)."""
+        buf = getattr(self, "_delta_buf", None)
+        if buf is None or buf.shape[0] < cap:
+            buf = self._delta_buf = np.empty(int(cap), dtype=np.uint32)
+        row = getattr(self, "_row_buf", None)
+        if row is None:
+            row = self._row_buf = np.zeros(8, dtype=np.int32)
+            self._el_buf = np.zeros(1, dtype=np.float64)
+        n_out = C.c_int32(0)
+        self._chk(self._L.sf_run_delta(self._h, int(n), int(env), _ptr(row), _ptr(self._el_buf), _ptr(buf), int(cap), C.byref(n_out)))
+        if n_out.value < 0:
+            return row, float(self._el_buf[0]), None
+        cells = buf[:n_out.value]
+        return row, float(self._el_buf[0]), ((cells >> 3).astype(np.int64), (cells & 7).astype(np.uint8))
+
     def burn(self, env=0):
         out = np.empty((self.H, self.W), dtype=np.float64)
         self._chk(self._L.sf_get_burn(self._h, int(env), _ptr(out)))

@@ -317,11 +317,12 @@ class FireSimulation:
             self._engine.load_fire_map(0, plain)
             self._map_flag.dirty = False
 
-    def _refresh_map(self) -> None:
+    def _refresh_map(self, delta="ask") -> None:
         """The host mirror after device updates: only the cells that changed cross PCIe (``sf_get_fire_map_delta``); the whole map when
         there is no reference point or too much changed (a long ``run``)."""
         plain = self._fire_map.view(np.ndarray)
-        delta = self._engine.fire_map_delta(0)
+        if isinstance(delta, str):
+            delta = self._engine.fire_map_delta(0)
         if delta is None:
             plain[...] = self._engine.fire_map(0)
         elif len(delta[0]):
@@ -337,14 +338,15 @@ class FireSimulation:
                 from .savedata import validate
                 validate(self.config.simulation.data_type)      # (raises before the device is stepped)
                 self._run_saving(before, total)
+                st, el = self._engine.status()
+                row, elapsed, delta = st[0], float(el[0]), "ask"
             else:
-                self._engine.step(total)
-            st, el = self._engine.status()
-            self._steps_done = int(st[0, 1])
+                row, elapsed, delta = self._engine.run_delta(total)      # the updates, the result row and the changed cells: one call, one wait
+            self._steps_done = int(row[1])
             self.elapsed_steps += self._steps_done - before
-            self.elapsed_time = float(el[0])
-            self.fire_status = GameStatus.RUNNING if st[0, 0] else GameStatus.QUIT
-            self._refresh_map()
+            self.elapsed_time = elapsed
+            self.fire_status = GameStatus.RUNNING if row[0] else GameStatus.QUIT
+            self._refresh_map(delta)
         self.active = self.fire_status == GameStatus.RUNNING
         return self.fire_map, self.active
 

@@ -545,6 +545,55 @@ def test_fire_map_delta_keeps_a_host_mirror_equal_to_the_whole_map():
     eng.close()
 
 
+def test_run_delta_is_step_status_and_delta_in_one_call():
+    """sf_run_delta = sf_step + sf_get_status (one row) + sf_get_fire_map_delta, waited for once: a twin handle driven by the three separate
+    calls sees the same rows, elapsed_time and changed cells at every tick - single updates (per-step kernels, then resident launches once the
+    caller is seen to poll), longer runs, control lines in between, no reference point (None), a cap too small (None), past the end of the fire."""
+    from simfire_amd.engine import FireEngine
+    from simfire_amd.parameters import fuel_planes
+    rng = np.random.default_rng(78)
+    H, W, E = 70, 100, 2
+    codes = rng.choice([1, 2, 4, 5, 8, 9, 10, 98], size=(H, W))
+    layers = (*fuel_planes(codes), rng.uniform(0, 50, (H, W)), rng.uniform(300, 2500, (H, W)), rng.uniform(0, 360, (H, W)))
+    engs = []
+    for _ in range(2):
+        eng = FireEngine((H, W), n_envs=E, max_fire_duration=5, pixel_scale=30.0, update_rate=1.0, attenuate_line_ros=True, M_f=0.03)
+        eng.set_layers(*layers)
+        eng.reset([(50, 35), (10, 10)])
+        engs.append(eng)
+    one, three = engs
+    for e in (0, 1):
+        assert three.fire_map_delta(e) is None
+    row, el, d = one.run_delta(0, env=1)                       # no reference point yet: the whole map is to be fetched
+    assert d is None and row[1] == 0
+    row, el, d = one.run_delta(0, env=0)
+    assert d is None
+    seen = 0
+    for t in range(60):
+        n = (1, 1, 1, 3, 1, 17)[t % 6] if t < 50 else 400      # (the last ticks run past the end of the fire)
+        e = t % 2 if t > 10 else 0
+        cap = 3 if t == 30 else 4096
+        if t % 9 == 4:
+            rows = [(int(rng.integers(2)), int(rng.integers(W)), int(rng.integers(H)), int(rng.integers(3, 6))) for _ in range(7)]
+            one.apply_mitigation(rows); three.apply_mitigation(rows)
+        row, el, d = one.run_delta(n, env=e, cap=cap)
+        three.step(n)
+        st, els = three.status()
+        d3 = three.fire_map_delta(e, cap)
+        assert (row == st[e]).all() and el == els[e], t
+        assert (d is None) == (d3 is None), t
+        if d is not None:
+            o, o3 = np.argsort(d[0]), np.argsort(d3[0])
+            assert (d[0][o] == d3[0][o3]).all() and (d[1][o] == d3[1][o3]).all(), t
+            seen += len(d[0])
+    assert seen > 500
+    assert (one.fire_map(0) == three.fire_map(0)).all() and (one.fire_map(1) == three.fire_map(1)).all()
+    with pytest.raises(ValueError):
+        one.run_delta(1, env=E)
+    for eng in engs:
+        eng.close()
+
+
 def test_simulation_fire_map_is_one_array_mutated_in_place_and_edits_are_taken_over():
     """simulation.py:546-553 / fire.py:140, 587, 719: ``run`` hands back the SAME array, mutated in place; what a caller writes into it
     (item assignment, a view, np.copyto, an in-place operator) is taken over by the next run like the reference's manager sees it; a new
