@@ -3,6 +3,9 @@
 // Replaces n calls of RothermelFireManager.update, simfire/game/managers/fire.py:616-719, per environment.
 #pragma once
 
+#ifndef SF_LOOP_ABL
+#define SF_LOOP_ABL 0      // (development: ablations of the closed loop, profiles/ab_loop.sh)
+#endif
 #include "sf_common.h"
 #include "sf_step_kernels.h"
 
@@ -108,6 +111,7 @@ struct RunEnv {                    // per-environment bases (wave-uniform)
     unsigned long long *vb;        // LDS bitmap [H][VW]
     unsigned long long *vf, *vl;   // one-word rows only: the vector's first / last cell holds a sprite bit (else null)
     uint8_t *tdirty;               // [TY][TX] of this environment: status histogram of the wave tile is stale
+    int32_t *tot;                  // the closed loop (run_walk<.., CNT = 1>): the environment's cells per BurnStatus [6] in LDS, kept up by difference
 };
 
 // The walk: frontier cells of a batch, one (or two) per lane and pass.  There is no list: walker j finds its cell itself.
@@ -127,7 +131,7 @@ struct WalkCell {
     double bn, r_tab;
 };
 
-template <int ATT>
+template <int ATT, int CNT = 0>
 __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev, const Masks &mk, int complete,
                                             uint32_t lo_mask, uint32_t hi_mask, const uint32_t *strips,
                                             uint32_t pend, int lane, int th_log, PhaseClock &pc,
@@ -230,6 +234,7 @@ __device__ __forceinline__ WalkAcc run_walk(const StepArgs &a, const RunEnv &ev,
                     if ((x & 15) == 15) atomicOr(&ev.vl[bw], 1ull << ((x >> 4) & 63));
                 }
                 ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                if (CNT && line) { atomicAdd(ev.tot + s_post, -1); atomicAdd(ev.tot + SF_UNBURNED, 1); }      // (the caller books every ignition as UNBURNED -> BURNING)
             }
         }
         acc.n_ignite += (uint32_t)__popcll(__ballot(ignited));
@@ -807,6 +812,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     ev.rt = a.rt + (long long)e * g.rt_env;
     ev.vb = vb; ev.vf = vf; ev.vl = vl;
     ev.tdirty = a.tdirty + (long long)e * g.TY * g.TX;
+    ev.tot = reinterpret_cast<int32_t *>(ctl + 10);
     int rpt = ((TEAM ? R1 - R0 : g.H) + nthr - 1) / nthr;            // rows per thread (contiguous, so the list runs by rows)
     int row0 = TEAM ? R0 : 0;                                         // first row of this workgroup's rows
     // this member's rows of the bitmaps -> the global array (the others' rows in its LDS are not maintained)
@@ -855,6 +861,12 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         __syncthreads();
         lseq = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[18]);
         n_steps = 0x7FFFFFFF;
+        // the environment counted ONCE, when the launch starts; from then on the row is kept up by difference (loop_finish)
+        counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, nullptr,
+                   reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
+        if (tid == 0)
+            for (int q = 0; q < 6; ++q) ev.tot[q] = a.res_block[e * 8 + 2 + q];      // (what this thread has just stored)
+        __syncthreads();
     }
     unsigned long long join_clk = __builtin_readcyclecounter();      // TEAM = 2, member 0: when the last cut was (what an update costs: the board)
     unsigned long long x_clocks = 0, x_steps = 0;      // TEAM statistics: clocks wave 0 spent at the team's step boundaries (publish + wait + read), boundaries
@@ -866,9 +878,17 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         auto loop_finish = [&]() {
             // the step is done: this environment's row of the result block goes straight to the host (posted writes are cheap, it is
             // reads of host memory that are not) together with its "done" number (which also goes to device memory for a restarted launch)
+            // The row by difference: what this step changed was booked cell by cell in LDS (the prune's BURNED cells, the ignitions, the
+            // control lines; the tiles are marked for whoever next counts tiles).  (Counting the environment - the dirty tiles' rows, the
+            // clean tiles' cached histograms - was 8 of a call's 25 us.)
             __syncthreads();
-            counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, nullptr,
-                       reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
+            if (tid == 0) {
+                const int32_t *tot = ev.tot;
+                int32_t *row = a.res_block + e * 8;
+                row[0] = st.running == 1; row[1] = st.steps;
+                for (int q = 0; q < 6; ++q) row[2 + q] = tot[q];
+                a.res_elapsed[e] = st.elapsed;
+            }
             ++lseq;
             // ONE 64-byte line per environment and step, written by one store instruction of 16 lanes (one PCIe write instead of six,
             // no drain between "row" and "done"): four 16-byte pieces, each ends in the step's number - the host takes the line
@@ -909,7 +929,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 }
                 __syncthreads();
                 const uint32_t db = ctl[19];
-                if ((db & ~kLoopStop) > lseq && a.mit_k > 0) {
+                if ((db & ~kLoopStop) > lseq && a.mit_k > 0 && SF_LOOP_ABL != 2) {
                     const int n16 = loop_slot_ints / 4;                        // the slot in 16-byte pieces
                     const size_t off = (size_t)((lseq + 1u) & 1u) * (size_t)n16 * 2;       // in 8-byte words
                     typedef unsigned long long u64;
@@ -997,12 +1017,14 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     uint32_t was = 0, owed_since = 0;
                     double bn = 0.0;
                     if (ATT && ok) { was = *cell & 7u; bn = ev.burn[o]; owed_since = ev.settled[o]; }
+                    else if (loop && ok) was = *cell & 7u;
                     // Two points of the step on one cell: every one of them stores the highest of their types (the reference's write
                     // order).  Whether any two points MAY share a cell: a 32 768-bit table in this wave's strip buffer (free between the
                     // steps), a bit per hashed cell; only then the exact answer, a scalar loop over the lanes that hold a higher type.
                     int fin = ty;
-                    const unsigned long long above = __ballot(ok && ty > SF_FIRELINE);
-                    if (above && (__ballot(ok && ty != SF_WETLINE) != 0ull)) {            // (all of one type: nothing to settle)
+                    bool first = ok;                      // (LOOP mode, the result row by difference: of the points on one cell the lowest lane books the change)
+                    const unsigned long long above = loop ? __ballot(ok) : __ballot(ok && ty > SF_FIRELINE);
+                    if (above && (loop || __ballot(ok && ty != SF_WETLINE) != 0ull)) {            // (all of one type: nothing to settle)
                         const uint32_t h = (o * 2654435761u) >> 17, bit = 1u << (h & 31);
                         if (ok) strips[h >> 5] = 0;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1016,6 +1038,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                                 const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
                                 const int tj = __builtin_amdgcn_readlane(ty, j);
                                 if (key == kj && tj > fin) fin = tj;
+                                if (loop && key == kj && j < lane) first = false;
                             }
                         }
                     }
@@ -1028,6 +1051,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     }
                     if (ok) *cell = (uint8_t)fin;
                     if (ok) ev.tdirty[(y >> th_log) * g.TX + ((x >> 4) >> g.logLC)] = 1;
+                    if (loop && first && was != (uint32_t)fin) { atomicAdd(ev.tot + was, -1); atomicAdd(ev.tot + fin, 1); }
                     pc.mark(14); // control lines: the wave's plane work issued
                 }
             } else {
@@ -1382,6 +1406,20 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 // the per-tile status histograms behind the result block (k_counts_tiles) go stale with any status write
                 const bool st_ch = ((snew.x ^ sr.x) | (snew.y ^ sr.y) | (snew.z ^ sr.z) | (snew.w ^ sr.w)) != 0;
                 if (st_ch) ev.tdirty[(y >> th_log) * g.TX + (v >> g.logLC)] = 1;
+                if (loop && st_ch) {
+                    // the closed loop's result row by difference: the cells the prune has just turned BURNED, by what they were (BURNING - or a
+                    // control line drawn over a burning cell)
+                    const uint4 s7o = and4(sr, 0x07070707u);
+                    const uint32_t wo[4] = {s7o.x, s7o.y, s7o.z, s7o.w}, wn[4] = {snew.x & 0x07070707u, snew.y & 0x07070707u, snew.z & 0x07070707u, snew.w & 0x07070707u};
+                    int n = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        for (uint32_t ch = nz01(wo[j] ^ wn[j]); ch; ch &= ch - 1) {
+                            atomicAdd(ev.tot + ((wo[j] >> (__ffs(ch) - 1)) & 7u), -1);
+                            ++n;
+                        }
+                    if (n) atomicAdd(ev.tot + SF_BURNED, n);
+                }
                 pc.mark(5);      // status arrived, SWAR, stores issued
 
                 // ---- frontier cells of this batch -> walk (the walkers find their cells themselves: run_walk)
@@ -1399,9 +1437,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     pc.mark(6);  // prefix sum
-                    const WalkAcc wk = run_walk<ATT>(a, ev, mk, st.complete, lo_mask, hi_mask, strips, total, lane, th_log, pc, excl, m16 | (line16 << 16), s7n);
+                    const WalkAcc wk = run_walk<ATT, loop ? 1 : 0>(a, ev, mk, st.complete, lo_mask, hi_mask, strips, total, lane, th_log, pc, excl, m16 | (line16 << 16), s7n);
                     n_active += wk.n_active;
                     n_ignite += wk.n_ignite;
+                    if (loop && wk.n_ignite && lane == 0) { atomicAdd(ev.tot + SF_UNBURNED, -(int32_t)wk.n_ignite); atomicAdd(ev.tot + SF_BURNING, (int32_t)wk.n_ignite); }
                     if (wk.cand && lane == 0) reinterpret_cast<uint8_t *>(ctl + 3 + k)[1] = 1;                 // FLAG_CAND
                     n_items_acc += (lane == 0) ? total : 0u;
                     n_phase2++;
