@@ -832,15 +832,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     const bool mit_one_wave = mit && a.mit_k <= 64;
     const int mit_wave = n_waves - 1;
     constexpr bool loop = MIT == -2;       // LOOP mode: steps on the host's doorbell (see below); its own instantiation, so that the others do not carry it
-    const int loop_slot_ints = (g.E * a.mit_k * 3 * 4 + 15) / 16 * 4;          // LOOP mode: a slot of the points ring, padded to 16 bytes
     auto load_pt = [&](int s) {
         if (wave == mit_wave && lane < a.mit_k) {
-            const int32_t *p = loop ? a.loop_pts + (long long)s * loop_slot_ints + ((long long)e * a.mit_k + lane) * 3
-                                    : mit + (((long long)s * g.E + e) * a.mit_k + lane) * 3;
-            if (loop) {      // the relay's copy, rewritten every other step: loads that skip the L1
-                px = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); py = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pty = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else { px = p[0]; py = p[1]; pty = p[2]; }
+            const int32_t *p = mit + (((long long)s * g.E + e) * a.mit_k + lane) * 3;      // (LOOP mode: the points come with the poll, below)
+            px = p[0]; py = p[1]; pty = p[2];
         }
     };
     if (mit_one_wave && n_steps > 0 && !loop && !kWinMit) load_pt(0);      // (kWinMit: the wave holds the points of step s_begin already - asked for in front of the window phase, kept up by it)
@@ -866,6 +861,18 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                    reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
         if (tid == 0)
             for (int q = 0; q < 6; ++q) ev.tot[q] = a.res_block[e * 8 + 2 + q];      // (what this thread has just stored)
+        if (e == 0 && a.mit_k > 0 && lseq > 0) {
+            // a launch started again (the one before left for lack of a ring): an environment that had not made the relay's last step yet
+            // still waits for that step's pieces - the relay brings them over once more (they are still in their slot; idempotent)
+            const int n16 = g.E * a.mit_k;
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.loop_pts_host) + (size_t)(lseq & 1u) * n16;
+            u32x4 *cpy = reinterpret_cast<u32x4 *>(a.loop_pts) + (size_t)(lseq & 1u) * n16;
+            for (int i = tid; i < n16; i += nthr) {
+                u32x4 v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src + i) : "memory");
+                if (v.w == lseq) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(cpy + i), "v"(v) : "memory");
+            }
+        }
         __syncthreads();
     }
     unsigned long long join_clk = __builtin_readcyclecounter();      // TEAM = 2, member 0: when the last cut was (what an update costs: the board)
@@ -913,7 +920,70 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     __hip_atomic_store(reinterpret_cast<uint32_t *>(a.loop_res_host) + (size_t)e * 16 + lane, stage[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         };
-        if (loop) {
+        if (loop && a.mit_k > 0) {
+            // ---- a step's points ARE its doorbell: 16-byte pieces (column, row, type, the step's number), valid when they carry the number
+            // the reader waits for - one PCIe round trip (the relay's poll reads the points themselves) and one round trip through the L2
+            // (every environment's control-line wave polls ITS pieces of the relay's copy) where the doorbell word in front of the points
+            // made two each.  (Pieces: one 16-byte store on the host, one 16-byte load here, one 16-byte store into the copy.)
+            const uint32_t want = lseq + 1u;
+            const int n16 = g.E * a.mit_k;
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.loop_pts_host) + (size_t)(want & 1u) * n16;
+            u32x4 *cpy = reinterpret_cast<u32x4 *>(a.loop_pts) + (size_t)(want & 1u) * n16;
+            if (e == 0) {
+                // the relay: one lane polls the doorbell word (every lane polling its own pieces - no doorbell at all - was measured: 256 PCIe
+                // reads per round instead of one, 34 us per call instead of 19); on the ring every lane brings up to four pieces at a time over
+                // (SYSTEM-scope loads, sc0 sc1: no cache may answer) - no wait for the stores, no barrier, no number to forward behind them:
+                // the pieces tell their readers themselves
+                if (tid == 0) {
+                    const unsigned long long t0 = __builtin_readcyclecounter();
+                    uint32_t db;
+                    for (;;) {
+                        db = __hip_atomic_load(a.loop_db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if ((db & ~kLoopStop) > lseq || (db & kLoopStop)) break;
+                        if (__builtin_readcyclecounter() - t0 > a.loop_timeout) { db = lseq | kLoopStop; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    ctl[19] = db;
+                    // the host says stop, or has gone away: everybody leaves
+                    if (!((db & ~kLoopStop) > lseq)) __hip_atomic_store(a.loop_seq, lseq | kLoopStop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if ((ctl[19] & ~kLoopStop) > lseq && SF_LOOP_ABL != 2)
+                    for (int i0 = tid; i0 < n16; i0 += 4 * nthr) {
+                        // (there is no 16-byte atomic load in HIP: inline assembly, four loads in flight per lane, one wait)
+                        u32x4 v[4] = {};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = i0 + q * nthr;
+                            if (i < n16) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q]) : "v"(src + i) : "memory");
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = i0 + q * nthr;
+                            if (i < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i), "v"(v[q]) : "memory");
+                        }
+                    }
+            }
+            if (wave == mit_wave) {
+                const u32x4 *mine = cpy + (size_t)e * a.mit_k + (lane < a.mit_k ? lane : 0);
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                uint32_t go = 0;
+                for (;;) {
+                    u32x4 v;
+                    uint32_t q;
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(v), "=&v"(q) : "v"(mine), "v"(a.loop_seq) : "memory");
+                    if (__ballot(lane < a.mit_k && v.w != want) == 0ull) { go = 1; px = (int32_t)v.x; py = (int32_t)v.y; pty = (int32_t)v.z; break; }
+                    if ((q & kLoopStop) || __builtin_readcyclecounter() - t0 > 2 * a.loop_timeout) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (lane == 0) ctl[17] = go;
+            }
+            __syncthreads();
+            if (!ctl[17]) break;            // (uniform)
+        } else if (loop) {
+            // ---- no points (sf_loop_start(0)): a doorbell word, forwarded by the relay
             if (e == 0) {
                 // ---- the relay: doorbell, points, forward
                 if (tid == 0) {
@@ -929,34 +999,6 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 }
                 __syncthreads();
                 const uint32_t db = ctl[19];
-                if ((db & ~kLoopStop) > lseq && a.mit_k > 0 && SF_LOOP_ABL != 2) {
-                    const int n16 = loop_slot_ints / 4;                        // the slot in 16-byte pieces
-                    const size_t off = (size_t)((lseq + 1u) & 1u) * (size_t)n16 * 2;       // in 8-byte words
-                    typedef unsigned long long u64;
-                    // 16 bytes per lane with SYSTEM-scope loads (sc0 sc1: no cache may answer; plain and nontemporal 16-byte loads of the ring
-                    // were measured to return a slot's contents of two steps earlier now and then).  There is no 16-byte atomic load in
-                    // HIP: inline assembly, four loads in flight per lane, one wait.
-                    const u32x4 *src = reinterpret_cast<const u32x4 *>(reinterpret_cast<const u64 *>(a.loop_pts_host) + off);
-                    u64 *dstp = reinterpret_cast<u64 *>(a.loop_pts) + off;
-                    for (int i0 = tid; i0 < n16; i0 += 4 * nthr) {
-                        u32x4 v[4] = {};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q * nthr;
-                            if (i < n16) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q]) : "v"(src + i) : "memory");
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q * nthr;
-                            if (i < n16) {
-                                __hip_atomic_store(dstp + 2 * i, (u64)v[q].x | ((u64)v[q].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(dstp + 2 * i + 1, (u64)v[q].z | ((u64)v[q].w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
                 __syncthreads();
                 if (tid == 0) __hip_atomic_store(a.loop_seq, db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -994,7 +1036,6 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                 // round trips with every wave waiting, 7.5 k clocks of a C5 step.  Measured and dropped: asking for the cells' old
                 // contents before the wave's own interest pass and storing behind it - the state held across the pass cost more in
                 // spilled registers than the hidden latency gave.)
-                if (loop) load_pt((int)((lseq + 1u) & 1u));      // (LOOP mode: the slot of the step the host has just posted)
                 bool ok = false;
                 int x = 0, y = 0;
                 if (wave == mit_wave) {

@@ -44,6 +44,7 @@
 // handful of float64 adds per frontier cell.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: burn_amounts and the
 // ignition test burn > pixel_scale must round exactly like IEEE float64 on the CPU).
+#include <emmintrin.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1921,7 +1922,7 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
         rc = pin((void **)&s->loop_res, (void **)&s->loop_res_dev, (size_t)64 * g.E); if (rc) return rc;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->loop_mem), sizeof(uint32_t) * (32 + (size_t)g.E)));
     }
-    s->loop_slot_ints = ((size_t)g.E * k * 3 * 4 + 15) / 16 * 4;
+    s->loop_slot_ints = (size_t)g.E * k * 4;        // a slot of the points ring: 16-byte pieces (column, row, type, the step's number)
     const size_t pts_bytes = sizeof(int32_t) * 2 * (s->loop_slot_ints ? s->loop_slot_ints : 4);
     if (pts_bytes > s->loop_pts_cap) {
         if (s->loop_pts) HIPCHK(hipHostFree(s->loop_pts));
@@ -1935,6 +1936,7 @@ extern "C" int sf_loop_start(sf_sim *s, int32_t k)
     volatile uint32_t *db = s->loop_db;
     for (int i = 0; i < 64; ++i) db[i] = 0;
     memset(s->loop_res, 0, (size_t)64 * g.E);
+    memset(s->loop_pts, 0, pts_bytes);             // (pieces of an earlier loop carry ITS step numbers)
     __sync_synchronize();
     HIPCHK(hipMemsetAsync(s->loop_mem, 0, sizeof(uint32_t) * (32 + (size_t)g.E), s->stream));
     HIPCHK(hipMemsetAsync(s->loop_pts_mem, 0, pts_bytes, s->stream));
@@ -1959,10 +1961,12 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
     const uint32_t seq = s->loop_seq + 1;
     if (seq >= 0x7FFFFFF0u) return fail(SF_ESTATE, "sf_loop_step: sequence numbers exhausted; sf_loop_stop and start again");
     if (s->loop_k > 0) {
-        int32_t *slot = s->loop_pts + (size_t)(seq & 1u) * s->loop_slot_ints;
-        const size_t n = (size_t)g.E * s->loop_k * 3;
-        if (pts) memcpy(slot, pts, sizeof(int32_t) * n);
-        else memset(slot, 0, sizeof(int32_t) * n);
+        // the points are their own doorbell: 16-byte pieces that carry the step's number, each written by ONE 16-byte store (the relay takes a
+        // piece when it carries the number it waits for)
+        __m128i *slot = reinterpret_cast<__m128i *>(s->loop_pts + (size_t)(seq & 1u) * s->loop_slot_ints);
+        const size_t n = (size_t)g.E * s->loop_k;
+        if (pts) for (size_t i = 0; i < n; ++i) _mm_store_si128(slot + i, _mm_set_epi32((int)seq, pts[3 * i + 2], pts[3 * i + 1], pts[3 * i]));
+        else for (size_t i = 0; i < n; ++i) _mm_store_si128(slot + i, _mm_set_epi32((int)seq, 0, 0, 0));
     }
     volatile uint32_t *db = s->loop_db;
     __sync_synchronize();                                    // the points are in memory before the number that announces them
