@@ -930,40 +930,60 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
             const u32x4 *src = reinterpret_cast<const u32x4 *>(a.loop_pts_host) + (size_t)(want & 1u) * n16;
             u32x4 *cpy = reinterpret_cast<u32x4 *>(a.loop_pts) + (size_t)(want & 1u) * n16;
             if (e == 0) {
-                // the relay: one lane polls the doorbell word (every lane polling its own pieces - no doorbell at all - was measured: 256 PCIe
-                // reads per round instead of one, 34 us per call instead of 19); on the ring every lane brings up to four pieces at a time over
-                // (SYSTEM-scope loads, sc0 sc1: no cache may answer) - no wait for the stores, no barrier, no number to forward behind them:
-                // the pieces tell their readers themselves
-                if (tid == 0) {
+                // the relay.  The doorbell word is polled (every lane polling its own pieces - no doorbell at all - was measured: 256 PCIe
+                // reads per round instead of one, 34 us per call instead of 19) by FOUR waves out of step with each other - a poll is a PCIe
+                // round trip of ~2 us, and a ring is seen by the first read that STARTS after it: on average a quarter of the wait of one
+                // poller -; whoever sees it first says so in LDS, where the other waves wait.  Then the waves bring the pieces over, 256 at
+                // a time from a queue (SYSTEM-scope loads, sc0 sc1: no cache may answer; four in flight per lane) - the pollers join when their
+                // last read is back.  No wait for the stores, no barrier, no number to forward behind them: the pieces tell their readers.
+                volatile uint32_t *flag = ctl + 19;
+                uint32_t db = 0;
+                if (wave < (n_waves >= 8 ? 4 : 1)) {
                     const unsigned long long t0 = __builtin_readcyclecounter();
-                    uint32_t db;
-                    for (;;) {
+                    if (wave) __builtin_amdgcn_s_sleep(1);      // (out of step: the waves' clocks drift apart by themselves after that)
+                    for (int it = 0;; ++it) {
+                        db = *flag;
+                        if (db) break;
+                        if (it == 0 && wave == 1) __builtin_amdgcn_s_sleep(20);
+                        if (it == 0 && wave == 2) __builtin_amdgcn_s_sleep(40);
+                        if (it == 0 && wave == 3) __builtin_amdgcn_s_sleep(60);
                         db = __hip_atomic_load(a.loop_db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if ((db & ~kLoopStop) > lseq || (db & kLoopStop)) break;
-                        if (__builtin_readcyclecounter() - t0 > a.loop_timeout) { db = lseq | kLoopStop; break; }
-                        __builtin_amdgcn_s_sleep(4);
+                        if (!((db & ~kLoopStop) > lseq || (db & kLoopStop))) {
+                            if (__builtin_readcyclecounter() - t0 <= a.loop_timeout) { __builtin_amdgcn_s_sleep(4); continue; }
+                            db = lseq | kLoopStop;          // the host has gone away
+                        }
+                        if (lane == 0) atomicCAS(ctl + 19, 0u, db);      // (the first decision stands)
+                        db = *flag;
+                        break;
                     }
-                    ctl[19] = db;
-                    // the host says stop, or has gone away: everybody leaves
-                    if (!((db & ~kLoopStop) > lseq)) __hip_atomic_store(a.loop_seq, lseq | kLoopStop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    while ((db = *flag) == 0u) __builtin_amdgcn_s_sleep(1);
                 }
-                __syncthreads();
-                if ((ctl[19] & ~kLoopStop) > lseq && SF_LOOP_ABL != 2)
-                    for (int i0 = tid; i0 < n16; i0 += 4 * nthr) {
+                db = (uint32_t)__builtin_amdgcn_readfirstlane((int)db);
+                if ((db & ~kLoopStop) > lseq) {
+                    for (;;) {
+                        uint32_t c = lane == 0 ? atomicAdd(ctl + 21, 1u) : 0u;
+                        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                        const int i0 = (int)c * 256 + lane;
+                        if ((int)c * 256 >= n16 || SF_LOOP_ABL == 2) break;
                         // (there is no 16-byte atomic load in HIP: inline assembly, four loads in flight per lane, one wait)
                         u32x4 v[4] = {};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q * nthr;
+                            const int i = i0 + q * 64;
                             if (i < n16) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q]) : "v"(src + i) : "memory");
                         }
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q * nthr;
+                            const int i = i0 + q * 64;
                             if (i < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i), "v"(v[q]) : "memory");
                         }
                     }
+                } else if (tid == 0) {
+                    // the host says stop, or has gone away: everybody leaves
+                    __hip_atomic_store(a.loop_seq, lseq | kLoopStop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if (wave == mit_wave) {
                 const u32x4 *mine = cpy + (size_t)e * a.mit_k + (lane < a.mit_k ? lane : 0);
@@ -982,6 +1002,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
             }
             __syncthreads();
             if (!ctl[17]) break;            // (uniform)
+            if (e == 0 && tid == 0) { ctl[19] = 0; ctl[21] = 0; }      // (the relay's flag and queue: every wave is through with them)
         } else if (loop) {
             // ---- no points (sf_loop_start(0)): a doorbell word, forwarded by the relay
             if (e == 0) {

@@ -1977,23 +1977,8 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
     // workgroup resumes from its own "done" number, the points of this step are still in their slot
     const volatile uint32_t *res = reinterpret_cast<const volatile uint32_t *>(s->loop_res);
     auto arrived = [&](int q) { const volatile uint32_t *l = res + (size_t)q * 16; return l[3] == seq && l[7] == seq && l[11] == seq && l[15] == seq; };
-    int e = 0;
-    for (unsigned long long spins = 0;; ++spins) {
-        while (e < g.E && arrived(e)) ++e;
-        if (e == g.E) break;
-        if ((spins & 0x3FFF) == 0x3FFF && hipStreamQuery(s->stream) == hipSuccess) {
-            bool all = true;
-            for (int q = 0; q < g.E; ++q) all = all && arrived(q);
-            if (all) break;
-            if (s->xerr_pinned && *s->xerr_pinned) return fail(SF_EHIP, "sf_loop_step: the resident launch failed");
-            HIPCHK(hipSetDevice(s->p.device));
-            s->loop_restarts++;
-            { int rc0 = loop_launch(s); if (rc0) return rc0; }
-            HIPCHK(hipGetLastError());
-        }
-    }
-    __sync_synchronize();
-    for (int q = 0; q < g.E; ++q) {
+    // (a row is taken out of its line as soon as the line is there: nothing is left to do behind the last arrival)
+    auto take = [&](int q) {
         const volatile uint32_t *l = res + (size_t)q * 16;
         if (status_out) {
             int32_t *o = status_out + (size_t)q * 8;
@@ -2003,6 +1988,21 @@ extern "C" int sf_loop_step(sf_sim *s, const int32_t *pts, int32_t *status_out, 
         if (elapsed_out) {
             const unsigned long long el = (unsigned long long)l[10] | ((unsigned long long)l[12] << 32);
             memcpy(elapsed_out + q, &el, sizeof el);
+        }
+    };
+    int e = 0;
+    for (unsigned long long spins = 0;; ++spins) {
+        while (e < g.E && arrived(e)) { take(e); ++e; }
+        if (e == g.E) break;
+        if ((spins & 0x3FFF) == 0x3FFF && hipStreamQuery(s->stream) == hipSuccess) {
+            bool all = true;
+            for (int q = 0; q < g.E; ++q) all = all && arrived(q);
+            if (all) { for (int q = e; q < g.E; ++q) take(q); break; }
+            if (s->xerr_pinned && *s->xerr_pinned) return fail(SF_EHIP, "sf_loop_step: the resident launch failed");
+            HIPCHK(hipSetDevice(s->p.device));
+            s->loop_restarts++;
+            { int rc0 = loop_launch(s); if (rc0) return rc0; }
+            HIPCHK(hipGetLastError());
         }
     }
     return SF_OK;
