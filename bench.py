@@ -156,8 +156,8 @@ def run_steps(eng, steps, first_step, agent_pts):
 
 
 def profile_file(stem):
-    """The newest committed round's copy of a replayed measurement under profiles/ (r05_<stem>, else r04_<stem>); None if absent."""
-    for rnd in ("r05", "r04"):
+    """The newest committed round's copy of a replayed measurement under profiles/ (r06_<stem>, else r05_ / r04_<stem>); None if absent."""
+    for rnd in ("r06", "r05", "r04"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
         if os.path.exists(p):
             return p

@@ -109,7 +109,7 @@ def world(seed):
             eng.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["SOAK_AT"].split(":", 1)[1].split(","))})
         if os.environ.get("SOAK_DEBUG"):
             print("t", t, "n", n, "r %.3f" % r, flush=True)
-        if rng.random() < 0.06 and md <= 5:
+        if rng.random() < float(os.environ.get("SOAK_LOOP_P", "0.06")) and md <= 5:      # (SOAK_LOOP_P: a soak that leans on the closed loop)
             # the closed loop (sf_loop_*): n calls of update_mitigation(points) + run(1) on a launch that stays resident
             K = int(rng.choice([0, 2, 9, 64]))
             try:
