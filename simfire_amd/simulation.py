@@ -57,6 +57,9 @@ def _engine_from_config(config: Config, n_envs: int, device: int,
                      particle=(fp.h, fp.S_T, fp.S_e, fp.p_p), device=device, per_env_terrain=per_env_terrain)
     if not per_env_terrain:
         _set_config_layers(eng, config, fuels, elev, None)
+    # calls that hand nothing back (update_mitigation, the updates of a run) only enqueue their work: whatever hands data back - the result row,
+    # the changed cells, a map - waits for the stream, once (sf_set_async; a tick of update_mitigation + run(1) waits once instead of three times)
+    eng.set_async(True)
     return eng, _TerrainView(fuels, elev, (H, W))
 
 

@@ -910,7 +910,7 @@ def test_bench_line_is_the_median_of_repeated_resets_and_rollouts():
 @pytest.mark.parametrize("att", [False, True])
 def test_closed_loop_steps_equal_update_mitigation_run_pairs(att):
     """sf_loop_start / sf_loop_step: update_mitigation(points) + run(1) per call on a launch that stays resident (doorbell and
-    points in host-mapped memory).  The points of a step DEPEND on the result block of the step before (a line is drawn next to
+    points in host-mapped memory; the result row kept up by difference from the second step on).  The points of a step DEPEND on the result block of the step before (a line is drawn next to
     a burning cell found in the returned counts' environment), some land on burning cells, some are padding; one environment
     runs out of fuel half-way (QUIT: lines keep being drawn); a pause longer than the launch's patience makes it leave and the
     next call start it again; other calls on the handle end the loop.  Equal to the oracle after every step."""
@@ -931,6 +931,8 @@ def test_closed_loop_steps_equal_update_mitigation_run_pairs(att):
         pts[..., 0] = rng.integers(0, W, size=(E, K))
         pts[..., 1] = rng.integers(0, H, size=(E, K))
         pts[..., 2] = rng.integers(2, 7, size=(E, K))
+        pts[:, 3] = pts[:, 2]                       # the same point twice, and a third time with a type of its own: the row is kept up by
+        pts[:, 5, :2] = pts[:, 2, :2]               # difference - one of a cell's points books the change, the highest type stands
         for e in range(E):
             burning = np.argwhere(o.fire_map(e) == 1)
             if len(burning) and (last is None or last[e, 3] > 0):          # (last[e, 3]: BURNING cells in the block of the step before)
