@@ -1,8 +1,8 @@
 #!/bin/bash
 # Development aid: the register / spill / scratch table of every kernel of the product build (the compiler's own report,
-# -Rpass-analysis=kernel-resource-usage), one translation unit after the other.  usage: bash profiles/resource_usage.sh > profiles/r05_resource_usage.txt
+# -Rpass-analysis=kernel-resource-usage), one translation unit after the other.  usage: bash profiles/resource_usage.sh > profiles/r06_resource_usage.txt
 cd "$(dirname "$0")/.."
-echo "# kernel resource usage, product build (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage), round 5"
+echo "# kernel resource usage, product build (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage), round 6"
 echo "# $(/opt/rocm/bin/hipcc --version | grep 'HIP version')"
 echo "# k_run<MAXD, ATT, DIAG, MIT, TEAM>: MIT 0 = sf_step (with the window phase where MAXD <= 2, TEAM != 2), -1 = sf_step_mitigated, -2 = the closed loop;"
 echo "#   TEAM 1 = teams of a size fixed for the launch, 2 = teams that grow inside the launch (NOTEBOOK.md 5.8)"
