@@ -1854,12 +1854,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     we.pre_w = pre_w; we.pre = true; we.hint = 0ull;
     __syncthreads();
     wpc.start();
+#ifdef SF_PHASES
+    wpc.tl = (e == g_timeline_env && g_timeline_step == -1) ? g_timeline + wave * 64 : nullptr;
+#endif
+    wpc.note(30);        // launch: state read
     // (A second window around a fire that reaches its ring while it still fits one - a loop around this call - was built and measured: the loop
     // costs the kernel its registers, 116 bytes of scratch and 194 spilled SGPRs under the 64 / 96 of eight waves to a SIMD, 62 -> 85 us on five
     // updates of 1024 environments.  Such a fire's remaining updates are the launch behind's, which places its own window anew.)
     const int s_done = run_window<ATT, 0, 0, 1>(a, we, st, n_steps, g.diag != 0, wl, ctl, th_log, n_active, n_ignite, n_vec_done, wpc, e, win_result);
     // what is left for the host's next launch: nothing once the call's updates are made or the fire is out (fire.py:637-643)
     const bool finished = s_done >= n_steps || !st.running;
+    wpc.note(35);        // steps done
     if (tid == 0) {
         if (s_done > 0) a.commit[e] = st;
         a.todo_out[e] = finished ? 0 : n_steps - s_done;
