@@ -60,3 +60,7 @@ for x in what:
         N_save, N = N, 2
         window("c3 long", workloads.c3(1024, 256), warm=20, steps=1000)
         N = N_save
+    elif x == "mid":
+        window("c3 mid (100 after 20)", workloads.c3(1024, 256), warm=20, steps=100)
+    elif x == "c4mid":
+        window("c4 mid (100 after 20)", workloads.c4(2048, 128), warm=20, steps=100)

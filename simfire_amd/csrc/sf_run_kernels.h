@@ -966,19 +966,20 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                         const int i0 = (int)c * 256 + lane;
                         if ((int)c * 256 >= n16 || SF_LOOP_ABL == 2) break;
-                        // (there is no 16-byte atomic load in HIP: inline assembly, four loads in flight per lane, one wait)
-                        u32x4 v[4] = {};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q * 64;
-                            if (i < n16) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q]) : "v"(src + i) : "memory");
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q * 64;
-                            if (i < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i), "v"(v[q]) : "memory");
-                        }
+                        // (there is no 16-byte atomic load in HIP: inline assembly - four loads in flight per lane and their wait in ONE statement, so
+                        // that nothing the compiler places can read a register before its load is back; a lane whose piece lies beyond the slot
+                        // loads the slot's last piece again and stores nothing)
+                        const int i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192, last = n16 - 1;
+                        u32x4 v0, v1, v2, v3;
+                        asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                                     "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                                     : "v"(src + (i0 < last ? i0 : last)), "v"(src + (i1 < last ? i1 : last)), "v"(src + (i2 < last ? i2 : last)), "v"(src + (i3 < last ? i3 : last))
+                                     : "memory");
+                        if (i0 < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i0), "v"(v0) : "memory");
+                        if (i1 < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i1), "v"(v1) : "memory");
+                        if (i2 < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i2), "v"(v2) : "memory");
+                        if (i3 < n16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cpy + i3), "v"(v3) : "memory");
                     }
                 } else if (tid == 0) {
                     // the host says stop, or has gone away: everybody leaves
@@ -1185,10 +1186,17 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     // were what got spilled - two scratch reloads with a full wait each in this pass of sf_step_mitigated's kernel, ~1.5 k clocks per update)
                     asm volatile("" : "+v"(o));
                     const int up_o = y > 0 ? -VW : 0, dn_o = y + 1 < g.H ? VW : 0;
-                    const unsigned long long b1 = vb[o], l1 = vl[o], f1 = vf[o], e1 = ve[o];
+                    const unsigned long long b1 = vb[o];
                     unsigned long long b02 = 0, l02 = 0, f02 = 0;
-                    if (up_o) { b02 = vb[o + up_o]; l02 = vl[o + up_o]; f02 = vf[o + up_o]; }
-                    if (dn_o) { b02 |= vb[o + dn_o]; l02 |= vl[o + dn_o]; f02 |= vf[o + dn_o]; }
+                    if (up_o) b02 = vb[o + up_o];
+                    if (dn_o) b02 |= vb[o + dn_o];
+                    // (a wave none of whose rows has a sprite in it, above or below it - most waves of most environments - has no vector to list:
+                    // the first-cell / last-cell bitmaps are subsets of B.  The interest pass is issue-bound - sixteen waves on four SIMDs -,
+                    // so what the idle waves do not execute the fire's waves get)
+                    if (MAXD == 1 && __ballot((b1 | b02) != 0ull) == 0ull) continue;
+                    const unsigned long long l1 = vl[o], f1 = vf[o], e1 = ve[o];
+                    if (up_o) { l02 = vl[o + up_o]; f02 = vf[o + up_o]; }
+                    if (dn_o) { l02 |= vl[o + dn_o]; f02 |= vf[o + dn_o]; }
                     unsigned long long edge = ((l02 | l1) << 1) | ((f02 | f1) >> 1);
                     if (MAXD > 1 && VW > 1) {
                         if (w > 0) edge |= (vl[o - 1] | vl[o - 1 + up_o] | vl[o - 1 + dn_o]) >> 63;
