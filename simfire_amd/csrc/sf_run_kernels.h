@@ -1186,17 +1186,13 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                     // were what got spilled - two scratch reloads with a full wait each in this pass of sf_step_mitigated's kernel, ~1.5 k clocks per update)
                     asm volatile("" : "+v"(o));
                     const int up_o = y > 0 ? -VW : 0, dn_o = y + 1 < g.H ? VW : 0;
-                    const unsigned long long b1 = vb[o];
+                    const unsigned long long b1 = vb[o], l1 = vl[o], f1 = vf[o], e1 = ve[o];
                     unsigned long long b02 = 0, l02 = 0, f02 = 0;
-                    if (up_o) b02 = vb[o + up_o];
-                    if (dn_o) b02 |= vb[o + dn_o];
-                    // (a wave none of whose rows has a sprite in it, above or below it - most waves of most environments - has no vector to list:
-                    // the first-cell / last-cell bitmaps are subsets of B.  The interest pass is issue-bound - sixteen waves on four SIMDs -,
-                    // so what the idle waves do not execute the fire's waves get)
-                    if (MAXD == 1 && __ballot((b1 | b02) != 0ull) == 0ull) continue;
-                    const unsigned long long l1 = vl[o], f1 = vf[o], e1 = ve[o];
-                    if (up_o) { l02 = vl[o + up_o]; f02 = vf[o + up_o]; }
-                    if (dn_o) { l02 |= vl[o + dn_o]; f02 |= vf[o + dn_o]; }
+                    if (up_o) { b02 = vb[o + up_o]; l02 = vl[o + up_o]; f02 = vf[o + up_o]; }
+                    if (dn_o) { b02 |= vb[o + dn_o]; l02 |= vl[o + dn_o]; f02 |= vf[o + dn_o]; }
+                    // (measured and dropped, round 6: the waves none of whose rows has a sprite near it - most waves of most environments - leaving
+                    // the pass after three LDS reads: C3's updates 21 .. 120 7.03 -> 7.04 us, the long window 9.66 -> 9.64 - what they execute is not
+                    // on the critical path)
                     unsigned long long edge = ((l02 | l1) << 1) | ((f02 | f1) >> 1);
                     if (MAXD > 1 && VW > 1) {
                         if (w > 0) edge |= (vl[o - 1] | vl[o - 1 + up_o] | vl[o - 1 + dn_o]) >> 63;
