@@ -545,6 +545,33 @@ def test_fire_map_delta_keeps_a_host_mirror_equal_to_the_whole_map():
     eng.close()
 
 
+def test_fire_map_delta_longer_than_what_travels_with_its_count():
+    """sf_get_fire_map_delta / sf_run_delta: the first 1024 entries travel with the count, a longer list (within the caller's cap) is fetched by
+    a second copy; a list longer than the cap says "fetch the whole map" and leaves the reference point current."""
+    from simfire_amd.engine import FireEngine
+    rng = np.random.default_rng(79)
+    H, W = 300, 320
+    eng = FireEngine((H, W), n_envs=2, max_fire_duration=4, pixel_scale=10.0, update_rate=1.0)
+    eng.set_rtable(rng.choice([7.5, 12.0, 30.0], size=(8, H, W)))
+    eng.reset([(160, 150), (20, 20)])
+    for e in (0, 1):
+        assert eng.fire_map_delta(e) is None
+    mirror = [eng.fire_map(e).astype(np.int64) for e in (0, 1)]
+    eng.step(40)
+    d = eng.fire_map_delta(0, cap=1 << 17)
+    assert d is not None and len(d[0]) > 1024 and len(np.unique(d[0])) == len(d[0])
+    mirror[0].reshape(-1)[d[0]] = d[1]
+    assert (mirror[0] == eng.fire_map(0)).all()
+    row, el, d = eng.run_delta(25, env=1, cap=1 << 17)          # environment 1: 65 updates' worth of cells in one list
+    assert d is not None and len(d[0]) > 1024
+    mirror[1].reshape(-1)[d[0]] = d[1]
+    assert (mirror[1] == eng.fire_map(1)).all() and row[1] == 65
+    row, el, d = eng.run_delta(30, env=0, cap=2000)             # more than 2000 cells changed: the whole map
+    assert d is None and row[1] == 95
+    assert len(eng.fire_map_delta(0, cap=2000)[0]) == 0         # ... and the reference point is current
+    eng.close()
+
+
 def test_run_delta_is_step_status_and_delta_in_one_call():
     """sf_run_delta = sf_step + sf_get_status (one row) + sf_get_fire_map_delta, waited for once: a twin handle driven by the three separate
     calls sees the same rows, elapsed_time and changed cells at every tick - single updates (per-step kernels, then resident launches once the
