@@ -590,6 +590,41 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     }
     if (TEAM == 2 && j_s0 >= 0) s_begin = j_s0;          // a workgroup that joins: the team's next update (st: what member 0 left in commit[] at the cut)
     const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && (st.running || mit));       // (uniform) the bitmaps in LDS, the loop over the vector list
+#ifndef SF_NO_EARLY_HANDBACK
+    if (TEAM == 0 && kWin && MIT == 0 && !general) {       // (sf_step's kernels: with control lines inside the launch the same lines cost C5's kernel 2 % - its code moved)
+        // A launch that never leaves the window phase - every launch of the driver's window - hands its environment back HERE: the general
+        // loop's own way out lies tens of KB of code further on, behind half a dozen skipped blocks, and every hop landed on a cold
+        // instruction-cache line (~2.3 k clocks between the window's last barrier and the state's store, r06_timeline_window_launch.txt).
+        // (The same stores as at the end of the kernel: state, cost, statistics, the result row unless the window phase has written it.)
+#ifdef SF_PHASES
+        if (lane == 0 && g_wave_log_launch == -2 && e < 4096) {
+            if (wave == 0) { g_wave_log[e * 4 + 0] = __builtin_readcyclecounter() - clk0; g_wave_log[e * 4 + 2] = (unsigned long long)st.steps; }
+            atomicAdd(&g_wave_log[e * 4 + 1], (unsigned long long)n_vec_done);
+        }
+#endif
+        wpc.note(35);            // steps done
+        if (tid == 0) {
+            a.commit[e] = st;
+            if (a.cost) {
+                const unsigned long long c = (__builtin_readcyclecounter() - clk0) >> 4;
+                a.cost[e] = c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c;
+            }
+        }
+        wpc.note(49);            // state committed
+        if (a.counters && lane == 0) {
+            unsigned long long *cs = a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow;
+            if (n_active) atomicAdd(&cs[0], (unsigned long long)n_active);
+            if (n_ignite) atomicAdd(&cs[1], (unsigned long long)n_ignite);
+            if (n_vec_done) atomicAdd(&cs[5], (unsigned long long)n_vec_done);
+        }
+        if (a.res_block && !win_result && !(a.row_valid && n_steps == 0 && !mit)) {
+            __syncthreads();
+            counts_env(g, e, a.status, a.cells, a.tdirty, a.thist, st.running, st.steps, st.elapsed, a.res_block, a.res_elapsed, a.res_sink,
+                       reinterpret_cast<int32_t (*)[6]>(vlist + vcap));
+        }
+        return;
+    }
+#endif
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;

@@ -839,7 +839,6 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
         for (int q = 0; q < 8; ++q) g_win_prof[((size_t)e * 16 + wave) * 8 + q] = wp_acc[q];
 #endif
     if (stats && lane == 0 && n_look) atomicAdd(a.counters + (size_t)((blockIdx.x * 16 + wave) & (kCounterShards - 1)) * kCounterRow + 9, (unsigned long long)n_look);
-    if (tid < 9) ctl[tid] = 0;                                 // (the general loop's list lengths, predicate bytes and batch cursors: rings of three)
     lpc.note(33);            // updates done
     // ---- back to memory: the cells and burn_amounts that changed, the dirty flags of their tiles, the window's part of the vector bitmaps
     const uint32_t ag = wm[own];
@@ -916,6 +915,12 @@ __device__ __forceinline__ int run_window(const StepArgs &a, const WinEnv &ev, E
     if (by_delta && (s >= n_steps || !st.running)) win_barrier<0>();
     else __syncthreads();
     lpc.note(34);            // window written back
+    // The general loop's list lengths, predicate bytes and batch cursors (rings of three), which this phase has used as its own: cleared BEHIND
+    // the barrier - every wave has folded the last step's predicates by now.  (Round 6 had the idle waves sleep a moment before they read
+    // them, and this store in front of the barrier: a sleeper now and then read the cleared bytes, folded "no sprite left" for itself and
+    // skipped the general loop that followed in the same launch - found by the soak, world 6507483, in the result row.  The general loop
+    // starts behind k_run's own barrier.)
+    if (tid < 9) ctl[tid] = 0;
     if (ADV && a.win_hint && tid < 16) {
         const int n_waves = nthr >> 6;
         const uint32_t mlo = row16_max(tid < n_waves ? wslot[tid * 4] : 0u), mhi = row16_max(tid < n_waves ? wslot[tid * 4 + 1] : 0u);

@@ -53,6 +53,7 @@ def world(seed):
     # front of k_run whatever the batch size (two workgroups to a CU; forced: run_compact = 2), and a host mirror of every environment's map
     # kept from sf_get_fire_map_delta
     rng2 = np.random.default_rng(seed + 10**9)
+    rng3 = np.random.default_rng(seed + 2 * 10**9)
     eng.set_tuning(run_compact=int(rng2.choice([1, 2, 2, 0])))
     mirror = [None] * E
     eng.set_dense(bool(rng.random() < 0.2))
@@ -153,6 +154,18 @@ def world(seed):
                 if rows:
                     o.apply_mitigation(rows)
                 o.step(1)
+        elif rng3.random() < 0.3 and not os.environ.get("SOAK_NO_RUN_DELTA"):
+            # sf_run_delta: the updates, one environment's result row and its changed cells in one call (a stream of random numbers of its own)
+            e3 = int(rng3.integers(E))
+            row, el3, d = eng.run_delta(n, env=e3, cap=int(rng3.choice([4096, 64, 3])))
+            o.step(n)
+            so, eo = o.status()
+            assert (row == so[e3]).all() and el3 == eo[e3], (seed, t, e3, "run_delta row", row.tolist(), so[e3].tolist(), el3, float(eo[e3]))
+            if d is None or mirror[e3] is None:
+                mirror[e3] = eng.fire_map(e3).astype(np.int64)
+            else:
+                mirror[e3].reshape(-1)[d[0]] = d[1]
+            assert (mirror[e3] == o.fire_map(e3)).all(), (seed, t, e3, "fire_map mirror kept from run_delta")
         else:
             eng.step(n)
             o.step(n)
@@ -182,7 +195,7 @@ def world(seed):
         if rng.random() < 0.6 or t == steps - 1:      # otherwise the states stay in the device rings
             st, el = eng.status()
             so, eo = o.status()
-            assert (st == so).all() and (el == eo).all(), (seed, t, "status")
+            assert (st == so).all() and (el == eo).all(), (seed, t, "status", st.tolist(), so.tolist())
         if rng2.random() < 0.5:
             e = int(rng2.integers(E))
             d = eng.fire_map_delta(e, cap=int(rng2.choice([4096, 64, 3])))

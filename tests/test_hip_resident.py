@@ -1987,7 +1987,37 @@ def test_teams_on_a_chip_that_holds_fewer_workgroups_than_the_host_believes():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [900540, 2000064, 2000357, 2000495, 5007397, 6005034])
+@pytest.mark.parametrize("shape", [(91, 1102), (200, 300)])
+def test_window_then_general_loop_in_one_launch_every_wave_stays_in_step(shape):
+    """The window phase hands over to the general loop INSIDE a launch (SF_TUNE_RUN_WINDOW = 3: left after three updates), hundreds of times
+    on one handle: the launch's result row - counted by all sixteen waves at its end, control lines in front of the call so that nothing is
+    known by difference - equals the oracle's every time.  (Round 6, the soak's world 6507483: the window phase cleared the general loop's
+    control words in front of its last barrier; an idle wave that read the last step's predicates late read the cleared bytes, folded "no
+    sprite left" for itself, skipped the general loop and counted the environment while the others were still stepping - its slot of the
+    count held whatever their strip buffers left there.  One call in ten, from the hundredth on.)"""
+    H, W = shape
+    rng = np.random.default_rng(6507483)
+    kw = dict(shape=(H, W), n_envs=1, max_fire_duration=5, pixel_scale=20.0, update_rate=1.0, diagonal_spread=True)
+    R8 = rng.choice([7.5, 12.0, 30.0, 99.0], size=(8, H, W))
+    eng, o = _pair(kw, R8, [(W // 2, H // 2)])
+    eng.set_tuning(run_window=3, run_waves=16)
+    eng.set_fused(2)
+    pts = [(0, 5, 5, 3), (0, W // 2 + 9, H // 2, 4)]
+    o.step(4); o.apply_mitigation(pts); o.step(5)
+    want, want_el = o.status()
+    for it in range(400):
+        eng.reset([(W // 2, H // 2)])
+        eng.step(4)
+        eng.apply_mitigation(pts)
+        eng.step(5)
+        st, el = eng.status()
+        assert (st == want).all() and (el == want_el).all(), (it, st.tolist(), want.tolist())
+    _same(eng, o, 1, tag="after 400 calls")
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [900540, 2000064, 2000357, 2000495, 5007397, 6005034, 6507483])
 def test_worlds_the_soak_found(seed):
     """Random worlds of tests/soak_gpu.py that once failed, replayed: 900540 - the window phase in a workgroup of one wave (result block by
     difference initialised by 'the first 128 threads'); 2000064 / 2000357 / 2000495 - teams that grow inside the launch on grids with fewer
@@ -1995,6 +2025,7 @@ def test_worlds_the_soak_found(seed):
     only written on the way into the loop, so a call whose updates the window phase made left a stale one behind (here: k_front's
     left-overs in the cross-check build) and the catch-up launch made the update a second time; 6005034 (round 6) - k_win in front of k_run
     with teams sized by cost switched on half-way: the call behind k_win was cut into the team rollout's segments, and every segment's launch made
-    the left-over updates again."""
+    the left-over updates again; 6507483 (round 6) - an idle wave that skipped the general loop behind the window phase (one call in ten: see
+    test_window_then_general_loop_in_one_launch_every_wave_stays_in_step)."""
     import soak_gpu
     assert soak_gpu.world(seed) > 0
