@@ -3,9 +3,6 @@
 // Replaces n calls of RothermelFireManager.update, simfire/game/managers/fire.py:616-719, per environment.
 #pragma once
 
-#ifndef SF_LOOP_ABL
-#define SF_LOOP_ABL 0      // (development: ablations of the closed loop, profiles/ab_loop.sh)
-#endif
 #include "sf_common.h"
 #include "sf_step_kernels.h"
 
@@ -590,11 +587,10 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
     }
     if (TEAM == 2 && j_s0 >= 0) s_begin = j_s0;          // a workgroup that joins: the team's next update (st: what member 0 left in commit[] at the cut)
     const bool general = !kWin || (TEAM && tn > 1) || (s_begin < n_steps && (st.running || mit));       // (uniform) the bitmaps in LDS, the loop over the vector list
-#ifndef SF_NO_EARLY_HANDBACK
     if (TEAM == 0 && kWin && MIT == 0 && !general) {       // (sf_step's kernels: with control lines inside the launch the same lines cost C5's kernel 2 % - its code moved)
         // A launch that never leaves the window phase - every launch of the driver's window - hands its environment back HERE: the general
         // loop's own way out lies tens of KB of code further on, behind half a dozen skipped blocks, and every hop landed on a cold
-        // instruction-cache line (~2.3 k clocks between the window's last barrier and the state's store, r06_timeline_window_launch.txt).
+        // instruction-cache line (2.6 k clocks between the window's last barrier and the state's store, 2.0 k now: NOTEBOOK.md 5.12).
         // (The same stores as at the end of the kernel: state, cost, statistics, the result row unless the window phase has written it.)
 #ifdef SF_PHASES
         if (lane == 0 && g_wave_log_launch == -2 && e < 4096) {
@@ -624,7 +620,6 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
         }
         return;
     }
-#endif
     // ---- TEAM: the member's band of rows [R0, R1).  Every member computes the same cut from the same bitmap (nobody writes it back
     // before the whole team is done): tile rows are dealt out so that every member gets about the same number of vectors with sprites.
     int R0 = 0, R1 = g.H;
@@ -1000,7 +995,7 @@ __global__ __launch_bounds__(1024) void k_run(StepArgs a_by_value, const int n_s
                         uint32_t c = lane == 0 ? atomicAdd(ctl + 21, 1u) : 0u;
                         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                         const int i0 = (int)c * 256 + lane;
-                        if ((int)c * 256 >= n16 || SF_LOOP_ABL == 2) break;
+                        if ((int)c * 256 >= n16) break;
                         // (there is no 16-byte atomic load in HIP: inline assembly - four loads in flight per lane and their wait in ONE statement, so
                         // that nothing the compiler places can read a register before its load is back; a lane whose piece lies beyond the slot
                         // loads the slot's last piece again and stores nothing)
