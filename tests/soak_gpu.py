@@ -58,6 +58,8 @@ def world(seed):
     mirror = [None] * E
     eng.set_dense(bool(rng.random() < 0.2))
     eng.set_generic(bool(rng.random() < 0.15))
+    if os.environ.get("SOAK_HANDOVER"):      # (a soak that leans on the hand-over from the window phase to the general loop inside a launch)
+        eng.set_tuning(run_window=int(rng3.choice([2, 3, 5, 7])))
     eng.set_rows_per_band(int(rng.choice([1, 2, 4, 8])))
     eng.set_rtable(R8)
     o.set_rtable(R8)
