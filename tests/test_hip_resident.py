@@ -2017,6 +2017,38 @@ def test_window_then_general_loop_in_one_launch_every_wave_stays_in_step(shape):
 
 
 @pytest.mark.gpu
+def test_window_hands_over_to_the_general_loop_at_c3_scale():
+    """The hand-over from the window phase to the general loop INSIDE a launch (SF_TUNE_RUN_WINDOW = k: the window is left after k updates) on
+    32 environments of C3 (1024 x 1024, one workgroup of sixteen waves each, most of them idle), calls of several lengths, repeated: every
+    environment's result row after every call and every fire map at the end equal the oracle's."""
+    from simfire_amd import workloads
+    from simfire_amd.engine import FireEngine
+    E = 32
+    w = workloads.c3(1024, E)
+    eng = FireEngine(M_f=w.M_f, device=0, **w.engine_kwargs())
+    eng.set_layers(*w.layers())
+    o = fire_dense.DenseOracle(**w.engine_kwargs())
+    o.set_rtable(eng.get_rtable())
+    for win in (2, 5):
+        for calls in ((6, 9, 30), (12, 40)):
+            o.reset(w.init_xy)
+            want = []
+            for n in calls:
+                o.step(n, 8)
+                want.append(o.status()[0].copy())
+            for rep in range(6):
+                eng.set_tuning(run_window=win)
+                eng.reset(w.init_xy)
+                for i, n in enumerate(calls):
+                    eng.step(n)
+                    assert (eng.status()[0] == want[i]).all(), (win, calls, rep, i)
+                maps = eng.fire_maps()
+                for e in range(E):
+                    assert (maps[e] == o.fire_map(e)).all(), (win, calls, rep, e)
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [900540, 2000064, 2000357, 2000495, 5007397, 6005034, 6507483])
 def test_worlds_the_soak_found(seed):
     """Random worlds of tests/soak_gpu.py that once failed, replayed: 900540 - the window phase in a workgroup of one wave (result block by
