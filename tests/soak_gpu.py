@@ -14,9 +14,9 @@ from simfire_amd.engine import FireEngine  # noqa: E402
 
 def world(seed):
     rng = np.random.default_rng(seed)
-    big = rng.random() < 0.25
+    big = rng.random() < (0.85 if os.environ.get("SOAK_BIG") else 0.25)      # (SOAK_BIG: grids that hold a window - 64 rows and more - in most worlds)
     H, W = (int(rng.integers(60, 300)), int(rng.integers(60, 300))) if big else (int(rng.integers(1, 70)), int(rng.integers(1, 70)))
-    if rng.random() < 0.04:
+    if rng.random() < (0.15 if os.environ.get("SOAK_BIG") else 0.04):
         H, W = int(rng.integers(70, 170)), int(rng.integers(1030, 1200))       # two-word rows: the resident launch runs as teams with windows of rows
     E = int(rng.integers(1, 5))
     md = int(rng.integers(1, 6)) if rng.random() < 0.8 else int(rng.integers(6, 29))
